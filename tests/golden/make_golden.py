@@ -1,0 +1,258 @@
+"""Generate golden vectors by running the REFERENCE ITSELF (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports /root/reference/src/models/{Hang2020,year}.py read-only (they need only torch; year.py's
+unused torchmetrics import is stubbed), loads weights from oracle/prng.py through load_state_dict,
+runs forward / loss / backward / Adam with torch, and stores ONLY inputs' recipe (seeds) and the
+reference's outputs as .npz.  No reference source is copied anywhere.  The reference never travels
+to the GPU box; these fixtures do.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+sys.modules.setdefault("torchmetrics", types.ModuleType("torchmetrics"))
+
+from oracle import hang2020_np as O  # noqa: E402
+from oracle import prng  # noqa: E402
+from src.models import Hang2020 as R  # noqa: E402  (the reference)
+from src.models import year as RY  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def load(module, params, prefix=""):
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        a = params[prefix + k]
+        assert tuple(v.shape) == tuple(a.shape), (k, v.shape, a.shape)
+        new[k] = torch.from_numpy(np.array(a)).to(v.dtype)
+    module.load_state_dict(new)
+    return list(sd.keys())
+
+
+def sample_idx(n, count=256):
+    return (prng.hash_u64(7, 99, count) % np.uint64(n)).astype(np.int64)
+
+
+def pack_grads(named, out, tag):
+    """full tensor when small, else L2 norm + 256 sampled entries."""
+    none = []
+    for k, prm in named:
+        g = prm.grad
+        if g is None:
+            none.append(k)
+            continue
+        g = g.detach().numpy()
+        out[f"{tag}norm/{k}"] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        if g.size <= 20000:
+            out[f"{tag}full/{k}"] = g
+        else:
+            out[f"{tag}samp/{k}"] = g.reshape(-1)[sample_idx(g.size)]
+    out[f"{tag}none"] = np.array(none)
+
+
+def inputs(seed, B, bands, H, W, classes):
+    x = prng.uniform01(seed, 1, (B, bands, H, W))
+    y = prng.randint(seed, 2, (B,), classes)
+    return x, y
+
+
+def case_modules():
+    out = {}
+    B = 3
+    # conv_module: tests/test_Hang2020.py:8-18 shapes, small bands
+    for name, cin, cout, pool in (("cm_nopool", 5, 32, False), ("cm_pool", 32, 64, True)):
+        spec = O.conv_module_spec("", cin, cout)
+        p = O.init_params(spec, seed=11)
+        m = R.conv_module(cin, cout, maxpool_kernel=(2, 2) if pool else None)
+        load(m, p)
+        x = torch.from_numpy(prng.uniform(12, 1, (B, cin, 11, 11), -1, 1)).requires_grad_(True)
+        m.train()
+        z = m(x, pool=pool)
+        dz = torch.from_numpy(prng.uniform(12, 3, tuple(z.shape), -1, 1))
+        (z * dz).sum().backward()
+        out[f"{name}/z"] = z.detach().numpy()
+        out[f"{name}/dx"] = x.grad.numpy()
+        for k, prm in m.named_parameters():
+            out[f"{name}/g/{k}"] = prm.grad.numpy()
+        for k, b in m.named_buffers():
+            out[f"{name}/buf/{k}"] = b.numpy().copy()
+        m.eval()
+        out[f"{name}/z_eval"] = m(x, pool=pool).detach().numpy()
+    # attention modules: tests/test_Hang2020.py:20-32 shapes
+    for C, hw in ((32, 11), (64, 5), (128, 2)):
+        for kind, cls, specf in (("spectral", R.spectral_attention, O.spectral_attention_spec),
+                                 ("spatial", R.spatial_attention, O.spatial_attention_spec)):
+            name = f"{kind}_att{C}"
+            p = O.init_params(specf("", C), seed=21)
+            m = cls(filters=C)
+            load(m, p)
+            x = torch.from_numpy(prng.uniform01(22, C, (B, C, hw, hw))).requires_grad_(True)
+            a, f = m(x)
+            da = torch.from_numpy(prng.uniform(22, 3, tuple(a.shape), -1, 1))
+            df = torch.from_numpy(prng.uniform(22, 4, tuple(f.shape), -1, 1))
+            ((a * da).sum() + (f * df).sum()).backward()
+            out[f"{name}/a"] = a.detach().numpy()
+            out[f"{name}/f"] = f.detach().numpy()
+            out[f"{name}/dx"] = x.grad.numpy()
+            for k, prm in m.named_parameters():
+                out[f"{name}/g/{k}"] = prm.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "modules.npz"), **out)
+    print("modules.npz", len(out))
+
+
+def run_hang(bands, classes, B, seed, tag, out, lr=1e-3, dtype=torch.float32, steps=3):
+    spec = O.hang2020_spec(bands, classes)
+    p = O.init_params(spec, seed=seed)
+    m = R.Hang2020(bands, classes)
+    keys = load(m, p)
+    out[f"{tag}keys"] = np.array(keys)
+    if dtype == torch.float64:
+        m = m.double()
+    xn, yn = inputs(seed + 1, B, bands, 11, 11, classes)
+    x = torch.from_numpy(xn).to(dtype)
+    y = torch.from_numpy(yn)
+    w_uni = torch.ones(classes, dtype=dtype)
+    w_non = torch.from_numpy((0.1 + (np.arange(classes) % 7)).astype(np.float32)).to(dtype)
+    # eval-mode logits first (running stats untouched)
+    m.eval()
+    with torch.no_grad():
+        out[f"{tag}eval_logits"] = m(x).numpy()
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    for step in range(steps):
+        opt.zero_grad()
+        if step == 0:
+            # all six heads from a separate forward; the BN buffers it touches are restored after
+            bufs = {k: b.clone() for k, b in m.named_buffers()}
+            with torch.no_grad():
+                spec_s = m.spectral_network(x)
+                spat_s = m.spatial_network(x)
+            for i in range(3):
+                out[f"{tag}spec_head{i + 1}"] = spec_s[i].numpy()
+                out[f"{tag}spat_head{i + 1}"] = spat_s[i].numpy()
+            for k, b in m.named_buffers():
+                b.copy_(bufs[k])
+        logits = m(x)
+        loss = F.cross_entropy(logits, y, weight=w_non)
+        loss.backward()
+        if step == 0:
+            out[f"{tag}logits"] = logits.detach().numpy()
+            out[f"{tag}loss_non"] = np.float64(loss.item())
+            out[f"{tag}loss_uni"] = np.float64(F.cross_entropy(logits, y, weight=w_uni).item())
+            out[f"{tag}sigmoid_alpha"] = np.float64(m.weighted_average.item())
+            pack_grads(list(m.named_parameters()), out, f"{tag}grad_")
+            tot = 0.0
+            for _, prm in m.named_parameters():
+                if prm.grad is not None:
+                    tot += float((prm.grad.double() ** 2).sum())
+            out[f"{tag}grad_total_norm"] = np.float64(np.sqrt(tot))
+            for k, b in m.named_buffers():
+                out[f"{tag}buf1/{k}"] = b.numpy().copy()
+        opt.step()
+        if step in (0, steps - 1):
+            for k, prm in m.named_parameters():
+                a = prm.detach().numpy()
+                out[f"{tag}p{step + 1}_norm/{k}"] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+                flat = a.reshape(-1)
+                out[f"{tag}p{step + 1}_samp/{k}"] = flat[sample_idx(flat.size, 64)] if flat.size > 64 else flat.copy()
+        out[f"{tag}loss_step{step}"] = np.float64(loss.item())
+
+
+def case_hang_full():
+    out = {}
+    run_hang(369, 200, 8, seed=31, tag="", out=out)
+    np.savez_compressed(os.path.join(OUT, "hang2020_369_200.npz"), **out)
+    print("hang2020_369_200.npz", len(out))
+    out = {}
+    run_hang(369, 200, 8, seed=31, tag="", out=out, dtype=torch.float64, steps=1)
+    keep = {k: v for k, v in out.items() if k in ("logits", "loss_non", "loss_uni", "grad_total_norm", "eval_logits")
+            or k.startswith("grad_norm/")}
+    np.savez_compressed(os.path.join(OUT, "hang2020_369_200_fp64.npz"), **keep)
+    print("hang2020_369_200_fp64.npz", len(keep))
+
+
+def case_hang_small():
+    """tests/test_Hang2020.py:60-64 configuration (bands=3, classes=10)."""
+    out = {}
+    run_hang(3, 10, 4, seed=41, tag="", out=out)
+    np.savez_compressed(os.path.join(OUT, "hang2020_3_10.npz"), **out)
+    print("hang2020_3_10.npz", len(out))
+
+
+def case_subnets():
+    out = {}
+    # spectral_network on a 24x24 crop (size-agnostic branch), heads summed into one loss
+    bands, classes, B = 16, 7, 2
+    for kind, cls, hw in (("spectral", R.spectral_network, 24), ("spectral", R.spectral_network, 11),
+                          ("spatial", R.spatial_network, 11)):
+        tag = f"{kind}{hw}/"
+        p = O.init_params(O.subnet_spec(kind, bands, classes), seed=51)
+        m = cls(bands, classes)
+        load(m, p)
+        x = torch.from_numpy(prng.uniform01(52, hw, (B, bands, hw, hw)))
+        m.train()
+        s = m(x)
+        ds = [torch.from_numpy(prng.uniform(52, 10 + i, (B, classes), -1, 1)) for i in range(3)]
+        sum((a * b).sum() for a, b in zip(s, ds)).backward()
+        for i in range(3):
+            out[f"{tag}head{i + 1}"] = s[i].detach().numpy()
+        for k, prm in m.named_parameters():
+            out[f"{tag}g/{k}"] = prm.grad.numpy()
+        for k, b in m.named_buffers():
+            out[f"{tag}buf/{k}"] = b.numpy().copy()
+    # learned_ensemble(years=3) with one all-zero year: tests/test_year.py:8-14
+    years = 3
+    p = O.init_params(O.learned_ensemble_spec(years, bands, classes), seed=61)
+    m = RY.learned_ensemble(years=years, classes=classes, config={"pretrain_state_dict": None, "bands": bands})
+    load(m, p)
+    imgs = [prng.uniform01(62, yy, (B, bands, 11, 11)) for yy in range(years)]
+    imgs[1] = np.zeros_like(imgs[1])
+    m.train()
+    s = m([torch.from_numpy(a) for a in imgs])
+    d = torch.from_numpy(prng.uniform(62, 9, (B, classes), -1, 1))
+    (s * d).sum().backward()
+    out["ens/score"] = s.detach().numpy()
+    none = []
+    for k, prm in m.named_parameters():
+        if prm.grad is None:
+            none.append(k)
+        else:
+            out[f"ens/gnorm/{k}"] = np.float64(prm.grad.double().norm().item())
+    out["ens/none"] = np.array(none)
+    # vanilla_CNN(bands=5, classes=3): BASELINE config 1
+    p = O.init_params(O.vanilla_spec(5, 3), seed=71)
+    m = R.vanilla_CNN(5, 3)
+    load(m, p)
+    xn, yn = inputs(72, 2, 5, 11, 11, 3)
+    m.train()
+    lg = m(torch.from_numpy(xn))
+    loss = F.cross_entropy(lg, torch.from_numpy(yn))
+    loss.backward()
+    out["vanilla/logits"] = lg.detach().numpy()
+    out["vanilla/loss"] = np.float64(loss.item())
+    for k, prm in m.named_parameters():
+        out[f"vanilla/g/{k}"] = prm.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "subnets.npz"), **out)
+    print("subnets.npz", len(out))
+
+
+if __name__ == "__main__":
+    case_modules()
+    case_hang_small()
+    case_subnets()
+    case_hang_full()
