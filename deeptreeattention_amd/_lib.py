@@ -1,0 +1,96 @@
+"""ctypes binding of libdta_hip.so (C ABI declared in include/dta_hip.h).
+
+The HIP library is the product; there is no CPU or PyTorch fallback.  If the library is missing or a call
+fails, a RuntimeError is raised with dta_last_error().
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdta_hip.so")
+
+DTA_F32, DTA_BF16 = 0, 1
+NET_HANG2020, NET_SPECTRAL, NET_SPATIAL, NET_VANILLA = 0, 1, 2, 3
+_DTYPES = {"fp32": DTA_F32, "f32": DTA_F32, "float32": DTA_F32, "bf16": DTA_BF16, "bfloat16": DTA_BF16}
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_ll_p = C.POINTER(C.c_longlong)
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("batch", C.c_int), ("bands", C.c_int), ("height", C.c_int), ("width", C.c_int),
+                ("classes", C.c_int), ("kind", C.c_int), ("dtype", C.c_int), ("training", C.c_int),
+                ("heads_mask", C.c_int), ("bn_momentum", C.c_float), ("bn_eps", C.c_float)]
+
+
+class SubnetParams(C.Structure):
+    _fields_ = [("conv_w", C.c_void_p * 3), ("conv_b", C.c_void_p * 3), ("bn_w", C.c_void_p * 3),
+                ("bn_b", C.c_void_p * 3), ("bn_rm", C.c_void_p * 3), ("bn_rv", C.c_void_p * 3),
+                ("bn_nbt", C.c_void_p * 3), ("att", (C.c_void_p * 6) * 3), ("fc_w", C.c_void_p * 3),
+                ("fc_b", C.c_void_p * 3)]
+
+
+class SubnetGrads(C.Structure):
+    _fields_ = [("conv_w", C.c_void_p * 3), ("conv_b", C.c_void_p * 3), ("bn_w", C.c_void_p * 3),
+                ("bn_b", C.c_void_p * 3), ("att", (C.c_void_p * 6) * 3), ("fc_w", C.c_void_p * 3),
+                ("fc_b", C.c_void_p * 3)]
+
+
+ScoreTable = (C.c_void_p * 3) * 2
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; fail loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m deeptreeattention_amd.build` "
+                "(hipcc, gfx950).  deeptreeattention_amd has no CPU/PyTorch fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.dta_abi_version.restype = C.c_int
+        L.dta_last_error.restype = C.c_char_p
+        L.dta_net_workspace_bytes.restype = C.c_size_t
+        L.dta_net_workspace_bytes.argtypes = [C.POINTER(NetDesc)]
+        L.dta_net_forward.restype = C.c_int
+        L.dta_net_forward.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.POINTER(ScoreTable), C.c_void_p, C.c_void_p]
+        L.dta_net_backward.restype = C.c_int
+        L.dta_net_backward.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p,
+                                       C.POINTER(ScoreTable), C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p,
+                                       C.c_int, C.c_void_p]
+        L.dta_weighted_ce.restype = C.c_int
+        L.dta_weighted_ce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_adam_step.restype = C.c_int
+        L.dta_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_void_p]
+        if L.dta_abi_version() != 1:
+            raise RuntimeError("libdta_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {lib().dta_last_error().decode()}")
+
+
+def dtype_code(name):
+    try:
+        return _DTYPES[str(name).lower()]
+    except KeyError:
+        raise ValueError(f"precision must be one of {sorted(_DTYPES)}, got {name!r}")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,495 @@
+// C-ABI entry points (include/dta_hip.h) and the launch orchestration of the Hang2020 hot path.
+// Host code only decides buffer carving and launch order; all arithmetic is in conv.hip / stage.hip / heads.hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dta_hip.h"
+#include "kernels.h"
+
+using namespace dta;
+
+static thread_local char g_err[512] = "";
+void dta_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+
+constexpr int CH[3] = {32, 64, 128};
+constexpr int SPEC_K[3] = {3, 5, 7};   // reference Hang2020.py:136-141
+constexpr int SPAT_K[3] = {7, 5, 3};   // :77-85
+constexpr int SPAT_P[3] = {4, 2, 1};   // :91-99
+
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+};
+
+// All workspace offsets for one network description (identical in forward and backward).
+struct Plan {
+  int G, B, bands, H, W, classes, esz;
+  int kinds[2];
+  int NC0;
+  int Hc[3], Wc[3], Hz[3], Wz[3], HWc[3], HWz[3], Qin[3];  // conv-res dims, post-pool dims, haloed grid of conv input
+  int Cin[3], NCin[3];
+  int F[2][3], Fmax[3], vec_ld[3];
+  int nwg[3], MWG[3];
+  int S[3], cgroups[3], CpadW[3];
+  size_t x_tl, wp[3], wd[3], y[3], stats[3], coef[3], a_tl[3], feat[3], attpk[2][3], scores[2][3];
+  size_t dsc[2], dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart, rowtmp;
+  size_t total;
+};
+
+int build_plan(const dta_net_desc* d, Plan* p) {
+  memset(p, 0, sizeof(*p));
+  if (d->batch < 1 || d->bands < 1 || d->height < 4 || d->width < 4 || d->classes < 1) {
+    dta_set_error("bad descriptor: batch=%d bands=%d H=%d W=%d classes=%d", d->batch, d->bands, d->height, d->width, d->classes);
+    return 1;
+  }
+  if (d->height + 2 > 255 || (d->height + 2) * (d->width + 2) > 65535) { dta_set_error("patch too large"); return 1; }
+  p->G = d->kind == DTA_NET_HANG2020 ? 2 : 1;
+  p->B = d->batch; p->bands = d->bands; p->H = d->height; p->W = d->width; p->classes = d->classes;
+  p->esz = d->dtype == DTA_BF16 ? 2 : 4;
+  switch (d->kind) {
+    case DTA_NET_HANG2020: p->kinds[0] = KIND_SPECTRAL; p->kinds[1] = KIND_SPATIAL; break;
+    case DTA_NET_SPECTRAL: p->kinds[0] = KIND_SPECTRAL; break;
+    case DTA_NET_SPATIAL: p->kinds[0] = KIND_SPATIAL; break;
+    case DTA_NET_VANILLA: p->kinds[0] = KIND_PLAIN; break;
+    default: dta_set_error("unknown network kind %d", d->kind); return 1;
+  }
+  const int G = p->G, B = p->B;
+  p->NC0 = (d->bands + 15) / 16;
+  p->Hc[0] = p->H; p->Wc[0] = p->W; p->Hz[0] = p->H; p->Wz[0] = p->W;
+  p->Hc[1] = p->H; p->Wc[1] = p->W; p->Hz[1] = p->H / 2; p->Wz[1] = p->W / 2;
+  p->Hc[2] = p->Hz[1]; p->Wc[2] = p->Wz[1]; p->Hz[2] = p->Hz[1] / 2; p->Wz[2] = p->Wz[1] / 2;
+  if (p->Hz[2] < 1 || p->Wz[2] < 1) { dta_set_error("patch %dx%d too small for two 2x2 pools", p->H, p->W); return 1; }
+  for (int L = 0; L < 3; ++L) {
+    p->HWc[L] = p->Hc[L] * p->Wc[L]; p->HWz[L] = p->Hz[L] * p->Wz[L];
+    p->Qin[L] = (p->Hc[L] + 2) * (p->Wc[L] + 2);
+    p->Cin[L] = L == 0 ? d->bands : CH[L - 1];
+    p->NCin[L] = (p->Cin[L] + 15) / 16;
+    p->Fmax[L] = 0; p->vec_ld[L] = 1;
+    for (int g = 0; g < G; ++g) {
+      int f = 0, vl = 1;
+      if (p->kinds[g] == KIND_SPECTRAL) { f = CH[L]; vl = 4 * CH[L]; }
+      else if (p->kinds[g] == KIND_SPATIAL) {
+        int hp = p->Hz[L] / SPAT_P[L], wp = p->Wz[L] / SPAT_P[L];
+        if (hp < 1 || wp < 1) { dta_set_error("spatial attention %d: %dx%d map smaller than its %d-pool", L + 1, p->Hz[L], p->Wz[L], SPAT_P[L]); return 1; }
+        f = CH[L] * hp * wp; vl = CH[L] + 2 * SPAT_K[L] * SPAT_K[L] + 3;
+      } else if (L == 2) f = CH[2] * p->HWz[2];
+      p->F[g][L] = f;
+      if (f > p->Fmax[L]) p->Fmax[L] = f;
+      if (vl > p->vec_ld[L]) p->vec_ld[L] = vl;
+    }
+    int Nconv = L == 0 ? 32 * G : CH[L];
+    p->MWG[L] = conv_mwg(Nconv);
+    int ppw, spp;
+    conv_geometry(p->HWc[L], p->MWG[L], B, &ppw, &spp, &p->nwg[L]);
+    // weight-gradient split
+    int cpw = wgrad_cpw(Nconv);
+    p->CpadW[L] = p->NCin[L] * 16;
+    p->cgroups[L] = (p->CpadW[L] + cpw - 1) / cpw;
+    int launchG = L == 0 ? 1 : G;
+    int S = (512 + p->cgroups[L] * launchG - 1) / (p->cgroups[L] * launchG);
+    p->S[L] = S < 1 ? 1 : (S > B ? B : S);
+  }
+  Carver c;
+  const size_t e = p->esz;
+  p->x_tl = c.take((size_t)B * p->NC0 * p->Qin[0] * 16 * e);
+  for (int L = 0; L < 3; ++L) {
+    int Nconv = L == 0 ? 32 * G : CH[L];
+    int gw = L == 0 ? 1 : G;
+    p->wp[L] = c.take((size_t)gw * p->NCin[L] * 9 * Nconv * 16 * e);
+    p->y[L] = c.take((size_t)G * B * p->HWc[L] * CH[L] * 4);
+    p->stats[L] = c.take((size_t)gw * p->nwg[L] * Nconv * 2 * 4);
+    p->coef[L] = c.take((size_t)G * CH[L] * 4 * 4);
+    if (L < 2) p->a_tl[L] = c.take((size_t)G * B * (CH[L] / 16) * p->Qin[L + 1] * 16 * e);
+    p->feat[L] = c.take((size_t)G * B * (p->Fmax[L] > 0 ? p->Fmax[L] : 1) * 4);
+    for (int g = 0; g < G; ++g) {
+      p->attpk[g][L] = c.take((size_t)4 * CH[L] * CH[L] * 4);
+      p->scores[g][L] = c.take((size_t)B * p->classes * 4);
+    }
+  }
+  // backward
+  for (int g = 0; g < 2; ++g) p->dsc[g] = c.take((size_t)B * p->classes * 4);
+  for (int L = 0; L < 3; ++L) {
+    p->dfeat[L] = c.take((size_t)G * B * (p->Fmax[L] > 0 ? p->Fmax[L] : 1) * 4);
+    p->dv[L] = c.take((size_t)G * B * p->HWc[L] * CH[L] * 4);
+    p->bnpart[L] = c.take((size_t)G * B * CH[L] * 2 * 4);
+    p->bcoef[L] = c.take((size_t)G * CH[L] * 4 * 4);
+    p->dy_tl[L] = c.take((size_t)G * B * (CH[L] / 16) * p->Qin[L] * 16 * e);
+    p->vec[L] = c.take((size_t)G * B * p->vec_ld[L] * 4);
+    if (L > 0) {
+      p->wd[L] = c.take((size_t)G * (CH[L] / 16) * 9 * CH[L - 1] * 16 * e);
+      p->da[L] = c.take((size_t)G * B * p->HWc[L] * CH[L - 1] * 4);   // grad wrt the conv's input map
+    }
+  }
+  size_t wpmax = 0;
+  for (int L = 0; L < 3; ++L) {
+    int Nconv = L == 0 ? 32 * G : CH[L];
+    int launchG = L == 0 ? 1 : G;
+    size_t w = (size_t)launchG * p->S[L] * 9 * p->CpadW[L] * Nconv * 4;
+    if (w > wpmax) wpmax = w;
+  }
+  p->wpart = c.take(wpmax);
+  p->rowtmp = c.take((size_t)(B + 1) * 4);
+  p->total = c.off;
+  return 0;
+}
+
+template <typename T> inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
+
+StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, void* ws, int L) {
+  StageArgs s;
+  memset(&s, 0, sizeof(s));
+  const int G = p.G, B = p.B, C = CH[L];
+  for (int g = 0; g < G; ++g) {
+    s.kind[g] = p.kinds[g];
+    s.F[g] = p.F[g][L];
+    if (p.kinds[g] == KIND_SPECTRAL) {
+      float* pk = at<float>(ws, p.attpk[g][L]);
+      s.att[g].p[0] = pk; s.att[g].p[1] = nets[g].att[L][1];
+      s.att[g].p[2] = pk + C * C; s.att[g].p[3] = nets[g].att[L][3];
+      s.att[g].p[4] = pk + 2 * C * C; s.att[g].p[5] = pk + 3 * C * C;
+    } else if (p.kinds[g] == KIND_SPATIAL) {
+      for (int i = 0; i < 6; ++i) s.att[g].p[i] = nets[g].att[L][i];
+      s.att_k[g] = SPAT_K[L]; s.att_pool[g] = SPAT_P[L];
+    }
+  }
+  s.y = at<float>(ws, p.y[L]);
+  if (L == 0) { s.y_gs = 32; s.y_rs = 32 * G; }
+  else { s.y_gs = (size_t)B * p.HWc[L] * C; s.y_rs = C; }
+  s.coef = at<float>(ws, p.coef[L]); s.coef_gs = C * 4;
+  s.apply_bn = 1; s.relu = 1; s.pool = L > 0;
+  s.B = B; s.C = C; s.Hc = p.Hc[L]; s.Wc = p.Wc[L];
+  if (L < 2) {
+    s.a_tl = at<char>(ws, p.a_tl[L]);
+    s.a_nc = C / 16; s.a_ch0 = 0;
+    s.a_gs = (size_t)B * (C / 16) * p.Qin[L + 1] * 16;
+  }
+  s.feat = at<float>(ws, p.feat[L]);
+  s.feat_gs = (size_t)B * (p.Fmax[L] > 0 ? p.Fmax[L] : 1);
+  // per-group row length of feat is F[g] (rows packed per group)
+  return s;
+}
+
+template <typename T>
+int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const float* x,
+              void* ws, float* const scores[2][3], float* joint, hipStream_t st) {
+  const int G = p.G, B = p.B;
+  if (launch_pack_input<T>(x, at<char>(ws, p.x_tl), B, p.bands, p.H, p.W, st)) return 1;
+  for (int L = 0; L < 3; ++L) {
+    const int C = CH[L];
+    const int Nconv = L == 0 ? 32 * G : C;
+    const int launchG = L == 0 ? 1 : G;
+    // weights
+    PackWArgs pw;
+    memset(&pw, 0, sizeof(pw));
+    pw.G = launchG; pw.NC = p.NCin[L]; pw.N = Nconv; pw.K = p.Cin[L];
+    pw.src[0] = nets[0].conv_w[L]; pw.src[1] = G == 2 ? nets[1].conv_w[L] : nullptr;
+    pw.mode = (L == 0 && G == 2) ? 1 : 0; pw.nsplit = 32;
+    if (launch_pack_conv_w<T>(pw, at<char>(ws, p.wp[L]), st)) return 1;
+    for (int g = 0; g < G; ++g)
+      if (p.kinds[g] == KIND_SPECTRAL)
+        if (launch_pack_spectral_att(nets[g].att[L][0], nets[g].att[L][2], C, SPEC_K[L], at<float>(ws, p.attpk[g][L]), st)) return 1;
+    // conv
+    ConvArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    if (L == 0) { ca.x_tl = at<char>(ws, p.x_tl); ca.x_gs = 0; }
+    else { ca.x_tl = at<char>(ws, p.a_tl[L - 1]); ca.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
+    ca.wp = at<char>(ws, p.wp[L]);
+    ca.bias[0] = nets[0].conv_b[L]; ca.bias[1] = G == 2 ? nets[1].conv_b[L] : nullptr;
+    ca.bias_mode = pw.mode; ca.bias_split = 32;
+    ca.y = at<float>(ws, p.y[L]);
+    if (L == 0) { ca.y_gs = 0; ca.y_rs = Nconv; } else { ca.y_gs = (size_t)B * p.HWc[L] * C; ca.y_rs = C; }
+    ca.stats = d->training ? at<float>(ws, p.stats[L]) : nullptr;
+    ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
+    if (launch_conv3x3<T>(ca, launchG, st)) return 1;
+    // BatchNorm statistics -> per-channel scale/shift
+    BnFinalizeArgs bf;
+    memset(&bf, 0, sizeof(bf));
+    bf.stats = at<float>(ws, p.stats[L]); bf.nwg = p.nwg[L]; bf.N = Nconv; bf.HW = p.HWc[L]; bf.MWG = p.MWG[L]; bf.B = B;
+    for (int g = 0; g < G; ++g) {
+      bf.gamma[g] = nets[g].bn_w[L]; bf.beta[g] = nets[g].bn_b[L];
+      bf.rmean[g] = nets[g].bn_rm[L]; bf.rvar[g] = nets[g].bn_rv[L]; bf.nbt[g] = nets[g].bn_nbt[L];
+    }
+    bf.cat_mode = (L == 0 && G == 2); bf.nsplit = 32;
+    bf.coef = at<float>(ws, p.coef[L]); bf.training = d->training; bf.momentum = d->bn_momentum; bf.eps = d->bn_eps;
+    if (launch_bn_finalize(bf, G, st)) return 1;
+    // BN + ReLU + pool + attention
+    StageArgs sa = stage_args(p, d, nets, ws, L);
+    if (launch_stage_fwd<T>(sa, G, st)) return 1;
+    // classifier heads
+    if (d->heads_mask & (1 << L)) {
+      for (int g = 0; g < G; ++g) {
+        if (p.F[g][L] == 0 || nets[g].fc_w[L] == nullptr) continue;
+        const int F = p.F[g][L];
+        GemmArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.A = at<float>(ws, p.feat[L]) + (size_t)g * sa.feat_gs; ga.sa_m = F; ga.sa_k = 1;
+        ga.Bm = nets[g].fc_w[L]; ga.sb_k = 1; ga.sb_n = F;
+        float* out = (scores && scores[g][L]) ? scores[g][L] : at<float>(ws, p.scores[g][L]);
+        if (d->kind == DTA_NET_VANILLA && joint) out = joint;
+        ga.C = out; ga.sc_m = p.classes; ga.sc_n = 1;
+        ga.bias = nets[g].fc_b[L];
+        ga.M = B; ga.N = p.classes; ga.K = F; ga.ksplit = 1; ga.accumulate = 0;
+        if (launch_gemm(ga, st)) return 1;
+      }
+    }
+  }
+  if (d->kind == DTA_NET_HANG2020) {
+    if (!(d->heads_mask & 4) || !joint || !alpha) { dta_set_error("Hang2020 forward needs head 3, alpha and a joint output"); return 1; }
+    BlendArgs ba;
+    ba.spec = (scores && scores[0][2]) ? scores[0][2] : at<float>(ws, p.scores[0][2]);
+    ba.spat = (scores && scores[1][2]) ? scores[1][2] : at<float>(ws, p.scores[1][2]);
+    ba.alpha = alpha; ba.joint = joint; ba.B = B; ba.classes = p.classes;
+    if (launch_blend(ba, st)) return 1;
+  }
+  return 0;
+}
+
+template <typename T>
+int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grads* grads, void* ws, int L, hipStream_t st) {
+  const int G = p.G, B = p.B, C = CH[L];
+  const int Nconv = L == 0 ? 32 * G : C;
+  const int launchG = L == 0 ? 1 : G;
+  bool want_w = false;
+  for (int g = 0; g < G; ++g) want_w |= grads[g].conv_w[L] != nullptr;
+  if (!want_w) return 0;
+  WgradArgs wa;
+  memset(&wa, 0, sizeof(wa));
+  if (L == 0) { wa.x_tl = at<char>(ws, p.x_tl); wa.x_gs = 0; }
+  else { wa.x_tl = at<char>(ws, p.a_tl[L - 1]); wa.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
+  wa.NCx = p.NCin[L];
+  wa.dy_tl = at<char>(ws, p.dy_tl[L]);
+  wa.dy_gs = L == 0 ? 0 : (size_t)B * (C / 16) * p.Qin[L] * 16;
+  wa.NCy = Nconv / 16; wa.ych0 = 0;
+  wa.partial = at<float>(ws, p.wpart);
+  wa.B = B; wa.H = p.Hc[L]; wa.W = p.Wc[L]; wa.Q = p.Qin[L]; wa.N = Nconv; wa.Cpad = p.CpadW[L]; wa.S = p.S[L];
+  if (launch_conv_wgrad<T>(wa, launchG, st)) return 1;
+  WgradReduceArgs wr;
+  memset(&wr, 0, sizeof(wr));
+  wr.partial = wa.partial; wr.G = launchG; wr.S = p.S[L]; wr.N = Nconv; wr.C = p.Cin[L]; wr.Cpad = p.CpadW[L];
+  wr.mode = (L == 0 && G == 2) ? 1 : 0; wr.nsplit = 32;
+  wr.dst[0] = grads[0].conv_w[L]; wr.dst[1] = G == 2 ? grads[1].conv_w[L] : nullptr;
+  return launch_wgrad_reduce(wr, st);
+}
+
+template <typename T>
+int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, void* ws,
+               const float* const dscores[2][3], const float* djoint, const dta_subnet_grads* grads, double* dalpha,
+               int phases, hipStream_t st) {
+  const int G = p.G, B = p.B;
+  if (!(phases & 1)) {
+    // phase 2 only: the first layer's weight gradient from tensors phase 1 left in the workspace
+    return conv_wgrad_layer<T>(p, d, grads, ws, 0, st);
+  }
+  const float* dsc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  if (dscores)
+    for (int g = 0; g < G; ++g)
+      for (int L = 0; L < 3; ++L) dsc[g][L] = dscores[g][L];
+  if (d->kind == DTA_NET_HANG2020) {
+    if (!djoint || !alpha) { dta_set_error("Hang2020 backward needs djoint and alpha"); return 1; }
+    // the forward kept both branch scores in the workspace unless the caller supplied its own buffers; the
+    // Python binding always lets the workspace hold them
+    BlendBwdArgs bb;
+    bb.spec = at<float>(ws, p.scores[0][2]); bb.spat = at<float>(ws, p.scores[1][2]);
+    bb.alpha = alpha; bb.djoint = djoint;
+    bb.dspec = at<float>(ws, p.dsc[0]); bb.dspat = at<float>(ws, p.dsc[1]);
+    bb.dalpha = dalpha ? dalpha : at<double>(ws, p.rowtmp);  // discard into scratch when not wanted
+    bb.rowtmp = at<float>(ws, p.rowtmp); bb.B = B; bb.classes = p.classes;
+    if (dalpha == nullptr) { dta_set_error("Hang2020 backward needs a dalpha destination"); return 1; }
+    if (launch_blend_bwd(bb, st)) return 1;
+    dsc[0][2] = bb.dspec; dsc[1][2] = bb.dspat;
+  } else if (d->kind == DTA_NET_VANILLA) {
+    dsc[0][2] = djoint ? djoint : dsc[0][2];
+  }
+
+  for (int L = 2; L >= 0; --L) {
+    const int C = CH[L];
+    const int Nconv = L == 0 ? 32 * G : C;
+    const int launchG = L == 0 ? 1 : G;
+    StageArgs sa = stage_args(p, d, nets, ws, L);
+    const size_t fgs = sa.feat_gs;
+    // ---- classifier backward -> dfeat, dW, db ----
+    hipMemsetAsync(at<char>(ws, p.dfeat[L]), 0, (size_t)G * fgs * 4, st);
+    for (int g = 0; g < G; ++g) {
+      const int F = p.F[g][L];
+      if (!dsc[g][L] || F == 0) continue;
+      GemmArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.A = dsc[g][L]; ga.sa_m = p.classes; ga.sa_k = 1;
+      ga.Bm = nets[g].fc_w[L]; ga.sb_k = F; ga.sb_n = 1;
+      ga.C = at<float>(ws, p.dfeat[L]) + (size_t)g * fgs; ga.sc_m = F; ga.sc_n = 1;
+      ga.M = B; ga.N = F; ga.K = p.classes; ga.ksplit = 1;
+      if (launch_gemm(ga, st)) return 1;
+      if (grads[g].fc_w[L]) {
+        hipMemsetAsync(grads[g].fc_w[L], 0, (size_t)p.classes * F * 4, st);
+        memset(&ga, 0, sizeof(ga));
+        ga.A = dsc[g][L]; ga.sa_m = 1; ga.sa_k = p.classes;
+        ga.Bm = at<float>(ws, p.feat[L]) + (size_t)g * fgs; ga.sb_k = F; ga.sb_n = 1;
+        ga.C = grads[g].fc_w[L]; ga.sc_m = F; ga.sc_n = 1;
+        ga.M = p.classes; ga.N = F; ga.K = B;
+        ga.ksplit = B >= 512 ? 8 : (B >= 64 ? 2 : 1);
+        if (launch_gemm(ga, st)) return 1;
+      }
+      if (grads[g].fc_b[L]) {
+        ColsumArgs cs;
+        memset(&cs, 0, sizeof(cs));
+        cs.A = dsc[g][L]; cs.rows = B; cs.cols = p.classes; cs.lda = p.classes;
+        cs.nseg = 1; cs.off[0] = 0; cs.len[0] = p.classes; cs.dst[0] = grads[g].fc_b[L]; cs.dst_stride[0] = 1;
+        if (launch_colsum_scatter(cs, st)) return 1;
+      }
+    }
+    // ---- attention + pool + ReLU backward ----
+    StageBwdArgs sb;
+    memset(&sb, 0, sizeof(sb));
+    sb.f = sa;
+    if (L < 2) { sb.da = at<float>(ws, p.da[L + 1]); sb.da_gs = (size_t)B * p.HWz[L] * C; }
+    sb.dfeat = at<float>(ws, p.dfeat[L]); sb.dfeat_gs = fgs;
+    sb.dv = at<float>(ws, p.dv[L]); sb.dv_gs = (size_t)B * p.HWc[L] * C;
+    sb.bnpart = at<float>(ws, p.bnpart[L]); sb.bnpart_gs = (size_t)B * C * 2;
+    sb.vec = at<float>(ws, p.vec[L]); sb.vec_gs = (size_t)B * p.vec_ld[L]; sb.vec_ld = p.vec_ld[L];
+    if (launch_stage_bwd(sb, G, st)) return 1;
+    // ---- attention parameter gradients (batch reductions) ----
+    for (int g = 0; g < G; ++g) {
+      const float* vec = at<float>(ws, p.vec[L]) + (size_t)g * sb.vec_gs;
+      const int ld = p.vec_ld[L];
+      if (p.kinds[g] == KIND_SPECTRAL) {
+        const int K = SPEC_K[L];
+        for (int which = 0; which < 2; ++which) {   // 0: attention_conv1 (d1 x pooled), 1: attention_conv2 (d2 x h)
+          float* gw = grads[g].att[L][which * 2];
+          if (!gw) continue;
+          hipMemsetAsync(gw, 0, (size_t)C * C * K * 4, st);
+          GemmArgs ga;
+          memset(&ga, 0, sizeof(ga));
+          ga.A = vec + (which ? 0 : 2 * C); ga.sa_m = 1; ga.sa_k = ld;
+          ga.Bm = vec + (which ? C : 3 * C); ga.sb_k = ld; ga.sb_n = 1;
+          ga.C = gw + K / 2; ga.sc_m = (long)C * K; ga.sc_n = K;
+          ga.M = C; ga.N = C; ga.K = B; ga.ksplit = B >= 512 ? 8 : (B >= 64 ? 2 : 1);
+          if (launch_gemm(ga, st)) return 1;
+        }
+        ColsumArgs cs;
+        memset(&cs, 0, sizeof(cs));
+        cs.A = vec; cs.rows = B; cs.cols = 3 * C; cs.lda = ld; cs.nseg = 2;
+        cs.off[0] = 0; cs.len[0] = C; cs.dst[0] = grads[g].att[L][3]; cs.dst_stride[0] = 1;       // conv2.bias <- d2
+        cs.off[1] = 2 * C; cs.len[1] = C; cs.dst[1] = grads[g].att[L][1]; cs.dst_stride[1] = 1;   // conv1.bias <- d1
+        if (launch_colsum_scatter(cs, st)) return 1;
+      } else if (p.kinds[g] == KIND_SPATIAL) {
+        const int kk = SPAT_K[L] * SPAT_K[L];
+        ColsumArgs cs;
+        memset(&cs, 0, sizeof(cs));
+        cs.A = vec; cs.rows = B; cs.cols = C + 2 * kk + 3; cs.lda = ld; cs.nseg = 6;
+        int offs[6] = {0, C, C + 1, C + 1 + kk, C + 2 + kk, C + 2 + 2 * kk};
+        int lens[6] = {C, 1, kk, 1, kk, 1};
+        for (int i = 0; i < 6; ++i) { cs.off[i] = offs[i]; cs.len[i] = lens[i]; cs.dst[i] = grads[g].att[L][i]; cs.dst_stride[i] = 1; }
+        if (launch_colsum_scatter(cs, st)) return 1;
+      }
+    }
+    // ---- BatchNorm backward ----
+    BnBwdFinalizeArgs bf;
+    memset(&bf, 0, sizeof(bf));
+    bf.bnpart = sb.bnpart; bf.bnpart_gs = sb.bnpart_gs; bf.B = B; bf.C = C; bf.HW = p.HWc[L];
+    bf.coef = sa.coef; bf.coef_gs = sa.coef_gs;
+    for (int g = 0; g < G; ++g) {
+      bf.gamma[g] = nets[g].bn_w[L]; bf.dgamma[g] = grads[g].bn_w[L]; bf.dbeta[g] = grads[g].bn_b[L];
+      bf.dconvbias[g] = grads[g].conv_b[L];
+    }
+    bf.bcoef = at<float>(ws, p.bcoef[L]); bf.bcoef_gs = C * 4; bf.training = d->training;
+    if (launch_bn_bwd_finalize(bf, G, st)) return 1;
+    BnBwdApplyArgs ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.dv = sb.dv; ap.dv_gs = sb.dv_gs; ap.y = sa.y; ap.y_gs = sa.y_gs; ap.y_rs = sa.y_rs;
+    ap.coef = sa.coef; ap.coef_gs = sa.coef_gs; ap.bcoef = bf.bcoef; ap.bcoef_gs = bf.bcoef_gs;
+    ap.B = B; ap.C = C; ap.H = p.Hc[L]; ap.W = p.Wc[L];
+    ap.dy_tl = at<char>(ws, p.dy_tl[L]);
+    if (L == 0) { ap.dy_gs = (size_t)2 * p.Qin[0] * 16; ap.dy_nc = 2 * G; ap.dy_ch0 = 0; }   // group g -> chunks [2g, 2g+2)
+    else { ap.dy_gs = (size_t)B * (C / 16) * p.Qin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
+    if (launch_bn_bwd_apply<T>(ap, G, st)) return 1;
+    // ---- conv weight gradient ----
+    if (L > 0 || (phases & 2))
+      if (conv_wgrad_layer<T>(p, d, grads, ws, L, st)) return 1;
+    // ---- conv input gradient (feeds the previous stage's gated map) ----
+    if (L > 0) {
+      PackWArgs pw;
+      memset(&pw, 0, sizeof(pw));
+      pw.G = G; pw.NC = C / 16; pw.N = CH[L - 1]; pw.K = C; pw.mode = 2;
+      pw.src[0] = nets[0].conv_w[L]; pw.src[1] = G == 2 ? nets[1].conv_w[L] : nullptr;
+      if (launch_pack_conv_w<T>(pw, at<char>(ws, p.wd[L]), st)) return 1;
+      ConvArgs ca;
+      memset(&ca, 0, sizeof(ca));
+      ca.x_tl = ap.dy_tl; ca.x_gs = ap.dy_gs; ca.wp = at<char>(ws, p.wd[L]);
+      ca.y = at<float>(ws, p.da[L]); ca.y_gs = (size_t)B * p.HWc[L] * CH[L - 1]; ca.y_rs = CH[L - 1];
+      ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = C / 16; ca.N = CH[L - 1]; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
+      if (launch_conv3x3<T>(ca, G, st)) return 1;
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dta_abi_version(void) { return DTA_ABI_VERSION; }
+const char* dta_last_error(void) { return g_err; }
+
+size_t dta_net_workspace_bytes(const dta_net_desc* d) {
+  Plan p;
+  if (!d || build_plan(d, &p)) return 0;
+  return p.total;
+}
+
+int dta_net_forward(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const float* x,
+                    void* workspace, float* const scores[2][3], float* joint, void* stream) {
+  Plan p;
+  if (!d || !nets || !x || !workspace) { dta_set_error("dta_net_forward: null argument"); return 1; }
+  if (build_plan(d, &p)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == DTA_BF16) return forward_t<bf16_t>(p, d, nets, alpha, x, workspace, scores, joint, st);
+  if (d->dtype == DTA_F32) return forward_t<float>(p, d, nets, alpha, x, workspace, scores, joint, st);
+  dta_set_error("unknown dtype %d", d->dtype);
+  return 1;
+}
+
+int dta_net_backward(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, void* workspace,
+                     const float* const dscores[2][3], const float* djoint, const dta_subnet_grads* grads,
+                     double* dalpha, int phases, void* stream) {
+  Plan p;
+  if (!d || !nets || !workspace || !grads || !(phases & 3)) { dta_set_error("dta_net_backward: null argument"); return 1; }
+  if (build_plan(d, &p)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == DTA_BF16) return backward_t<bf16_t>(p, d, nets, alpha, workspace, dscores, djoint, grads, dalpha, phases, st);
+  if (d->dtype == DTA_F32) return backward_t<float>(p, d, nets, alpha, workspace, dscores, djoint, grads, dalpha, phases, st);
+  dta_set_error("unknown dtype %d", d->dtype);
+  return 1;
+}
+
+int dta_weighted_ce(const float* logits, const long long* labels, const float* weight, int batch, int classes,
+                    float* loss, float* dlogits, float* scratch, void* stream) {
+  if (!logits || !labels || !loss || !scratch || batch < 1 || classes < 1) { dta_set_error("dta_weighted_ce: bad argument"); return 1; }
+  CeArgs a;
+  a.logits = logits; a.labels = labels; a.weight = weight; a.dlogits = dlogits; a.loss = loss; a.rowtmp = scratch;
+  a.B = batch; a.classes = classes;
+  return launch_weighted_ce(a, (hipStream_t)stream);
+}
+
+int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double* alpha_p, const double* alpha_g,
+                  double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
+                  float grad_scale, void* stream) {
+  if (step < 1 || (n && (!p || !g || !m || !v))) { dta_set_error("dta_adam_step: bad argument"); return 1; }
+  AdamArgs a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+  a.alpha_p = alpha_p; a.alpha_g = alpha_g; a.alpha_m = alpha_m; a.alpha_v = alpha_v;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
+  double b1 = 1.0, b2 = 1.0;
+  for (int i = 0; i < step; ++i) { b1 *= (double)beta1; b2 *= (double)beta2; }
+  a.bc1 = (float)(1.0 - b1); a.bc2 = (float)(1.0 - b2);
+  return launch_adam(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

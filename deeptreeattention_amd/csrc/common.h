@@ -1,0 +1,78 @@
+// Shared device/host helpers for the gfx950 (MI355X) kernels of the Hang2020 hot path.
+// Written for CDNA4 only: 64-lane wavefronts, MFMA 32x32 tiles, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dta {
+
+typedef unsigned short bf16_t;  // storage type of a bfloat16
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+  __device__ static __forceinline__ float to(float v) { return v; }
+  __device__ static __forceinline__ float from(float v) { return v; }
+};
+template <> struct Cvt<bf16_t> {
+  __device__ static __forceinline__ bf16_t to(float v) { return f2bf(v); }
+  __device__ static __forceinline__ float from(bf16_t v) { return bf2f(v); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// "Tile layout" (TL): the HBM/LDS image every 3x3 convolution operand uses.
+//   TL[g][b][chunk][q][16]  with  q = (h+1)*(W+2) + (w+1)  over the zero-haloed (H+2)x(W+2) grid,
+//   chunk = c/16, and the 16 channels of a row stored at a swizzled position so that the MFMA
+//   fragment reads out of LDS are bank-conflict free (the LDS image is a linear copy of HBM):
+//     fp32 : pos = (c%16) ^ (q & 15)              (ds_read_b32, one element per lane)
+//     bf16 : pos = (c%16) ^ (((q >> 3) & 1) << 3) (ds_read_b128 / ds_read_b64_tr_b16, 8/4 per lane)
+// The same rule applies to packed conv weights with row index (tap*N + n).
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __host__ __forceinline__ int tl_pos(int row, int c16);
+template <> __device__ __host__ __forceinline__ int tl_pos<float>(int row, int c16) { return c16 ^ (row & 15); }
+template <> __device__ __host__ __forceinline__ int tl_pos<bf16_t>(int row, int c16) { return c16 ^ (((row >> 3) & 1) << 3); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// Block-wide sum for 256-thread blocks (4 waves); scratch must hold 4 floats.  All threads get the sum.
+__device__ __forceinline__ float block_sum256(float v, float* scratch) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+}  // namespace dta
+
+// Error plumbing: kernels launch asynchronously on the caller's stream; launch errors are caught here
+// and surfaced through dta_last_error() (no exceptions cross the C ABI).
+void dta_set_error(const char* fmt, ...);
+#define DTA_CHECK_LAUNCH(name)                                                      \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess) {                                                         \
+      dta_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));          \
+      return 1;                                                                     \
+    }                                                                               \
+  } while (0)

@@ -1,0 +1,505 @@
+// 3x3 'same' convolution family for the Hang2020 hot path on gfx950 (MI355X):
+//   k_pack_input   NCHW fp32 patches  -> tile layout (TL, see common.h)
+//   k_pack_conv_w  torch conv weights -> [chunk][tap][n][16] MFMA B-operand image (fwd or dgrad form)
+//   k_conv3x3      implicit-GEMM forward / input-gradient conv on the matrix cores (+bias, +BN partials)
+//   k_conv_wgrad   weight-gradient conv (K = batch x pixels) + k_wgrad_reduce (split-K reduce, torch layout)
+// Replaces nn.Conv2d(3x3, padding="same") forward/backward of /root/reference/src/models/Hang2020.py:18,25
+// (conv_module), i.e. the ops torch dispatches to MIOpen/oneDNN in the reference.
+#include "kernels.h"
+
+namespace dta {
+
+// ------------------------------------------------------------------------------------------------
+// pack input
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x, T* __restrict__ out, int B, int C,
+                                                    int H, int W, int NC, int CG) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s = (float*)smem;  // [CG*16][HW]
+  const int HW = H * W, Q = (H + 2) * (W + 2);
+  const int b = blockIdx.x, chunk0 = blockIdx.y * CG;
+  const int nch = min(CG, NC - chunk0);
+  const int c0 = chunk0 * 16;
+  const int creal = max(0, min(nch * 16, C - c0));
+  const float* src = x + ((size_t)b * C + c0) * HW;
+  for (int i = threadIdx.x; i < nch * 16 * HW; i += 256) s[i] = (i < creal * HW) ? src[i] : 0.f;
+  __syncthreads();
+  T* dst = out + ((size_t)b * NC + chunk0) * Q * 16;
+  for (int i = threadIdx.x; i < nch * Q * 16; i += 256) {
+    int ch = i / (Q * 16), rem = i - ch * Q * 16;
+    int q = rem >> 4, pos = rem & 15;
+    int c16 = tl_pos<T>(q, pos);  // the swizzle is an involution
+    int hh = q / (W + 2) - 1, ww = q % (W + 2) - 1;
+    float v = 0.f;
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = s[(ch * 16 + c16) * HW + hh * W + ww];
+    dst[i] = Cvt<T>::to(v);
+  }
+}
+
+template <typename T>
+int launch_pack_input(const float* x, void* out, int B, int C, int H, int W, hipStream_t st) {
+  int NC = (C + 15) / 16, HW = H * W;
+  int CG = 4;
+  while (CG > 1 && (size_t)CG * 16 * HW * 4 > 65536) CG >>= 1;
+  size_t lds = (size_t)CG * 16 * HW * 4;
+  if (lds > 160 * 1024) { dta_set_error("pack_input: %dx%d patch does not fit LDS", H, W); return 1; }
+  dim3 grid(B, (NC + CG - 1) / CG);
+  hipLaunchKernelGGL(k_pack_input<T>, grid, dim3(256), lds, st, x, (T*)out, B, C, H, W, NC, CG);
+  DTA_CHECK_LAUNCH("k_pack_input");
+  return 0;
+}
+template int launch_pack_input<float>(const float*, void*, int, int, int, int, hipStream_t);
+template int launch_pack_input<bf16_t>(const float*, void*, int, int, int, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// pack weights: dst[g][chunk][tap][n][16], row = tap*N+n swizzled like TL rows.
+//   mode 0: forward, one source per group                 val = W_g[n][kc][tap]
+//   mode 1: forward, G==1, output columns concatenated     val = (n<nsplit ? W_0[n] : W_1[n-nsplit])[kc][tap]
+//   mode 2: input-gradient form (transposed + flipped)     val = W_g[kc][n][8-tap]   (W_g is [Kdim][N][9])
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_pack_conv_w(PackWArgs a, T* __restrict__ dst) {
+  const int N = a.N, NC = a.NC;
+  size_t total = (size_t)a.G * NC * 9 * N * 16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int pos = i & 15;
+    size_t r = i >> 4;
+    int n = r % N; r /= N;
+    int tap = r % 9; r /= 9;
+    int chunk = r % NC;
+    int g = r / NC;
+    int row = tap * N + n;
+    int kc = chunk * 16 + tl_pos<T>(row, pos);
+    float v = 0.f;
+    if (kc < a.K) {
+      if (a.mode == 0) {
+        v = a.src[g][((size_t)n * a.K + kc) * 9 + tap];
+      } else if (a.mode == 1) {
+        const float* w = n < a.nsplit ? a.src[0] : a.src[1];
+        int nn = n < a.nsplit ? n : n - a.nsplit;
+        v = w[((size_t)nn * a.K + kc) * 9 + tap];
+      } else {
+        v = a.src[g][((size_t)kc * N + n) * 9 + (8 - tap)];
+      }
+    }
+    dst[i] = Cvt<T>::to(v);
+  }
+}
+
+template <typename T>
+int launch_pack_conv_w(const PackWArgs& a, void* dst, hipStream_t st) {
+  size_t total = (size_t)a.G * a.NC * 9 * a.N * 16;
+  int blocks = (int)min((size_t)1024, (total + 255) / 256);
+  hipLaunchKernelGGL(k_pack_conv_w<T>, dim3(blocks), dim3(256), 0, st, a, (T*)dst);
+  DTA_CHECK_LAUNCH("k_pack_conv_w");
+  return 0;
+}
+template int launch_pack_conv_w<float>(const PackWArgs&, void*, hipStream_t);
+template int launch_pack_conv_w<bf16_t>(const PackWArgs&, void*, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// MFMA fragment helpers.  A 32x32 output tile per MFMA; K step = 2 (fp32, exact) or 16 (bf16).
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<float> {
+  static constexpr int KS = 2;
+  typedef float reg;
+  // element offset inside a 16-wide TL row for k-step ks (0..7): one float per lane, k = 2*ks + lane/32
+  __device__ static __forceinline__ reg load(const float* rowbase, int row, int ks, int lane) {
+    return rowbase[tl_pos<float>(row, ks * 2 + (lane >> 5))];
+  }
+  __device__ static __forceinline__ f32x16 mfma(reg a, reg b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Frag<bf16_t> {
+  static constexpr int KS = 16;
+  typedef bf16x8 reg;
+  __device__ static __forceinline__ reg load(const bf16_t* rowbase, int row, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8*>(rowbase + tl_pos<bf16_t>(row, (lane >> 5) << 3));
+  }
+  __device__ static __forceinline__ f32x16 mfma(reg a, reg b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_conv3x3: implicit GEMM.  M = (patch, pixel) rows, N = output channels, K = 9 taps x Cin.
+// One workgroup = 4 waves; wave w owns MT consecutive 32-row tiles x all NT 32-column tiles.
+// Per 16-channel chunk the haloed input tiles of the workgroup's patches and the [9][N][16] weight
+// slab are copied linearly HBM->LDS; the 9 taps are 9 row-shifted reads of the same LDS tile.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MWG = 4 * MT * 32;
+  constexpr int N = NT * 32;
+  int* rowtab = (int*)smem;            // [MWG] global output row or -1
+  int* plq = rowtab + MWG;             // [MWG] (pl << 16) | q_topleft
+  float* red = (float*)(plq + MWG);    // [4][N]
+  float* cmean = red + 4 * N;          // [N]
+  T* sx = (T*)(cmean + N);
+  const int Q = a.Q, HW = a.HW, W2 = a.W + 2;
+  T* sw = sx + (size_t)a.ppw * Q * 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.y;
+  const int pg = blockIdx.x / a.spp, split = blockIdx.x - pg * a.spp;
+  const int b0 = pg * a.ppw;
+  const int npatch = min(a.ppw, a.B - b0);
+
+  for (int lr = tid; lr < MWG; lr += 256) {
+    int pl, pix;
+    bool valid;
+    if (a.spp == 1) { pl = lr / HW; pix = lr - pl * HW; valid = pl < npatch; }
+    else { pl = 0; pix = split * MWG + lr; valid = pix < HW; }
+    int h = valid ? pix / a.W : 0, w = valid ? pix - h * a.W : 0;
+    rowtab[lr] = valid ? (b0 + pl) * HW + pix : -1;
+    plq[lr] = valid ? ((pl << 16) | (h * W2 + w)) : 0;
+  }
+  __syncthreads();
+
+  int base[MT], ql[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int v = plq[(wave * MT + mt) * 32 + (lane & 31)];
+    base[mt] = (v >> 16) * Q * 16;
+    ql[mt] = v & 0xFFFF;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int vpp = Q * 16 * (int)sizeof(T) / 16;        // 16-byte vectors per patch tile
+  const int wvec = 9 * N * 16 * (int)sizeof(T) / 16;   // 16-byte vectors of the weight slab
+  const T* xg = (const T*)a.x_tl + (size_t)g * a.x_gs;
+  const T* wg = (const T*)a.wp + (size_t)g * a.NC * 9 * N * 16;
+
+  for (int chunk = 0; chunk < a.NC; ++chunk) {
+    __syncthreads();
+    {
+      uint4* d = reinterpret_cast<uint4*>(sx);
+      for (int v = tid; v < npatch * vpp; v += 256) {
+        int pl = v / vpp, o = v - pl * vpp;
+        const uint4* s = reinterpret_cast<const uint4*>(xg + (((size_t)(b0 + pl) * a.NC + chunk) * Q) * 16);
+        d[v] = s[o];
+      }
+      uint4* dw = reinterpret_cast<uint4*>(sw);
+      const uint4* swp = reinterpret_cast<const uint4*>(wg + (size_t)chunk * 9 * N * 16);
+      for (int v = tid; v < wvec; v += 256) dw[v] = swp[v];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = (tap / 3) * W2 + (tap % 3);
+      const T* wrow[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wrow[nt] = sw + (size_t)(tap * N + nt * 32 + (lane & 31)) * 16;
+      const T* xrow[MT];
+      int xq[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { xq[mt] = ql[mt] + toff; xrow[mt] = sx + base[mt] + xq[mt] * 16; }
+#pragma unroll
+      for (int ks = 0; ks < 16 / Frag<T>::KS; ++ks) {
+        typename Frag<T>::reg af[MT], bf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = Frag<T>::load(xrow[mt], xq[mt], ks, lane);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = Frag<T>::load(wrow[nt], lane & 31, ks, lane);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Frag<T>::mfma(af[mt], bf[nt], acc[mt][nt]);
+      }
+    }
+  }
+
+  // ---- epilogue: bias, store, per-workgroup (mean, M2) per column for BatchNorm batch statistics ----
+  float bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int n = nt * 32 + (lane & 31);
+    float bv = 0.f;
+    if (a.bias[0]) {
+      if (a.bias_mode == 1) bv = n < a.bias_split ? a.bias[0][n] : a.bias[1][n - a.bias_split];
+      else bv = a.bias[g][n];
+    }
+    bias[nt] = bv;
+  }
+  float csum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) csum[nt] = 0.f;
+  float* yg = a.y + (size_t)g * a.y_gs;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int lr = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      int orow = rowtab[lr];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float v = acc[mt][nt][r] + bias[nt];
+        acc[mt][nt][r] = v;
+        if (orow >= 0) {
+          yg[(size_t)orow * a.y_rs + nt * 32 + (lane & 31)] = v;
+          csum[nt] += v;
+        }
+      }
+    }
+  }
+  if (a.stats == nullptr) return;
+  const int cnt = (a.spp == 1) ? npatch * HW : min(MWG, HW - split * MWG);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float v = csum[nt] + __shfl_xor(csum[nt], 32);
+    if (lane < 32) red[wave * N + nt * 32 + lane] = v;
+  }
+  __syncthreads();
+  if (tid < N) cmean[tid] = (red[tid] + red[N + tid] + red[2 * N + tid] + red[3 * N + tid]) / (float)cnt;
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float mu = cmean[nt * 32 + (lane & 31)];
+    float m2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (rowtab[lr] >= 0) { float d = acc[mt][nt][r] - mu; m2 += d * d; }
+      }
+    csum[nt] = m2 + __shfl_xor(m2, 32);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    if (lane < 32) red[wave * N + nt * 32 + lane] = csum[nt];
+  __syncthreads();
+  if (tid < N) {
+    float m2 = red[tid] + red[N + tid] + red[2 * N + tid] + red[3 * N + tid];
+    float* o = a.stats + (((size_t)g * gridDim.x + blockIdx.x) * N + tid) * 2;
+    o[0] = cmean[tid];
+    o[1] = m2;
+  }
+}
+
+void conv_geometry(int HW, int MWG, int B, int* ppw, int* spp, int* nwg) {
+  if (HW <= MWG) { *ppw = MWG / HW; *spp = 1; *nwg = (B + *ppw - 1) / *ppw; }
+  else { *ppw = 1; *spp = (HW + MWG - 1) / MWG; *nwg = B * *spp; }
+}
+
+template <typename T, int MT, int NT>
+static int launch_conv_t(ConvArgs a, int G, hipStream_t st) {
+  constexpr int MWG = 4 * MT * 32, N = NT * 32;
+  int nwg;
+  conv_geometry(a.HW, MWG, a.B, &a.ppw, &a.spp, &nwg);
+  size_t lds = (size_t)MWG * 8 + (size_t)5 * N * 4 + ((size_t)a.ppw * a.Q * 16 + (size_t)9 * N * 16) * sizeof(T);
+  if (lds > 160 * 1024) { dta_set_error("conv3x3: LDS need %zu B exceeds 160 KiB (H=%d W=%d)", lds, a.H, a.W); return 1; }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)k_conv3x3<T, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_conv3x3<T, MT, NT>), dim3(nwg, G), dim3(256), lds, st, a);
+  DTA_CHECK_LAUNCH("k_conv3x3");
+  return 0;
+}
+
+int conv_mwg(int N) { return N >= 128 ? 256 : 512; }
+
+template <typename T>
+int launch_conv3x3(const ConvArgs& a, int G, hipStream_t st) {
+  switch (a.N) {
+    case 32: return launch_conv_t<T, 4, 1>(a, G, st);
+    case 64: return launch_conv_t<T, 4, 2>(a, G, st);
+    case 128: return launch_conv_t<T, 2, 4>(a, G, st);
+  }
+  dta_set_error("conv3x3: unsupported output width %d", a.N);
+  return 1;
+}
+template int launch_conv3x3<float>(const ConvArgs&, int, hipStream_t);
+template int launch_conv3x3<bf16_t>(const ConvArgs&, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// k_conv_wgrad: dW[tap][c][n] = sum_{b,q} X[b][c][q + shift(tap)] * dY[b][n][q], K runs over the haloed
+// grid rows q in [W+3, Q-W-3) (dY halo rows are zero, so the side-halo rows contribute nothing).
+// Workgroup = (channel group of CT*32 inputs, batch split s, group g); wave w -> (c-tile, n-tile), 9 taps.
+// fp32: element reads + 32x32x2 MFMA.  bf16: ds_read_b64_tr_b16 transposing reads + 32x32x16 MFMA.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct WFrag;
+template <> struct WFrag<float> {
+  static constexpr int KS = 2;
+  typedef float reg;
+  // operand element (column col of a 32-wide tile spanning two 16-chunks, haloed-grid row q0 + lane/32)
+  __device__ static __forceinline__ reg load(const float* tile0, int rows_per_chunk, int q0, int lane) {
+    int q = q0 + (lane >> 5);
+    int col = lane & 31;
+    return tile0[((size_t)(col >> 4) * rows_per_chunk + q) * 16 + tl_pos<float>(q, col & 15)];
+  }
+  __device__ static __forceinline__ f32x16 mfma(reg a, reg b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct WFrag<bf16_t> {
+  static constexpr int KS = 16;
+  typedef bf16x8 reg;
+  __device__ static __forceinline__ reg load(const bf16_t* tile0, int rows_per_chunk, int q0, int lane) {
+    // lane i of 16-lane group gq supplies the address of 4 consecutive channels (col group i&3) of row
+    // q0 + 8*(gq>>1) + 4*half + (i>>2) in chunk (gq&1); it receives channel i of those 4 rows.
+    const int gq = lane >> 4, i = lane & 15;
+    bf16x8 out;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      int q = q0 + 8 * (gq >> 1) + 4 * half + (i >> 2);
+      const bf16_t* p = tile0 + ((size_t)(gq & 1) * rows_per_chunk + q) * 16 + tl_pos<bf16_t>(q, (i & 3) * 4);
+      s16x4 v;
+      asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+      out[half * 4 + 0] = v[0]; out[half * 4 + 1] = v[1]; out[half * 4 + 2] = v[2]; out[half * 4 + 3] = v[3];
+    }
+    return out;
+  }
+  __device__ static __forceinline__ f32x16 mfma(reg a, reg b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int WG_PAD_ROWS = 16;
+
+template <typename T, int NTT>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CT = 4 / NTT;          // c-tiles (32 input channels each) per workgroup
+  constexpr int N = NTT * 32;
+  constexpr int XCH = CT * 2, YCH = NTT * 2;
+  const int Q = a.Q, Qp = Q + WG_PAD_ROWS, W2 = a.W + 2;
+  T* sx = (T*)smem;                    // [XCH][Qp][16]
+  T* sy = sx + (size_t)XCH * Qp * 16;  // [YCH][Qp][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
+  const int ct = wave / NTT, nt = wave % NTT;
+  const int chunk0 = cg * XCH;
+  const int nxch = max(0, min(XCH, a.NCx - chunk0));
+
+  // zero everything once: pad rows and absent chunks stay zero for the whole kernel
+  {
+    uint4 z = {0, 0, 0, 0};
+    uint4* d = reinterpret_cast<uint4*>(smem);
+    int tot = (XCH + YCH) * Qp * 16 * (int)sizeof(T) / 16;
+    for (int v = tid; v < tot; v += 256) d[v] = z;
+  }
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int vpc = Q * 16 * (int)sizeof(T) / 16;  // vectors per chunk tile
+  const T* xg = (const T*)a.x_tl + (size_t)g * a.x_gs;
+  const T* yg = (const T*)a.dy_tl + (size_t)g * a.dy_gs;
+  const int q0 = a.W + 3, q1 = Q - a.W - 3;
+  const T* xt = sx + (size_t)ct * 2 * Qp * 16;
+  const T* yt = sy + (size_t)nt * 2 * Qp * 16;
+
+  for (int b = s; b < a.B; b += a.S) {
+    __syncthreads();
+    for (int v = tid; v < nxch * vpc; v += 256) {
+      int ch = v / vpc, o = v - ch * vpc;
+      reinterpret_cast<uint4*>(sx + (size_t)ch * Qp * 16)[o] =
+          reinterpret_cast<const uint4*>(xg + (((size_t)b * a.NCx + chunk0 + ch) * Q) * 16)[o];
+    }
+    for (int v = tid; v < YCH * vpc; v += 256) {
+      int ch = v / vpc, o = v - ch * vpc;
+      reinterpret_cast<uint4*>(sy + (size_t)ch * Qp * 16)[o] =
+          reinterpret_cast<const uint4*>(yg + (((size_t)b * a.NCy + a.ych0 + ch) * Q) * 16)[o];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int q = q0; q < q1; q += WFrag<T>::KS) {
+      typename WFrag<T>::reg bf = WFrag<T>::load(yt, Qp, q, lane);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int shift = (tap / 3 - 1) * W2 + (tap % 3 - 1);
+        typename WFrag<T>::reg af = WFrag<T>::load(xt, Qp, q + shift, lane);
+        acc[tap] = WFrag<T>::mfma(af, bf, acc[tap]);
+      }
+    }
+  }
+  // partial[g][s][tap][c][n]
+  float* out = a.partial + ((size_t)(g * a.S + s) * 9) * a.Cpad * N;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int c = cg * CT * 32 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (c < a.Cpad) out[((size_t)tap * a.Cpad + c) * N + nt * 32 + (lane & 31)] = acc[tap][r];
+    }
+}
+
+// out_g[n][c][tap] (torch layout) = sum_s partial[g][s][tap][c][n]
+__global__ void k_wgrad_reduce(WgradReduceArgs a) {
+  const int N = a.N;
+  size_t total = (size_t)a.G * 9 * a.C * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int n = i % N;
+    size_t r = i / N;
+    int c = r % a.C; r /= a.C;
+    int tap = r % 9;
+    int g = r / 9;
+    const float* p = a.partial + ((size_t)g * a.S * 9 + tap) * a.Cpad * N + (size_t)c * N + n;
+    float acc = 0.f;
+    for (int s = 0; s < a.S; ++s) acc += p[(size_t)s * 9 * a.Cpad * N];
+    float* dst;
+    int nn = n;
+    if (a.mode == 1) { dst = n < a.nsplit ? a.dst[0] : a.dst[1]; nn = n < a.nsplit ? n : n - a.nsplit; }
+    else dst = a.dst[g];
+    if (dst) dst[((size_t)nn * a.C + c) * 9 + tap] = acc;
+  }
+}
+
+int wgrad_cpw(int N) { return (4 / (N / 32)) * 32; }
+
+template <typename T, int NTT>
+static int launch_wgrad_t(const WgradArgs& a, int G, int cgroups, hipStream_t st) {
+  constexpr int CT = 4 / NTT;
+  size_t lds = (size_t)(CT * 2 + NTT * 2) * (a.Q + WG_PAD_ROWS) * 16 * sizeof(T);
+  if (lds > 160 * 1024) { dta_set_error("conv_wgrad: LDS need %zu B exceeds 160 KiB", lds); return 1; }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)k_conv_wgrad<T, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_conv_wgrad<T, NTT>), dim3(cgroups, a.S, G), dim3(256), lds, st, a);
+  DTA_CHECK_LAUNCH("k_conv_wgrad");
+  return 0;
+}
+
+template <typename T>
+int launch_conv_wgrad(const WgradArgs& a, int G, hipStream_t st) {
+  int cpw = wgrad_cpw(a.N);
+  int cgroups = (a.Cpad + cpw - 1) / cpw;
+  switch (a.N) {
+    case 32: return launch_wgrad_t<T, 1>(a, G, cgroups, st);
+    case 64: return launch_wgrad_t<T, 2>(a, G, cgroups, st);
+    case 128: return launch_wgrad_t<T, 4>(a, G, cgroups, st);
+  }
+  dta_set_error("conv_wgrad: unsupported width %d", a.N);
+  return 1;
+}
+template int launch_conv_wgrad<float>(const WgradArgs&, int, hipStream_t);
+template int launch_conv_wgrad<bf16_t>(const WgradArgs&, int, hipStream_t);
+
+int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {
+  size_t total = (size_t)a.G * 9 * a.C * a.N;
+  int blocks = (int)min((size_t)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_wgrad_reduce");
+  return 0;
+}
+
+}  // namespace dta

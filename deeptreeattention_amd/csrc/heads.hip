@@ -1,0 +1,247 @@
+// Small dense pieces of the Hang2020 hot path on gfx950: classifier heads (nn.Linear forward/backward,
+// reference src/models/Hang2020.py:55-66), batch reductions of attention/bias gradients, the
+// sigmoid(alpha) blend (:260-261), class-weighted cross-entropy (src/main.py:78) and Adam (src/main.py:136).
+#include "kernels.h"
+
+namespace dta {
+
+// ------------------------------------------------------------------------------------------------
+// Strided fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products/accumulation).
+// 64x64 output tile per workgroup, wave w -> 32x32 quadrant, K chunk 32 staged in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int GK = 32;
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
+  __shared__ float As[64][GK + 1];
+  __shared__ float Bs[GK][64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int kper = (a.K + a.ksplit - 1) / a.ksplit;
+  const int kbeg = blockIdx.z * kper, kend = min(a.K, kbeg + kper);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    __syncthreads();
+    for (int i = t; i < 64 * GK; i += 256) {
+      int m, k;
+      if (a.sa_k == 1) { m = i / GK; k = i % GK; } else { k = i / 64; m = i % 64; }
+      float v = 0.f;
+      if (m0 + m < a.M && k0 + k < kend) v = a.A[(size_t)(m0 + m) * a.sa_m + (size_t)(k0 + k) * a.sa_k];
+      As[m][k] = v;
+    }
+    for (int i = t; i < 64 * GK; i += 256) {
+      int n, k;
+      if (a.sb_n == 1) { k = i / 64; n = i % 64; } else { n = i / GK; k = i % GK; }
+      float v = 0.f;
+      if (n0 + n < a.N && k0 + k < kend) v = a.Bm[(size_t)(k0 + k) * a.sb_k + (size_t)(n0 + n) * a.sb_n];
+      Bs[k][n] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 2) {
+      float av = As[wm + (lane & 31)][kk + (lane >> 5)];
+      float bv = Bs[kk + (lane >> 5)][wn + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  const int n = n0 + wn + (lane & 31);
+  if (n >= a.N) return;
+  const float bias = (a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m >= a.M) continue;
+    float* c = a.C + (size_t)m * a.sc_m + (size_t)n * a.sc_n;
+    float v = acc[r] + bias;
+    if (a.ksplit > 1) atomicAdd(c, v);
+    else if (a.accumulate) *c += v;
+    else *c = v;
+  }
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+  dim3 grid((a.M + 63) / 64, (a.N + 63) / 64, a.ksplit);
+  hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_gemm");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column sums over the batch with a segment table: column j of A[rows][lda] lands in dst[seg][j - off].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colsum_scatter(ColsumArgs a) {
+  __shared__ float sc[256];
+  const int t = threadIdx.x, j = blockIdx.x * 64 + (t & 63), sl = t >> 6;
+  float acc = 0.f;
+  if (j < a.cols)
+    for (int r = sl; r < a.rows; r += 4) acc += a.A[(size_t)r * a.lda + j];
+  sc[t] = acc;
+  __syncthreads();
+  if (t < 64 && j < a.cols) {
+    float v = sc[t] + sc[64 + t] + sc[128 + t] + sc[192 + t];
+    for (int s = 0; s < a.nseg; ++s)
+      if (j >= a.off[s] && j < a.off[s] + a.len[s]) {
+        if (a.dst[s]) a.dst[s][(size_t)(j - a.off[s]) * a.dst_stride[s]] = v;
+        break;
+      }
+  }
+}
+
+int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_colsum_scatter, dim3((a.cols + 63) / 64), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_colsum_scatter");
+  return 0;
+}
+
+// spectral attention Conv1d weights [C][C][K]: only tap K/2 is live on a length-1 sequence.
+// packed = [a1t | a2t | a1 | a2], each [C][C]; *t is input-major (a_t[i][o] = W[o][i][K/2]).
+__global__ void k_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * C) return;
+  int o = i / C, in = i - o * C;
+  float v1 = w1[(size_t)i * K + K / 2], v2 = w2[(size_t)i * K + K / 2];
+  packed[in * C + o] = v1;
+  packed[C * C + in * C + o] = v2;
+  packed[2 * C * C + i] = v1;
+  packed[3 * C * C + i] = v2;
+}
+int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_spectral_att, dim3((C * C + 255) / 256), dim3(256), 0, st, w1, w2, C, K, packed);
+  DTA_CHECK_LAUNCH("k_pack_spectral_att");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hang2020 blend: joint = spec * sigmoid(alpha) + spat * (1 - sigmoid(alpha)); alpha is float64.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_blend(BlendArgs a) {
+  const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
+  const float w = (float)wd, w1 = (float)(1.0 - wd);
+  size_t n = (size_t)a.B * a.classes;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    a.joint[i] = a.spec[i] * w + a.spat[i] * w1;
+}
+int launch_blend(const BlendArgs& a, hipStream_t st) {
+  size_t n = (size_t)a.B * a.classes;
+  hipLaunchKernelGGL(k_blend, dim3((unsigned)min((size_t)1024, (n + 255) / 256)), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_blend");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_blend_bwd_rows(BlendBwdArgs a) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.B) return;
+  const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
+  const float w = (float)wd, w1 = (float)(1.0 - wd);
+  float acc = 0.f;
+  for (int n = lane; n < a.classes; n += 64) {
+    size_t i = (size_t)row * a.classes + n;
+    float d = a.djoint[i];
+    a.dspec[i] = d * w;
+    a.dspat[i] = d * w1;
+    acc += d * (a.spec[i] - a.spat[i]);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) a.rowtmp[row] = acc;
+}
+__global__ __launch_bounds__(256) void k_blend_bwd_fin(BlendBwdArgs a) {
+  __shared__ double sd[256];
+  double acc = 0;
+  for (int r = threadIdx.x; r < a.B; r += 256) acc += a.rowtmp[r];
+  sd[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
+    a.dalpha[0] = sd[0] * wd * (1.0 - wd);
+  }
+}
+int launch_blend_bwd(const BlendBwdArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_blend_bwd_rows, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_blend_bwd_rows");
+  hipLaunchKernelGGL(k_blend_bwd_fin, dim3(1), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_blend_bwd_fin");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F.cross_entropy(logits, y, weight=w): loss = sum_i w[y_i] * nll_i / sum_i w[y_i], plus dlogits.
+// Labels outside [0, classes) are ignored (torch's ignore_index behaviour).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ce_rows(CeArgs a) {
+  __shared__ float sc[4];
+  const int t = threadIdx.x, lane = t & 63, row = blockIdx.x * 4 + (t >> 6);
+  float part = 0.f;
+  for (int i = t; i < a.B; i += 256) {
+    long long y = a.labels[i];
+    if (y >= 0 && y < a.classes) part += a.weight ? a.weight[y] : 1.f;
+  }
+  const float den = block_sum256(part, sc);
+  if (blockIdx.x == 0 && t == 0) a.rowtmp[a.B] = den;
+  if (row >= a.B) return;
+  const float* z = a.logits + (size_t)row * a.classes;
+  const long long y = a.labels[row];
+  const bool ok = y >= 0 && y < a.classes;
+  const float wy = ok ? (a.weight ? a.weight[y] : 1.f) : 0.f;
+  float mx = -3.4e38f;
+  for (int n = lane; n < a.classes; n += 64) mx = fmaxf(mx, z[n]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int n = lane; n < a.classes; n += 64) se += __expf(z[n] - mx);
+  se = wave_sum(se);
+  const float lse = __logf(se);
+  if (lane == 0) a.rowtmp[row] = ok ? wy * (lse + mx - z[y]) : 0.f;
+  if (a.dlogits) {
+    const float sc2 = den > 0.f ? wy / den : 0.f;
+    float* d = a.dlogits + (size_t)row * a.classes;
+    for (int n = lane; n < a.classes; n += 64) {
+      float p = __expf(z[n] - mx - lse);
+      d[n] = sc2 * (p - ((ok && n == (int)y) ? 1.f : 0.f));
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_ce_fin(CeArgs a) {
+  __shared__ double sd[256];
+  double acc = 0;
+  for (int r = threadIdx.x; r < a.B; r += 256) acc += a.rowtmp[r];
+  sd[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) a.loss[0] = (float)(sd[0] / (double)a.rowtmp[a.B]);
+}
+int launch_weighted_ce(const CeArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_ce_rows, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_ce_rows");
+  hipLaunchKernelGGL(k_ce_fin, dim3(1), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_ce_fin");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// torch.optim.Adam (defaults: no weight decay, no amsgrad) over one flat fp32 buffer + the fp64 alpha.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_adam(AdamArgs a) {
+  const float ss = a.lr / a.bc1, rbc2 = rsqrtf(a.bc2);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+    float g = a.g[i] * a.grad_scale;
+    float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    a.m[i] = m; a.v[i] = v;
+    a.p[i] -= ss * (m / (sqrtf(v) * rbc2 + a.eps));
+  }
+  if (a.alpha_p && blockIdx.x == 0 && threadIdx.x == 0) {
+    double g = a.alpha_g[0] * (double)a.grad_scale;
+    double m = (double)a.beta1 * a.alpha_m[0] + (1.0 - (double)a.beta1) * g;
+    double v = (double)a.beta2 * a.alpha_v[0] + (1.0 - (double)a.beta2) * g * g;
+    a.alpha_m[0] = m; a.alpha_v[0] = v;
+    a.alpha_p[0] -= ((double)a.lr / (double)a.bc1) * (m / (sqrt(v) / sqrt((double)a.bc2) + (double)a.eps));
+  }
+}
+int launch_adam(const AdamArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)min((size_t)2048, (a.n + 255) / 256)), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_adam");
+  return 0;
+}
+
+}  // namespace dta

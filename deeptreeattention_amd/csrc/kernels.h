@@ -1,0 +1,140 @@
+// Internal launch interface between the C-ABI orchestration (capi.hip) and the kernel files.
+#pragma once
+#include "common.h"
+
+namespace dta {
+
+enum { KIND_SPECTRAL = 0, KIND_SPATIAL = 1, KIND_PLAIN = 2 };
+
+// ---- conv.hip ----------------------------------------------------------------------------------
+struct PackWArgs {
+  const float* src[2];
+  int G, NC, N, K;   // K = real size of the contraction-channel dim (Cin for fwd, Cout for dgrad)
+  int mode, nsplit;
+};
+struct ConvArgs {
+  const void* x_tl; size_t x_gs;      // input tiles, group stride in elements (0 = shared by groups)
+  const void* wp;                     // [G][NC][9][N][16]
+  const float* bias[2]; int bias_mode, bias_split;
+  float* y; size_t y_gs; int y_rs;    // fp32 output rows [row][y_rs], group offset y_gs
+  float* stats;                       // [G][nwg][N][2] (mean, M2) or null
+  int B, H, W, NC, N, Q, HW, ppw, spp;
+};
+struct WgradArgs {
+  const void* x_tl; size_t x_gs; int NCx;
+  const void* dy_tl; size_t dy_gs; int NCy, ych0;
+  float* partial;                     // [G][S][9][Cpad][N]
+  int B, H, W, Q, N, Cpad, S;
+};
+struct WgradReduceArgs {
+  const float* partial; float* dst[2];
+  int G, S, N, C, Cpad, mode, nsplit;
+};
+template <typename T> int launch_pack_input(const float* x, void* out, int B, int C, int H, int W, hipStream_t st);
+template <typename T> int launch_pack_conv_w(const PackWArgs& a, void* dst, hipStream_t st);
+template <typename T> int launch_conv3x3(const ConvArgs& a, int G, hipStream_t st);
+template <typename T> int launch_conv_wgrad(const WgradArgs& a, int G, hipStream_t st);
+int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st);
+void conv_geometry(int HW, int MWG, int B, int* ppw, int* spp, int* nwg);
+int conv_mwg(int N);
+int wgrad_cpw(int N);
+
+// ---- stage.hip (BatchNorm + ReLU + pool + attention, forward and backward) ------------------------
+struct BnFinalizeArgs {
+  const float* stats; int nwg, N, HW, MWG, B;          // partials of one conv launch (per group)
+  const float* gamma[2]; const float* beta[2];         // per group (bias_mode 1: concatenated columns)
+  float* rmean[2]; float* rvar[2]; long long* nbt[2];
+  int cat_mode, nsplit;                                // 1: G==1 launch whose columns are [branch0|branch1]
+  float* coef;                                         // [G][N][4] = scale, shift, mean, rstd
+  int training; float momentum, eps;
+};
+int launch_bn_finalize(const BnFinalizeArgs& a, int G, hipStream_t st);
+
+struct AttParams {          // forward-side attention parameters of one branch/stage (device pointers)
+  // spectral: a1t/a2t = dense transposed centre taps [C][C] (in-major), c1/c2 biases
+  // spatial : wc [C], bc, k1 [k*k], b1, k2 [k*k], b2
+  const float* p[6];
+};
+struct StageArgs {
+  int kind[2];                         // per group
+  const float* y; size_t y_gs; int y_rs;        // conv output (or raw activations when !apply_bn)
+  const float* coef; int coef_gs;      // [..][C][4]
+  int apply_bn, relu, pool;            // pool: 2x2 floor max-pool after ReLU
+  int B, C, Hc, Wc;                    // conv-resolution dims
+  AttParams att[2];
+  int att_k[2], att_pool[2];           // spatial stencil size / class-pool size
+  void* a_tl; size_t a_gs; int a_nc, a_ch0;      // gated map as tiles for the next conv (or null)
+  float* a_nchw; size_t a_nchw_gs;     // gated map as fp32 NCHW (standalone modules) or null
+  float* feat; size_t feat_gs; int F[2];         // [B][F]
+};
+template <typename T> int launch_stage_fwd(const StageArgs& a, int G, hipStream_t st);
+
+struct StageBwdArgs {
+  StageArgs f;                         // forward description (recomputed per patch)
+  const float* da; size_t da_gs;       // grad wrt gated map, fp32 [B][HWz][C] (or null)
+  const float* da_nchw; size_t da_nchw_gs;       // same as NCHW (standalone modules) or null
+  const float* dfeat; size_t dfeat_gs; // [B][F] or null
+  float* dv; size_t dv_gs;             // out: grad wrt BN output (pre-ReLU), fp32 [B][HWc][C]
+  float* bnpart; size_t bnpart_gs;     // out: [B][C][2] per-patch (sum dv, sum dv*xhat)
+  float* vec; size_t vec_gs; int vec_ld;         // out: per-patch attention-gradient vectors [B][vec_ld]
+};
+int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st);
+
+struct BnBwdFinalizeArgs {
+  const float* bnpart; size_t bnpart_gs; int B, C, HW;
+  const float* coef; int coef_gs;
+  const float* gamma[2];
+  float* dgamma[2]; float* dbeta[2]; float* dconvbias[2];
+  int cat_mode, nsplit;                // G==1 launch with concatenated branch columns
+  float* bcoef; int bcoef_gs;          // out [..][C][4] = A (gamma*rstd), Bc (dbeta/n), Cc (dgamma/n), 0
+  int training;
+};
+int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, int G, hipStream_t st);
+
+struct BnBwdApplyArgs {
+  const float* dv; size_t dv_gs; const float* y; size_t y_gs; int y_rs;
+  const float* coef; int coef_gs; const float* bcoef; int bcoef_gs;
+  int B, C, H, W;
+  void* dy_tl; size_t dy_gs; int dy_nc, dy_ch0;
+};
+template <typename T> int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st);
+
+// ---- heads.hip -----------------------------------------------------------------------------------
+// C[m][n] (+)= sum_k A(m,k) * B(k,n) + bias[n]; arbitrary element strides; fp32 MFMA 32x32x2.
+struct GemmArgs {
+  const float* A; long sa_m, sa_k;
+  const float* Bm; long sb_k, sb_n;
+  float* C; long sc_m, sc_n;
+  const float* bias;
+  int M, N, K, ksplit, accumulate;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t st);
+struct ColsumArgs {
+  const float* A; int rows, cols; long lda;
+  int nseg; int off[8], len[8]; float* dst[8]; long dst_stride[8];
+};
+int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st);
+int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed, hipStream_t st);
+
+struct BlendArgs {
+  const float* spec; const float* spat; const double* alpha; float* joint; int B, classes;
+};
+int launch_blend(const BlendArgs& a, hipStream_t st);
+struct BlendBwdArgs {
+  const float* spec; const float* spat; const double* alpha; const float* djoint;
+  float* dspec; float* dspat; double* dalpha; float* rowtmp; int B, classes;
+};
+int launch_blend_bwd(const BlendBwdArgs& a, hipStream_t st);
+struct CeArgs {
+  const float* logits; const long long* labels; const float* weight;  // weight may be null (= ones)
+  float* dlogits; float* loss; float* rowtmp; int B, classes;
+};
+int launch_weighted_ce(const CeArgs& a, hipStream_t st);
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v; size_t n;
+  double* alpha_p; const double* alpha_g; double* alpha_m; double* alpha_v;
+  float lr, beta1, beta2, eps, bc1, bc2; float grad_scale;
+};
+int launch_adam(const AdamArgs& a, hipStream_t st);
+
+}  // namespace dta

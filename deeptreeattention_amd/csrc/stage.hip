@@ -1,0 +1,562 @@
+// Per-patch fused stages of the Hang2020 sub-networks on gfx950:
+//   BatchNorm (batch or running statistics) -> ReLU -> optional 2x2 max-pool -> spectral / spatial attention
+//   -> gated map written as conv tiles for the next layer + pooled classifier features,
+// and the matching backward (recompute-from-conv-output, no saved activations besides the conv output).
+// Restates /root/reference/src/models/Hang2020.py:24-31 (conv_module after the conv), :105-124
+// (spatial_attention.forward) and :149-168 (spectral_attention.forward).
+#include "kernels.h"
+
+namespace dta {
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm statistics: combine the conv workgroups' (mean, M2) partials (Chan et al.) in double.
+// ------------------------------------------------------------------------------------------------
+struct BnFinK {
+  const float* stats; size_t stats_goff; int stats_ld;
+  int nwg, C, HW, MWG, B;
+  const float* gamma[2]; const float* beta[2];
+  float* rmean[2]; float* rvar[2]; long long* nbt[2];
+  float* coef; int training; float momentum, eps;
+};
+
+__device__ __forceinline__ int conv_wg_count(int wg, int HW, int MWG, int B) {
+  if (HW <= MWG) { int ppw = MWG / HW; return min(ppw, B - wg * ppw) * HW; }
+  int spp = (HW + MWG - 1) / MWG;
+  return min(MWG, HW - (wg % spp) * MWG);
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize(BnFinK a) {
+  __shared__ double sn[256], smean[256], sm2[256];
+  const int g = blockIdx.x, t = threadIdx.x, C = a.C;
+  const int c = t % C, sl = t / C, nsl = 256 / C;
+  float* coef = a.coef + (size_t)g * C * 4;
+  if (!a.training) {
+    if (t < C) {
+      float rstd = rsqrtf(a.rvar[g][t] + a.eps);
+      float sc = a.gamma[g][t] * rstd;
+      coef[t * 4 + 0] = sc; coef[t * 4 + 1] = a.beta[g][t] - a.rmean[g][t] * sc;
+      coef[t * 4 + 2] = a.rmean[g][t]; coef[t * 4 + 3] = rstd;
+    }
+    return;
+  }
+  double n = 0, mean = 0, m2 = 0;
+  if (sl < nsl) {
+    const float* st = a.stats + (size_t)g * a.stats_goff;
+    for (int wg = sl; wg < a.nwg; wg += nsl) {
+      double nb = conv_wg_count(wg, a.HW, a.MWG, a.B);
+      double mb = st[((size_t)wg * a.stats_ld + c) * 2 + 0], qb = st[((size_t)wg * a.stats_ld + c) * 2 + 1];
+      double nt = n + nb, d = mb - mean;
+      mean += d * nb / nt;
+      m2 += qb + d * d * n * nb / nt;
+      n = nt;
+    }
+  }
+  sn[t] = n; smean[t] = mean; sm2[t] = m2;
+  __syncthreads();
+  if (t < C) {
+    n = 0; mean = 0; m2 = 0;
+    for (int s = 0; s < nsl; ++s) {
+      double nb = sn[s * C + t];
+      if (nb == 0) continue;
+      double mb = smean[s * C + t], qb = sm2[s * C + t];
+      double nt = n + nb, d = mb - mean;
+      mean += d * nb / nt;
+      m2 += qb + d * d * n * nb / nt;
+      n = nt;
+    }
+    double var = m2 / n;
+    float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    float sc = a.gamma[g][t] * rstd;
+    coef[t * 4 + 0] = sc; coef[t * 4 + 1] = a.beta[g][t] - (float)mean * sc;
+    coef[t * 4 + 2] = (float)mean; coef[t * 4 + 3] = rstd;
+    if (a.rmean[g]) {
+      double unb = n > 1 ? m2 / (n - 1) : var;
+      a.rmean[g][t] = (1.f - a.momentum) * a.rmean[g][t] + a.momentum * (float)mean;
+      a.rvar[g][t] = (1.f - a.momentum) * a.rvar[g][t] + a.momentum * (float)unb;
+      if (t == 0 && a.nbt[g]) a.nbt[g][0] += 1;
+    }
+  }
+}
+
+int launch_bn_finalize(const BnFinalizeArgs& b, int G, hipStream_t st) {
+  BnFinK a;
+  a.stats = b.stats; a.nwg = b.nwg; a.HW = b.HW; a.MWG = b.MWG; a.B = b.B;
+  if (b.cat_mode) { a.C = b.nsplit; a.stats_goff = (size_t)b.nsplit * 2; a.stats_ld = b.N; }
+  else { a.C = b.N; a.stats_goff = (size_t)b.nwg * b.N * 2; a.stats_ld = b.N; }
+  for (int g = 0; g < 2; ++g) {
+    a.gamma[g] = b.gamma[g]; a.beta[g] = b.beta[g]; a.rmean[g] = b.rmean[g]; a.rvar[g] = b.rvar[g]; a.nbt[g] = b.nbt[g];
+  }
+  a.coef = b.coef; a.training = b.training; a.momentum = b.momentum; a.eps = b.eps;
+  hipLaunchKernelGGL(k_bn_finalize, dim3(G), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_bn_finalize");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-patch stage: LDS plan (floats).  Rows padded to C+1 so per-pixel loops over channels and
+// per-channel loops over pixels are both bank-conflict free.
+// ------------------------------------------------------------------------------------------------
+struct StageGeom {
+  int C, ld, Hc, Wc, HWc, Hz, Wz, HWz;
+};
+__device__ __forceinline__ StageGeom stage_geom(const StageArgs& a) {
+  StageGeom s;
+  s.C = a.C; s.ld = a.C + 1; s.Hc = a.Hc; s.Wc = a.Wc; s.HWc = a.Hc * a.Wc;
+  s.Hz = a.pool ? a.Hc / 2 : a.Hc; s.Wz = a.pool ? a.Wc / 2 : a.Wc; s.HWz = s.Hz * s.Wz;
+  return s;
+}
+static size_t stage_lds_floats(const StageArgs& a, bool bwd) {
+  int HWc = a.Hc * a.Wc;
+  int Hz = a.pool ? a.Hc / 2 : a.Hc, Wz = a.pool ? a.Wc / 2 : a.Wc;
+  int HWz = Hz * Wz, ld = a.C + 1;
+  size_t n = (size_t)HWz * ld;                 // Z
+  if (a.pool) n += (size_t)HWc * ld;            // R
+  if (bwd) n += (size_t)HWz * ld;               // D
+  int vmax = a.C > HWz ? a.C : HWz;
+  n += (size_t)(bwd ? 8 : 4) * vmax + 512;      // vectors + reduction scratch
+  return n;
+}
+
+// Partitioned reduction helper: 256 threads = (256/C) slices x C columns.  f(c, i) summed over i in [0, n).
+template <typename F>
+__device__ __forceinline__ void colreduce(int C, int n, float* scratch, float* out, float scale, F f) {
+  const int t = threadIdx.x, c = t % C, sl = t / C, nsl = 256 / C;
+  float acc = 0.f;
+  if (sl < nsl)
+    for (int i = sl; i < n; i += nsl) acc += f(c, i);
+  __syncthreads();
+  scratch[t] = acc;
+  __syncthreads();
+  if (t < C) {
+    float s = 0.f;
+    for (int k = 0; k < nsl; ++k) s += scratch[k * C + t];
+    out[t] = s * scale;
+  }
+  __syncthreads();
+}
+
+// Forward recompute shared by both kernels.  On return (all threads synced):
+//   Z [HWz][ld]  post BN/ReLU/pool activations,  R [HWc][ld] pre-pool (only if pool)
+//   spectral: v0 = pooled, v1 = h (post ReLU), v2 = gate
+//   spatial : v0 = m (post ReLU), v1 = t1 (post ReLU), v2 = s (sigmoid gate)
+__device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeom& s, int g, int b, int kind,
+                                              float* Z, float* R, float* v0, float* v1, float* v2, float* scratch) {
+  const int t = threadIdx.x, C = s.C, ld = s.ld;
+  const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
+  const float* coef = a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr;
+  float* dst = a.pool ? R : Z;
+  for (int i = t; i < s.HWc * C; i += 256) {
+    int p = i / C, c = i - p * C;
+    float v = y[(size_t)p * a.y_rs + c];
+    if (a.apply_bn) v = v * coef[c * 4 + 0] + coef[c * 4 + 1];
+    if (a.relu) v = fmaxf(v, 0.f);
+    dst[p * ld + c] = v;
+  }
+  __syncthreads();
+  if (a.pool) {
+    for (int i = t; i < s.HWz * C; i += 256) {
+      int pz = i / C, c = i - pz * C;
+      int hz = pz / s.Wz, wz = pz - hz * s.Wz;
+      const float* r0 = R + ((2 * hz) * s.Wc + 2 * wz) * ld + c;
+      float m = fmaxf(fmaxf(r0[0], r0[ld]), fmaxf(r0[s.Wc * ld], r0[(s.Wc + 1) * ld]));
+      Z[pz * ld + c] = m;
+    }
+    __syncthreads();
+  }
+  if (kind == KIND_SPECTRAL) {
+    const float* a1t = a.att[g].p[0]; const float* c1 = a.att[g].p[1];
+    const float* a2t = a.att[g].p[2]; const float* c2 = a.att[g].p[3];
+    colreduce(C, s.HWz, scratch, v0, 1.f / (float)s.HWz, [&](int c, int i) { return Z[i * ld + c]; });
+    colreduce(C, C, scratch, v1, 1.f, [&](int o, int i) { return a1t[i * C + o] * v0[i]; });
+    if (t < C) v1[t] = fmaxf(v1[t] + c1[t], 0.f);
+    __syncthreads();
+    colreduce(C, C, scratch, v2, 1.f, [&](int o, int i) { return a2t[i * C + o] * v1[i]; });
+    if (t < C) v2[t] = sigmoidf_(v2[t] + c2[t]);
+    __syncthreads();
+  } else if (kind == KIND_SPATIAL) {
+    const float* wc = a.att[g].p[0]; const float bc = a.att[g].p[1][0];
+    const float* k1 = a.att[g].p[2]; const float b1 = a.att[g].p[3][0];
+    const float* k2 = a.att[g].p[4]; const float b2 = a.att[g].p[5][0];
+    const int k = a.att_k[g], r = k / 2;
+    for (int p = t; p < s.HWz; p += 256) {
+      float acc = bc;
+      for (int c = 0; c < C; ++c) acc += wc[c] * Z[p * ld + c];
+      v0[p] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int p = t; p < s.HWz; p += 256) {
+      int h = p / s.Wz, w = p - h * s.Wz;
+      float acc = b1;
+      for (int ky = 0; ky < k; ++ky) {
+        int hh = h + ky - r;
+        if (hh < 0 || hh >= s.Hz) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          int ww = w + kx - r;
+          if (ww >= 0 && ww < s.Wz) acc += k1[ky * k + kx] * v0[hh * s.Wz + ww];
+        }
+      }
+      v1[p] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int p = t; p < s.HWz; p += 256) {
+      int h = p / s.Wz, w = p - h * s.Wz;
+      float acc = b2;
+      for (int ky = 0; ky < k; ++ky) {
+        int hh = h + ky - r;
+        if (hh < 0 || hh >= s.Hz) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          int ww = w + kx - r;
+          if (ww >= 0 && ww < s.Wz) acc += k2[ky * k + kx] * v1[hh * s.Wz + ww];
+        }
+      }
+      v2[p] = sigmoidf_(acc);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ float gate_of(int kind, const float* v2, int p, int c) {
+  return kind == KIND_SPECTRAL ? v2[c] : (kind == KIND_SPATIAL ? v2[p] : 1.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const StageGeom s = stage_geom(a);
+  const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = s.C, ld = s.ld;
+  const int kind = a.kind[g];
+  const int vmax = C > s.HWz ? C : s.HWz;
+  float* Z = sm;
+  float* R = Z + (size_t)s.HWz * ld;
+  float* v0 = R + (a.pool ? (size_t)s.HWc * ld : 0);
+  float* v1 = v0 + vmax; float* v2 = v1 + vmax; float* v3 = v2 + vmax;
+  float* scratch = v3 + vmax;
+  stage_forward(a, s, g, b, kind, Z, R, v0, v1, v2, scratch);
+
+  // classifier features
+  if (a.feat) {
+    float* f = a.feat + (size_t)g * a.feat_gs + (size_t)b * a.F[g];
+    if (kind == KIND_SPECTRAL) {
+      if (t < C) f[t] = v2[t] * v0[t];  // mean_p(z*gate) == gate * mean_p(z)
+    } else if (kind == KIND_SPATIAL) {
+      const int ps = a.att_pool[g], hp = s.Hz / ps, wp = s.Wz / ps;
+      for (int i = t; i < C * hp * wp; i += 256) {
+        int c = i / (hp * wp), rem = i - c * hp * wp, ph = rem / wp, pw = rem - ph * wp;
+        float m = -3.4e38f;
+        for (int dy = 0; dy < ps; ++dy)
+          for (int dx = 0; dx < ps; ++dx) {
+            int p = (ph * ps + dy) * s.Wz + pw * ps + dx;
+            m = fmaxf(m, Z[p * ld + c] * v2[p]);
+          }
+        f[i] = m;
+      }
+    } else if (a.F[g] > 0) {
+      for (int i = t; i < C * s.HWz; i += 256) { int c = i / s.HWz, p = i - c * s.HWz; f[i] = Z[p * ld + c]; }
+    }
+  }
+  // gated map as conv tiles for the next layer (zero halo written here: the workspace is borrowed, not ours)
+  if (a.a_tl) {
+    const int W2 = s.Wz + 2, Qz = (s.Hz + 2) * W2, nch = C / 16;
+    T* dst = (T*)a.a_tl + (size_t)g * a.a_gs + ((size_t)b * a.a_nc + a.a_ch0) * Qz * 16;
+    for (int i = t; i < nch * Qz * 16; i += 256) {
+      int ch = i / (Qz * 16), rem = i - ch * Qz * 16, q = rem >> 4, pos = rem & 15;
+      int c = ch * 16 + tl_pos<T>(q, pos);
+      int hh = q / W2 - 1, ww = q % W2 - 1;
+      float v = 0.f;
+      if (hh >= 0 && hh < s.Hz && ww >= 0 && ww < s.Wz) { int p = hh * s.Wz + ww; v = Z[p * ld + c] * gate_of(kind, v2, p, c); }
+      dst[i] = Cvt<T>::to(v);
+    }
+  }
+  if (a.a_nchw) {
+    float* dst = a.a_nchw + (size_t)g * a.a_nchw_gs + (size_t)b * C * s.HWz;
+    for (int i = t; i < C * s.HWz; i += 256) {
+      int c = i / s.HWz, p = i - c * s.HWz;
+      dst[i] = Z[p * ld + c] * gate_of(kind, v2, p, c);
+    }
+  }
+}
+
+template <typename T>
+int launch_stage_fwd(const StageArgs& a, int G, hipStream_t st) {
+  size_t lds = stage_lds_floats(a, false) * 4;
+  if (lds > 160 * 1024) { dta_set_error("stage_fwd: %dx%dx%d patch needs %zu B of LDS", a.Hc, a.Wc, a.C, lds); return 1; }
+  hipFuncSetAttribute((const void*)k_stage_fwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(k_stage_fwd<T>, dim3(a.B, G), dim3(256), lds, st, a);
+  DTA_CHECK_LAUNCH("k_stage_fwd");
+  return 0;
+}
+template int launch_stage_fwd<float>(const StageArgs&, int, hipStream_t);
+template int launch_stage_fwd<bf16_t>(const StageArgs&, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// Backward of one stage for one patch.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const StageArgs& a = ba.f;
+  const StageGeom s = stage_geom(a);
+  const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = s.C, ld = s.ld;
+  const int kind = a.kind[g];
+  const int vmax = C > s.HWz ? C : s.HWz;
+  float* Z = sm;
+  float* R = Z + (size_t)s.HWz * ld;
+  float* D = R + (a.pool ? (size_t)s.HWc * ld : 0);
+  float* v0 = D + (size_t)s.HWz * ld;
+  float* v1 = v0 + vmax; float* v2 = v1 + vmax; float* v3 = v2 + vmax;
+  float* v4 = v3 + vmax; float* v5 = v4 + vmax; float* v6 = v5 + vmax; float* v7 = v6 + vmax;
+  float* scratch = v7 + vmax;
+  stage_forward(a, s, g, b, kind, Z, R, v0, v1, v2, scratch);
+
+  // D = incoming gradient wrt the gated map
+  if (ba.da) {
+    const float* da = ba.da + (size_t)g * ba.da_gs + (size_t)b * s.HWz * C;
+    for (int i = t; i < s.HWz * C; i += 256) { int p = i / C, c = i - p * C; D[p * ld + c] = da[i]; }
+  } else if (ba.da_nchw) {
+    const float* da = ba.da_nchw + (size_t)g * ba.da_nchw_gs + (size_t)b * C * s.HWz;
+    for (int i = t; i < s.HWz * C; i += 256) { int c = i / s.HWz, p = i - c * s.HWz; D[p * ld + c] = da[i]; }
+  } else {
+    for (int i = t; i < s.HWz * ld; i += 256) D[i] = 0.f;
+  }
+  __syncthreads();
+  const float* df = ba.dfeat ? ba.dfeat + (size_t)g * ba.dfeat_gs + (size_t)b * a.F[g] : nullptr;
+  float* vec = ba.vec ? ba.vec + (size_t)g * ba.vec_gs + (size_t)b * ba.vec_ld : nullptr;
+
+  if (kind == KIND_SPECTRAL) {
+    const float* a1 = a.att[g].p[4]; const float* a2 = a.att[g].p[5];  // dense [o][i] forms
+    const float inv = 1.f / (float)s.HWz;
+    if (df) {
+      for (int i = t; i < s.HWz * C; i += 256) { int p = i / C, c = i - p * C; D[p * ld + c] += df[c] * inv; }
+      __syncthreads();
+    }
+    // dg -> d2 (v3), dh -> d1 (v4), dp (v5)
+    colreduce(C, s.HWz, scratch, v3, 1.f, [&](int c, int i) { return D[i * ld + c] * Z[i * ld + c]; });
+    if (t < C) v3[t] = v3[t] * v2[t] * (1.f - v2[t]);
+    __syncthreads();
+    colreduce(C, C, scratch, v4, 1.f, [&](int i, int o) { return a2[o * C + i] * v3[o]; });
+    if (t < C) v4[t] = v1[t] > 0.f ? v4[t] : 0.f;
+    __syncthreads();
+    colreduce(C, C, scratch, v5, inv, [&](int i, int o) { return a1[o * C + i] * v4[o]; });
+    for (int i = t; i < s.HWz * C; i += 256) {
+      int p = i / C, c = i - p * C;
+      D[p * ld + c] = D[p * ld + c] * v2[c] + v5[c];
+    }
+    if (vec && t < C) { vec[t] = v3[t]; vec[C + t] = v1[t]; vec[2 * C + t] = v4[t]; vec[3 * C + t] = v0[t]; }
+    __syncthreads();
+  } else if (kind == KIND_SPATIAL) {
+    const float* wc = a.att[g].p[0];
+    const float* k1 = a.att[g].p[2];
+    const float* k2 = a.att[g].p[4];
+    const int k = a.att_k[g], r = k / 2, kk = k * k;
+    if (df) {
+      const int ps = a.att_pool[g], hp = s.Hz / ps, wp = s.Wz / ps;
+      for (int i = t; i < C * hp * wp; i += 256) {
+        int c = i / (hp * wp), rem = i - c * hp * wp, ph = rem / wp, pw = rem - ph * wp;
+        float m = -3.4e38f; int arg = 0;
+        for (int dy = 0; dy < ps; ++dy)
+          for (int dx = 0; dx < ps; ++dx) {
+            int p = (ph * ps + dy) * s.Wz + pw * ps + dx;
+            float v = Z[p * ld + c] * v2[p];
+            if (v > m) { m = v; arg = p; }
+          }
+        D[arg * ld + c] += df[i];
+      }
+      __syncthreads();
+    }
+    // ds -> d2 (v3) per pixel
+    for (int p = t; p < s.HWz; p += 256) {
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) acc += D[p * ld + c] * Z[p * ld + c];
+      v3[p] = acc * v2[p] * (1.f - v2[p]);
+    }
+    __syncthreads();
+    // dt1 = convT(d2, k2) masked by t1>0 -> d1 (v4)
+    for (int p = t; p < s.HWz; p += 256) {
+      int h = p / s.Wz, w = p - h * s.Wz;
+      float acc = 0.f;
+      for (int ky = 0; ky < k; ++ky) {
+        int hh = h - (ky - r);
+        if (hh < 0 || hh >= s.Hz) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          int ww = w - (kx - r);
+          if (ww >= 0 && ww < s.Wz) acc += k2[ky * k + kx] * v3[hh * s.Wz + ww];
+        }
+      }
+      v4[p] = v1[p] > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    // dm = convT(d1, k1) masked by m>0 -> dm0 (v5)
+    for (int p = t; p < s.HWz; p += 256) {
+      int h = p / s.Wz, w = p - h * s.Wz;
+      float acc = 0.f;
+      for (int ky = 0; ky < k; ++ky) {
+        int hh = h - (ky - r);
+        if (hh < 0 || hh >= s.Hz) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          int ww = w - (kx - r);
+          if (ww >= 0 && ww < s.Wz) acc += k1[ky * k + kx] * v4[hh * s.Wz + ww];
+        }
+      }
+      v5[p] = v0[p] > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    if (vec) {
+      // [dwc (C) | dbc | dK1 (kk) | db1 | dK2 (kk) | db2]
+      for (int i = t; i < C + 2 * kk + 3; i += 256) {
+        float acc = 0.f;
+        if (i < C) { for (int p = 0; p < s.HWz; ++p) acc += v5[p] * Z[p * ld + i]; }
+        else if (i == C) { for (int p = 0; p < s.HWz; ++p) acc += v5[p]; }
+        else if (i == C + 1 + kk) { for (int p = 0; p < s.HWz; ++p) acc += v4[p]; }
+        else if (i == C + 2 + 2 * kk) { for (int p = 0; p < s.HWz; ++p) acc += v3[p]; }
+        else {
+          const bool first = i < C + 1 + kk;
+          const int j = first ? i - (C + 1) : i - (C + 2 + kk);
+          const int ky = j / k - r, kx = j % k - r;
+          const float* src = first ? v0 : v1;   // conv input (m for K1, t1 for K2)
+          const float* dd = first ? v4 : v3;    // grad wrt the conv output
+          for (int h = 0; h < s.Hz; ++h) {
+            int hh = h + ky;
+            if (hh < 0 || hh >= s.Hz) continue;
+            for (int w = 0; w < s.Wz; ++w) {
+              int ww = w + kx;
+              if (ww >= 0 && ww < s.Wz) acc += src[hh * s.Wz + ww] * dd[h * s.Wz + w];
+            }
+          }
+        }
+        vec[i] = acc;
+      }
+    }
+    for (int i = t; i < s.HWz * C; i += 256) {
+      int p = i / C, c = i - p * C;
+      D[p * ld + c] = D[p * ld + c] * v2[p] + v5[p] * wc[c];
+    }
+    __syncthreads();
+  } else {
+    if (df && a.F[g] > 0) {
+      for (int i = t; i < C * s.HWz; i += 256) { int c = i / s.HWz, p = i - c * s.HWz; D[p * ld + c] += df[i]; }
+      __syncthreads();
+    }
+  }
+
+  // pool + ReLU backward, write dv and the per-patch BatchNorm-backward partial sums
+  float* dv = ba.dv + (size_t)g * ba.dv_gs + (size_t)b * s.HWc * C;
+  const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
+  const float* coef = a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr;
+  const int c = t % C, sl = t / C, nsl = 256 / C;
+  float s1 = 0.f, s2 = 0.f;
+  if (sl < nsl) {
+    for (int p = sl; p < s.HWc; p += nsl) {
+      float d;
+      if (a.pool) {
+        int h = p / s.Wc, w = p - h * s.Wc, hz = h >> 1, wz = w >> 1;
+        d = 0.f;
+        if (hz < s.Hz && wz < s.Wz) {
+          float zv = Z[(hz * s.Wz + wz) * ld + c];
+          const float* r0 = R + ((2 * hz) * s.Wc + 2 * wz) * ld + c;
+          int first = (r0[0] == zv) ? 0 : (r0[ld] == zv) ? 1 : (r0[s.Wc * ld] == zv) ? 2 : 3;
+          int me = (h & 1) * 2 + (w & 1);
+          if (me == first) d = D[(hz * s.Wz + wz) * ld + c];
+        }
+        if (a.relu && R[p * ld + c] <= 0.f) d = 0.f;
+      } else {
+        d = D[p * ld + c];
+        if (a.relu && Z[p * ld + c] <= 0.f) d = 0.f;
+      }
+      dv[(size_t)p * C + c] = d;
+      if (a.apply_bn) {
+        float xh = (y[(size_t)p * a.y_rs + c] - coef[c * 4 + 2]) * coef[c * 4 + 3];
+        s1 += d; s2 += d * xh;
+      }
+    }
+  }
+  if (ba.bnpart) {
+    __syncthreads();
+    scratch[t] = s1; scratch[256 + t] = s2;
+    __syncthreads();
+    if (t < C) {
+      float q1 = 0.f, q2 = 0.f;
+      for (int k2 = 0; k2 < nsl; ++k2) { q1 += scratch[k2 * C + t]; q2 += scratch[256 + k2 * C + t]; }
+      float* o = ba.bnpart + (size_t)g * ba.bnpart_gs + ((size_t)b * C + t) * 2;
+      o[0] = q1; o[1] = q2;
+    }
+  }
+}
+
+int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st) {
+  size_t lds = stage_lds_floats(a.f, true) * 4;
+  if (lds > 160 * 1024) { dta_set_error("stage_bwd: %dx%dx%d patch needs %zu B of LDS", a.f.Hc, a.f.Wc, a.f.C, lds); return 1; }
+  hipFuncSetAttribute((const void*)k_stage_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(k_stage_bwd, dim3(a.f.B, G), dim3(256), lds, st, a);
+  DTA_CHECK_LAUNCH("k_stage_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward: reduce per-patch partials -> dgamma, dbeta and the apply coefficients.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(BnBwdFinalizeArgs a) {
+  __shared__ double s1[256], s2[256];
+  const int g = blockIdx.x, t = threadIdx.x, C = a.C;
+  const int c = t % C, sl = t / C, nsl = 256 / C;
+  const float* part = a.bnpart + (size_t)g * a.bnpart_gs;
+  double q1 = 0, q2 = 0;
+  if (sl < nsl)
+    for (int b = sl; b < a.B; b += nsl) { q1 += part[((size_t)b * C + c) * 2]; q2 += part[((size_t)b * C + c) * 2 + 1]; }
+  s1[t] = q1; s2[t] = q2;
+  __syncthreads();
+  if (t < C) {
+    q1 = 0; q2 = 0;
+    for (int k = 0; k < nsl; ++k) { q1 += s1[k * C + t]; q2 += s2[k * C + t]; }
+    const float* coef = a.coef + (size_t)g * a.coef_gs;
+    float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
+    float A = a.gamma[g][t] * coef[t * 4 + 3];
+    double n = (double)a.B * a.HW;
+    bc[t * 4 + 0] = A;
+    bc[t * 4 + 1] = a.training ? (float)(q1 / n) : 0.f;
+    bc[t * 4 + 2] = a.training ? (float)(q2 / n) : 0.f;
+    bc[t * 4 + 3] = 0.f;
+    if (a.dbeta[g]) a.dbeta[g][t] = (float)q1;
+    if (a.dgamma[g]) a.dgamma[g][t] = (float)q2;
+    // conv bias feeds BN directly: with batch statistics its gradient is exactly zero
+    if (a.dconvbias[g]) a.dconvbias[g][t] = a.training ? 0.f : A * (float)q1;
+  }
+}
+
+int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, int G, hipStream_t st) {
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(G), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_bn_bwd_finalize");
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
+  const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = a.C;
+  const int W2 = a.W + 2, Q = (a.H + 2) * W2, HW = a.H * a.W, nch = C / 16;
+  const float* dv = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
+  const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs;
+  const float* coef = a.coef + (size_t)g * a.coef_gs;
+  const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
+  T* dst = (T*)a.dy_tl + (size_t)g * a.dy_gs + ((size_t)b * a.dy_nc + a.dy_ch0) * Q * 16;
+  for (int i = t; i < nch * Q * 16; i += 256) {
+    int ch = i / (Q * 16), rem = i - ch * Q * 16, q = rem >> 4, pos = rem & 15;
+    int c = ch * 16 + tl_pos<T>(q, pos);
+    int hh = q / W2 - 1, ww = q % W2 - 1;
+    float v = 0.f;
+    if (hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) {
+      int p = hh * a.W + ww;
+      float xh = (y[(size_t)p * a.y_rs + c] - coef[c * 4 + 2]) * coef[c * 4 + 3];
+      v = bc[c * 4 + 0] * (dv[(size_t)p * C + c] - bc[c * 4 + 1] - xh * bc[c * 4 + 2]);
+    }
+    dst[i] = Cvt<T>::to(v);
+  }
+}
+
+template <typename T>
+int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st) {
+  hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(a.B, G), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_bn_bwd_apply");
+  return 0;
+}
+template int launch_bn_bwd_apply<float>(const BnBwdApplyArgs&, int, hipStream_t);
+template int launch_bn_bwd_apply<bf16_t>(const BnBwdApplyArgs&, int, hipStream_t);
+
+}  // namespace dta

@@ -1,0 +1,99 @@
+/* dta_hip.h - C ABI of the MI355X-native (gfx950) Hang2020 hot path.
+ *
+ * This is the drop-in boundary.  The reference has no native layer: its boundary is the
+ * torch.nn.Module contract `cls(bands, classes)` / `forward(x)` of /root/reference/src/models/Hang2020.py
+ * plus autograd + torch.optim.Adam.  Each entry point below names the reference interface it replaces; the
+ * Python binding a reference maintainer adds is shown in INTEGRATION.md (ctypes, raw device pointers).
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every pointer is a DEVICE pointer unless said otherwise
+ *  - every buffer is allocated by the caller (PyTorch caching allocator) and only borrowed for the call;
+ *    the library allocates nothing on the device and keeps no state between calls
+ *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no internal syncs
+ *  - return 0 on success; otherwise non-zero and dta_last_error() describes the failure (thread-local text)
+ *  - parameters/gradients use the reference's torch layouts and state_dict shapes
+ */
+#ifndef DTA_HIP_H
+#define DTA_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTA_ABI_VERSION 1
+
+enum { DTA_F32 = 0, DTA_BF16 = 1 };               /* arithmetic type of the conv contractions */
+enum { DTA_NET_HANG2020 = 0, DTA_NET_SPECTRAL = 1, DTA_NET_SPATIAL = 2, DTA_NET_VANILLA = 3 };
+
+typedef struct dta_net_desc {
+  int batch, bands, height, width, classes;
+  int kind;          /* DTA_NET_* */
+  int dtype;         /* DTA_F32 (exact fp32 MFMA) or DTA_BF16 (bf16 MFMA inputs, fp32 accumulate) */
+  int training;      /* 1: BatchNorm batch statistics + running-stat update; 0: running statistics */
+  int heads_mask;    /* bit L-1 set: compute classifier head L (Hang2020.forward only needs head 3 = 4) */
+  float bn_momentum, bn_eps;
+} dta_net_desc;
+
+/* One spectral_network / spatial_network (Hang2020.py:170-240) or the vanilla_CNN conv stack (:33-53).
+ * att[L][*]: spectral_attention -> {attention_conv1.weight (C,C,K), .bias, attention_conv2.weight, .bias, 0, 0}
+ *            spatial_attention  -> {channel_pool.weight (1,C,1,1), .bias, attention_conv1.weight (1,1,k,k), .bias,
+ *                                   attention_conv2.weight, .bias};  vanilla: all null.
+ * fc_w/fc_b : classifier{L}.fc1 (vanilla: only index 2 = fc1). */
+typedef struct dta_subnet_params {
+  const float* conv_w[3]; const float* conv_b[3];
+  const float* bn_w[3]; const float* bn_b[3];
+  float* bn_rm[3]; float* bn_rv[3]; long long* bn_nbt[3];
+  const float* att[3][6];
+  const float* fc_w[3]; const float* fc_b[3];
+} dta_subnet_params;
+
+/* Gradient destinations, same shapes as the parameters; a null pointer skips that gradient. */
+typedef struct dta_subnet_grads {
+  float* conv_w[3]; float* conv_b[3];
+  float* bn_w[3]; float* bn_b[3];
+  float* att[3][6];
+  float* fc_w[3]; float* fc_b[3];
+} dta_subnet_grads;
+
+int dta_abi_version(void);
+const char* dta_last_error(void);
+
+/* Bytes of scratch + saved-activation workspace dta_net_forward/backward need for `d` (same blob for both;
+ * keep it alive and untouched between a training forward and its backward). */
+size_t dta_net_workspace_bytes(const dta_net_desc* d);
+
+/* Replaces Hang2020.forward (Hang2020.py:251-263), spectral_network.forward (:226-240), spatial_network.forward
+ * (:190-204), vanilla_CNN.forward (:45-53) incl. every conv_module / attention / Classifier inside.
+ *  nets   : 2 entries {spectral, spatial} for DTA_NET_HANG2020, otherwise 1
+ *  alpha  : float64 scalar (Hang2020.alpha), HANG2020 only
+ *  x      : float32 NCHW contiguous [batch][bands][height][width]
+ *  scores : [net][L] -> float32 [batch][classes] outputs of the classifier heads selected by heads_mask
+ *  joint  : HANG2020: sigmoid(alpha)-blended scores; VANILLA: fc1 output; else unused (may be null) */
+int dta_net_forward(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const float* x,
+                    void* workspace, float* const scores[2][3], float* joint, void* stream);
+
+/* Replaces autograd's backward through the module above.  `workspace` is the blob the matching training (or eval)
+ * forward filled.  dscores[net][L] / djoint: gradients wrt the forward outputs (null = that output unused; for
+ * HANG2020 pass djoint, for the others dscores).  Writes (overwrites) every non-null gradient in `grads`.
+ * phases: bit 0 = everything except the first conv's weight gradient, bit 1 = the first conv's weight gradient
+ * (the largest and last piece); 3 = all.  Two calls (1, then 2) let the caller start the gradient all-reduce of
+ * the rest (RCCL on a side stream) while the first conv's weight gradient is still being computed. */
+int dta_net_backward(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, void* workspace,
+                     const float* const dscores[2][3], const float* djoint, const dta_subnet_grads* grads,
+                     double* dalpha, int phases, void* stream);
+
+/* Replaces F.cross_entropy(logits, y, weight=w) forward+backward (src/main.py:78, multi_stage.py:285).
+ * weight may be null (= ones, metadata.py:61).  scratch: batch+1 floats.  dlogits may be null. */
+int dta_weighted_ce(const float* logits, const long long* labels, const float* weight, int batch, int classes,
+                    float* loss, float* dlogits, float* scratch, void* stream);
+
+/* Replaces torch.optim.Adam(params, lr).step() (src/main.py:136) over one flat fp32 buffer plus the float64
+ * alpha (alpha_* may be null).  step = 1-based step count; grads are multiplied by grad_scale first. */
+int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double* alpha_p, const double* alpha_g,
+                  double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
+                  float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
