@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py - patches/sec of the full Hang2020 train step (forward + weighted CE + backward + Adam, + RCCL gradient
+all-reduce when >1 GPU) at bands=369, 11x11, 200 classes (BASELINE.json metric / configs[1], configs[2]).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 50 --warmup 10
+
+One process per GPU; per-GPU batch is fixed (weak scaling; 1024 per GPU = 8192 global on 8 GPUs).  Synthetic
+patches (U[0,1), like the reference's min-max-scaled crops) are resident in HBM before the timed region.  Rank 0
+prints ONE JSON line.  `roofline` times the dominant kernel with HIP events recorded on its own stream inside the
+timed loop; `cpu_baseline` times the torch-eager port of the reference step (oracle/hang2020_torch.py) on the
+host cores of the same box (rank 0, N=1 only, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+BANDS, HW, CLASSES = 369, 11, 200
+FLOP_PER_PATCH_STEP = 154_486_824       # torch FlopCounterMode on the reference, fwd+bwd
+BYTES_PER_PATCH_STEP = 358_000          # compulsory HBM bytes per patch (fp32 input read twice)
+CONV1_FLOP_PER_PATCH = 2 * 25_717_824   # both branches' first conv, forward (== its weight-gradient FLOPs)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024, help="patches per GPU per step")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--site", default="wgrad0", help="kernel site timed for the roofline object")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=128)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-overlap", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, seconds):
+    """Reference step (stock torch ops + autograd + Adam) on the host cores; bounded sample."""
+    import numpy as np
+    from oracle import hang2020_np as O
+    from oracle import hang2020_torch as TP
+    from oracle import prng
+    threads = torch.get_num_threads()
+    p = TP.to_tensors(O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=1, randomize_bn=False))
+    x = torch.from_numpy(prng.uniform01(0, 1, (batch, BANDS, HW, HW)))
+    y = torch.from_numpy(prng.randint(0, 2, (batch,), CLASSES))
+    step = TP.TrainStep(p, lr=1e-4, loss_weight=torch.ones(CLASSES))
+    for _ in range(2):
+        step(x, y)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(x, y)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {"value": round(n * batch / el, 1), "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"{n} train steps of batch {batch} (fp32, torch {torch.__version__} eager on host CPU, "
+                      f"{threads} threads), {el:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd import _lib
+    from deeptreeattention_amd.engine import FusedTrainer
+
+    torch.manual_seed(1234)                      # same initial weights on every rank (then broadcast anyway)
+    model = H.Hang2020(BANDS, CLASSES, precision=a.precision).to(dev)
+    model.train()
+    trainer = FusedTrainer(model, lr=1e-4, loss_weight=torch.ones(CLASSES), overlap_comm=not a.no_overlap)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)                   # each rank owns a different shard of the global batch
+    nb = 2
+    xs = [torch.rand(a.batch, BANDS, HW, HW, device=dev, generator=g) for _ in range(nb)]
+    ys = [torch.randint(0, CLASSES, (a.batch,), device=dev, generator=g) for _ in range(nb)]
+
+    L = _lib.lib()
+    sites = {"fwd0": _lib.SITE_CONV_FWD, "wgrad0": _lib.SITE_CONV_WGRAD, "fwd1": _lib.SITE_CONV_FWD + 1,
+             "fwd2": _lib.SITE_CONV_FWD + 2, "wgrad1": _lib.SITE_CONV_WGRAD + 1, "wgrad2": _lib.SITE_CONV_WGRAD + 2,
+             "dgrad1": _lib.SITE_CONV_DGRAD + 1, "dgrad2": _lib.SITE_CONV_DGRAD + 2}
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(a.warmup):
+        trainer.train_step(xs[i % nb], ys[i % nb])
+    torch.cuda.synchronize()
+    barrier()
+    if rank == 0:
+        L.dta_profile_enable(sites[a.site])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = trainer.train_step(xs[i % nb], ys[i % nb])
+    torch.cuda.synchronize()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        buf = (C.c_float * 512)()
+        n = L.dta_profile_collect(buf, 512)
+        L.dta_profile_enable(-1)
+        roof = None
+        if n > 0:
+            avg_ms = sum(buf[i] for i in range(n)) / n
+            flops = CONV1_FLOP_PER_PATCH * a.batch if a.site in ("fwd0", "wgrad0") else None
+            if flops:
+                ach = flops / (avg_ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": {"fwd0": "k_conv3x3 (conv1, both branches)",
+                                                    "wgrad0": "k_conv_wgrad (conv1, both branches)"}[a.site],
+                        "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_TFLOPS[a.precision], 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4), "launches": n,
+                        "algorithmic_flop_per_launch": flops}
+        total = a.steps * a.batch * world
+        value = total / el
+        out = {
+            "metric": "patches/sec (train step) Hang2020 369-band 11x11",
+            "value": round(value, 1), "unit": "patches/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": "Hang2020 spectral+spatial attention train step (fwd + weighted CE + bwd + Adam"
+                                   + (" + RCCL grad all-reduce" if world > 1 else "") + "), bands=369 11x11 classes=200",
+                       "per_gpu_batch": a.batch, "global_batch": a.batch * world,
+                       "parallelism": f"dp{world}", "overlap_comm": bool(world > 1 and not a.no_overlap)},
+            "achieved_tflops_step": round(value * FLOP_PER_PATCH_STEP / 1e12, 2),
+            "achieved_hbm_gbs_algorithmic": round(value * BYTES_PER_PATCH_STEP / 1e9, 1),
+            "final_loss": round(final_loss, 5),
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

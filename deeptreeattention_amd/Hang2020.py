@@ -249,18 +249,24 @@ class _NetFn(torch.autograd.Function):
                         keep.append(g)
                         table[0][Lv] = g.data_ptr()
                         used_heads |= 1 << Lv
+        # one zero-filled flat buffer for all gradients (the C ABI accumulates split-K partials into them)
+        wanted = []
+        q = pos
+        for kind, mod, names in subnets:
+            for j, n in enumerate(names):
+                head = int(n.split("classifier")[1][0]) - 1 if "classifier" in n else None
+                if head is None or (used_heads & (1 << head)):
+                    wanted.append(q + j)          # heads unused by the loss keep grad None (as in torch)
+            q += len(names)
+        flat = torch.zeros(sum(params[i].numel() for i in wanted), dtype=torch.float32, device=ws.device)
+        off = 0
+        for i in wanted:
+            k = params[i].numel()
+            grads[i] = flat[off:off + k].view(params[i].shape)
+            off += k
         for i, (kind, mod, names) in enumerate(subnets):
             tensors = {n: params[pos + j] for j, n in enumerate(names)}
-            gt = {}
-            for j, n in enumerate(names):
-                head = None
-                if "classifier" in n:
-                    head = int(n.split("classifier")[1][0]) - 1
-                if head is not None and not (used_heads & (1 << head)):
-                    continue                      # head unused by the loss: gradient stays None (as in torch)
-                g = torch.empty_like(params[pos + j])
-                gt[n] = g
-                grads[pos + j] = g
+            gt = {n: grads[pos + j] for j, n in enumerate(names) if grads[pos + j] is not None}
             pos += len(names)
             for Lv in (1, 2, 3):
                 bn = _get(mod, f"conv{Lv}.bn1")

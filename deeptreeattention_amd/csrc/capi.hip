@@ -19,6 +19,20 @@ void dta_set_error(const char* fmt, ...) {
 
 namespace {
 
+// Optional HIP-event timing of one launch site (bench.py's roofline leg): events are recorded on the same
+// stream as the kernel, immediately before and after its launch.  Host-side state only; off by default.
+struct Prof {
+  int site = -1, n = 0;
+  bool created = false;
+  hipEvent_t ev[512][2];
+} g_prof;
+inline void prof_begin(int site, hipStream_t st) {
+  if (site == g_prof.site && g_prof.n < 512) hipEventRecord(g_prof.ev[g_prof.n][0], st);
+}
+inline void prof_end(int site, hipStream_t st) {
+  if (site == g_prof.site && g_prof.n < 512) { hipEventRecord(g_prof.ev[g_prof.n][1], st); ++g_prof.n; }
+}
+
 constexpr int CH[3] = {32, 64, 128};
 constexpr int SPEC_K[3] = {3, 5, 7};   // reference Hang2020.py:136-141
 constexpr int SPAT_K[3] = {7, 5, 3};   // :77-85
@@ -41,6 +55,7 @@ struct Plan {
   int S[3], cgroups[3], CpadW[3];
   size_t x_tl, wp[3], wd[3], y[3], stats[3], coef[3], a_tl[3], feat[3], attpk[2][3], scores[2][3];
   size_t dsc[2], dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart, rowtmp;
+  size_t scores_all, scores_bytes, dfeat_all, dfeat_bytes;
   size_t total;
 };
 
@@ -109,15 +124,18 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     p->coef[L] = c.take((size_t)G * CH[L] * 4 * 4);
     if (L < 2) p->a_tl[L] = c.take((size_t)G * B * (CH[L] / 16) * p->Qin[L + 1] * 16 * e);
     p->feat[L] = c.take((size_t)G * B * (p->Fmax[L] > 0 ? p->Fmax[L] : 1) * 4);
-    for (int g = 0; g < G; ++g) {
-      p->attpk[g][L] = c.take((size_t)4 * CH[L] * CH[L] * 4);
-      p->scores[g][L] = c.take((size_t)B * p->classes * 4);
-    }
+    for (int g = 0; g < G; ++g) p->attpk[g][L] = c.take((size_t)4 * CH[L] * CH[L] * 4);
   }
+  p->scores_all = c.off;
+  for (int g = 0; g < G; ++g)
+    for (int L = 0; L < 3; ++L) p->scores[g][L] = c.take((size_t)B * p->classes * 4);
+  p->scores_bytes = c.off - p->scores_all;
   // backward
   for (int g = 0; g < 2; ++g) p->dsc[g] = c.take((size_t)B * p->classes * 4);
+  p->dfeat_all = c.off;
+  for (int L = 0; L < 3; ++L) p->dfeat[L] = c.take((size_t)G * B * (p->Fmax[L] > 0 ? p->Fmax[L] : 1) * 4);
+  p->dfeat_bytes = c.off - p->dfeat_all;
   for (int L = 0; L < 3; ++L) {
-    p->dfeat[L] = c.take((size_t)G * B * (p->Fmax[L] > 0 ? p->Fmax[L] : 1) * 4);
     p->dv[L] = c.take((size_t)G * B * p->HWc[L] * CH[L] * 4);
     p->bnpart[L] = c.take((size_t)G * B * CH[L] * 2 * 4);
     p->bcoef[L] = c.take((size_t)G * CH[L] * 4 * 4);
@@ -181,6 +199,7 @@ template <typename T>
 int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const float* x,
               void* ws, float* const scores[2][3], float* joint, hipStream_t st) {
   const int G = p.G, B = p.B;
+  if (d->heads_mask) hipMemsetAsync(at<char>(ws, p.scores_all), 0, p.scores_bytes, st);   // split-K GEMM targets
   if (launch_pack_input<T>(x, at<char>(ws, p.x_tl), B, p.bands, p.H, p.W, st)) return 1;
   for (int L = 0; L < 3; ++L) {
     const int C = CH[L];
@@ -208,7 +227,9 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     if (L == 0) { ca.y_gs = 0; ca.y_rs = Nconv; } else { ca.y_gs = (size_t)B * p.HWc[L] * C; ca.y_rs = C; }
     ca.stats = d->training ? at<float>(ws, p.stats[L]) : nullptr;
     ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
+    prof_begin(DTA_SITE_CONV_FWD + L, st);
     if (launch_conv3x3<T>(ca, launchG, st)) return 1;
+    prof_end(DTA_SITE_CONV_FWD + L, st);
     // BatchNorm statistics -> per-channel scale/shift
     BnFinalizeArgs bf;
     memset(&bf, 0, sizeof(bf));
@@ -222,7 +243,9 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     if (launch_bn_finalize(bf, G, st)) return 1;
     // BN + ReLU + pool + attention
     StageArgs sa = stage_args(p, d, nets, ws, L);
+    prof_begin(DTA_SITE_STAGE_FWD + L, st);
     if (launch_stage_fwd<T>(sa, G, st)) return 1;
+    prof_end(DTA_SITE_STAGE_FWD + L, st);
     // classifier heads
     if (d->heads_mask & (1 << L)) {
       for (int g = 0; g < G; ++g) {
@@ -232,11 +255,16 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
         memset(&ga, 0, sizeof(ga));
         ga.A = at<float>(ws, p.feat[L]) + (size_t)g * sa.feat_gs; ga.sa_m = F; ga.sa_k = 1;
         ga.Bm = nets[g].fc_w[L]; ga.sb_k = 1; ga.sb_n = F;
-        float* out = (scores && scores[g][L]) ? scores[g][L] : at<float>(ws, p.scores[g][L]);
-        if (d->kind == DTA_NET_VANILLA && joint) out = joint;
+        float* out = at<float>(ws, p.scores[g][L]);
+        ga.M = B; ga.N = p.classes; ga.K = F; ga.ksplit = gemm_auto_ksplit(B, p.classes, F); ga.accumulate = 0;
+        float* user = (scores && scores[g][L]) ? scores[g][L] : nullptr;
+        if (d->kind == DTA_NET_VANILLA && joint) user = joint;
+        if (user) {
+          out = user;
+          if (ga.ksplit > 1) hipMemsetAsync(user, 0, (size_t)B * p.classes * 4, st);
+        }
         ga.C = out; ga.sc_m = p.classes; ga.sc_n = 1;
         ga.bias = nets[g].fc_b[L];
-        ga.M = B; ga.N = p.classes; ga.K = F; ga.ksplit = 1; ga.accumulate = 0;
         if (launch_gemm(ga, st)) return 1;
       }
     }
@@ -270,7 +298,9 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
   wa.NCy = Nconv / 16; wa.ych0 = 0;
   wa.partial = at<float>(ws, p.wpart);
   wa.B = B; wa.H = p.Hc[L]; wa.W = p.Wc[L]; wa.Q = p.Qin[L]; wa.N = Nconv; wa.Cpad = p.CpadW[L]; wa.S = p.S[L];
+  prof_begin(DTA_SITE_CONV_WGRAD + L, st);
   if (launch_conv_wgrad<T>(wa, launchG, st)) return 1;
+  prof_end(DTA_SITE_CONV_WGRAD + L, st);
   WgradReduceArgs wr;
   memset(&wr, 0, sizeof(wr));
   wr.partial = wa.partial; wr.G = launchG; wr.S = p.S[L]; wr.N = Nconv; wr.C = p.Cin[L]; wr.Cpad = p.CpadW[L];
@@ -309,40 +339,35 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     dsc[0][2] = djoint ? djoint : dsc[0][2];
   }
 
+  hipMemsetAsync(at<char>(ws, p.dfeat_all), 0, p.dfeat_bytes, st);   // split-K GEMM targets
   for (int L = 2; L >= 0; --L) {
     const int C = CH[L];
     const int Nconv = L == 0 ? 32 * G : C;
     const int launchG = L == 0 ? 1 : G;
     StageArgs sa = stage_args(p, d, nets, ws, L);
     const size_t fgs = sa.feat_gs;
-    // ---- classifier backward -> dfeat, dW, db ----
-    hipMemsetAsync(at<char>(ws, p.dfeat[L]), 0, (size_t)G * fgs * 4, st);
+    // ---- classifier backward -> dfeat, dW, db (gradient buffers arrive zeroed: split-K accumulates) ----
+    bool any_head = false;
     for (int g = 0; g < G; ++g) {
       const int F = p.F[g][L];
       if (!dsc[g][L] || F == 0) continue;
+      any_head = true;
       GemmArgs ga;
       memset(&ga, 0, sizeof(ga));
       ga.A = dsc[g][L]; ga.sa_m = p.classes; ga.sa_k = 1;
       ga.Bm = nets[g].fc_w[L]; ga.sb_k = F; ga.sb_n = 1;
       ga.C = at<float>(ws, p.dfeat[L]) + (size_t)g * fgs; ga.sc_m = F; ga.sc_n = 1;
-      ga.M = B; ga.N = F; ga.K = p.classes; ga.ksplit = 1;
+      ga.M = B; ga.N = F; ga.K = p.classes; ga.ksplit = gemm_auto_ksplit(B, F, p.classes);
       if (launch_gemm(ga, st)) return 1;
       if (grads[g].fc_w[L]) {
-        hipMemsetAsync(grads[g].fc_w[L], 0, (size_t)p.classes * F * 4, st);
         memset(&ga, 0, sizeof(ga));
         ga.A = dsc[g][L]; ga.sa_m = 1; ga.sa_k = p.classes;
         ga.Bm = at<float>(ws, p.feat[L]) + (size_t)g * fgs; ga.sb_k = F; ga.sb_n = 1;
         ga.C = grads[g].fc_w[L]; ga.sc_m = F; ga.sc_n = 1;
         ga.M = p.classes; ga.N = F; ga.K = B;
-        ga.ksplit = B >= 512 ? 8 : (B >= 64 ? 2 : 1);
+        ga.ksplit = gemm_auto_ksplit(p.classes, F, B);
+        ga.rowsum_out = grads[g].fc_b[L];      // db[n] = sum_b dscore[b][n]
         if (launch_gemm(ga, st)) return 1;
-      }
-      if (grads[g].fc_b[L]) {
-        ColsumArgs cs;
-        memset(&cs, 0, sizeof(cs));
-        cs.A = dsc[g][L]; cs.rows = B; cs.cols = p.classes; cs.lda = p.classes;
-        cs.nseg = 1; cs.off[0] = 0; cs.len[0] = p.classes; cs.dst[0] = grads[g].fc_b[L]; cs.dst_stride[0] = 1;
-        if (launch_colsum_scatter(cs, st)) return 1;
       }
     }
     // ---- attention + pool + ReLU backward ----
@@ -350,11 +375,13 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     memset(&sb, 0, sizeof(sb));
     sb.f = sa;
     if (L < 2) { sb.da = at<float>(ws, p.da[L + 1]); sb.da_gs = (size_t)B * p.HWz[L] * C; }
-    sb.dfeat = at<float>(ws, p.dfeat[L]); sb.dfeat_gs = fgs;
+    sb.dfeat = any_head ? at<float>(ws, p.dfeat[L]) : nullptr; sb.dfeat_gs = fgs;
     sb.dv = at<float>(ws, p.dv[L]); sb.dv_gs = (size_t)B * p.HWc[L] * C;
     sb.bnpart = at<float>(ws, p.bnpart[L]); sb.bnpart_gs = (size_t)B * C * 2;
     sb.vec = at<float>(ws, p.vec[L]); sb.vec_gs = (size_t)B * p.vec_ld[L]; sb.vec_ld = p.vec_ld[L];
+    prof_begin(DTA_SITE_STAGE_BWD + L, st);
     if (launch_stage_bwd(sb, G, st)) return 1;
+    prof_end(DTA_SITE_STAGE_BWD + L, st);
     // ---- attention parameter gradients (batch reductions) ----
     for (int g = 0; g < G; ++g) {
       const float* vec = at<float>(ws, p.vec[L]) + (size_t)g * sb.vec_gs;
@@ -364,21 +391,15 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
         for (int which = 0; which < 2; ++which) {   // 0: attention_conv1 (d1 x pooled), 1: attention_conv2 (d2 x h)
           float* gw = grads[g].att[L][which * 2];
           if (!gw) continue;
-          hipMemsetAsync(gw, 0, (size_t)C * C * K * 4, st);
           GemmArgs ga;
           memset(&ga, 0, sizeof(ga));
           ga.A = vec + (which ? 0 : 2 * C); ga.sa_m = 1; ga.sa_k = ld;
           ga.Bm = vec + (which ? C : 3 * C); ga.sb_k = ld; ga.sb_n = 1;
-          ga.C = gw + K / 2; ga.sc_m = (long)C * K; ga.sc_n = K;
-          ga.M = C; ga.N = C; ga.K = B; ga.ksplit = B >= 512 ? 8 : (B >= 64 ? 2 : 1);
+          ga.C = gw + K / 2; ga.sc_m = (long)C * K; ga.sc_n = K;    // only the centre tap is live
+          ga.M = C; ga.N = C; ga.K = B; ga.ksplit = gemm_auto_ksplit(C, C, B);
+          ga.rowsum_out = grads[g].att[L][which * 2 + 1];            // bias gradient = sum_b d{1,2}
           if (launch_gemm(ga, st)) return 1;
         }
-        ColsumArgs cs;
-        memset(&cs, 0, sizeof(cs));
-        cs.A = vec; cs.rows = B; cs.cols = 3 * C; cs.lda = ld; cs.nseg = 2;
-        cs.off[0] = 0; cs.len[0] = C; cs.dst[0] = grads[g].att[L][3]; cs.dst_stride[0] = 1;       // conv2.bias <- d2
-        cs.off[1] = 2 * C; cs.len[1] = C; cs.dst[1] = grads[g].att[L][1]; cs.dst_stride[1] = 1;   // conv1.bias <- d1
-        if (launch_colsum_scatter(cs, st)) return 1;
       } else if (p.kinds[g] == KIND_SPATIAL) {
         const int kk = SPAT_K[L] * SPAT_K[L];
         ColsumArgs cs;
@@ -425,7 +446,9 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       ca.x_tl = ap.dy_tl; ca.x_gs = ap.dy_gs; ca.wp = at<char>(ws, p.wd[L]);
       ca.y = at<float>(ws, p.da[L]); ca.y_gs = (size_t)B * p.HWc[L] * CH[L - 1]; ca.y_rs = CH[L - 1];
       ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = C / 16; ca.N = CH[L - 1]; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
+      prof_begin(DTA_SITE_CONV_DGRAD + L, st);
       if (launch_conv3x3<T>(ca, G, st)) return 1;
+      prof_end(DTA_SITE_CONV_DGRAD + L, st);
     }
   }
   return 0;
@@ -436,6 +459,31 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
 extern "C" {
 
 int dta_abi_version(void) { return DTA_ABI_VERSION; }
+
+int dta_profile_enable(int site) {
+  if (site >= 0 && !g_prof.created) {
+    for (int i = 0; i < 512; ++i)
+      for (int j = 0; j < 2; ++j)
+        if (hipEventCreate(&g_prof.ev[i][j]) != hipSuccess) { dta_set_error("hipEventCreate failed"); return 1; }
+    g_prof.created = true;
+  }
+  g_prof.site = site;
+  g_prof.n = 0;
+  return 0;
+}
+
+int dta_profile_collect(float* ms, int max) {
+  int n = g_prof.n < max ? g_prof.n : max;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_prof.ev[i][1]) != hipSuccess ||
+        hipEventElapsedTime(&ms[i], g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) {
+      dta_set_error("profile event readback failed");
+      return -1;
+    }
+  }
+  g_prof.n = 0;
+  return n;
+}
 const char* dta_last_error(void) { return g_err; }
 
 size_t dta_net_workspace_bytes(const dta_net_desc* d) {

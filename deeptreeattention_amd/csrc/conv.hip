@@ -16,24 +16,29 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x, T* __restrict__ out, int B, int C,
                                                     int H, int W, int NC, int CG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s = (float*)smem;  // [CG*16][HW]
   const int HW = H * W, Q = (H + 2) * (W + 2);
+  float* s = (float*)smem;                 // [CG*16][HW]
+  int* lut = (int*)(s + CG * 16 * HW);     // [Q] pixel index of haloed-grid row q, or -1 on the halo
   const int b = blockIdx.x, chunk0 = blockIdx.y * CG;
   const int nch = min(CG, NC - chunk0);
   const int c0 = chunk0 * 16;
   const int creal = max(0, min(nch * 16, C - c0));
   const float* src = x + ((size_t)b * C + c0) * HW;
+  for (int q = threadIdx.x; q < Q; q += 256) {
+    int hh = q / (W + 2) - 1, ww = q % (W + 2) - 1;
+    lut[q] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? hh * W + ww : -1;
+  }
   for (int i = threadIdx.x; i < nch * 16 * HW; i += 256) s[i] = (i < creal * HW) ? src[i] : 0.f;
   __syncthreads();
-  T* dst = out + ((size_t)b * NC + chunk0) * Q * 16;
-  for (int i = threadIdx.x; i < nch * Q * 16; i += 256) {
-    int ch = i / (Q * 16), rem = i - ch * Q * 16;
-    int q = rem >> 4, pos = rem & 15;
-    int c16 = tl_pos<T>(q, pos);  // the swizzle is an involution
-    int hh = q / (W + 2) - 1, ww = q % (W + 2) - 1;
-    float v = 0.f;
-    if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = s[(ch * 16 + c16) * HW + hh * W + ww];
-    dst[i] = Cvt<T>::to(v);
+  for (int ch = 0; ch < nch; ++ch) {
+    T* dst = out + ((size_t)b * NC + chunk0 + ch) * Q * 16;
+    const float* sc = s + ch * 16 * HW;
+    for (int r = threadIdx.x; r < Q * 16; r += 256) {
+      int q = r >> 4, pos = r & 15;
+      int c16 = tl_pos<T>(q, pos);  // the swizzle is an involution
+      int p = lut[q];
+      dst[r] = Cvt<T>::to(p >= 0 ? sc[c16 * HW + p] : 0.f);
+    }
   }
 }
 
@@ -42,7 +47,7 @@ int launch_pack_input(const float* x, void* out, int B, int C, int H, int W, hip
   int NC = (C + 15) / 16, HW = H * W;
   int CG = 4;
   while (CG > 1 && (size_t)CG * 16 * HW * 4 > 65536) CG >>= 1;
-  size_t lds = (size_t)CG * 16 * HW * 4;
+  size_t lds = (size_t)CG * 16 * HW * 4 + (size_t)(H + 2) * (W + 2) * 4;
   if (lds > 160 * 1024) { dta_set_error("pack_input: %dx%d patch does not fit LDS", H, W); return 1; }
   dim3 grid(B, (NC + CG - 1) / CG);
   hipLaunchKernelGGL(k_pack_input<T>, grid, dim3(256), lds, st, x, (T*)out, B, C, H, W, NC, CG);

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float rsum = 0.f;   // row sums of A over this block's K range (bias gradients), first column-tile only
   for (int k0 = kbeg; k0 < kend; k0 += GK) {
     __syncthreads();
     for (int i = t; i < 64 * GK; i += 256) {
@@ -38,6 +39,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
       Bs[k][n] = v;
     }
     __syncthreads();
+    if (a.rowsum_out && blockIdx.y == 0 && t < 64) {
+#pragma unroll
+      for (int k = 0; k < GK; ++k) rsum += As[t][k];
+    }
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 2) {
       float av = As[wm + (lane & 31)][kk + (lane >> 5)];
@@ -45,6 +50,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
   }
+  if (a.rowsum_out && blockIdx.y == 0 && t < 64 && m0 + t < a.M) atomicAdd(a.rowsum_out + m0 + t, rsum);
   const int n = n0 + wn + (lane & 31);
   if (n >= a.N) return;
   const float bias = (a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
@@ -60,6 +66,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   }
 }
 
+int gemm_auto_ksplit(int M, int N, int K) {
+  int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  int ks = (256 + tiles - 1) / tiles;
+  int kmax = (K + 63) / 64;
+  if (ks > kmax) ks = kmax;
+  return ks < 1 ? 1 : ks;
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   dim3 grid((a.M + 63) / 64, (a.N + 63) / 64, a.ksplit);
   hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, a);
@@ -70,16 +84,26 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // Column sums over the batch with a segment table: column j of A[rows][lda] lands in dst[seg][j - off].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_colsum_scatter(ColsumArgs a) {
-  __shared__ float sc[256];
-  const int t = threadIdx.x, j = blockIdx.x * 64 + (t & 63), sl = t >> 6;
-  float acc = 0.f;
-  if (j < a.cols)
-    for (int r = sl; r < a.rows; r += 4) acc += a.A[(size_t)r * a.lda + j];
-  sc[t] = acc;
+__global__ __launch_bounds__(1024) void k_colsum_scatter(ColsumArgs a) {
+  __shared__ float sc[32][33];
+  const int t = threadIdx.x, jl = t & 31, sl = t >> 5, j = blockIdx.x * 32 + jl;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  if (j < a.cols) {
+    int r = sl;
+    for (; r + 96 < a.rows; r += 128) {
+      acc0 += a.A[(size_t)r * a.lda + j];
+      acc1 += a.A[(size_t)(r + 32) * a.lda + j];
+      acc2 += a.A[(size_t)(r + 64) * a.lda + j];
+      acc3 += a.A[(size_t)(r + 96) * a.lda + j];
+    }
+    for (; r < a.rows; r += 32) acc0 += a.A[(size_t)r * a.lda + j];
+  }
+  sc[sl][jl] = (acc0 + acc1) + (acc2 + acc3);
   __syncthreads();
-  if (t < 64 && j < a.cols) {
-    float v = sc[t] + sc[64 + t] + sc[128 + t] + sc[192 + t];
+  if (t < 32 && j < a.cols) {
+    float v = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) v += sc[s][t];
     for (int s = 0; s < a.nseg; ++s)
       if (j >= a.off[s] && j < a.off[s] + a.len[s]) {
         if (a.dst[s]) a.dst[s][(size_t)(j - a.off[s]) * a.dst_stride[s]] = v;
@@ -89,7 +113,7 @@ __global__ __launch_bounds__(256) void k_colsum_scatter(ColsumArgs a) {
 }
 
 int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_colsum_scatter, dim3((a.cols + 63) / 64), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_colsum_scatter, dim3((a.cols + 31) / 32), dim3(1024), 0, st, a);
   DTA_CHECK_LAUNCH("k_colsum_scatter");
   return 0;
 }

@@ -106,9 +106,11 @@ struct GemmArgs {
   const float* Bm; long sb_k, sb_n;
   float* C; long sc_m, sc_n;
   const float* bias;
-  int M, N, K, ksplit, accumulate;
+  float* rowsum_out;                  // optional: rowsum_out[m] += sum_k A(m,k) (atomic; must be pre-zeroed)
+  int M, N, K, ksplit, accumulate;    // ksplit > 1: atomic accumulation into a pre-zeroed C
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
+int gemm_auto_ksplit(int M, int N, int K);
 struct ColsumArgs {
   const float* A; int rows, cols; long lda;
   int nseg; int off[8], len[8]; float* dst[8]; long dst_stride[8];

@@ -493,36 +493,48 @@ int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // BatchNorm backward: reduce per-patch partials -> dgamma, dbeta and the apply coefficients.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(BnBwdFinalizeArgs a) {
-  __shared__ double s1[256], s2[256];
-  const int g = blockIdx.x, t = threadIdx.x, C = a.C;
-  const int c = t % C, sl = t / C, nsl = 256 / C;
+__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(BnBwdFinalizeArgs a) {
+  // block = 32 channels x 32 batch slices; grid = (C/32, G)
+  __shared__ float s1[32][33], s2[32][33];
+  const int g = blockIdx.y, t = threadIdx.x, C = a.C;
+  const int cl = t & 31, sl = t >> 5, c = blockIdx.x * 32 + cl;
   const float* part = a.bnpart + (size_t)g * a.bnpart_gs;
-  double q1 = 0, q2 = 0;
-  if (sl < nsl)
-    for (int b = sl; b < a.B; b += nsl) { q1 += part[((size_t)b * C + c) * 2]; q2 += part[((size_t)b * C + c) * 2 + 1]; }
-  s1[t] = q1; s2[t] = q2;
+  float q1 = 0.f, q2 = 0.f, r1 = 0.f, r2 = 0.f;
+  if (c < C) {
+    int b = sl;
+    for (; b + 32 < a.B; b += 64) {
+      const float2 v0 = *reinterpret_cast<const float2*>(part + ((size_t)b * C + c) * 2);
+      const float2 v1 = *reinterpret_cast<const float2*>(part + ((size_t)(b + 32) * C + c) * 2);
+      q1 += v0.x; q2 += v0.y; r1 += v1.x; r2 += v1.y;
+    }
+    for (; b < a.B; b += 32) {
+      const float2 v0 = *reinterpret_cast<const float2*>(part + ((size_t)b * C + c) * 2);
+      q1 += v0.x; q2 += v0.y;
+    }
+  }
+  s1[sl][cl] = q1 + r1; s2[sl][cl] = q2 + r2;
   __syncthreads();
-  if (t < C) {
-    q1 = 0; q2 = 0;
-    for (int k = 0; k < nsl; ++k) { q1 += s1[k * C + t]; q2 += s2[k * C + t]; }
+  if (t < 32 && c < C) {
+    double d1 = 0, d2 = 0;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) { d1 += s1[s][t]; d2 += s2[s][t]; }
     const float* coef = a.coef + (size_t)g * a.coef_gs;
     float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
-    float A = a.gamma[g][t] * coef[t * 4 + 3];
+    float A = a.gamma[g][c] * coef[c * 4 + 3];
     double n = (double)a.B * a.HW;
-    bc[t * 4 + 0] = A;
-    bc[t * 4 + 1] = a.training ? (float)(q1 / n) : 0.f;
-    bc[t * 4 + 2] = a.training ? (float)(q2 / n) : 0.f;
-    bc[t * 4 + 3] = 0.f;
-    if (a.dbeta[g]) a.dbeta[g][t] = (float)q1;
-    if (a.dgamma[g]) a.dgamma[g][t] = (float)q2;
+    bc[c * 4 + 0] = A;
+    bc[c * 4 + 1] = a.training ? (float)(d1 / n) : 0.f;
+    bc[c * 4 + 2] = a.training ? (float)(d2 / n) : 0.f;
+    bc[c * 4 + 3] = 0.f;
+    if (a.dbeta[g]) a.dbeta[g][c] = (float)d1;
+    if (a.dgamma[g]) a.dgamma[g][c] = (float)d2;
     // conv bias feeds BN directly: with batch statistics its gradient is exactly zero
-    if (a.dconvbias[g]) a.dconvbias[g][t] = a.training ? 0.f : A * (float)q1;
+    if (a.dconvbias[g]) a.dconvbias[g][c] = a.training ? 0.f : A * (float)d1;
   }
 }
 
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, int G, hipStream_t st) {
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(G), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((a.C + 31) / 32, G), dim3(1024), 0, st, a);
   DTA_CHECK_LAUNCH("k_bn_bwd_finalize");
   return 0;
 }

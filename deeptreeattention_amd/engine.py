@@ -151,6 +151,7 @@ class FusedTrainer:
                                      m._classes, _lib.ptr(self.loss), _lib.ptr(self.dlogits), _lib.ptr(self.ce_scratch),
                                      st), "dta_weighted_ce")
         dalpha = _lib.ptr(self.alpha_g) if self.hang else None
+        self.flat_g.zero_()            # C-ABI contract: gradient buffers arrive zero-filled
         if not self.overlap:
             _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table),
                                           _lib.ptr(self.dlogits), self.grads, dalpha, 3, st), "dta_net_backward")

@@ -74,7 +74,8 @@ int dta_net_forward(const dta_net_desc* d, const dta_subnet_params* nets, const 
 
 /* Replaces autograd's backward through the module above.  `workspace` is the blob the matching training (or eval)
  * forward filled.  dscores[net][L] / djoint: gradients wrt the forward outputs (null = that output unused; for
- * HANG2020 pass djoint, for the others dscores).  Writes (overwrites) every non-null gradient in `grads`.
+ * HANG2020 pass djoint, for the others dscores).  Every non-null gradient buffer in `grads` must arrive ZERO-FILLED
+ * (split-K partial sums are accumulated with atomics); on return it holds the gradient.
  * phases: bit 0 = everything except the first conv's weight gradient, bit 1 = the first conv's weight gradient
  * (the largest and last piece); 3 = all.  Two calls (1, then 2) let the caller start the gradient all-reduce of
  * the rest (RCCL on a side stream) while the first conv's weight gradient is still being computed. */
@@ -92,6 +93,14 @@ int dta_weighted_ce(const float* logits, const long long* labels, const float* w
 int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double* alpha_p, const double* alpha_g,
                   double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
                   float grad_scale, void* stream);
+
+/* Measurement aid (host-side state only): record a HIP-event pair around every launch of one kernel site, on the
+ * stream the kernel is launched on.  site = DTA_SITE_* + layer (0..2); -1 disables.  dta_profile_collect waits
+ * for the recorded events, writes up to `max` durations in milliseconds (HOST pointer) and returns the count. */
+enum { DTA_SITE_CONV_FWD = 0, DTA_SITE_CONV_WGRAD = 3, DTA_SITE_CONV_DGRAD = 6, DTA_SITE_STAGE_FWD = 9,
+       DTA_SITE_STAGE_BWD = 12 };
+int dta_profile_enable(int site);
+int dta_profile_collect(float* ms, int max);
 
 #ifdef __cplusplus
 }

@@ -198,6 +198,28 @@ def sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
 
+def bf16_round(a):
+    """Round to bfloat16 (nearest-even) and return in the input's dtype: emulates where the bf16 mode of the
+    HIP path quantises conv operands (inputs, weights, output gradients); everything else stays wide."""
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    u = a32.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(a.dtype if hasattr(a, "dtype") else np.float32)
+
+
+_QUANT = None
+
+
+def set_conv_operand_quantizer(fn):
+    """None (default) = exact; bf16_round = emulate the bf16 compute mode's operand rounding."""
+    global _QUANT
+    _QUANT = fn
+
+
+def _q(a):
+    return a if _QUANT is None else _QUANT(a)
+
+
 # ----------------------------------------------------------------------------------------
 # conv_module  (src/models/Hang2020.py:14-31)
 # ----------------------------------------------------------------------------------------
@@ -205,8 +227,9 @@ def conv_module_fwd(p, pre, x, pool, training, dt=np.float32):
     """conv3x3+bias (:25) -> BatchNorm2d (:26; batch stats when training, running stats otherwise)
     -> ReLU (:27) -> optional MaxPool2d(2) (:28-29).  Returns output, cache, and the running-stat
     updates torch would apply (momentum 0.1, unbiased variance)."""
-    w = p[pre + "conv_layer.weight"].astype(dt)
-    y = conv2d_same(x.astype(dt), w, p[pre + "conv_layer.bias"].astype(dt))
+    w = _q(p[pre + "conv_layer.weight"].astype(dt))
+    x = _q(x.astype(dt))
+    y = conv2d_same(x, w, p[pre + "conv_layer.bias"].astype(dt))
     g, be = p[pre + "bn1.weight"].astype(dt), p[pre + "bn1.bias"].astype(dt)
     upd = {}
     if training:
@@ -248,7 +271,7 @@ def conv_module_bwd(cache, pre, dz, need_dx=True):
             dv - dbeta[None, :, None, None] / n - c["xhat"] * dgamma[None, :, None, None] / n)
     else:
         dy = (c["g"] * c["rstd"])[None, :, None, None] * dv
-    dx, dw, db = conv2d_same_bwd(c["x"], c["w"], dy, need_dx)
+    dx, dw, db = conv2d_same_bwd(c["x"], c["w"], _q(dy), need_dx)
     grads = {pre + "conv_layer.weight": dw, pre + "conv_layer.bias": db,
              pre + "bn1.weight": dgamma, pre + "bn1.bias": dbeta}
     return dx, grads

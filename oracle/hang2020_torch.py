@@ -1,0 +1,91 @@
+"""ORACLE / CPU BASELINE (test infrastructure, never shipped as the product path).
+
+PyTorch-eager functional restatement of the reference's Hang2020 train step, written over a flat
+{state_dict name: tensor} dict instead of the reference's nn.Module classes.  It exists for one purpose the
+NumPy oracle cannot serve: bench.py's `cpu_baseline` leg needs the reference's own execution model (stock
+torch ops dispatched to oneDNN on the host cores, autograd backward, torch.optim.Adam) timed on the GPU box,
+where /root/reference does not exist.  tests/test_oracle_golden.py pins it to the golden vectors produced by
+the reference itself.  Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import it.
+
+Reference lines restated: src/models/Hang2020.py:24-31 (conv_module), :105-124 (spatial_attention),
+:149-168 (spectral_attention), :190-204/:226-240 (networks), :251-263 (Hang2020), src/main.py:71-80 (step),
+:135-137 (Adam).
+"""
+import torch
+import torch.nn.functional as F
+
+_SPATIAL_POOL = {32: 4, 64: 2, 128: 1}
+
+
+def _conv_block(p, pre, x, pool, training):
+    y = F.conv2d(x, p[pre + "conv_layer.weight"], p[pre + "conv_layer.bias"], padding=1)
+    y = F.batch_norm(y, p[pre + "bn1.running_mean"], p[pre + "bn1.running_var"], p[pre + "bn1.weight"],
+                     p[pre + "bn1.bias"], training, 0.1, 1e-5)
+    if training:
+        p[pre + "bn1.num_batches_tracked"] += 1
+    y = F.relu(y)
+    return F.max_pool2d(y, 2) if pool else y
+
+
+def _spectral_gate(p, pre, z):
+    v = z.mean(dim=(2, 3)).unsqueeze(-1)
+    k = p[pre + "attention_conv1.weight"].shape[-1]
+    h = F.relu(F.conv1d(v, p[pre + "attention_conv1.weight"], p[pre + "attention_conv1.bias"], padding=k // 2))
+    g = torch.sigmoid(F.conv1d(h, p[pre + "attention_conv2.weight"], p[pre + "attention_conv2.bias"], padding=k // 2))
+    a = z * g.unsqueeze(-1)
+    return a, a.mean(dim=(2, 3))
+
+
+def _spatial_gate(p, pre, z):
+    m = F.relu(F.conv2d(z, p[pre + "channel_pool.weight"], p[pre + "channel_pool.bias"]))
+    k = p[pre + "attention_conv1.weight"].shape[-1]
+    t = F.relu(F.conv2d(m, p[pre + "attention_conv1.weight"], p[pre + "attention_conv1.bias"], padding=k // 2))
+    s = torch.sigmoid(F.conv2d(t, p[pre + "attention_conv2.weight"], p[pre + "attention_conv2.bias"], padding=k // 2))
+    a = z * s
+    return a, torch.flatten(F.max_pool2d(a, _SPATIAL_POOL[z.shape[1]]), 1)
+
+
+def subnet(p, pre, kind, x, training):
+    gate = _spectral_gate if kind == "spectral" else _spatial_gate
+    scores = []
+    u = x
+    for L in (1, 2, 3):
+        z = _conv_block(p, f"{pre}conv{L}.", u, L > 1, training)
+        u, f = gate(p, f"{pre}attention_{L}.", z)
+        scores.append(F.linear(f, p[f"{pre}classifier{L}.fc1.weight"], p[f"{pre}classifier{L}.fc1.bias"]))
+    return scores
+
+
+def hang2020(p, x, training=True):
+    spec = subnet(p, "spectral_network.", "spectral", x, training)[-1]
+    spat = subnet(p, "spatial_network.", "spatial", x, training)[-1]
+    w = torch.sigmoid(p["alpha"])
+    return spec * w + spat * (1 - w)
+
+
+def to_tensors(params_np):
+    """NumPy parameter dict -> torch tensors (trainable ones require grad)."""
+    out = {}
+    for k, v in params_np.items():
+        t = torch.tensor(v)
+        if t.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+class TrainStep:
+    """forward + weighted CE + backward + Adam: the reference's TreeModel step on stock torch ops."""
+
+    def __init__(self, params, lr, loss_weight=None):
+        self.p = params
+        self.w = loss_weight
+        self.opt = torch.optim.Adam([t for t in params.values() if t.requires_grad], lr=lr)
+
+    def __call__(self, x, y):
+        self.opt.zero_grad(set_to_none=True)
+        logits = hang2020(self.p, x, True)
+        loss = F.cross_entropy(logits, y, weight=self.w)
+        loss.backward()
+        self.opt.step()
+        return logits.detach(), loss.detach()

@@ -205,3 +205,26 @@ def test_subnets_and_callers(golden):
         if k.endswith("conv_layer.bias"):
             continue
         assert rel_l2(v, g[f"vanilla/g/{k}"]) < 1e-4, k
+
+
+def test_torch_port_matches_reference_golden(golden):
+    """The torch-eager port (bench.py's cpu_baseline) against the reference's own outputs."""
+    import torch
+    from oracle import hang2020_torch as TP
+    g = golden("hang2020_3_10.npz")
+    p = TP.to_tensors(O.init_params(O.hang2020_spec(3, 10), seed=41))
+    x = torch.from_numpy(prng.uniform01(42, 1, (4, 3, 11, 11)))
+    y = torch.from_numpy(prng.randint(42, 2, (4,), 10))
+    w = torch.from_numpy((0.1 + (np.arange(10) % 7)).astype(np.float32))
+    step = TP.TrainStep(p, lr=1e-3, loss_weight=w)
+    for i in range(3):
+        logits, loss = step(x, y)
+        if i == 0:
+            assert rel_l2(logits.numpy(), g["logits"]) < 1e-5
+        assert abs(loss.item() - g[f"loss_step{i}"]) / g[f"loss_step{i}"] < 1e-4
+    for k, t in p.items():
+        if not t.requires_grad or k.endswith("conv_layer.bias"):
+            continue
+        a = t.detach().numpy().reshape(-1)
+        s = a[(prng.hash_u64(7, 99, 64) % np.uint64(a.size)).astype(np.int64)] if a.size > 64 else a
+        assert rel_l2(s, g[f"p3_samp/{k}"]) < 2e-3, k
