@@ -109,7 +109,9 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     p->CpadW[L] = p->NCin[L] * 16;
     p->cgroups[L] = (p->CpadW[L] + cpw - 1) / cpw;
     int launchG = L == 0 ? 1 : G;
-    int S = (512 + p->cgroups[L] * launchG - 1) / (p->cgroups[L] * launchG);
+    // bf16 path: register-prefetch pipeline, 1 workgroup per CU; fp32 path: 2 workgroups per CU overlap each other
+    int target = d->dtype == DTA_BF16 ? 256 : 512;
+    int S = (target + p->cgroups[L] * launchG - 1) / (p->cgroups[L] * launchG);
     p->S[L] = S < 1 ? 1 : (S > B ? B : S);
   }
   Carver c;
@@ -201,6 +203,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
   const int G = p.G, B = p.B;
   if (d->heads_mask) hipMemsetAsync(at<char>(ws, p.scores_all), 0, p.scores_bytes, st);   // split-K GEMM targets
   if (launch_pack_input<T>(x, at<char>(ws, p.x_tl), B, p.bands, p.H, p.W, st)) return 1;
+  GemmGroup heads;
   for (int L = 0; L < 3; ++L) {
     const int C = CH[L];
     const int Nconv = L == 0 ? 32 * G : C;
@@ -265,10 +268,11 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
         }
         ga.C = out; ga.sc_m = p.classes; ga.sc_n = 1;
         ga.bias = nets[g].fc_b[L];
-        if (launch_gemm(ga, st)) return 1;
+        if (!heads.add(ga)) { dta_set_error("too many head GEMMs"); return 1; }
       }
     }
   }
+  if (launch_gemm_group(heads, st)) return 1;   // all classifier heads of all branches in one launch
   if (d->kind == DTA_NET_HANG2020) {
     if (!(d->heads_mask & 4) || !joint || !alpha) { dta_set_error("Hang2020 forward needs head 3, alpha and a joint output"); return 1; }
     BlendArgs ba;
@@ -340,6 +344,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
   }
 
   hipMemsetAsync(at<char>(ws, p.dfeat_all), 0, p.dfeat_bytes, st);   // split-K GEMM targets
+  GemmGroup deferred;   // parameter-gradient GEMMs nothing downstream waits for: one grouped launch at the end
   for (int L = 2; L >= 0; --L) {
     const int C = CH[L];
     const int Nconv = L == 0 ? 32 * G : C;
@@ -348,6 +353,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     const size_t fgs = sa.feat_gs;
     // ---- classifier backward -> dfeat, dW, db (gradient buffers arrive zeroed: split-K accumulates) ----
     bool any_head = false;
+    GemmGroup dfeat_grp;
     for (int g = 0; g < G; ++g) {
       const int F = p.F[g][L];
       if (!dsc[g][L] || F == 0) continue;
@@ -358,7 +364,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       ga.Bm = nets[g].fc_w[L]; ga.sb_k = F; ga.sb_n = 1;
       ga.C = at<float>(ws, p.dfeat[L]) + (size_t)g * fgs; ga.sc_m = F; ga.sc_n = 1;
       ga.M = B; ga.N = F; ga.K = p.classes; ga.ksplit = gemm_auto_ksplit(B, F, p.classes);
-      if (launch_gemm(ga, st)) return 1;
+      dfeat_grp.add(ga);
       if (grads[g].fc_w[L]) {
         memset(&ga, 0, sizeof(ga));
         ga.A = dsc[g][L]; ga.sa_m = 1; ga.sa_k = p.classes;
@@ -367,9 +373,10 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
         ga.M = p.classes; ga.N = F; ga.K = B;
         ga.ksplit = gemm_auto_ksplit(p.classes, F, B);
         ga.rowsum_out = grads[g].fc_b[L];      // db[n] = sum_b dscore[b][n]
-        if (launch_gemm(ga, st)) return 1;
+        if (!deferred.add(ga)) { if (launch_gemm_group(deferred, st)) return 1; deferred.n = 0; deferred.add(ga); }
       }
     }
+    if (launch_gemm_group(dfeat_grp, st)) return 1;
     // ---- attention + pool + ReLU backward ----
     StageBwdArgs sb;
     memset(&sb, 0, sizeof(sb));
@@ -398,7 +405,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
           ga.C = gw + K / 2; ga.sc_m = (long)C * K; ga.sc_n = K;    // only the centre tap is live
           ga.M = C; ga.N = C; ga.K = B; ga.ksplit = gemm_auto_ksplit(C, C, B);
           ga.rowsum_out = grads[g].att[L][which * 2 + 1];            // bias gradient = sum_b d{1,2}
-          if (launch_gemm(ga, st)) return 1;
+          if (!deferred.add(ga)) { if (launch_gemm_group(deferred, st)) return 1; deferred.n = 0; deferred.add(ga); }
         }
       } else if (p.kinds[g] == KIND_SPATIAL) {
         const int kk = SPAT_K[L] * SPAT_K[L];
@@ -432,6 +439,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     else { ap.dy_gs = (size_t)B * (C / 16) * p.Qin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
     if (launch_bn_bwd_apply<T>(ap, G, st)) return 1;
     // ---- conv weight gradient ----
+    if (L == 0 && launch_gemm_group(deferred, st)) return 1;   // end of phase 1: flush the deferred GEMMs
     if (L > 0 || (phases & 2))
       if (conv_wgrad_layer<T>(p, d, grads, ws, L, st)) return 1;
     // ---- conv input gradient (feeds the previous stage's gated map) ----

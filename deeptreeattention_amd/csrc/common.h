@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
   unsigned u = __float_as_uint(f);
@@ -41,6 +42,23 @@ template <> struct Cvt<bf16_t> {
 template <typename T> __device__ __host__ __forceinline__ int tl_pos(int row, int c16);
 template <> __device__ __host__ __forceinline__ int tl_pos<float>(int row, int c16) { return c16 ^ (row & 15); }
 template <> __device__ __host__ __forceinline__ int tl_pos<bf16_t>(int row, int c16) { return c16 ^ (((row >> 3) & 1) << 3); }
+
+// Vector width (elements per 16-byte store) of a TL row segment.
+template <typename T> struct TlVec { static constexpr int VW = 16 / (int)sizeof(T); };
+
+// Store segment `part` (VW consecutive stored positions) of haloed-grid row q: vals[j] must be the value of
+// channel tl_pos<T>(q, part*VW + j).  One 16-byte store.
+__device__ __forceinline__ void tl_store_vec(float* rowbase, int part, const float* vals) {
+  *reinterpret_cast<float4*>(rowbase + part * 4) = make_float4(vals[0], vals[1], vals[2], vals[3]);
+}
+__device__ __forceinline__ void tl_store_vec(bf16_t* rowbase, int part, const float* vals) {
+  uint4 u;
+  u.x = (unsigned)f2bf(vals[0]) | ((unsigned)f2bf(vals[1]) << 16);
+  u.y = (unsigned)f2bf(vals[2]) | ((unsigned)f2bf(vals[3]) << 16);
+  u.z = (unsigned)f2bf(vals[4]) | ((unsigned)f2bf(vals[5]) << 16);
+  u.w = (unsigned)f2bf(vals[6]) | ((unsigned)f2bf(vals[7]) << 16);
+  *reinterpret_cast<uint4*>(rowbase + part * 8) = u;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

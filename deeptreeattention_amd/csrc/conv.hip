@@ -30,14 +30,17 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x,
   }
   for (int i = threadIdx.x; i < nch * 16 * HW; i += 256) s[i] = (i < creal * HW) ? src[i] : 0.f;
   __syncthreads();
+  constexpr int VW = TlVec<T>::VW, PARTS = 16 / VW;
   for (int ch = 0; ch < nch; ++ch) {
     T* dst = out + ((size_t)b * NC + chunk0 + ch) * Q * 16;
     const float* sc = s + ch * 16 * HW;
-    for (int r = threadIdx.x; r < Q * 16; r += 256) {
-      int q = r >> 4, pos = r & 15;
-      int c16 = tl_pos<T>(q, pos);  // the swizzle is an involution
+    for (int r = threadIdx.x; r < Q * PARTS; r += 256) {
+      int q = r / PARTS, part = r % PARTS;
       int p = lut[q];
-      dst[r] = Cvt<T>::to(p >= 0 ? sc[c16 * HW + p] : 0.f);
+      float v[VW];
+#pragma unroll
+      for (int j = 0; j < VW; ++j) v[j] = p >= 0 ? sc[tl_pos<T>(q, part * VW + j) * HW + p] : 0.f;
+      tl_store_vec(dst + (size_t)q * 16, part, v);
     }
   }
 }
@@ -186,20 +189,49 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   const T* xg = (const T*)a.x_tl + (size_t)g * a.x_gs;
   const T* wg = (const T*)a.wp + (size_t)g * a.NC * 9 * N * 16;
 
+  // Staging: 16-byte vectors, thread t owns vectors t, t+256, ...  With PIPE the next chunk's vectors are fetched
+  // into registers while the current chunk is being multiplied (global latency hidden behind the MFMAs).
+  constexpr bool PIPE = sizeof(T) == 2;
+  constexpr int XV = PIPE ? 6 : 1, WV = PIPE ? (9 * N * 2 + 255) / 256 : 1;
+  u32x4 rx[XV], rw[WV];
+  const int nxv = npatch * vpp;
+#define DTA_CONV_FETCH(chunk_)                                                                              \
+  {                                                                                                         \
+    _Pragma("unroll") for (int u = 0; u < XV; ++u) {                                                        \
+      int v = min(tid + u * 256, nxv - 1);                                                                  \
+      int pl = v / vpp, o = v - pl * vpp;                                                                   \
+      rx[u] = reinterpret_cast<const u32x4*>(xg + (((size_t)(b0 + pl) * a.NC + (chunk_)) * Q) * 16)[o];     \
+    }                                                                                                       \
+    const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)(chunk_) * 9 * N * 16);                 \
+    _Pragma("unroll") for (int u = 0; u < WV; ++u) {                                                        \
+      int v = min(tid + u * 256, wvec - 1);                                                                 \
+      rw[u] = swp_[v];                                                                                      \
+    }                                                                                                       \
+  }
+  const bool pipe = PIPE && nxv <= XV * 256;
+  if (pipe) DTA_CONV_FETCH(0)
   for (int chunk = 0; chunk < a.NC; ++chunk) {
     __syncthreads();
-    {
-      uint4* d = reinterpret_cast<uint4*>(sx);
-      for (int v = tid; v < npatch * vpp; v += 256) {
+    if (pipe) {
+      u32x4* d = reinterpret_cast<u32x4*>(sx);
+#pragma unroll
+      for (int u = 0; u < XV; ++u) { int v = tid + u * 256; if (v < nxv) d[v] = rx[u]; }
+      u32x4* dw = reinterpret_cast<u32x4*>(sw);
+#pragma unroll
+      for (int u = 0; u < WV; ++u) { int v = tid + u * 256; if (v < wvec) dw[v] = rw[u]; }
+    } else {
+      u32x4* d = reinterpret_cast<u32x4*>(sx);
+      for (int v = tid; v < nxv; v += 256) {
         int pl = v / vpp, o = v - pl * vpp;
-        const uint4* s = reinterpret_cast<const uint4*>(xg + (((size_t)(b0 + pl) * a.NC + chunk) * Q) * 16);
+        const u32x4* s = reinterpret_cast<const u32x4*>(xg + (((size_t)(b0 + pl) * a.NC + chunk) * Q) * 16);
         d[v] = s[o];
       }
-      uint4* dw = reinterpret_cast<uint4*>(sw);
-      const uint4* swp = reinterpret_cast<const uint4*>(wg + (size_t)chunk * 9 * N * 16);
+      u32x4* dw = reinterpret_cast<u32x4*>(sw);
+      const u32x4* swp = reinterpret_cast<const u32x4*>(wg + (size_t)chunk * 9 * N * 16);
       for (int v = tid; v < wvec; v += 256) dw[v] = swp[v];
     }
     __syncthreads();
+    if (pipe && chunk + 1 < a.NC) DTA_CONV_FETCH(chunk + 1)
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       const int toff = (tap / 3) * W2 + (tap % 3);
@@ -359,12 +391,12 @@ template <> struct WFrag<bf16_t> {
     // q0 + 8*(gq>>1) + 4*half + (i>>2) in chunk (gq&1); it receives channel i of those 4 rows.
     const int gq = lane >> 4, i = lane & 15;
     bf16x8 out;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       int q = q0 + 8 * (gq >> 1) + 4 * half + (i >> 2);
       const bf16_t* p = tile0 + ((size_t)(gq & 1) * rows_per_chunk + q) * 16 + tl_pos<bf16_t>(q, (i & 3) * 4);
-      s16x4 v;
-      asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+      s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
       out[half * 4 + 0] = v[0]; out[half * 4 + 1] = v[1]; out[half * 4 + 2] = v[2]; out[half * 4 + 3] = v[3];
     }
     return out;
@@ -377,7 +409,7 @@ template <> struct WFrag<bf16_t> {
 constexpr int WG_PAD_ROWS = 16;
 
 template <typename T, int NTT>
-__global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 1 : 2) void k_conv_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CT = 4 / NTT;          // c-tiles (32 input channels each) per workgroup
   constexpr int N = NTT * 32;
@@ -393,8 +425,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
 
   // zero everything once: pad rows and absent chunks stay zero for the whole kernel
   {
-    uint4 z = {0, 0, 0, 0};
-    uint4* d = reinterpret_cast<uint4*>(smem);
+    u32x4 z = {0, 0, 0, 0};
+    u32x4* d = reinterpret_cast<u32x4*>(smem);
     int tot = (XCH + YCH) * Qp * 16 * (int)sizeof(T) / 16;
     for (int v = tid; v < tot; v += 256) d[v] = z;
   }
@@ -411,19 +443,52 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
   const T* xt = sx + (size_t)ct * 2 * Qp * 16;
   const T* yt = sy + (size_t)nt * 2 * Qp * 16;
 
+  constexpr bool PIPE = sizeof(T) == 2;
+  constexpr int XV = PIPE ? 6 : 1, YV = PIPE ? 6 : 1;
+  u32x4 rx[XV], ry[YV];
+  const int nxv = nxch * vpc, nyv = YCH * vpc;
+#define DTA_WGRAD_FETCH(b_)                                                                                  \
+  {                                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < XV; ++u) {                                                         \
+      int v = min(tid + u * 256, max(nxv, 1) - 1);                                                           \
+      int ch = v / vpc, o = v - ch * vpc;                                                                    \
+      rx[u] = reinterpret_cast<const u32x4*>(xg + (((size_t)(b_) * a.NCx + chunk0 + ch) * Q) * 16)[o];       \
+    }                                                                                                        \
+    _Pragma("unroll") for (int u = 0; u < YV; ++u) {                                                         \
+      int v = min(tid + u * 256, nyv - 1);                                                                   \
+      int ch = v / vpc, o = v - ch * vpc;                                                                    \
+      ry[u] = reinterpret_cast<const u32x4*>(yg + (((size_t)(b_) * a.NCy + a.ych0 + ch) * Q) * 16)[o];       \
+    }                                                                                                        \
+  }
+  const bool pipe = PIPE && nxv <= XV * 256 && nyv <= YV * 256;
+  if (pipe && s < a.B) DTA_WGRAD_FETCH(s)
   for (int b = s; b < a.B; b += a.S) {
     __syncthreads();
-    for (int v = tid; v < nxch * vpc; v += 256) {
-      int ch = v / vpc, o = v - ch * vpc;
-      reinterpret_cast<uint4*>(sx + (size_t)ch * Qp * 16)[o] =
-          reinterpret_cast<const uint4*>(xg + (((size_t)b * a.NCx + chunk0 + ch) * Q) * 16)[o];
-    }
-    for (int v = tid; v < YCH * vpc; v += 256) {
-      int ch = v / vpc, o = v - ch * vpc;
-      reinterpret_cast<uint4*>(sy + (size_t)ch * Qp * 16)[o] =
-          reinterpret_cast<const uint4*>(yg + (((size_t)b * a.NCy + a.ych0 + ch) * Q) * 16)[o];
+    if (pipe) {
+#pragma unroll
+      for (int u = 0; u < XV; ++u) {
+        int v = tid + u * 256;
+        if (v < nxv) { int ch = v / vpc, o = v - ch * vpc; reinterpret_cast<u32x4*>(sx + (size_t)ch * Qp * 16)[o] = rx[u]; }
+      }
+#pragma unroll
+      for (int u = 0; u < YV; ++u) {
+        int v = tid + u * 256;
+        if (v < nyv) { int ch = v / vpc, o = v - ch * vpc; reinterpret_cast<u32x4*>(sy + (size_t)ch * Qp * 16)[o] = ry[u]; }
+      }
+    } else {
+      for (int v = tid; v < nxv; v += 256) {
+        int ch = v / vpc, o = v - ch * vpc;
+        reinterpret_cast<u32x4*>(sx + (size_t)ch * Qp * 16)[o] =
+            reinterpret_cast<const u32x4*>(xg + (((size_t)b * a.NCx + chunk0 + ch) * Q) * 16)[o];
+      }
+      for (int v = tid; v < nyv; v += 256) {
+        int ch = v / vpc, o = v - ch * vpc;
+        reinterpret_cast<u32x4*>(sy + (size_t)ch * Qp * 16)[o] =
+            reinterpret_cast<const u32x4*>(yg + (((size_t)b * a.NCy + a.ych0 + ch) * Q) * 16)[o];
+      }
     }
     __syncthreads();
+    if (pipe && b + a.S < a.B) DTA_WGRAD_FETCH(b + a.S)
 #pragma unroll 1
     for (int q = q0; q < q1; q += WFrag<T>::KS) {
       typename WFrag<T>::reg bf = WFrag<T>::load(yt, Qp, q, lane);
@@ -446,24 +511,39 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
     }
 }
 
-// out_g[n][c][tap] (torch layout) = sum_s partial[g][s][tap][c][n]
-__global__ void k_wgrad_reduce(WgradReduceArgs a) {
-  const int N = a.N;
-  size_t total = (size_t)a.G * 9 * a.C * N;
+// out_g[n][c][tap] (torch layout) = sum_s partial[g][s][tap][c][n]; each thread sums 4 consecutive n.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(WgradReduceArgs a) {
+  const int N = a.N, N4 = N / 4;
+  size_t total = (size_t)a.G * 9 * a.C * N4;
+  const size_t sstride = (size_t)9 * a.Cpad * N;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    int n = i % N;
-    size_t r = i / N;
+    int n4 = i % N4;
+    size_t r = i / N4;
     int c = r % a.C; r /= a.C;
     int tap = r % 9;
     int g = r / 9;
-    const float* p = a.partial + ((size_t)g * a.S * 9 + tap) * a.Cpad * N + (size_t)c * N + n;
-    float acc = 0.f;
-    for (int s = 0; s < a.S; ++s) acc += p[(size_t)s * 9 * a.Cpad * N];
-    float* dst;
-    int nn = n;
-    if (a.mode == 1) { dst = n < a.nsplit ? a.dst[0] : a.dst[1]; nn = n < a.nsplit ? n : n - a.nsplit; }
-    else dst = a.dst[g];
-    if (dst) dst[((size_t)nn * a.C + c) * 9 + tap] = acc;
+    const float* p = a.partial + ((size_t)g * a.S * 9 + tap) * a.Cpad * N + (size_t)c * N + n4 * 4;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+    int s = 0;
+    for (; s + 1 < a.S; s += 2) {
+      float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)s * sstride);
+      float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(s + 1) * sstride);
+      acc0.x += v0.x; acc0.y += v0.y; acc0.z += v0.z; acc0.w += v0.w;
+      acc1.x += v1.x; acc1.y += v1.y; acc1.z += v1.z; acc1.w += v1.w;
+    }
+    if (s < a.S) {
+      float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)s * sstride);
+      acc0.x += v0.x; acc0.y += v0.y; acc0.z += v0.z; acc0.w += v0.w;
+    }
+    float out[4] = {acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int n = n4 * 4 + k, nn = n;
+      float* dst;
+      if (a.mode == 1) { dst = n < a.nsplit ? a.dst[0] : a.dst[1]; nn = n < a.nsplit ? n : n - a.nsplit; }
+      else dst = a.dst[g];
+      if (dst) dst[((size_t)nn * a.C + c) * 9 + tap] = out[k];
+    }
   }
 }
 
@@ -500,8 +580,8 @@ template int launch_conv_wgrad<float>(const WgradArgs&, int, hipStream_t);
 template int launch_conv_wgrad<bf16_t>(const WgradArgs&, int, hipStream_t);
 
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {
-  size_t total = (size_t)a.G * 9 * a.C * a.N;
-  int blocks = (int)min((size_t)2048, (total + 255) / 256);
+  size_t total = (size_t)a.G * 9 * a.C * (a.N / 4);
+  int blocks = (int)min((size_t)4096, (total + 255) / 256);
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, a);
   DTA_CHECK_LAUNCH("k_wgrad_reduce");
   return 0;

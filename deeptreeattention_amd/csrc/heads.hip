@@ -10,36 +10,38 @@ namespace dta {
 // 64x64 output tile per workgroup, wave w -> 32x32 quadrant, K chunk 32 staged in LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int GK = 32;
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
-  __shared__ float As[64][GK + 1];
-  __shared__ float Bs[GK][64];
+__device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, int bz, float (*As)[GK + 1], float (*Bs)[64]) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int m0 = bx * 64, n0 = by * 64;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const int kper = (a.K + a.ksplit - 1) / a.ksplit;
-  const int kbeg = blockIdx.z * kper, kend = min(a.K, kbeg + kper);
+  const int kbeg = bz * kper, kend = min(a.K, kbeg + kper);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float rsum = 0.f;   // row sums of A over this block's K range (bias gradients), first column-tile only
+  const bool a_kfast = a.sa_k == 1, b_nfast = a.sb_n == 1;
   for (int k0 = kbeg; k0 < kend; k0 += GK) {
-    __syncthreads();
-    for (int i = t; i < 64 * GK; i += 256) {
-      int m, k;
-      if (a.sa_k == 1) { m = i / GK; k = i % GK; } else { k = i / 64; m = i % 64; }
-      float v = 0.f;
-      if (m0 + m < a.M && k0 + k < kend) v = a.A[(size_t)(m0 + m) * a.sa_m + (size_t)(k0 + k) * a.sa_k];
-      As[m][k] = v;
-    }
-    for (int i = t; i < 64 * GK; i += 256) {
-      int n, k;
-      if (a.sb_n == 1) { k = i / 64; n = i % 64; } else { n = i / GK; k = i % GK; }
-      float v = 0.f;
-      if (n0 + n < a.N && k0 + k < kend) v = a.Bm[(size_t)(k0 + k) * a.sb_k + (size_t)(n0 + n) * a.sb_n];
-      Bs[k][n] = v;
+    float ra[8], rb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int i = t + u * 256;
+      int m = a_kfast ? i / GK : i % 64, k = a_kfast ? i % GK : i / 64;
+      ra[u] = (m0 + m < a.M && k0 + k < kend) ? a.A[(size_t)(m0 + m) * a.sa_m + (size_t)(k0 + k) * a.sa_k] : 0.f;
+      int n = b_nfast ? i % 64 : i / GK, kb = b_nfast ? i / 64 : i % GK;
+      rb[u] = (n0 + n < a.N && k0 + kb < kend) ? a.Bm[(size_t)(k0 + kb) * a.sb_k + (size_t)(n0 + n) * a.sb_n] : 0.f;
     }
     __syncthreads();
-    if (a.rowsum_out && blockIdx.y == 0 && t < 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int i = t + u * 256;
+      int m = a_kfast ? i / GK : i % 64, k = a_kfast ? i % GK : i / 64;
+      As[m][k] = ra[u];
+      int n = b_nfast ? i % 64 : i / GK, kb = b_nfast ? i / 64 : i % GK;
+      Bs[kb][n] = rb[u];
+    }
+    __syncthreads();
+    if (a.rowsum_out && by == 0 && t < 64) {
 #pragma unroll
       for (int k = 0; k < GK; ++k) rsum += As[t][k];
     }
@@ -50,10 +52,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
   }
-  if (a.rowsum_out && blockIdx.y == 0 && t < 64 && m0 + t < a.M) atomicAdd(a.rowsum_out + m0 + t, rsum);
+  if (a.rowsum_out && by == 0 && t < 64 && m0 + t < a.M) atomicAdd(a.rowsum_out + m0 + t, rsum);
   const int n = n0 + wn + (lane & 31);
   if (n >= a.N) return;
-  const float bias = (a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
+  const float bias = (a.bias && bz == 0) ? a.bias[n] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -66,19 +68,47 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   }
 }
 
+// Several independent small GEMMs in one launch: block -> (problem, m-tile, n-tile, k-slice).
+__global__ __launch_bounds__(256) void k_gemm_group(GemmGroup gg) {
+  __shared__ float As[64][GK + 1];
+  __shared__ float Bs[GK][64];
+  int pi = 0;
+  while (pi + 1 < gg.n && (int)blockIdx.x >= gg.start[pi + 1]) ++pi;
+  const GemmArgs& a = gg.g[pi];
+  int local = blockIdx.x - gg.start[pi];
+  const int tm = (a.M + 63) / 64, tn = (a.N + 63) / 64;
+  const int bx = local % tm; local /= tm;
+  const int by = local % tn;
+  const int bz = local / tn;
+  gemm_block(a, bx, by, bz, As, Bs);
+}
+
 int gemm_auto_ksplit(int M, int N, int K) {
   int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  int ks = (256 + tiles - 1) / tiles;
+  int ks = (128 + tiles - 1) / tiles;
   int kmax = (K + 63) / 64;
   if (ks > kmax) ks = kmax;
   return ks < 1 ? 1 : ks;
 }
 
-int launch_gemm(const GemmArgs& a, hipStream_t st) {
-  dim3 grid((a.M + 63) / 64, (a.N + 63) / 64, a.ksplit);
-  hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, st, a);
-  DTA_CHECK_LAUNCH("k_gemm");
+int launch_gemm_group(GemmGroup& gg, hipStream_t st) {
+  if (gg.n == 0) return 0;
+  int total = 0;
+  for (int i = 0; i < gg.n; ++i) {
+    gg.start[i] = total;
+    total += ((gg.g[i].M + 63) / 64) * ((gg.g[i].N + 63) / 64) * gg.g[i].ksplit;
+  }
+  gg.start[gg.n] = total;
+  hipLaunchKernelGGL(k_gemm_group, dim3(total), dim3(256), 0, st, gg);
+  DTA_CHECK_LAUNCH("k_gemm_group");
   return 0;
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+  GemmGroup gg;
+  gg.n = 1;
+  gg.g[0] = a;
+  return launch_gemm_group(gg, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -109,7 +109,15 @@ struct GemmArgs {
   float* rowsum_out;                  // optional: rowsum_out[m] += sum_k A(m,k) (atomic; must be pre-zeroed)
   int M, N, K, ksplit, accumulate;    // ksplit > 1: atomic accumulation into a pre-zeroed C
 };
+constexpr int GEMM_GROUP_MAX = 12;
+struct GemmGroup {
+  GemmArgs g[GEMM_GROUP_MAX];
+  int start[GEMM_GROUP_MAX + 1];
+  int n = 0;
+  bool add(const GemmArgs& a) { if (n >= GEMM_GROUP_MAX) return false; g[n++] = a; return true; }
+};
 int launch_gemm(const GemmArgs& a, hipStream_t st);
+int launch_gemm_group(GemmGroup& gg, hipStream_t st);
 int gemm_auto_ksplit(int M, int N, int K);
 struct ColsumArgs {
   const float* A; int rows, cols; long lda;

@@ -25,55 +25,61 @@ __device__ __forceinline__ int conv_wg_count(int wg, int HW, int MWG, int B) {
   return min(MWG, HW - (wg % spp) * MWG);
 }
 
-__global__ __launch_bounds__(256) void k_bn_finalize(BnFinK a) {
-  __shared__ double sn[256], smean[256], sm2[256];
-  const int g = blockIdx.x, t = threadIdx.x, C = a.C;
-  const int c = t % C, sl = t / C, nsl = 256 / C;
+__global__ __launch_bounds__(1024) void k_bn_finalize(BnFinK a) {
+  // block = 32 channels x 32 slices of the conv workgroups' partials; grid = (C/32, G)
+  __shared__ double red[32][33];
+  const int g = blockIdx.y, t = threadIdx.x, C = a.C;
+  const int cl = t & 31, sl = t >> 5, c = blockIdx.x * 32 + cl;
   float* coef = a.coef + (size_t)g * C * 4;
   if (!a.training) {
-    if (t < C) {
-      float rstd = rsqrtf(a.rvar[g][t] + a.eps);
-      float sc = a.gamma[g][t] * rstd;
-      coef[t * 4 + 0] = sc; coef[t * 4 + 1] = a.beta[g][t] - a.rmean[g][t] * sc;
-      coef[t * 4 + 2] = a.rmean[g][t]; coef[t * 4 + 3] = rstd;
+    if (t < 32 && c < C) {
+      float rstd = rsqrtf(a.rvar[g][c] + a.eps);
+      float sc = a.gamma[g][c] * rstd;
+      coef[c * 4 + 0] = sc; coef[c * 4 + 1] = a.beta[g][c] - a.rmean[g][c] * sc;
+      coef[c * 4 + 2] = a.rmean[g][c]; coef[c * 4 + 3] = rstd;
     }
     return;
   }
-  double n = 0, mean = 0, m2 = 0;
-  if (sl < nsl) {
-    const float* st = a.stats + (size_t)g * a.stats_goff;
-    for (int wg = sl; wg < a.nwg; wg += nsl) {
+  const float* st = a.stats + (size_t)g * a.stats_goff;
+  // pass 1: grand mean = sum n_i mean_i / sum n_i
+  double sn = 0, sm = 0;
+  if (c < C)
+    for (int wg = sl; wg < a.nwg; wg += 32) {
       double nb = conv_wg_count(wg, a.HW, a.MWG, a.B);
-      double mb = st[((size_t)wg * a.stats_ld + c) * 2 + 0], qb = st[((size_t)wg * a.stats_ld + c) * 2 + 1];
-      double nt = n + nb, d = mb - mean;
-      mean += d * nb / nt;
-      m2 += qb + d * d * n * nb / nt;
-      n = nt;
+      sn += nb; sm += nb * (double)st[((size_t)wg * a.stats_ld + c) * 2];
     }
-  }
-  sn[t] = n; smean[t] = mean; sm2[t] = m2;
+  red[sl][cl] = sm;
   __syncthreads();
-  if (t < C) {
-    n = 0; mean = 0; m2 = 0;
-    for (int s = 0; s < nsl; ++s) {
-      double nb = sn[s * C + t];
-      if (nb == 0) continue;
-      double mb = smean[s * C + t], qb = sm2[s * C + t];
-      double nt = n + nb, d = mb - mean;
-      mean += d * nb / nt;
-      m2 += qb + d * d * n * nb / nt;
-      n = nt;
+  double tot = 0;
+#pragma unroll 8
+  for (int s = 0; s < 32; ++s) tot += red[s][cl];
+  const double n = (double)a.B * a.HW;
+  const double mean = tot / n;
+  __syncthreads();
+  // pass 2: M2 = sum M2_i + n_i (mean_i - mean)^2
+  double m2 = 0;
+  if (c < C)
+    for (int wg = sl; wg < a.nwg; wg += 32) {
+      double nb = conv_wg_count(wg, a.HW, a.MWG, a.B);
+      double d = (double)st[((size_t)wg * a.stats_ld + c) * 2] - mean;
+      m2 += (double)st[((size_t)wg * a.stats_ld + c) * 2 + 1] + nb * d * d;
     }
+  red[sl][cl] = m2;
+  __syncthreads();
+  if (t < 32 && c < C) {
+    m2 = 0;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) m2 += red[s][t];
     double var = m2 / n;
     float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-    float sc = a.gamma[g][t] * rstd;
-    coef[t * 4 + 0] = sc; coef[t * 4 + 1] = a.beta[g][t] - (float)mean * sc;
-    coef[t * 4 + 2] = (float)mean; coef[t * 4 + 3] = rstd;
+    float sc = a.gamma[g][c] * rstd;
+    coef[c * 4 + 0] = sc; coef[c * 4 + 1] = a.beta[g][c] - (float)mean * sc;
+    coef[c * 4 + 2] = (float)mean; coef[c * 4 + 3] = rstd;
     if (a.rmean[g]) {
       double unb = n > 1 ? m2 / (n - 1) : var;
-      a.rmean[g][t] = (1.f - a.momentum) * a.rmean[g][t] + a.momentum * (float)mean;
-      a.rvar[g][t] = (1.f - a.momentum) * a.rvar[g][t] + a.momentum * (float)unb;
-      if (t == 0 && a.nbt[g]) a.nbt[g][0] += 1;
+      a.rmean[g][c] = (1.f - a.momentum) * a.rmean[g][c] + a.momentum * (float)mean;
+      a.rvar[g][c] = (1.f - a.momentum) * a.rvar[g][c] + a.momentum * (float)unb;
+      if (c == 0 && a.nbt[g]) a.nbt[g][0] += 1;
     }
   }
 }
@@ -87,7 +93,7 @@ int launch_bn_finalize(const BnFinalizeArgs& b, int G, hipStream_t st) {
     a.gamma[g] = b.gamma[g]; a.beta[g] = b.beta[g]; a.rmean[g] = b.rmean[g]; a.rvar[g] = b.rvar[g]; a.nbt[g] = b.nbt[g];
   }
   a.coef = b.coef; a.training = b.training; a.momentum = b.momentum; a.eps = b.eps;
-  hipLaunchKernelGGL(k_bn_finalize, dim3(G), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((a.C + 31) / 32, G), dim3(1024), 0, st, a);
   DTA_CHECK_LAUNCH("k_bn_finalize");
   return 0;
 }
@@ -258,13 +264,19 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
   if (a.a_tl) {
     const int W2 = s.Wz + 2, Qz = (s.Hz + 2) * W2, nch = C / 16;
     T* dst = (T*)a.a_tl + (size_t)g * a.a_gs + ((size_t)b * a.a_nc + a.a_ch0) * Qz * 16;
-    for (int i = t; i < nch * Qz * 16; i += 256) {
-      int ch = i / (Qz * 16), rem = i - ch * Qz * 16, q = rem >> 4, pos = rem & 15;
-      int c = ch * 16 + tl_pos<T>(q, pos);
+    constexpr int VW = TlVec<T>::VW, PARTS = 16 / VW;
+    for (int i = t; i < nch * Qz * PARTS; i += 256) {
+      int ch = i / (Qz * PARTS), rem = i - ch * Qz * PARTS, q = rem / PARTS, part = rem % PARTS;
       int hh = q / W2 - 1, ww = q % W2 - 1;
-      float v = 0.f;
-      if (hh >= 0 && hh < s.Hz && ww >= 0 && ww < s.Wz) { int p = hh * s.Wz + ww; v = Z[p * ld + c] * gate_of(kind, v2, p, c); }
-      dst[i] = Cvt<T>::to(v);
+      const bool in = hh >= 0 && hh < s.Hz && ww >= 0 && ww < s.Wz;
+      const int p = in ? hh * s.Wz + ww : 0;
+      float v[VW];
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        int c = ch * 16 + tl_pos<T>(q, part * VW + j);
+        v[j] = in ? Z[p * ld + c] * gate_of(kind, v2, p, c) : 0.f;
+      }
+      tl_store_vec(dst + ((size_t)ch * Qz + q) * 16, part, v);
     }
   }
   if (a.a_nchw) {
@@ -548,17 +560,32 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
   const float* coef = a.coef + (size_t)g * a.coef_gs;
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
   T* dst = (T*)a.dy_tl + (size_t)g * a.dy_gs + ((size_t)b * a.dy_nc + a.dy_ch0) * Q * 16;
-  for (int i = t; i < nch * Q * 16; i += 256) {
-    int ch = i / (Q * 16), rem = i - ch * Q * 16, q = rem >> 4, pos = rem & 15;
-    int c = ch * 16 + tl_pos<T>(q, pos);
+  constexpr int VW = TlVec<T>::VW, PARTS = 16 / VW;
+  for (int i = t; i < nch * Q * PARTS; i += 256) {
+    int ch = i / (Q * PARTS), rem = i - ch * Q * PARTS, q = rem / PARTS, part = rem % PARTS;
     int hh = q / W2 - 1, ww = q % W2 - 1;
-    float v = 0.f;
-    if (hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) {
-      int p = hh * a.W + ww;
-      float xh = (y[(size_t)p * a.y_rs + c] - coef[c * 4 + 2]) * coef[c * 4 + 3];
-      v = bc[c * 4 + 0] * (dv[(size_t)p * C + c] - bc[c * 4 + 1] - xh * bc[c * 4 + 2]);
+    const bool in = hh >= 0 && hh < a.H && ww >= 0 && ww < a.W;
+    const int p = in ? hh * a.W + ww : 0;
+    // the VW stored positions of this segment are one aligned group of VW channels (permuted inside for fp32)
+    const int cb = ch * 16 + (tl_pos<T>(q, part * VW) & ~(VW - 1));
+    float yv[VW], dvv[VW];
+#pragma unroll
+    for (int k = 0; k < VW; k += 4) {
+      float4 t4 = *reinterpret_cast<const float4*>(y + (size_t)p * a.y_rs + cb + k);
+      yv[k] = t4.x; yv[k + 1] = t4.y; yv[k + 2] = t4.z; yv[k + 3] = t4.w;
+      float4 d4 = *reinterpret_cast<const float4*>(dv + (size_t)p * C + cb + k);
+      dvv[k] = d4.x; dvv[k + 1] = d4.y; dvv[k + 2] = d4.z; dvv[k + 3] = d4.w;
     }
-    dst[i] = Cvt<T>::to(v);
+    float v[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      int c = ch * 16 + tl_pos<T>(q, part * VW + j);
+      int k = c - cb;
+      float xh = (yv[k] - coef[c * 4 + 2]) * coef[c * 4 + 3];
+      float d = bc[c * 4 + 0] * (dvv[k] - bc[c * 4 + 1] - xh * bc[c * 4 + 2]);
+      v[j] = in ? d : 0.f;
+    }
+    tl_store_vec(dst + ((size_t)ch * Q + q) * 16, part, v);
   }
 }
 

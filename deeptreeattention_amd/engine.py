@@ -13,6 +13,7 @@ import torch
 
 from . import _lib
 from . import Hang2020 as H
+from .dist import GradSync
 
 
 class FusedTrainer:
@@ -74,17 +75,14 @@ class FusedTrainer:
         self._ws = None
         self._ws_key = None
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
+        self.sync = GradSync(self.world, self.pg, self._side)
         if self.world > 1:
             self.broadcast_parameters()
 
     # ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src=0):
         """DDP start-up semantics: every rank starts from rank `src`'s parameters and buffers."""
-        torch.distributed.broadcast(self.flat_p, src, group=self.pg)
-        if self.hang:
-            torch.distributed.broadcast(self.alpha.data, src, group=self.pg)
-        for b in self.model.buffers():
-            torch.distributed.broadcast(b, src, group=self.pg)
+        self.sync.broadcast([self.flat_p] + ([self.alpha.data] if self.hang else []) + list(self.model.buffers()), src)
 
     def grad_of(self, param):
         """Gradient view (inside the flat gradient buffer) of one of the model's fp32 parameters."""
@@ -152,28 +150,19 @@ class FusedTrainer:
                                      st), "dta_weighted_ce")
         dalpha = _lib.ptr(self.alpha_g) if self.hang else None
         self.flat_g.zero_()            # C-ABI contract: gradient buffers arrive zero-filled
-        if not self.overlap:
+        if self.world == 1:
             _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table),
                                           _lib.ptr(self.dlogits), self.grads, dalpha, 3, st), "dta_net_backward")
-            if self.world > 1:
-                self._allreduce(self.flat_g)
-                if self.hang:
-                    self._allreduce(self.alpha_g)
         else:
-            main = torch.cuda.current_stream()
+            # phase 1: everything but the first conv's weight gradient; its all-reduce (side stream when overlap is
+            # on) runs while phase 2, the first conv's weight gradient, is computed
             _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table),
                                           _lib.ptr(self.dlogits), self.grads, dalpha, 1, st), "dta_net_backward")
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                self._allreduce(self.flat_g[:self.split])
-                if self.hang:
-                    self._allreduce(self.alpha_g)
+            self.sync.reduce_early(self.flat_g[:self.split], self.alpha_g if self.hang else None)
             _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table),
                                           _lib.ptr(self.dlogits), self.grads, dalpha, 2, st), "dta_net_backward")
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                self._allreduce(self.flat_g[self.split:])
-            main.wait_stream(self._side)
+            self.sync.reduce_late(self.flat_g[self.split:])
+            self.sync.finish()
         self.step_count += 1
         _lib.check(L.dta_adam_step(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m),
                                    _lib.ptr(self.flat_v), self.n,
@@ -182,11 +171,8 @@ class FusedTrainer:
                                    _lib.ptr(self.alpha_m) if self.hang else None,
                                    _lib.ptr(self.alpha_v) if self.hang else None,
                                    self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
-                                   1.0 / self.world, st), "dta_adam_step")
+                                   self.sync.grad_scale, st), "dta_adam_step")
         return self.loss
-
-    def _allreduce(self, t):
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def forward_loss(self, x, y):
         """Forward + loss only (validation_step, reference src/main.py:82-94); returns (logits, loss)."""

@@ -1,0 +1,68 @@
+"""CPU-side checks of the C-ABI boundary: the in-tree library loads, exports every symbol include/dta_hip.h
+declares, and the host-only entry points (no kernel launch) behave.  No GPU needed."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from deeptreeattention_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    return _lib.lib()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "dta_hip.h")).read()
+    names = set(re.findall(r"\b(dta_[a-z_0-9]+)\s*\(", hdr))
+    assert {"dta_net_forward", "dta_net_backward", "dta_weighted_ce", "dta_adam_step", "dta_net_workspace_bytes",
+            "dta_last_error", "dta_abi_version", "dta_profile_enable", "dta_profile_collect"} <= names
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_workspace_bytes_and_errors(lib):
+    from deeptreeattention_amd import _lib
+    ok = _lib.NetDesc(1024, 369, 11, 11, 200, _lib.NET_HANG2020, _lib.DTA_BF16, 1, 4, 0.1, 1e-5)
+    n = lib.dta_net_workspace_bytes(C.byref(ok))
+    assert 100e6 < n < 4e9
+    f32 = _lib.NetDesc(1024, 369, 11, 11, 200, _lib.NET_HANG2020, _lib.DTA_F32, 1, 4, 0.1, 1e-5)
+    assert lib.dta_net_workspace_bytes(C.byref(f32)) > n
+    bad = _lib.NetDesc(0, 369, 11, 11, 200, _lib.NET_HANG2020, _lib.DTA_BF16, 1, 4, 0.1, 1e-5)
+    assert lib.dta_net_workspace_bytes(C.byref(bad)) == 0
+    assert b"bad descriptor" in lib.dta_last_error()
+    tiny = _lib.NetDesc(4, 3, 3, 3, 10, _lib.NET_SPECTRAL, _lib.DTA_F32, 1, 7, 0.1, 1e-5)
+    assert lib.dta_net_workspace_bytes(C.byref(tiny)) == 0      # too small for two 2x2 pools: refused, not UB
+    # null arguments are reported, not dereferenced
+    assert lib.dta_net_forward(None, None, None, None, None, None, None, None) != 0
+    assert lib.dta_adam_step(None, None, None, None, 10, None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None) != 0
+
+
+def test_state_dict_contract_matches_reference_names():
+    """67 parameters + 18 buffers, reference key order (pinned by the golden 'keys')."""
+    import numpy as np
+    from deeptreeattention_amd import Hang2020 as H
+    g = np.load(os.path.join(REPO, "tests", "golden", "hang2020_369_200.npz"))
+    m = H.Hang2020(369, 200)
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in m.parameters()) == 900736
+    assert m.alpha.dtype.is_floating_point and m.alpha.element_size() == 8
+    v = H.vanilla_CNN(5, 3)
+    assert sum(p.numel() for p in v.parameters()) == 95811
+
+
+def test_load_from_backbone_roundtrip(tmp_path):
+    """reference tests/test_Hang2020.py:66-75 (without the forward, which needs the GPU)."""
+    import torch
+    from deeptreeattention_amd import Hang2020 as H
+    ten = H.Hang2020(bands=3, classes=10)
+    path = str(tmp_path / "state_dict.pt")
+    torch.save(ten.spectral_network.state_dict(), path)
+    twenty = H.load_from_backbone(state_dict=path, classes=20, bands=3)
+    assert twenty.classifier3.fc1.weight.shape == (20, 128)
+    assert torch.equal(twenty.conv1.conv_layer.weight, ten.spectral_network.conv1.conv_layer.weight)

@@ -1,0 +1,69 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel host logic: gradient chunk all-reduce + averaging as the fused
+trainer does it, parameter broadcast at start-up, and per-rank data sharding.  The HIP kernels need a GPU; what
+is exercised here is deeptreeattention_amd.dist (the part of the N>1 path that is not a kernel)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deeptreeattention_amd.dist import GradSync, shard_seed, flat_layout
+    torch.manual_seed(100 + rank)
+    n, split = 1000, 700
+    g = torch.randn(n, dtype=torch.float32)
+    alpha_g = torch.tensor(float(rank + 1), dtype=torch.float64)
+    mine = g.clone()
+    sync = GradSync(world=world, group=None, side_stream=None)
+    # two-phase reduction exactly as FusedTrainer.train_step issues it
+    sync.reduce_early(g[:split], alpha_g)
+    sync.reduce_late(g[split:])
+    sync.finish()
+    gathered = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    want = torch.stack(gathered).sum(0)
+    ok_sum = torch.allclose(g, want, atol=1e-6)
+    ok_alpha = abs(alpha_g.item() - sum(range(1, world + 1))) < 1e-12
+    # averaging is applied by the optimizer kernel through grad_scale = 1/world
+    ok_scale = abs(sync.grad_scale - 1.0 / world) < 1e-12
+    # parameter broadcast
+    p = torch.full((10,), float(rank))
+    sync.broadcast([p], src=0)
+    ok_bc = bool((p == 0).all())
+    seeds = [shard_seed(1234, r) for r in range(world)]
+    ok_seed = len(set(seeds)) == world
+    out[rank] = (ok_sum, ok_alpha, ok_scale, ok_bc, ok_seed)
+    dist.destroy_process_group()
+
+
+def test_gradsync_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert all(out[r]), (r, out[r])
+
+
+def test_flat_layout_puts_first_conv_last():
+    from deeptreeattention_amd.dist import flat_layout
+    sizes = [("a.conv1.conv_layer.weight", 100), ("a.conv1.conv_layer.bias", 4), ("a.fc", 30),
+             ("b.conv1.conv_layer.weight", 50), ("b.x", 7)]
+    order, split, total = flat_layout(sizes, late=lambda k: k.endswith("conv1.conv_layer.weight"))
+    assert total == 191 and split == 41
+    assert [k for k, _ in order[-2:]] == ["a.conv1.conv_layer.weight", "b.conv1.conv_layer.weight"]
