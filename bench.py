@@ -41,34 +41,51 @@ def parse():
     ap.add_argument("--site", default="wgrad0", help="kernel site timed for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=128)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-overlap", action="store_true")
     return ap.parse_args()
 
 
 def cpu_baseline(batch, seconds):
-    """Reference step (stock torch ops + autograd + Adam) on the host cores; bounded sample."""
-    import numpy as np
+    """Reference step (stock torch ops + autograd + Adam) on the host cores; bounded sample.  oneDNN's scaling on
+    this small model is poor beyond a few dozen threads, so a few (threads, batch) settings are tried for an equal
+    slice of the time budget and the best is reported (with the threads actually used)."""
     from oracle import hang2020_np as O
     from oracle import hang2020_torch as TP
     from oracle import prng
-    threads = torch.get_num_threads()
-    p = TP.to_tensors(O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=1, randomize_bn=False))
-    x = torch.from_numpy(prng.uniform01(0, 1, (batch, BANDS, HW, HW)))
-    y = torch.from_numpy(prng.randint(0, 2, (batch,), CLASSES))
-    step = TP.TrainStep(p, lr=1e-4, loss_weight=torch.ones(CLASSES))
-    for _ in range(2):
+    ncpu = os.cpu_count() or 1
+    settings = []
+    for thr in (16, 32, 64, ncpu // 2):
+        thr = max(1, min(thr, ncpu))
+        for b in (batch, 1024):
+            if (thr, b) not in settings:
+                settings.append((thr, b))
+    base = O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=1, randomize_bn=False)
+    best = None
+    tried = []
+    budget = seconds / len(settings)
+    for thr, b in settings:
+        torch.set_num_threads(thr)
+        p = TP.to_tensors(base)
+        x = torch.from_numpy(prng.uniform01(0, 1, (b, BANDS, HW, HW)))
+        y = torch.from_numpy(prng.randint(0, 2, (b,), CLASSES))
+        step = TP.TrainStep(p, lr=1e-4, loss_weight=torch.ones(CLASSES))
         step(x, y)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        step(x, y)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 200:
-            break
-    return {"value": round(n * batch / el, 1), "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"{n} train steps of batch {batch} (fp32, torch {torch.__version__} eager on host CPU, "
-                      f"{threads} threads), {el:.1f} s"}
+        n, t0 = 0, time.perf_counter()
+        while True:
+            step(x, y)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget or n >= 100:
+                break
+        rate = n * b / el
+        tried.append(f"{thr}thr/b{b}:{rate:.0f}")
+        if best is None or rate > best[0]:
+            best = (rate, thr, b, n, el)
+    rate, thr, b, n, el = best
+    return {"value": round(rate, 1), "unit": "patches/s", "cores": thr, "kind": "port",
+            "sample": f"best of {len(settings)} settings ({', '.join(tried)} patches/s); reported: {n} train steps of "
+                      f"batch {b}, fp32, torch {torch.__version__} eager on host CPU, {thr} threads, {el:.1f} s"}
 
 
 def main():
