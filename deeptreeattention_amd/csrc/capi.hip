@@ -111,7 +111,7 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     int launchG = L == 0 ? 1 : G;
     // bf16 path: register-prefetch pipeline, 1 workgroup per CU; fp32 path: 2 workgroups per CU overlap each other
     int target = d->dtype == DTA_BF16 ? 256 : 512;
-    int S = (target + p->cgroups[L] * launchG - 1) / (p->cgroups[L] * launchG);
+    int S = target / (p->cgroups[L] * launchG);   // floor: never spill into a second round of workgroups
     p->S[L] = S < 1 ? 1 : (S > B ? B : S);
   }
   Carver c;

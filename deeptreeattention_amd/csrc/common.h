@@ -35,13 +35,13 @@ template <> struct Cvt<bf16_t> {
 //   TL[g][b][chunk][q][16]  with  q = (h+1)*(W+2) + (w+1)  over the zero-haloed (H+2)x(W+2) grid,
 //   chunk = c/16, and the 16 channels of a row stored at a swizzled position so that the MFMA
 //   fragment reads out of LDS are bank-conflict free (the LDS image is a linear copy of HBM):
-//     fp32 : pos = (c%16) ^ (q & 15)              (ds_read_b32, one element per lane)
-//     bf16 : pos = (c%16) ^ (((q >> 3) & 1) << 3) (ds_read_b128 / ds_read_b64_tr_b16, 8/4 per lane)
+//     fp32 : pos = (c%16) ^ (q & 15)   (ds_read_b32, one element per lane; LDS image = linear copy of HBM)
+//     bf16 : pos = c%16                (no swizzle: the bf16 kernels pad LDS rows to 48 B while staging instead)
 // The same rule applies to packed conv weights with row index (tap*N + n).
 // ---------------------------------------------------------------------------------------------
 template <typename T> __device__ __host__ __forceinline__ int tl_pos(int row, int c16);
 template <> __device__ __host__ __forceinline__ int tl_pos<float>(int row, int c16) { return c16 ^ (row & 15); }
-template <> __device__ __host__ __forceinline__ int tl_pos<bf16_t>(int row, int c16) { return c16 ^ (((row >> 3) & 1) << 3); }
+template <> __device__ __host__ __forceinline__ int tl_pos<bf16_t>(int row, int c16) { return c16; }
 
 // Vector width (elements per 16-byte store) of a TL row segment.
 template <typename T> struct TlVec { static constexpr int VW = 16 / (int)sizeof(T); };

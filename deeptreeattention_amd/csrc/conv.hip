@@ -360,8 +360,7 @@ int launch_conv3x3(const ConvArgs& a, int G, hipStream_t st) {
   dta_set_error("conv3x3: unsupported output width %d", a.N);
   return 1;
 }
-template int launch_conv3x3<float>(const ConvArgs&, int, hipStream_t);
-template int launch_conv3x3<bf16_t>(const ConvArgs&, int, hipStream_t);
+template int launch_conv3x3<float>(const ConvArgs&, int, hipStream_t);   // bf16: conv_bf16.hip
 
 // ------------------------------------------------------------------------------------------------
 // k_conv_wgrad: dW[tap][c][n] = sum_{b,q} X[b][c][q + shift(tap)] * dY[b][n][q], K runs over the haloed
@@ -576,8 +575,7 @@ int launch_conv_wgrad(const WgradArgs& a, int G, hipStream_t st) {
   dta_set_error("conv_wgrad: unsupported width %d", a.N);
   return 1;
 }
-template int launch_conv_wgrad<float>(const WgradArgs&, int, hipStream_t);
-template int launch_conv_wgrad<bf16_t>(const WgradArgs&, int, hipStream_t);
+template int launch_conv_wgrad<float>(const WgradArgs&, int, hipStream_t);   // bf16: conv_bf16.hip
 
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {
   size_t total = (size_t)a.G * 9 * a.C * (a.N / 4);

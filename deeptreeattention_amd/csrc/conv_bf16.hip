@@ -1,0 +1,408 @@
+// bf16 specialisations of the two convolution kernels (the bench path): 8-wave workgroups (2 waves per SIMD),
+// register-prefetch staging, LDS rows padded to 48 bytes instead of swizzled (the HBM tile image stays compact and
+// unswizzled for bf16), LDS addresses precomputed per lane so the tap loops are MFMA + ds_read only.
+//   k_conv3x3_bf16<MT,NT>   forward / input-gradient 3x3 conv (same contract as k_conv3x3 in conv.hip)
+//   k_conv_wgrad_bf16<NTT>  weight gradient (same contract as k_conv_wgrad in conv.hip)
+#include "kernels.h"
+
+namespace dta {
+
+constexpr int RB = 48;   // LDS bytes per 16-channel bf16 row: 32 data + 16 pad -> conflict-free b128 / tr_b16 reads
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+
+__device__ __forceinline__ bf16x8 lds_b128(const unsigned char* base, int off) {
+  return *reinterpret_cast<const bf16x8*>(base + off);
+}
+// Transposing fragment read: 8 k-values (rows r..r+7 in two groups of 4) of one 16-channel column block.
+__device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* base, int off) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(base + off));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(base + off + 4 * RB));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad conv
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+__global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NW = 8, NTHR = 512;
+  constexpr int MWG = NW * MT * 32;
+  constexpr int N = NT * 32;
+  int* rowtab = (int*)smem;                 // [MWG] global output row or -1
+  int* plq = rowtab + MWG;                  // [MWG] (pl << 16) | q_topleft
+  float* red = (float*)(plq + MWG);         // [NW][N]
+  float* cmean = red + NW * N;              // [N]
+  unsigned char* sx = (unsigned char*)(cmean + N);
+  const int Q = a.Q, HW = a.HW, W2 = a.W + 2;
+  unsigned char* sw = sx + (size_t)a.ppw * Q * RB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.y;
+  const int pg = blockIdx.x / a.spp, split = blockIdx.x - pg * a.spp;
+  const int b0 = pg * a.ppw;
+  const int npatch = min(a.ppw, a.B - b0);
+
+  for (int lr = tid; lr < MWG; lr += NTHR) {
+    int pl, pix;
+    bool valid;
+    if (a.spp == 1) { pl = lr / HW; pix = lr - pl * HW; valid = pl < npatch; }
+    else { pl = 0; pix = split * MWG + lr; valid = pix < HW; }
+    int h = valid ? pix / a.W : 0, w = valid ? pix - h * a.W : 0;
+    rowtab[lr] = valid ? (b0 + pl) * HW + pix : -1;
+    plq[lr] = valid ? ((pl << 16) | (h * W2 + w)) : 0;
+  }
+  __syncthreads();
+
+  const int khalf16 = (lane >> 5) * 16;
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int v = plq[(wave * MT + mt) * 32 + (lane & 31)];
+    abase[mt] = ((v >> 16) * Q + (v & 0xFFFF)) * RB + khalf16;
+  }
+  const int bbase = (lane & 31) * RB + khalf16;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  // ---- staging plan: 16-byte vectors; thread t owns vectors t, t+512, ... (fixed per thread for all chunks) ----
+  constexpr int XV = 4, WV = (9 * N * 2 + NTHR - 1) / NTHR;
+  const int vpp = Q * 2;                      // vectors per patch tile
+  const int nxv = npatch * vpp, wvec = 9 * N * 2;
+  const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs;
+  const bf16_t* wg = (const bf16_t*)a.wp + (size_t)g * a.NC * 9 * N * 16;
+  const size_t xchunk = (size_t)Q * 16;       // elements between consecutive chunks of one patch
+  size_t xsrc[XV];
+  int xdst[XV], wdst[WV];
+#pragma unroll
+  for (int u = 0; u < XV; ++u) {
+    int v = min(tid + u * NTHR, max(nxv, 1) - 1);
+    int pl = v / vpp, o = v - pl * vpp;
+    xsrc[u] = ((size_t)(b0 + pl) * a.NC) * xchunk + (size_t)o * 8;
+    xdst[u] = (pl * Q + (o >> 1)) * RB + (o & 1) * 16;
+  }
+#pragma unroll
+  for (int u = 0; u < WV; ++u) {
+    int v = min(tid + u * NTHR, wvec - 1);
+    wdst[u] = (v >> 1) * RB + (v & 1) * 16;
+  }
+  const bool pipe = nxv <= XV * NTHR;
+  u32x4 rx[XV], rw[WV];
+#define DTA_FETCH(chunk_)                                                                             \
+  {                                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                    \
+        rx[u] = *reinterpret_cast<const u32x4*>(xg + xsrc[u] + (size_t)(chunk_) * xchunk);            \
+    const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)(chunk_) * 9 * N * 16);           \
+    _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[min(tid + u * NTHR, wvec - 1)];       \
+  }
+  if (pipe) DTA_FETCH(0)
+
+  for (int chunk = 0; chunk < a.NC; ++chunk) {
+    __syncthreads();
+    if (pipe) {
+#pragma unroll
+      for (int u = 0; u < XV; ++u)
+        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>(sx + xdst[u]) = rx[u];
+#pragma unroll
+      for (int u = 0; u < WV; ++u)
+        if (tid + u * NTHR < wvec) *reinterpret_cast<u32x4*>(sw + wdst[u]) = rw[u];
+    } else {
+      for (int v = tid; v < nxv; v += NTHR) {
+        int pl = v / vpp, o = v - pl * vpp;
+        *reinterpret_cast<u32x4*>(sx + (pl * Q + (o >> 1)) * RB + (o & 1) * 16) =
+            *reinterpret_cast<const u32x4*>(xg + ((size_t)(b0 + pl) * a.NC + chunk) * xchunk + (size_t)o * 8);
+      }
+      const u32x4* swp = reinterpret_cast<const u32x4*>(wg + (size_t)chunk * 9 * N * 16);
+      for (int v = tid; v < wvec; v += NTHR) *reinterpret_cast<u32x4*>(sw + (v >> 1) * RB + (v & 1) * 16) = swp[v];
+    }
+    __syncthreads();
+    if (pipe && chunk + 1 < a.NC) DTA_FETCH(chunk + 1)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toffB = ((tap / 3) * W2 + (tap % 3)) * RB;
+      bf16x8 af[MT], bf[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = lds_b128(sx, abase[mt] + toffB);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = lds_b128(sw, bbase + (tap * N + nt * 32) * RB);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+#undef DTA_FETCH
+
+  // ---- epilogue: bias, store, per-workgroup (mean, M2) per column ----
+  float bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int n = nt * 32 + (lane & 31);
+    float bv = 0.f;
+    if (a.bias[0]) {
+      if (a.bias_mode == 1) bv = n < a.bias_split ? a.bias[0][n] : a.bias[1][n - a.bias_split];
+      else bv = a.bias[g][n];
+    }
+    bias[nt] = bv;
+  }
+  float csum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) csum[nt] = 0.f;
+  float* yg = a.y + (size_t)g * a.y_gs;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int lr = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      int orow = rowtab[lr];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float v = acc[mt][nt][r] + bias[nt];
+        acc[mt][nt][r] = v;
+        if (orow >= 0) {
+          yg[(size_t)orow * a.y_rs + nt * 32 + (lane & 31)] = v;
+          csum[nt] += v;
+        }
+      }
+    }
+  }
+  if (a.stats == nullptr) return;
+  const int cnt = (a.spp == 1) ? npatch * HW : min(MWG, HW - split * MWG);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float v = csum[nt] + __shfl_xor(csum[nt], 32);
+    if (lane < 32) red[wave * N + nt * 32 + lane] = v;
+  }
+  __syncthreads();
+  if (tid < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * N + tid];
+    cmean[tid] = s / (float)cnt;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float mu = cmean[nt * 32 + (lane & 31)];
+    float m2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (rowtab[lr] >= 0) { float d = acc[mt][nt][r] - mu; m2 += d * d; }
+      }
+    csum[nt] = m2 + __shfl_xor(m2, 32);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    if (lane < 32) red[wave * N + nt * 32 + lane] = csum[nt];
+  __syncthreads();
+  if (tid < N) {
+    float m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m2 += red[w * N + tid];
+    float* o = a.stats + (((size_t)g * gridDim.x + blockIdx.x) * N + tid) * 2;
+    o[0] = cmean[tid];
+    o[1] = m2;
+  }
+}
+
+template <int MT, int NT>
+static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
+  constexpr int MWG = 8 * MT * 32, N = NT * 32;
+  int nwg;
+  conv_geometry(a.HW, MWG, a.B, &a.ppw, &a.spp, &nwg);
+  size_t lds = (size_t)MWG * 8 + (size_t)9 * N * 4 + ((size_t)a.ppw * a.Q + (size_t)9 * N) * RB;
+  if (lds > 160 * 1024) { dta_set_error("conv3x3(bf16): LDS need %zu B exceeds 160 KiB (H=%d W=%d)", lds, a.H, a.W); return 1; }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT>), dim3(nwg, G), dim3(512), lds, st, a);
+  DTA_CHECK_LAUNCH("k_conv3x3_bf16");
+  return 0;
+}
+
+template <>
+int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
+  switch (a.N) {     // workgroup rows must match conv_mwg(N): 512 for N<=64, 256 for N=128
+    case 32: return launch_conv_bf16_t<2, 1>(a, G, st);
+    case 64: return launch_conv_bf16_t<2, 2>(a, G, st);
+    case 128: return launch_conv_bf16_t<1, 4>(a, G, st);
+  }
+  dta_set_error("conv3x3: unsupported output width %d", a.N);
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+constexpr int WGB_PAD_ROWS = 16;
+
+template <int NTT>
+__global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NTHR = 512;
+  constexpr int CT = 4 / NTT;            // 32-channel input tiles per workgroup
+  constexpr int N = NTT * 32;
+  constexpr int XCH = CT * 2, YCH = NTT * 2;
+  const int Q = a.Q, Qp = Q + WGB_PAD_ROWS, W2 = a.W + 2;
+  unsigned char* sx = smem;                               // [XCH][Qp][48 B]
+  unsigned char* sy = sx + (size_t)XCH * Qp * RB;         // [YCH][Qp][48 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
+  const int tg = wave & 1, pair = wave >> 1;              // tap group (0: taps 0-4, 1: taps 5-8), (c-tile, n-tile)
+  const int ct = pair / NTT, nt = pair % NTT;
+  const int tap0 = tg ? 5 : 0, ntap = tg ? 4 : 5;
+  const int chunk0 = cg * XCH;
+  const int nxch = max(0, min(XCH, a.NCx - chunk0));
+
+  {  // zero everything once: pad rows, row padding and absent chunks stay zero for the whole kernel
+    u32x4 z = {0, 0, 0, 0};
+    u32x4* d = reinterpret_cast<u32x4*>(smem);
+    int tot = (XCH + YCH) * Qp * RB / 16;
+    for (int v = tid; v < tot; v += NTHR) d[v] = z;
+  }
+  f32x16 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int q0 = a.W + 3, q1 = Q - a.W - 3;
+  const int nks = (q1 - q0 + 15) / 16;
+  const int gq = lane >> 4, li = lane & 15;
+  const int lane_off = (8 * (gq >> 1) + (li >> 2)) * RB + (li & 3) * 8;
+  const int b_off = ((nt * 2 + (gq & 1)) * Qp + q0) * RB + lane_off;
+  int a_tap[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    int tap = min(tap0 + j, 8);
+    int shift = (tap / 3 - 1) * W2 + (tap % 3 - 1);
+    a_tap[j] = ((ct * 2 + (gq & 1)) * Qp + q0 + shift) * RB + lane_off;
+  }
+
+  // ---- staging plan ----
+  constexpr int XV = 3, YV = 3;
+  const int vpc = Q * 2;
+  const int nxv = nxch * vpc, nyv = YCH * vpc;
+  const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs;
+  const bf16_t* yg = (const bf16_t*)a.dy_tl + (size_t)g * a.dy_gs;
+  const size_t xpatch = (size_t)a.NCx * Q * 16, ypatch = (size_t)a.NCy * Q * 16;
+  size_t xsrc[XV], ysrc[YV];
+  int xdst[XV], ydst[YV];
+#pragma unroll
+  for (int u = 0; u < XV; ++u) {
+    int v = min(tid + u * NTHR, max(nxv, 1) - 1);
+    int ch = v / vpc, o = v - ch * vpc;
+    xsrc[u] = (size_t)(chunk0 + ch) * Q * 16 + (size_t)o * 8;
+    xdst[u] = (ch * Qp + (o >> 1)) * RB + (o & 1) * 16;
+  }
+#pragma unroll
+  for (int u = 0; u < YV; ++u) {
+    int v = min(tid + u * NTHR, nyv - 1);
+    int ch = v / vpc, o = v - ch * vpc;
+    ysrc[u] = (size_t)(a.ych0 + ch) * Q * 16 + (size_t)o * 8;
+    ydst[u] = (ch * Qp + (o >> 1)) * RB + (o & 1) * 16;
+  }
+  const bool pipe = nxv <= XV * NTHR && nyv <= YV * NTHR;
+  u32x4 rx[XV], ry[YV];
+#define DTA_FETCH(b_)                                                                                             \
+  {                                                                                                               \
+    if (nxv > 0) { _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                 \
+        rx[u] = *reinterpret_cast<const u32x4*>(xg + (size_t)(b_) * xpatch + xsrc[u]); }                          \
+    _Pragma("unroll") for (int u = 0; u < YV; ++u)                                                                \
+        ry[u] = *reinterpret_cast<const u32x4*>(yg + (size_t)(b_) * ypatch + ysrc[u]);                            \
+  }
+  if (pipe && s < a.B) DTA_FETCH(s)
+
+  for (int b = s; b < a.B; b += a.S) {
+    __syncthreads();
+    if (pipe) {
+#pragma unroll
+      for (int u = 0; u < XV; ++u)
+        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>(sx + xdst[u]) = rx[u];
+#pragma unroll
+      for (int u = 0; u < YV; ++u)
+        if (tid + u * NTHR < nyv) *reinterpret_cast<u32x4*>(sy + ydst[u]) = ry[u];
+    } else {
+      for (int v = tid; v < nxv; v += NTHR) {
+        int ch = v / vpc, o = v - ch * vpc;
+        *reinterpret_cast<u32x4*>(sx + (ch * Qp + (o >> 1)) * RB + (o & 1) * 16) =
+            *reinterpret_cast<const u32x4*>(xg + (size_t)b * xpatch + (size_t)(chunk0 + ch) * Q * 16 + (size_t)o * 8);
+      }
+      for (int v = tid; v < nyv; v += NTHR) {
+        int ch = v / vpc, o = v - ch * vpc;
+        *reinterpret_cast<u32x4*>(sy + (ch * Qp + (o >> 1)) * RB + (o & 1) * 16) =
+            *reinterpret_cast<const u32x4*>(yg + (size_t)b * ypatch + (size_t)(a.ych0 + ch) * Q * 16 + (size_t)o * 8);
+      }
+    }
+    __syncthreads();
+    if (pipe && b + a.S < a.B) DTA_FETCH(b + a.S)
+#pragma unroll 1
+    for (int ks = 0; ks < nks; ++ks) {
+      const int koff = ks * 16 * RB;
+      bf16x8 bfr = lds_tr8(sy, b_off + koff);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        if (j < ntap) {
+          bf16x8 afr = lds_tr8(sx, a_tap[j] + koff);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+#undef DTA_FETCH
+  // partial[g][s][tap][c][n]
+  float* out = a.partial + ((size_t)(g * a.S + s) * 9) * a.Cpad * N;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    if (j < ntap) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int c = cg * CT * 32 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (c < a.Cpad) out[((size_t)(tap0 + j) * a.Cpad + c) * N + nt * 32 + (lane & 31)] = acc[j][r];
+      }
+    }
+  }
+}
+
+template <int NTT>
+static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream_t st) {
+  constexpr int CT = 4 / NTT;
+  size_t lds = (size_t)(CT * 2 + NTT * 2) * (a.Q + WGB_PAD_ROWS) * RB;
+  if (lds > 160 * 1024) { dta_set_error("conv_wgrad(bf16): LDS need %zu B exceeds 160 KiB", lds); return 1; }
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_conv_wgrad_bf16<NTT>), dim3(cgroups, a.S, G), dim3(512), lds, st, a);
+  DTA_CHECK_LAUNCH("k_conv_wgrad_bf16");
+  return 0;
+}
+
+template <>
+int launch_conv_wgrad<bf16_t>(const WgradArgs& a, int G, hipStream_t st) {
+  int cpw = wgrad_cpw(a.N);
+  int cgroups = (a.Cpad + cpw - 1) / cpw;
+  switch (a.N) {
+    case 32: return launch_wgrad_bf16_t<1>(a, G, cgroups, st);
+    case 64: return launch_wgrad_bf16_t<2>(a, G, cgroups, st);
+    case 128: return launch_wgrad_bf16_t<4>(a, G, cgroups, st);
+  }
+  dta_set_error("conv_wgrad: unsupported width %d", a.N);
+  return 1;
+}
+
+}  // namespace dta

@@ -34,6 +34,8 @@ template <typename T> int launch_pack_input(const float* x, void* out, int B, in
 template <typename T> int launch_pack_conv_w(const PackWArgs& a, void* dst, hipStream_t st);
 template <typename T> int launch_conv3x3(const ConvArgs& a, int G, hipStream_t st);
 template <typename T> int launch_conv_wgrad(const WgradArgs& a, int G, hipStream_t st);
+template <> int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st);       // conv_bf16.hip
+template <> int launch_conv_wgrad<bf16_t>(const WgradArgs& a, int G, hipStream_t st);   // conv_bf16.hip
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st);
 void conv_geometry(int HW, int MWG, int B, int* ppw, int* spp, int* nwg);
 int conv_mwg(int N);
