@@ -33,9 +33,10 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   int* plq = rowtab + MWG;                  // [MWG] (pl << 16) | q_topleft
   float* red = (float*)(plq + MWG);         // [NW][N]
   float* cmean = red + NW * N;              // [N]
-  unsigned char* sx = (unsigned char*)(cmean + N);
+  unsigned char* sbuf = (unsigned char*)(cmean + N);
   const int Q = a.Q, HW = a.HW, W2 = a.W + 2;
-  unsigned char* sw = sx + (size_t)a.ppw * Q * RB;
+  const int xbytes = a.ppw * Q * RB, wbytes = 9 * N * RB, stage = xbytes + wbytes;
+  const bool dbuf = a.dbuf != 0;            // two LDS stages: staging of chunk k+1 overlaps the MFMAs of chunk k
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.y;
@@ -92,7 +93,6 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     int v = min(tid + u * NTHR, wvec - 1);
     wdst[u] = (v >> 1) * RB + (v & 1) * 16;
   }
-  const bool pipe = nxv <= XV * NTHR;
   u32x4 rx[XV], rw[WV];
 #define DTA_FETCH(chunk_)                                                                             \
   {                                                                                                   \
@@ -101,43 +101,48 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)(chunk_) * 9 * N * 16);           \
     _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[min(tid + u * NTHR, wvec - 1)];       \
   }
-  if (pipe) DTA_FETCH(0)
+#define DTA_STORE(sx_, sw_)                                                                           \
+  {                                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                    \
+        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((sx_) + xdst[u]) = rx[u];                 \
+    _Pragma("unroll") for (int u = 0; u < WV; ++u)                                                    \
+        if (tid + u * NTHR < wvec) *reinterpret_cast<u32x4*>((sw_) + wdst[u]) = rw[u];                \
+  }
+#define DTA_COMPUTE(sx_, sw_)                                                                         \
+  _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                               \
+    const int toffB = ((tap / 3) * W2 + (tap % 3)) * RB;                                              \
+    bf16x8 af[MT], bf[NT];                                                                            \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[mt] = lds_b128((sx_), abase[mt] + toffB);    \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                 \
+        bf[nt] = lds_b128((sw_), bbase + (tap * N + nt * 32) * RB);                                   \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                               \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0); \
+  }
 
+  // chunk k+1 sits in registers while chunk k is multiplied; with two LDS stages its ds_writes also overlap
+  DTA_FETCH(0)
+  DTA_STORE(sbuf, sbuf + xbytes)
+  if (a.NC > 1) DTA_FETCH(1)
+  __syncthreads();
   for (int chunk = 0; chunk < a.NC; ++chunk) {
-    __syncthreads();
-    if (pipe) {
-#pragma unroll
-      for (int u = 0; u < XV; ++u)
-        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>(sx + xdst[u]) = rx[u];
-#pragma unroll
-      for (int u = 0; u < WV; ++u)
-        if (tid + u * NTHR < wvec) *reinterpret_cast<u32x4*>(sw + wdst[u]) = rw[u];
-    } else {
-      for (int v = tid; v < nxv; v += NTHR) {
-        int pl = v / vpp, o = v - pl * vpp;
-        *reinterpret_cast<u32x4*>(sx + (pl * Q + (o >> 1)) * RB + (o & 1) * 16) =
-            *reinterpret_cast<const u32x4*>(xg + ((size_t)(b0 + pl) * a.NC + chunk) * xchunk + (size_t)o * 8);
-      }
-      const u32x4* swp = reinterpret_cast<const u32x4*>(wg + (size_t)chunk * 9 * N * 16);
-      for (int v = tid; v < wvec; v += NTHR) *reinterpret_cast<u32x4*>(sw + (v >> 1) * RB + (v & 1) * 16) = swp[v];
+    unsigned char* cx = sbuf + ((dbuf && (chunk & 1)) ? stage : 0);
+    unsigned char* nx = sbuf + ((dbuf && !(chunk & 1)) ? stage : 0);
+    const bool more = chunk + 1 < a.NC;
+    if (dbuf && more) {
+      DTA_STORE(nx, nx + xbytes)
+      if (chunk + 2 < a.NC) DTA_FETCH(chunk + 2)
     }
+    DTA_COMPUTE(cx, cx + xbytes)
     __syncthreads();
-    if (pipe && chunk + 1 < a.NC) DTA_FETCH(chunk + 1)
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toffB = ((tap / 3) * W2 + (tap % 3)) * RB;
-      bf16x8 af[MT], bf[NT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) af[mt] = lds_b128(sx, abase[mt] + toffB);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[nt] = lds_b128(sw, bbase + (tap * N + nt * 32) * RB);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    if (!dbuf && more) {
+      DTA_STORE(nx, nx + xbytes)
+      if (chunk + 2 < a.NC) DTA_FETCH(chunk + 2)
+      __syncthreads();
     }
   }
+#undef DTA_COMPUTE
+#undef DTA_STORE
 #undef DTA_FETCH
 
   // ---- epilogue: bias, store, per-workgroup (mean, M2) per column ----
@@ -221,8 +226,11 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   constexpr int MWG = 8 * MT * 32, N = NT * 32;
   int nwg;
   conv_geometry(a.HW, MWG, a.B, &a.ppw, &a.spp, &nwg);
-  size_t lds = (size_t)MWG * 8 + (size_t)9 * N * 4 + ((size_t)a.ppw * a.Q + (size_t)9 * N) * RB;
+  size_t tab = (size_t)MWG * 8 + (size_t)9 * N * 4, stage = ((size_t)a.ppw * a.Q + (size_t)9 * N) * RB;
+  a.dbuf = tab + 2 * stage <= 160 * 1024;
+  size_t lds = tab + (a.dbuf ? 2 : 1) * stage;
   if (lds > 160 * 1024) { dta_set_error("conv3x3(bf16): LDS need %zu B exceeds 160 KiB (H=%d W=%d)", lds, a.H, a.W); return 1; }
+  if (a.ppw * a.Q * 2 > 4 * 512) { dta_set_error("conv3x3(bf16): %dx%d tile exceeds the staging plan", a.H, a.W); return 1; }
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -249,6 +257,22 @@ int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 constexpr int WGB_PAD_ROWS = 16;
 
+// One patch: K runs over the haloed-grid rows in steps of 16; NTAP accumulators share each dY fragment.
+template <int NTAP>
+__device__ __forceinline__ void wgrad_ksteps(const unsigned char* bx, const unsigned char* by, const int* a_tap,
+                                             int b_off, int nks, f32x16* acc) {
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ++ks) {
+    const int koff = ks * 16 * RB;
+    bf16x8 bfr = lds_tr8(by, b_off + koff);
+    bf16x8 afr[NTAP];
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) afr[j] = lds_tr8(bx, a_tap[j] + koff);
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[j], bfr, acc[j], 0, 0, 0);
+  }
+}
+
 template <int NTT>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -257,8 +281,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   constexpr int N = NTT * 32;
   constexpr int XCH = CT * 2, YCH = NTT * 2;
   const int Q = a.Q, Qp = Q + WGB_PAD_ROWS, W2 = a.W + 2;
-  unsigned char* sx = smem;                               // [XCH][Qp][48 B]
-  unsigned char* sy = sx + (size_t)XCH * Qp * RB;         // [YCH][Qp][48 B]
+  const int xbytes = XCH * Qp * RB, stage = (XCH + YCH) * Qp * RB;   // stage = [XCH][Qp][48 B] | [YCH][Qp][48 B]
+  const bool dbuf = a.dbuf != 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
   const int tg = wave & 1, pair = wave >> 1;              // tap group (0: taps 0-4, 1: taps 5-8), (c-tile, n-tile)
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   {  // zero everything once: pad rows, row padding and absent chunks stay zero for the whole kernel
     u32x4 z = {0, 0, 0, 0};
     u32x4* d = reinterpret_cast<u32x4*>(smem);
-    int tot = (XCH + YCH) * Qp * RB / 16;
+    int tot = (dbuf ? 2 : 1) * stage / 16;
     for (int v = tid; v < tot; v += NTHR) d[v] = z;
   }
   f32x16 acc[5];
@@ -315,7 +339,6 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     ysrc[u] = (size_t)(a.ych0 + ch) * Q * 16 + (size_t)o * 8;
     ydst[u] = (ch * Qp + (o >> 1)) * RB + (o & 1) * 16;
   }
-  const bool pipe = nxv <= XV * NTHR && nyv <= YV * NTHR;
   u32x4 rx[XV], ry[YV];
 #define DTA_FETCH(b_)                                                                                             \
   {                                                                                                               \
@@ -324,44 +347,39 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     _Pragma("unroll") for (int u = 0; u < YV; ++u)                                                                \
         ry[u] = *reinterpret_cast<const u32x4*>(yg + (size_t)(b_) * ypatch + ysrc[u]);                            \
   }
-  if (pipe && s < a.B) DTA_FETCH(s)
-
-  for (int b = s; b < a.B; b += a.S) {
-    __syncthreads();
-    if (pipe) {
-#pragma unroll
-      for (int u = 0; u < XV; ++u)
-        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>(sx + xdst[u]) = rx[u];
-#pragma unroll
-      for (int u = 0; u < YV; ++u)
-        if (tid + u * NTHR < nyv) *reinterpret_cast<u32x4*>(sy + ydst[u]) = ry[u];
-    } else {
-      for (int v = tid; v < nxv; v += NTHR) {
-        int ch = v / vpc, o = v - ch * vpc;
-        *reinterpret_cast<u32x4*>(sx + (ch * Qp + (o >> 1)) * RB + (o & 1) * 16) =
-            *reinterpret_cast<const u32x4*>(xg + (size_t)b * xpatch + (size_t)(chunk0 + ch) * Q * 16 + (size_t)o * 8);
-      }
-      for (int v = tid; v < nyv; v += NTHR) {
-        int ch = v / vpc, o = v - ch * vpc;
-        *reinterpret_cast<u32x4*>(sy + (ch * Qp + (o >> 1)) * RB + (o & 1) * 16) =
-            *reinterpret_cast<const u32x4*>(yg + (size_t)b * ypatch + (size_t)(a.ych0 + ch) * Q * 16 + (size_t)o * 8);
-      }
+#define DTA_STORE(base_)                                                                                          \
+  {                                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                                \
+        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((base_) + xdst[u]) = rx[u];                           \
+    _Pragma("unroll") for (int u = 0; u < YV; ++u)                                                                \
+        if (tid + u * NTHR < nyv) *reinterpret_cast<u32x4*>((base_) + xbytes + ydst[u]) = ry[u];                  \
+  }
+  if (s < a.B) {
+    DTA_FETCH(s)
+    __syncthreads();                       // zero fill complete before the first tile lands
+    DTA_STORE(smem)
+    if (s + a.S < a.B) DTA_FETCH(s + a.S)
+  }
+  __syncthreads();
+  int it = 0;
+  for (int b = s; b < a.B; b += a.S, ++it) {
+    unsigned char* cur = smem + ((dbuf && (it & 1)) ? stage : 0);
+    unsigned char* nxt = smem + ((dbuf && !(it & 1)) ? stage : 0);
+    const bool more = b + a.S < a.B;
+    if (dbuf && more) {
+      DTA_STORE(nxt)
+      if (b + 2 * a.S < a.B) DTA_FETCH(b + 2 * a.S)
     }
+    if (tg == 0) wgrad_ksteps<5>(cur, cur + xbytes, a_tap, b_off, nks, acc);
+    else wgrad_ksteps<4>(cur, cur + xbytes, a_tap, b_off, nks, acc);
     __syncthreads();
-    if (pipe && b + a.S < a.B) DTA_FETCH(b + a.S)
-#pragma unroll 1
-    for (int ks = 0; ks < nks; ++ks) {
-      const int koff = ks * 16 * RB;
-      bf16x8 bfr = lds_tr8(sy, b_off + koff);
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        if (j < ntap) {
-          bf16x8 afr = lds_tr8(sx, a_tap[j] + koff);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[j], 0, 0, 0);
-        }
-      }
+    if (!dbuf && more) {
+      DTA_STORE(nxt)
+      if (b + 2 * a.S < a.B) DTA_FETCH(b + 2 * a.S)
+      __syncthreads();
     }
   }
+#undef DTA_STORE
 #undef DTA_FETCH
   // partial[g][s][tap][c][n]
   float* out = a.partial + ((size_t)(g * a.S + s) * 9) * a.Cpad * N;
@@ -380,14 +398,18 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
 template <int NTT>
 static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream_t st) {
   constexpr int CT = 4 / NTT;
-  size_t lds = (size_t)(CT * 2 + NTT * 2) * (a.Q + WGB_PAD_ROWS) * RB;
+  size_t stage = (size_t)(CT * 2 + NTT * 2) * (a.Q + WGB_PAD_ROWS) * RB;
+  WgradArgs a2 = a;
+  a2.dbuf = 2 * stage <= 160 * 1024;
+  size_t lds = (a2.dbuf ? 2 : 1) * stage;
   if (lds > 160 * 1024) { dta_set_error("conv_wgrad(bf16): LDS need %zu B exceeds 160 KiB", lds); return 1; }
+  if (4 * a.Q * 2 > 3 * 512) { dta_set_error("conv_wgrad(bf16): %dx%d tile exceeds the staging plan", a.H, a.W); return 1; }
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_conv_wgrad_bf16<NTT>), dim3(cgroups, a.S, G), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((k_conv_wgrad_bf16<NTT>), dim3(cgroups, a.S, G), dim3(512), lds, st, a2);
   DTA_CHECK_LAUNCH("k_conv_wgrad_bf16");
   return 0;
 }

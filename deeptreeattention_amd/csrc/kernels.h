@@ -18,13 +18,13 @@ struct ConvArgs {
   const float* bias[2]; int bias_mode, bias_split;
   float* y; size_t y_gs; int y_rs;    // fp32 output rows [row][y_rs], group offset y_gs
   float* stats;                       // [G][nwg][N][2] (mean, M2) or null
-  int B, H, W, NC, N, Q, HW, ppw, spp;
+  int B, H, W, NC, N, Q, HW, ppw, spp, dbuf;
 };
 struct WgradArgs {
   const void* x_tl; size_t x_gs; int NCx;
   const void* dy_tl; size_t dy_gs; int NCy, ych0;
   float* partial;                     // [G][S][9][Cpad][N]
-  int B, H, W, Q, N, Cpad, S;
+  int B, H, W, Q, N, Cpad, S, dbuf;
 };
 struct WgradReduceArgs {
   const float* partial; float* dst[2];
