@@ -100,16 +100,44 @@ int launch_bn_finalize(const BnFinalizeArgs& b, int G, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------
 // Per-patch stage: LDS plan (floats).  Rows padded to C+1 so per-pixel loops over channels and
-// per-channel loops over pixels are both bank-conflict free.
+// per-channel loops over pixels are both bank-conflict free.  The spatial branch keeps its single-channel
+// maps zero-padded by the stencil radius so the k x k stencils and their transposes run without bounds checks.
 // ------------------------------------------------------------------------------------------------
 struct StageGeom {
-  int C, ld, Hc, Wc, HWc, Hz, Wz, HWz;
+  int C, ld, Hc, Wc, HWc, Hz, Wz, HWz, vslot;
 };
+__host__ __device__ inline int stage_vslot(int C, int Hz, int Wz) {
+  int pm = (Hz + 6) * (Wz + 6);   // padded map for stencil radius <= 3
+  int v = C > pm ? C : pm;
+  return v;
+}
+// Compile-time specialisation of a stage: CT channels, HT x WT conv-resolution map, PT = 2x2 pool after ReLU.
+// HT == 0 keeps the geometry (and the stencil sizes) as run-time values.
+template <int CT, int HT, int WT, int PT>
+struct StageCfg {
+  static constexpr int C = CT, H = HT, W = WT, P = PT;
+  static constexpr bool fixed = HT > 0;
+};
+template <typename CFG>
 __device__ __forceinline__ StageGeom stage_geom(const StageArgs& a) {
   StageGeom s;
-  s.C = a.C; s.ld = a.C + 1; s.Hc = a.Hc; s.Wc = a.Wc; s.HWc = a.Hc * a.Wc;
-  s.Hz = a.pool ? a.Hc / 2 : a.Hc; s.Wz = a.pool ? a.Wc / 2 : a.Wc; s.HWz = s.Hz * s.Wz;
+  s.C = CFG::C ? CFG::C : a.C; s.ld = s.C + 1;
+  s.Hc = CFG::fixed ? CFG::H : a.Hc; s.Wc = CFG::fixed ? CFG::W : a.Wc; s.HWc = s.Hc * s.Wc;
+  const bool pool = CFG::fixed ? (CFG::P != 0) : (a.pool != 0);
+  s.Hz = pool ? s.Hc / 2 : s.Hc; s.Wz = pool ? s.Wc / 2 : s.Wc; s.HWz = s.Hz * s.Wz;
+  s.vslot = stage_vslot(s.C, s.Hz, s.Wz);
   return s;
+}
+// spatial-attention stencil size / class-pool size are functions of the channel count in the reference
+// (Hang2020.py:77-99): compile-time when the stage is specialised
+template <typename CFG> __device__ __forceinline__ int cfg_att_k(const StageArgs& a, int g) {
+  return CFG::fixed ? (CFG::C == 32 ? 7 : CFG::C == 64 ? 5 : 3) : a.att_k[g];
+}
+template <typename CFG> __device__ __forceinline__ int cfg_att_pool(const StageArgs& a, int g) {
+  return CFG::fixed ? (CFG::C == 32 ? 4 : CFG::C == 64 ? 2 : 1) : a.att_pool[g];
+}
+template <typename CFG> __device__ __forceinline__ bool cfg_pool(const StageArgs& a) {
+  return CFG::fixed ? (CFG::P != 0) : (a.pool != 0);
 }
 static size_t stage_lds_floats(const StageArgs& a, bool bwd) {
   int HWc = a.Hc * a.Wc;
@@ -118,8 +146,7 @@ static size_t stage_lds_floats(const StageArgs& a, bool bwd) {
   size_t n = (size_t)HWz * ld;                 // Z
   if (a.pool) n += (size_t)HWc * ld;            // R
   if (bwd) n += (size_t)HWz * ld;               // D
-  int vmax = a.C > HWz ? a.C : HWz;
-  n += (size_t)(bwd ? 8 : 4) * vmax + 512;      // vectors + reduction scratch
+  n += (size_t)(bwd ? 8 : 4) * stage_vslot(a.C, Hz, Wz) + 512;   // vectors / padded maps + reduction scratch
   return n;
 }
 
@@ -141,25 +168,57 @@ __device__ __forceinline__ void colreduce(int C, int n, float* scratch, float* o
   __syncthreads();
 }
 
+// k x k cross-correlation of a zero-padded single-channel map (radius r = k/2, row pitch Wp = Wz + 2r) at pixel
+// (h, w): no bounds checks.  flip = true gives the transposed stencil (gradient wrt the input map).
+__device__ __forceinline__ float stencil_at(const float* mp, const float* kw, int k, int Wp, int h, int w, bool flip) {
+  float acc = 0.f;
+  const float* row = mp + h * Wp + w;
+  if (!flip) {
+    for (int ky = 0; ky < k; ++ky, row += Wp)
+      for (int kx = 0; kx < k; ++kx) acc += kw[ky * k + kx] * row[kx];
+  } else {
+    for (int ky = 0; ky < k; ++ky, row += Wp)
+      for (int kx = 0; kx < k; ++kx) acc += kw[(k - 1 - ky) * k + (k - 1 - kx)] * row[kx];
+  }
+  return acc;
+}
+
 // Forward recompute shared by both kernels.  On return (all threads synced):
 //   Z [HWz][ld]  post BN/ReLU/pool activations,  R [HWc][ld] pre-pool (only if pool)
 //   spectral: v0 = pooled, v1 = h (post ReLU), v2 = gate
-//   spatial : v0 = m (post ReLU), v1 = t1 (post ReLU), v2 = s (sigmoid gate)
+//   spatial : v0 = m (post ReLU, zero-padded map), v1 = t1 (post ReLU, zero-padded map), v2 = s (gate, per pixel)
+template <typename CFG>
 __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeom& s, int g, int b, int kind,
                                               float* Z, float* R, float* v0, float* v1, float* v2, float* scratch) {
+  constexpr int CT = CFG::C;
+  const bool pool = cfg_pool<CFG>(a);
   const int t = threadIdx.x, C = s.C, ld = s.ld;
   const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
   const float* coef = a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr;
-  float* dst = a.pool ? R : Z;
-  for (int i = t; i < s.HWc * C; i += 256) {
-    int p = i / C, c = i - p * C;
-    float v = y[(size_t)p * a.y_rs + c];
-    if (a.apply_bn) v = v * coef[c * 4 + 0] + coef[c * 4 + 1];
-    if (a.relu) v = fmaxf(v, 0.f);
-    dst[p * ld + c] = v;
+  float* dst = pool ? R : Z;
+  if (CT > 0) {
+    // 256 % C == 0: every thread keeps one channel, its BN coefficients live in registers
+    const int c = t % C, p0 = t / C, pstep = 256 / C;
+    const float sc = a.apply_bn ? coef[c * 4 + 0] : 1.f, sh = a.apply_bn ? coef[c * 4 + 1] : 0.f;
+    for (int p = p0; p < s.HWc; p += pstep) {
+      float v = y[(size_t)p * a.y_rs + c] * sc + sh;
+      if (a.relu) v = fmaxf(v, 0.f);
+      dst[p * ld + c] = v;
+    }
+  } else {
+    for (int i = t; i < s.HWc * C; i += 256) {
+      int p = i / C, c = i - p * C;
+      float v = y[(size_t)p * a.y_rs + c];
+      if (a.apply_bn) v = v * coef[c * 4 + 0] + coef[c * 4 + 1];
+      if (a.relu) v = fmaxf(v, 0.f);
+      dst[p * ld + c] = v;
+    }
+  }
+  if (kind == KIND_SPATIAL) {   // zero the padded maps' borders (interiors are overwritten below)
+    for (int i = t; i < 2 * s.vslot; i += 256) v0[i] = 0.f;   // v0 and v1 are adjacent
   }
   __syncthreads();
-  if (a.pool) {
+  if (pool) {
     for (int i = t; i < s.HWz * C; i += 256) {
       int pz = i / C, c = i - pz * C;
       int hz = pz / s.Wz, wz = pz - hz * s.Wz;
@@ -183,39 +242,22 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
     const float* wc = a.att[g].p[0]; const float bc = a.att[g].p[1][0];
     const float* k1 = a.att[g].p[2]; const float b1 = a.att[g].p[3][0];
     const float* k2 = a.att[g].p[4]; const float b2 = a.att[g].p[5][0];
-    const int k = a.att_k[g], r = k / 2;
+    const int k = cfg_att_k<CFG>(a, g), r = k / 2, Wp = s.Wz + 2 * r;
     for (int p = t; p < s.HWz; p += 256) {
       float acc = bc;
       for (int c = 0; c < C; ++c) acc += wc[c] * Z[p * ld + c];
-      v0[p] = fmaxf(acc, 0.f);
+      int h = p / s.Wz, w = p - h * s.Wz;
+      v0[(h + r) * Wp + w + r] = fmaxf(acc, 0.f);
     }
     __syncthreads();
     for (int p = t; p < s.HWz; p += 256) {
       int h = p / s.Wz, w = p - h * s.Wz;
-      float acc = b1;
-      for (int ky = 0; ky < k; ++ky) {
-        int hh = h + ky - r;
-        if (hh < 0 || hh >= s.Hz) continue;
-        for (int kx = 0; kx < k; ++kx) {
-          int ww = w + kx - r;
-          if (ww >= 0 && ww < s.Wz) acc += k1[ky * k + kx] * v0[hh * s.Wz + ww];
-        }
-      }
-      v1[p] = fmaxf(acc, 0.f);
+      v1[(h + r) * Wp + w + r] = fmaxf(b1 + stencil_at(v0, k1, k, Wp, h, w, false), 0.f);
     }
     __syncthreads();
     for (int p = t; p < s.HWz; p += 256) {
       int h = p / s.Wz, w = p - h * s.Wz;
-      float acc = b2;
-      for (int ky = 0; ky < k; ++ky) {
-        int hh = h + ky - r;
-        if (hh < 0 || hh >= s.Hz) continue;
-        for (int kx = 0; kx < k; ++kx) {
-          int ww = w + kx - r;
-          if (ww >= 0 && ww < s.Wz) acc += k2[ky * k + kx] * v1[hh * s.Wz + ww];
-        }
-      }
-      v2[p] = sigmoidf_(acc);
+      v2[p] = sigmoidf_(b2 + stencil_at(v1, k2, k, Wp, h, w, false));
     }
     __syncthreads();
   }
@@ -225,19 +267,18 @@ __device__ __forceinline__ float gate_of(int kind, const float* v2, int p, int c
   return kind == KIND_SPECTRAL ? v2[c] : (kind == KIND_SPATIAL ? v2[p] : 1.f);
 }
 
-template <typename T>
+template <typename T, typename CFG>
 __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const StageGeom s = stage_geom(a);
+  const StageGeom s = stage_geom<CFG>(a);
   const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = s.C, ld = s.ld;
   const int kind = a.kind[g];
-  const int vmax = C > s.HWz ? C : s.HWz;
   float* Z = sm;
   float* R = Z + (size_t)s.HWz * ld;
-  float* v0 = R + (a.pool ? (size_t)s.HWc * ld : 0);
-  float* v1 = v0 + vmax; float* v2 = v1 + vmax; float* v3 = v2 + vmax;
-  float* scratch = v3 + vmax;
-  stage_forward(a, s, g, b, kind, Z, R, v0, v1, v2, scratch);
+  float* v0 = R + (cfg_pool<CFG>(a) ? (size_t)s.HWc * ld : 0);
+  float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
+  float* scratch = v3 + s.vslot;
+  stage_forward<CFG>(a, s, g, b, kind, Z, R, v0, v1, v2, scratch);
 
   // classifier features
   if (a.feat) {
@@ -245,7 +286,7 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
     if (kind == KIND_SPECTRAL) {
       if (t < C) f[t] = v2[t] * v0[t];  // mean_p(z*gate) == gate * mean_p(z)
     } else if (kind == KIND_SPATIAL) {
-      const int ps = a.att_pool[g], hp = s.Hz / ps, wp = s.Wz / ps;
+      const int ps = cfg_att_pool<CFG>(a, g), hp = s.Hz / ps, wp = s.Wz / ps;
       for (int i = t; i < C * hp * wp; i += 256) {
         int c = i / (hp * wp), rem = i - c * hp * wp, ph = rem / wp, pw = rem - ph * wp;
         float m = -3.4e38f;
@@ -288,14 +329,44 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
   }
 }
 
+template <typename T, typename CFG>
+static int launch_stage_fwd_c(const StageArgs& a, int G, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)k_stage_fwd<T, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_stage_fwd<T, CFG>), dim3(a.B, G), dim3(256), lds, st, a);
+  DTA_CHECK_LAUNCH("k_stage_fwd");
+  return 0;
+}
+
+// true when (C, Hc, Wc, pool, stencil/pool sizes) are those of one of the 11x11 network's three stages
+static bool stage_net_cfg(const StageArgs& a) {
+  int lvl = a.C == 32 ? 0 : a.C == 64 ? 1 : a.C == 128 ? 2 : -1;
+  if (lvl < 0) return false;
+  const int H[3] = {11, 11, 5}, P[3] = {0, 1, 1}, K[3] = {7, 5, 3}, CP[3] = {4, 2, 1};
+  if (a.Hc != H[lvl] || a.Wc != H[lvl] || (a.pool != 0) != (P[lvl] != 0)) return false;
+  for (int g = 0; g < 2; ++g)
+    if (a.kind[g] == KIND_SPATIAL && (a.att_k[g] != K[lvl] || a.att_pool[g] != CP[lvl])) return false;
+  return true;
+}
+
 template <typename T>
 int launch_stage_fwd(const StageArgs& a, int G, hipStream_t st) {
   size_t lds = stage_lds_floats(a, false) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_fwd: %dx%dx%d patch needs %zu B of LDS", a.Hc, a.Wc, a.C, lds); return 1; }
-  hipFuncSetAttribute((const void*)k_stage_fwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(k_stage_fwd<T>, dim3(a.B, G), dim3(256), lds, st, a);
-  DTA_CHECK_LAUNCH("k_stage_fwd");
-  return 0;
+  // the three stages of the 11x11 network are fully specialised (stencils unroll, no index divisions)
+  const bool net = a.apply_bn && a.relu && stage_net_cfg(a);
+  if (net && a.C == 32) return launch_stage_fwd_c<T, StageCfg<32, 11, 11, 0>>(a, G, lds, st);
+  if (net && a.C == 64) return launch_stage_fwd_c<T, StageCfg<64, 11, 11, 1>>(a, G, lds, st);
+  if (net && a.C == 128) return launch_stage_fwd_c<T, StageCfg<128, 5, 5, 1>>(a, G, lds, st);
+  switch (a.C) {
+    case 32: return launch_stage_fwd_c<T, StageCfg<32, 0, 0, 0>>(a, G, lds, st);
+    case 64: return launch_stage_fwd_c<T, StageCfg<64, 0, 0, 0>>(a, G, lds, st);
+    case 128: return launch_stage_fwd_c<T, StageCfg<128, 0, 0, 0>>(a, G, lds, st);
+  }
+  return launch_stage_fwd_c<T, StageCfg<0, 0, 0, 0>>(a, G, lds, st);
 }
 template int launch_stage_fwd<float>(const StageArgs&, int, hipStream_t);
 template int launch_stage_fwd<bf16_t>(const StageArgs&, int, hipStream_t);
@@ -303,21 +374,24 @@ template int launch_stage_fwd<bf16_t>(const StageArgs&, int, hipStream_t);
 // ------------------------------------------------------------------------------------------------
 // Backward of one stage for one patch.
 // ------------------------------------------------------------------------------------------------
+template <typename CFG>
 __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const StageArgs& a = ba.f;
-  const StageGeom s = stage_geom(a);
+  const StageGeom s = stage_geom<CFG>(a);
+  const bool pool = cfg_pool<CFG>(a);
   const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = s.C, ld = s.ld;
   const int kind = a.kind[g];
-  const int vmax = C > s.HWz ? C : s.HWz;
   float* Z = sm;
   float* R = Z + (size_t)s.HWz * ld;
-  float* D = R + (a.pool ? (size_t)s.HWc * ld : 0);
+  float* D = R + (pool ? (size_t)s.HWc * ld : 0);
   float* v0 = D + (size_t)s.HWz * ld;
-  float* v1 = v0 + vmax; float* v2 = v1 + vmax; float* v3 = v2 + vmax;
-  float* v4 = v3 + vmax; float* v5 = v4 + vmax; float* v6 = v5 + vmax; float* v7 = v6 + vmax;
-  float* scratch = v7 + vmax;
-  stage_forward(a, s, g, b, kind, Z, R, v0, v1, v2, scratch);
+  float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
+  float* v4 = v3 + s.vslot; float* v5 = v4 + s.vslot; float* v6 = v5 + s.vslot; float* v7 = v6 + s.vslot;
+  float* scratch = v7 + s.vslot;
+  if (kind == KIND_SPATIAL)
+    for (int i = t; i < 2 * s.vslot; i += 256) v3[i] = 0.f;   // padded maps d2 (v3) and d1 (v4)
+  stage_forward<CFG>(a, s, g, b, kind, Z, R, v0, v1, v2, scratch);
 
   // D = incoming gradient wrt the gated map
   if (ba.da) {
@@ -358,9 +432,9 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
     const float* wc = a.att[g].p[0];
     const float* k1 = a.att[g].p[2];
     const float* k2 = a.att[g].p[4];
-    const int k = a.att_k[g], r = k / 2, kk = k * k;
+    const int k = cfg_att_k<CFG>(a, g), r = k / 2, kk = k * k, Wp = s.Wz + 2 * r;
     if (df) {
-      const int ps = a.att_pool[g], hp = s.Hz / ps, wp = s.Wz / ps;
+      const int ps = cfg_att_pool<CFG>(a, g), hp = s.Hz / ps, wp = s.Wz / ps;
       for (int i = t; i < C * hp * wp; i += 256) {
         int c = i / (hp * wp), rem = i - c * hp * wp, ph = rem / wp, pw = rem - ph * wp;
         float m = -3.4e38f; int arg = 0;
@@ -374,41 +448,26 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
       }
       __syncthreads();
     }
-    // ds -> d2 (v3) per pixel
+    // ds -> d2 (v3, padded map)
     for (int p = t; p < s.HWz; p += 256) {
       float acc = 0.f;
       for (int c = 0; c < C; ++c) acc += D[p * ld + c] * Z[p * ld + c];
-      v3[p] = acc * v2[p] * (1.f - v2[p]);
+      int h = p / s.Wz, w = p - h * s.Wz;
+      v3[(h + r) * Wp + w + r] = acc * v2[p] * (1.f - v2[p]);
     }
     __syncthreads();
-    // dt1 = convT(d2, k2) masked by t1>0 -> d1 (v4)
+    // dt1 = transposed stencil of d2 with k2, masked by t1 > 0 -> d1 (v4, padded map)
     for (int p = t; p < s.HWz; p += 256) {
-      int h = p / s.Wz, w = p - h * s.Wz;
-      float acc = 0.f;
-      for (int ky = 0; ky < k; ++ky) {
-        int hh = h - (ky - r);
-        if (hh < 0 || hh >= s.Hz) continue;
-        for (int kx = 0; kx < k; ++kx) {
-          int ww = w - (kx - r);
-          if (ww >= 0 && ww < s.Wz) acc += k2[ky * k + kx] * v3[hh * s.Wz + ww];
-        }
-      }
-      v4[p] = v1[p] > 0.f ? acc : 0.f;
+      int h = p / s.Wz, w = p - h * s.Wz, pi = (h + r) * Wp + w + r;
+      float acc = stencil_at(v3, k2, k, Wp, h, w, true);
+      v4[pi] = v1[pi] > 0.f ? acc : 0.f;
     }
     __syncthreads();
-    // dm = convT(d1, k1) masked by m>0 -> dm0 (v5)
+    // dm = transposed stencil of d1 with k1, masked by m > 0 -> dm0 (v5, per pixel)
     for (int p = t; p < s.HWz; p += 256) {
-      int h = p / s.Wz, w = p - h * s.Wz;
-      float acc = 0.f;
-      for (int ky = 0; ky < k; ++ky) {
-        int hh = h - (ky - r);
-        if (hh < 0 || hh >= s.Hz) continue;
-        for (int kx = 0; kx < k; ++kx) {
-          int ww = w - (kx - r);
-          if (ww >= 0 && ww < s.Wz) acc += k1[ky * k + kx] * v4[hh * s.Wz + ww];
-        }
-      }
-      v5[p] = v0[p] > 0.f ? acc : 0.f;
+      int h = p / s.Wz, w = p - h * s.Wz, pi = (h + r) * Wp + w + r;
+      float acc = stencil_at(v4, k1, k, Wp, h, w, true);
+      v5[p] = v0[pi] > 0.f ? acc : 0.f;
     }
     __syncthreads();
     if (vec) {
@@ -417,21 +476,19 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
         float acc = 0.f;
         if (i < C) { for (int p = 0; p < s.HWz; ++p) acc += v5[p] * Z[p * ld + i]; }
         else if (i == C) { for (int p = 0; p < s.HWz; ++p) acc += v5[p]; }
-        else if (i == C + 1 + kk) { for (int p = 0; p < s.HWz; ++p) acc += v4[p]; }
-        else if (i == C + 2 + 2 * kk) { for (int p = 0; p < s.HWz; ++p) acc += v3[p]; }
-        else {
+        else if (i == C + 1 + kk || i == C + 2 + 2 * kk) {
+          const float* dd = (i == C + 1 + kk) ? v4 : v3;    // padded maps: borders are zero
+          for (int q = 0; q < (s.Hz + 2 * r) * Wp; ++q) acc += dd[q];
+        } else {
           const bool first = i < C + 1 + kk;
           const int j = first ? i - (C + 1) : i - (C + 2 + kk);
-          const int ky = j / k - r, kx = j % k - r;
-          const float* src = first ? v0 : v1;   // conv input (m for K1, t1 for K2)
-          const float* dd = first ? v4 : v3;    // grad wrt the conv output
+          const int ky = j / k, kx = j - ky * k;
+          const float* src = first ? v0 : v1;   // conv input map (m for K1, t1 for K2), padded
+          const float* dd = first ? v4 : v3;    // grad wrt the conv output, padded
           for (int h = 0; h < s.Hz; ++h) {
-            int hh = h + ky;
-            if (hh < 0 || hh >= s.Hz) continue;
-            for (int w = 0; w < s.Wz; ++w) {
-              int ww = w + kx;
-              if (ww >= 0 && ww < s.Wz) acc += src[hh * s.Wz + ww] * dd[h * s.Wz + w];
-            }
+            const float* sr = src + (h + ky) * Wp + kx;
+            const float* dr = dd + (h + r) * Wp + r;
+            for (int w = 0; w < s.Wz; ++w) acc += sr[w] * dr[w];
           }
         }
         vec[i] = acc;
@@ -456,9 +513,10 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
   const int c = t % C, sl = t / C, nsl = 256 / C;
   float s1 = 0.f, s2 = 0.f;
   if (sl < nsl) {
+    const float mean = a.apply_bn ? coef[c * 4 + 2] : 0.f, rstd = a.apply_bn ? coef[c * 4 + 3] : 0.f;
     for (int p = sl; p < s.HWc; p += nsl) {
       float d;
-      if (a.pool) {
+      if (pool) {
         int h = p / s.Wc, w = p - h * s.Wc, hz = h >> 1, wz = w >> 1;
         d = 0.f;
         if (hz < s.Hz && wz < s.Wz) {
@@ -475,7 +533,7 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
       }
       dv[(size_t)p * C + c] = d;
       if (a.apply_bn) {
-        float xh = (y[(size_t)p * a.y_rs + c] - coef[c * 4 + 2]) * coef[c * 4 + 3];
+        float xh = (y[(size_t)p * a.y_rs + c] - mean) * rstd;
         s1 += d; s2 += d * xh;
       }
     }
@@ -493,13 +551,31 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
   }
 }
 
+template <typename CFG>
+static int launch_stage_bwd_c(const StageBwdArgs& a, int G, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)k_stage_bwd<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_stage_bwd<CFG>), dim3(a.f.B, G), dim3(256), lds, st, a);
+  DTA_CHECK_LAUNCH("k_stage_bwd");
+  return 0;
+}
+
 int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st) {
   size_t lds = stage_lds_floats(a.f, true) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_bwd: %dx%dx%d patch needs %zu B of LDS", a.f.Hc, a.f.Wc, a.f.C, lds); return 1; }
-  hipFuncSetAttribute((const void*)k_stage_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(k_stage_bwd, dim3(a.f.B, G), dim3(256), lds, st, a);
-  DTA_CHECK_LAUNCH("k_stage_bwd");
-  return 0;
+  const bool net = a.f.apply_bn && a.f.relu && stage_net_cfg(a.f);
+  if (net && a.f.C == 32) return launch_stage_bwd_c<StageCfg<32, 11, 11, 0>>(a, G, lds, st);
+  if (net && a.f.C == 64) return launch_stage_bwd_c<StageCfg<64, 11, 11, 1>>(a, G, lds, st);
+  if (net && a.f.C == 128) return launch_stage_bwd_c<StageCfg<128, 5, 5, 1>>(a, G, lds, st);
+  switch (a.f.C) {
+    case 32: return launch_stage_bwd_c<StageCfg<32, 0, 0, 0>>(a, G, lds, st);
+    case 64: return launch_stage_bwd_c<StageCfg<64, 0, 0, 0>>(a, G, lds, st);
+    case 128: return launch_stage_bwd_c<StageCfg<128, 0, 0, 0>>(a, G, lds, st);
+  }
+  return launch_stage_bwd_c<StageCfg<0, 0, 0, 0>>(a, G, lds, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -553,37 +629,49 @@ int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, int G, hipStream_t st) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
+  // per channel: dy = k0 * dv + k1 * y + k2  (folded from A*(dv - Bc - ((y-mean)*rstd)*Cc)), coefficients in LDS
+  __shared__ float sk[3][128];
   const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = a.C;
   const int W2 = a.W + 2, Q = (a.H + 2) * W2, HW = a.H * a.W, nch = C / 16;
   const float* dv = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
   const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs;
   const float* coef = a.coef + (size_t)g * a.coef_gs;
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
+  for (int c = t; c < C; c += 256) {
+    float A = bc[c * 4 + 0], Bc = bc[c * 4 + 1], Cc = bc[c * 4 + 2], mean = coef[c * 4 + 2], rstd = coef[c * 4 + 3];
+    sk[0][c] = A;
+    sk[1][c] = -A * Cc * rstd;
+    sk[2][c] = A * (Cc * rstd * mean - Bc);
+  }
+  __syncthreads();
   T* dst = (T*)a.dy_tl + (size_t)g * a.dy_gs + ((size_t)b * a.dy_nc + a.dy_ch0) * Q * 16;
   constexpr int VW = TlVec<T>::VW, PARTS = 16 / VW;
   for (int i = t; i < nch * Q * PARTS; i += 256) {
     int ch = i / (Q * PARTS), rem = i - ch * Q * PARTS, q = rem / PARTS, part = rem % PARTS;
     int hh = q / W2 - 1, ww = q % W2 - 1;
     const bool in = hh >= 0 && hh < a.H && ww >= 0 && ww < a.W;
-    const int p = in ? hh * a.W + ww : 0;
-    // the VW stored positions of this segment are one aligned group of VW channels (permuted inside for fp32)
-    const int cb = ch * 16 + (tl_pos<T>(q, part * VW) & ~(VW - 1));
-    float yv[VW], dvv[VW];
-#pragma unroll
-    for (int k = 0; k < VW; k += 4) {
-      float4 t4 = *reinterpret_cast<const float4*>(y + (size_t)p * a.y_rs + cb + k);
-      yv[k] = t4.x; yv[k + 1] = t4.y; yv[k + 2] = t4.z; yv[k + 3] = t4.w;
-      float4 d4 = *reinterpret_cast<const float4*>(dv + (size_t)p * C + cb + k);
-      dvv[k] = d4.x; dvv[k + 1] = d4.y; dvv[k + 2] = d4.z; dvv[k + 3] = d4.w;
-    }
     float v[VW];
+    if (in) {
+      const int p = hh * a.W + ww;
+      // the VW stored positions of this segment are one aligned group of VW channels (permuted inside for fp32)
+      const int cb = ch * 16 + (tl_pos<T>(q, part * VW) & ~(VW - 1));
+      float yv[VW], dvv[VW];
 #pragma unroll
-    for (int j = 0; j < VW; ++j) {
-      int c = ch * 16 + tl_pos<T>(q, part * VW + j);
-      int k = c - cb;
-      float xh = (yv[k] - coef[c * 4 + 2]) * coef[c * 4 + 3];
-      float d = bc[c * 4 + 0] * (dvv[k] - bc[c * 4 + 1] - xh * bc[c * 4 + 2]);
-      v[j] = in ? d : 0.f;
+      for (int k = 0; k < VW; k += 4) {
+        float4 t4 = *reinterpret_cast<const float4*>(y + (size_t)p * a.y_rs + cb + k);
+        yv[k] = t4.x; yv[k + 1] = t4.y; yv[k + 2] = t4.z; yv[k + 3] = t4.w;
+        float4 d4 = *reinterpret_cast<const float4*>(dv + (size_t)p * C + cb + k);
+        dvv[k] = d4.x; dvv[k + 1] = d4.y; dvv[k + 2] = d4.z; dvv[k + 3] = d4.w;
+      }
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        int c = ch * 16 + tl_pos<T>(q, part * VW + j);
+        int k = c - cb;
+        v[j] = sk[0][c] * dvv[k] + sk[1][c] * yv[k] + sk[2][c];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VW; ++j) v[j] = 0.f;
     }
     tl_store_vec(dst + ((size_t)ch * Q + q) * 16, part, v);
   }
