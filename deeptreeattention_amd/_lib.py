@@ -38,6 +38,17 @@ class SubnetGrads(C.Structure):
                 ("fc_b", C.c_void_p * 3)]
 
 
+class ConvModuleDesc(C.Structure):
+    _fields_ = [("batch", C.c_int), ("in_channels", C.c_int), ("filters", C.c_int), ("height", C.c_int),
+                ("width", C.c_int), ("pool", C.c_int), ("training", C.c_int), ("dtype", C.c_int),
+                ("bn_momentum", C.c_float), ("bn_eps", C.c_float)]
+
+
+class AttentionDesc(C.Structure):
+    _fields_ = [("batch", C.c_int), ("filters", C.c_int), ("height", C.c_int), ("width", C.c_int), ("kind", C.c_int)]
+
+
+PtrArray6 = C.c_void_p * 6
 ScoreTable = (C.c_void_p * 3) * 2
 
 _lib = None
@@ -70,6 +81,24 @@ def lib():
         L.dta_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_void_p]
+        vp = C.c_void_p
+        L.dta_conv_module_workspace_bytes.restype = C.c_size_t
+        L.dta_conv_module_workspace_bytes.argtypes = [C.POINTER(ConvModuleDesc)]
+        L.dta_conv_module_forward.restype = C.c_int
+        L.dta_conv_module_forward.argtypes = [C.POINTER(ConvModuleDesc)] + [vp] * 11
+        L.dta_conv_module_backward.restype = C.c_int
+        L.dta_conv_module_backward.argtypes = [C.POINTER(ConvModuleDesc)] + [vp] * 10
+        L.dta_attention_workspace_bytes.restype = C.c_size_t
+        L.dta_attention_workspace_bytes.argtypes = [C.POINTER(AttentionDesc)]
+        L.dta_attention_forward.restype = C.c_int
+        L.dta_attention_forward.argtypes = [C.POINTER(AttentionDesc), C.POINTER(PtrArray6), vp, vp, vp, vp, vp]
+        L.dta_attention_backward.restype = C.c_int
+        L.dta_attention_backward.argtypes = [C.POINTER(AttentionDesc), C.POINTER(PtrArray6), vp, vp, vp, vp, vp,
+                                             C.POINTER(PtrArray6), vp]
+        L.dta_linear_forward.restype = C.c_int
+        L.dta_linear_forward.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.dta_linear_backward.restype = C.c_int
+        L.dta_linear_backward.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
         L.dta_profile_enable.restype = C.c_int
         L.dta_profile_enable.argtypes = [C.c_int]
         L.dta_profile_collect.restype = C.c_int

@@ -94,6 +94,49 @@ int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double
                   double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
                   float grad_scale, void* stream);
 
+/* ---- stand-alone building blocks (same kernels as the network-level path) ------------------------------------ */
+
+typedef struct dta_conv_module_desc {
+  int batch, in_channels, filters, height, width;   /* filters in {32, 64, 128} */
+  int pool;        /* 1: MaxPool2d(2) after ReLU (conv_module.forward(x, pool=True)) */
+  int training, dtype;
+  float bn_momentum, bn_eps;
+} dta_conv_module_desc;
+
+/* Replaces conv_module.forward (Hang2020.py:24-31): x NCHW float32 -> out NCHW float32 [batch][filters][H'][W'].
+ * Workspace (dta_conv_module_workspace_bytes) is kept for the backward call. */
+size_t dta_conv_module_workspace_bytes(const dta_conv_module_desc* d);
+int dta_conv_module_forward(const dta_conv_module_desc* d, const float* conv_w, const float* conv_b, const float* bn_w,
+                            const float* bn_b, float* bn_rm, float* bn_rv, long long* bn_nbt, const float* x,
+                            void* workspace, float* out, void* stream);
+/* dout: NCHW gradient of `out`.  dx_nhwc (optional, needs in_channels in {32,64,128}): gradient wrt x as
+ * [batch][H*W][in_channels].  g_* arrive zero-filled. */
+int dta_conv_module_backward(const dta_conv_module_desc* d, const float* conv_w, const float* bn_w, void* workspace,
+                             const float* dout, float* dx_nhwc, float* g_conv_w, float* g_conv_b, float* g_bn_w,
+                             float* g_bn_b, void* stream);
+
+typedef struct dta_attention_desc {
+  int batch, filters, height, width;   /* filters in {32, 64, 128} */
+  int kind;                            /* 0 spectral_attention, 1 spatial_attention */
+} dta_attention_desc;
+
+/* Replaces spectral_attention.forward (Hang2020.py:149-168) / spatial_attention.forward (:105-124).
+ * params: the module's tensors in the order of dta_subnet_params.att.  x_nhwc: [batch][H*W][filters] float32.
+ * out_nchw: gated map [batch][filters][H][W]; feat: pooled features [batch][F]. */
+size_t dta_attention_workspace_bytes(const dta_attention_desc* d);
+int dta_attention_forward(const dta_attention_desc* d, const float* const params[6], const float* x_nhwc, void* workspace,
+                          float* out_nchw, float* feat, void* stream);
+/* dout_nchw / dfeat: gradients of the two outputs (either may be null).  dx_nhwc: [batch][H*W][filters].
+ * grads[6] arrive zero-filled (null entries are skipped). */
+int dta_attention_backward(const dta_attention_desc* d, const float* const params[6], const float* x_nhwc, void* workspace,
+                           const float* dout_nchw, const float* dfeat, float* dx_nhwc, float* const grads[6], void* stream);
+
+/* Replaces Classifier.forward / nn.Linear (Hang2020.py:63-66) and its backward.  gw / gb arrive zero-filled. */
+int dta_linear_forward(const float* x, const float* w, const float* b, int batch, int in_features, int out_features,
+                       float* out, void* stream);
+int dta_linear_backward(const float* x, const float* w, const float* dout, int batch, int in_features, int out_features,
+                        float* dx, float* gw, float* gb, void* stream);
+
 /* Measurement aid (host-side state only): record a HIP-event pair around every launch of one kernel site, on the
  * stream the kernel is launched on.  site = DTA_SITE_* + layer (0..2); -1 disables.  dta_profile_collect waits
  * for the recorded events, writes up to `max` durations in milliseconds (HOST pointer) and returns the count. */

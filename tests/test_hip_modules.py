@@ -1,0 +1,140 @@
+"""GPU parity of the stand-alone building blocks and the callers (year ensemble, metadata fusion) against the
+reference's own outputs (tests/golden/modules.npz, subnets.npz) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import hang2020_np as O
+from oracle import prng
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+TIGHT = 2e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def load(mod, params):
+    mod.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in params.items()})
+    return mod.to(dev())
+
+
+@pytest.mark.parametrize("name,cin,cout,pool", [("cm_nopool", 5, 32, False), ("cm_pool", 32, 64, True)])
+def test_conv_module_vs_reference_golden(golden, name, cin, cout, pool):
+    from deeptreeattention_amd import Hang2020 as H
+    g = golden("modules.npz")
+    p = O.init_params(O.conv_module_spec("", cin, cout), seed=11)
+    m = load(H.conv_module(cin, cout, maxpool_kernel=(2, 2) if pool else None), p)
+    x = torch.from_numpy(prng.uniform(12, 1, (3, cin, 11, 11), -1, 1)).to(dev())
+    x.requires_grad_(cin in (32, 64, 128))
+    m.train()
+    z = m(x, pool=pool)
+    assert rel_l2(z.detach().cpu().numpy(), g[f"{name}/z"]) < TIGHT
+    dz = torch.from_numpy(prng.uniform(12, 3, tuple(z.shape), -1, 1)).to(dev())
+    (z * dz).sum().backward()
+    if x.requires_grad:
+        assert rel_l2(x.grad.cpu().numpy(), g[f"{name}/dx"]) < TOL
+    for k, prm in m.named_parameters():
+        if k.endswith("conv_layer.bias"):
+            continue
+        assert rel_l2(prm.grad.cpu().numpy(), g[f"{name}/g/{k}"]) < TOL, k
+    for k, b in m.named_buffers():
+        assert rel_l2(b.cpu().numpy(), g[f"{name}/buf/{k}"]) < TIGHT, k
+    m.eval()
+    with torch.no_grad():
+        assert rel_l2(m(x, pool=pool).cpu().numpy(), g[f"{name}/z_eval"]) < TIGHT
+
+
+@pytest.mark.parametrize("C,hw", [(32, 11), (64, 5), (128, 2)])
+@pytest.mark.parametrize("kind", ["spectral", "spatial"])
+def test_attention_vs_reference_golden(golden, kind, C, hw):
+    from deeptreeattention_amd import Hang2020 as H
+    g = golden("modules.npz")
+    name = f"{kind}_att{C}"
+    specf = O.spectral_attention_spec if kind == "spectral" else O.spatial_attention_spec
+    cls = H.spectral_attention if kind == "spectral" else H.spatial_attention
+    m = load(cls(filters=C), O.init_params(specf("", C), seed=21))
+    x = torch.from_numpy(prng.uniform01(22, C, (3, C, hw, hw))).to(dev()).requires_grad_(True)
+    a, f = m(x)
+    assert rel_l2(a.detach().cpu().numpy(), g[f"{name}/a"]) < TIGHT
+    assert rel_l2(f.detach().cpu().numpy(), g[f"{name}/f"]) < TIGHT
+    da = torch.from_numpy(prng.uniform(22, 3, tuple(a.shape), -1, 1)).to(dev())
+    df = torch.from_numpy(prng.uniform(22, 4, tuple(f.shape), -1, 1)).to(dev())
+    ((a * da).sum() + (f * df).sum()).backward()
+    assert rel_l2(x.grad.cpu().numpy(), g[f"{name}/dx"]) < TOL
+    for k, prm in m.named_parameters():
+        ref = g[f"{name}/g/{k}"]
+        assert prm.grad.shape == ref.shape
+        assert rel_l2(prm.grad.cpu().numpy(), ref) < TOL, k
+
+
+def test_reference_shape_tests():
+    """The reference's own unit tests (tests/test_Hang2020.py:8-75) at their shapes."""
+    from deeptreeattention_amd import Hang2020 as H
+    d = dev()
+    m = H.conv_module(in_channels=369, filters=32).to(d)
+    assert m(torch.randn(20, 369, 11, 11, device=d)).shape == (20, 32, 11, 11)
+    m = H.conv_module(in_channels=32, filters=64, maxpool_kernel=(2, 2)).to(d)
+    assert m(torch.randn(20, 32, 11, 11, device=d), pool=True).shape == (20, 64, 5, 5)
+    for shape in [(20, 32, 11, 11), (20, 64, 5, 5), (20, 128, 2, 2)]:
+        a, s = H.spatial_attention(filters=shape[1]).to(d)(torch.randn(shape, device=d))
+        assert a.shape == shape
+        a, s = H.spectral_attention(filters=shape[1]).to(d)(torch.randn(shape, device=d))
+        assert a.shape == shape and s.shape == (20, shape[1])
+    for cls in (H.spectral_network, H.spatial_network):
+        out = cls(bands=369, classes=10).to(d)(torch.randn(20, 369, 11, 11, device=d))
+        assert len(out) == 3 and out[0].shape == (20, 10)
+    assert H.vanilla_CNN(bands=369, classes=10).to(d)(torch.randn(20, 369, 11, 11, device=d)).shape == (20, 10)
+    assert H.vanilla_CNN(bands=3, classes=10).to(d)(torch.randn(20, 3, 11, 11, device=d)).shape == (20, 10)
+    assert H.Hang2020(bands=3, classes=10).to(d)(torch.randn(20, 3, 11, 11, device=d)).shape == (20, 10)
+    c = H.Classifier(in_features=128, classes=10).to(d)
+    f = torch.randn(20, 128, device=d)
+    assert rel_l2(c(f).detach().cpu().numpy(), torch.nn.functional.linear(f, c.fc1.weight, c.fc1.bias).detach().cpu().numpy()) < 1e-5
+
+
+def test_learned_ensemble_vs_reference_golden(golden):
+    """reference tests/test_year.py:8-14: three years, one all-zero year."""
+    from deeptreeattention_amd.year import learned_ensemble
+    g = golden("subnets.npz")
+    bands, classes, B = 16, 7, 2
+    p = O.init_params(O.learned_ensemble_spec(3, bands, classes), seed=61)
+    m = load(learned_ensemble(years=3, classes=classes, config={"pretrain_state_dict": None, "bands": bands}), p)
+    imgs = [prng.uniform01(62, yy, (B, bands, 11, 11)) for yy in range(3)]
+    imgs[1] = np.zeros_like(imgs[1])
+    m.train()
+    s = m([torch.from_numpy(a).to(dev()) for a in imgs])
+    assert rel_l2(s.detach().cpu().numpy(), g["ens/score"]) < TIGHT
+    d = torch.from_numpy(prng.uniform(62, 9, (B, classes), -1, 1)).to(dev())
+    (s * d).sum().backward()
+    none = set(g["ens/none"].tolist())
+    for k, prm in m.named_parameters():
+        if k in none:
+            assert prm.grad is None, k
+            continue
+        if k.endswith("conv_layer.bias"):
+            continue
+        ref = float(g[f"ens/gnorm/{k}"])
+        assert abs(float(prm.grad.double().norm()) - ref) <= TOL * max(ref, 1e-9), k
+
+
+def test_metadata_sensor_fusion_eval_matches_oracle_composition():
+    from deeptreeattention_amd.metadata import metadata_sensor_fusion
+    bands, classes, sites, B = 12, 5, 4, 6
+    torch.manual_seed(0)
+    m = metadata_sensor_fusion(bands=bands, sites=sites, classes=classes)
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=9)
+    m.sensor_model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in p.items()})
+    m = m.to(dev()).eval()
+    x = prng.uniform01(10, 1, (B, bands, 11, 11))
+    site = prng.randint(10, 2, (B,), sites)
+    with torch.no_grad():
+        out = m(torch.from_numpy(x).to(dev()), torch.from_numpy(site).to(dev())).cpu().numpy()
+        sensor, _, _ = O.hang2020_fwd(p, x, False, np.float64)
+        meta = m.metadata_model(torch.from_numpy(site).to(dev())).cpu().numpy()
+        w, b = m.fc1.weight.cpu().numpy(), m.fc1.bias.cpu().numpy()
+    ref = np.maximum(np.concatenate([meta, sensor], axis=1) @ w.T + b, 0)
+    assert out.shape == (B, classes)
+    assert rel_l2(out, ref) < TIGHT
