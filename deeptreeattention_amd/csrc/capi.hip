@@ -204,20 +204,39 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
   if (d->heads_mask) hipMemsetAsync(at<char>(ws, p.scores_all), 0, p.scores_bytes, st);   // split-K GEMM targets
   if (launch_pack_input<T>(x, at<char>(ws, p.x_tl), B, p.bands, p.H, p.W, st)) return 1;
   GemmGroup heads;
+  // ---- all weight re-layouts of the step in two launches (forward forms, and when training the transposed
+  //      forms the input-gradient convs will need) ----
+  PackWGroup packs;
+  SpecPackGroup spacks;
+  int pack_mode[3];
+  for (int L = 0; L < 3; ++L) {
+    const int C = CH[L];
+    PackWArgs pw;
+    memset(&pw, 0, sizeof(pw));
+    pw.G = L == 0 ? 1 : G; pw.NC = p.NCin[L]; pw.N = L == 0 ? 32 * G : C; pw.K = p.Cin[L];
+    pw.src[0] = nets[0].conv_w[L]; pw.src[1] = G == 2 ? nets[1].conv_w[L] : nullptr;
+    pw.mode = (L == 0 && G == 2) ? 1 : 0; pw.nsplit = 32;
+    pack_mode[L] = pw.mode;
+    packs.job[packs.n] = pw; packs.dst[packs.n++] = at<char>(ws, p.wp[L]);
+    if (L > 0 && d->training) {
+      memset(&pw, 0, sizeof(pw));
+      pw.G = G; pw.NC = C / 16; pw.N = CH[L - 1]; pw.K = C; pw.mode = 2;
+      pw.src[0] = nets[0].conv_w[L]; pw.src[1] = G == 2 ? nets[1].conv_w[L] : nullptr;
+      packs.job[packs.n] = pw; packs.dst[packs.n++] = at<char>(ws, p.wd[L]);
+    }
+    for (int g = 0; g < G; ++g)
+      if (p.kinds[g] == KIND_SPECTRAL) {
+        int j = spacks.n++;
+        spacks.w1[j] = nets[g].att[L][0]; spacks.w2[j] = nets[g].att[L][2];
+        spacks.packed[j] = at<float>(ws, p.attpk[g][L]); spacks.C[j] = C; spacks.K[j] = SPEC_K[L];
+      }
+  }
+  if (launch_pack_conv_w_group<T>(packs, st)) return 1;
+  if (launch_pack_spectral_att_group(spacks, st)) return 1;
   for (int L = 0; L < 3; ++L) {
     const int C = CH[L];
     const int Nconv = L == 0 ? 32 * G : C;
     const int launchG = L == 0 ? 1 : G;
-    // weights
-    PackWArgs pw;
-    memset(&pw, 0, sizeof(pw));
-    pw.G = launchG; pw.NC = p.NCin[L]; pw.N = Nconv; pw.K = p.Cin[L];
-    pw.src[0] = nets[0].conv_w[L]; pw.src[1] = G == 2 ? nets[1].conv_w[L] : nullptr;
-    pw.mode = (L == 0 && G == 2) ? 1 : 0; pw.nsplit = 32;
-    if (launch_pack_conv_w<T>(pw, at<char>(ws, p.wp[L]), st)) return 1;
-    for (int g = 0; g < G; ++g)
-      if (p.kinds[g] == KIND_SPECTRAL)
-        if (launch_pack_spectral_att(nets[g].att[L][0], nets[g].att[L][2], C, SPEC_K[L], at<float>(ws, p.attpk[g][L]), st)) return 1;
     // conv
     ConvArgs ca;
     memset(&ca, 0, sizeof(ca));
@@ -225,7 +244,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     else { ca.x_tl = at<char>(ws, p.a_tl[L - 1]); ca.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
     ca.wp = at<char>(ws, p.wp[L]);
     ca.bias[0] = nets[0].conv_b[L]; ca.bias[1] = G == 2 ? nets[1].conv_b[L] : nullptr;
-    ca.bias_mode = pw.mode; ca.bias_split = 32;
+    ca.bias_mode = pack_mode[L]; ca.bias_split = 32;
     ca.y = at<float>(ws, p.y[L]);
     if (L == 0) { ca.y_gs = 0; ca.y_rs = Nconv; } else { ca.y_gs = (size_t)B * p.HWc[L] * C; ca.y_rs = C; }
     ca.stats = d->training ? at<float>(ws, p.stats[L]) : nullptr;
@@ -448,7 +467,8 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       memset(&pw, 0, sizeof(pw));
       pw.G = G; pw.NC = C / 16; pw.N = CH[L - 1]; pw.K = C; pw.mode = 2;
       pw.src[0] = nets[0].conv_w[L]; pw.src[1] = G == 2 ? nets[1].conv_w[L] : nullptr;
-      if (launch_pack_conv_w<T>(pw, at<char>(ws, p.wd[L]), st)) return 1;
+      if (!d->training)   // a training forward already packed the transposed weights into the workspace
+        if (launch_pack_conv_w<T>(pw, at<char>(ws, p.wd[L]), st)) return 1;
       ConvArgs ca;
       memset(&ca, 0, sizeof(ca));
       ca.x_tl = ap.dy_tl; ca.x_gs = ap.dy_gs; ca.wp = at<char>(ws, p.wd[L]);

@@ -69,10 +69,10 @@ template int launch_pack_input<bf16_t>(const float*, void*, int, int, int, int, 
 //   mode 2: input-gradient form (transposed + flipped)     val = W_g[kc][n][8-tap]   (W_g is [Kdim][N][9])
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_pack_conv_w(PackWArgs a, T* __restrict__ dst) {
+__device__ __forceinline__ void pack_conv_w_job(const PackWArgs& a, T* __restrict__ dst, size_t i0, size_t stride) {
   const int N = a.N, NC = a.NC;
   size_t total = (size_t)a.G * NC * 9 * N * 16;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = i0; i < total; i += stride) {
     int pos = i & 15;
     size_t r = i >> 4;
     int n = r % N; r /= N;
@@ -97,13 +97,29 @@ __global__ void k_pack_conv_w(PackWArgs a, T* __restrict__ dst) {
   }
 }
 
+// several packing jobs in one launch: blockIdx.y selects the job
 template <typename T>
-int launch_pack_conv_w(const PackWArgs& a, void* dst, hipStream_t st) {
-  size_t total = (size_t)a.G * a.NC * 9 * a.N * 16;
-  int blocks = (int)min((size_t)1024, (total + 255) / 256);
-  hipLaunchKernelGGL(k_pack_conv_w<T>, dim3(blocks), dim3(256), 0, st, a, (T*)dst);
+__global__ void k_pack_conv_w(PackWGroup gr) {
+  const PackWArgs& a = gr.job[blockIdx.y];
+  pack_conv_w_job<T>(a, (T*)gr.dst[blockIdx.y], blockIdx.x * (size_t)blockDim.x + threadIdx.x,
+                     (size_t)gridDim.x * blockDim.x);
+}
+
+template <typename T>
+int launch_pack_conv_w_group(const PackWGroup& gr, hipStream_t st) {
+  if (gr.n == 0) return 0;
+  hipLaunchKernelGGL(k_pack_conv_w<T>, dim3(256, gr.n), dim3(256), 0, st, gr);
   DTA_CHECK_LAUNCH("k_pack_conv_w");
   return 0;
+}
+template int launch_pack_conv_w_group<float>(const PackWGroup&, hipStream_t);
+template int launch_pack_conv_w_group<bf16_t>(const PackWGroup&, hipStream_t);
+
+template <typename T>
+int launch_pack_conv_w(const PackWArgs& a, void* dst, hipStream_t st) {
+  PackWGroup gr;
+  gr.n = 1; gr.job[0] = a; gr.dst[0] = dst;
+  return launch_pack_conv_w_group<T>(gr, st);
 }
 template int launch_pack_conv_w<float>(const PackWArgs&, void*, hipStream_t);
 template int launch_pack_conv_w<bf16_t>(const PackWArgs&, void*, hipStream_t);
@@ -524,17 +540,27 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradReduceArgs a) {
     int tap = r % 9;
     int g = r / 9;
     const float* p = a.partial + ((size_t)g * a.S * 9 + tap) * a.Cpad * N + (size_t)c * N + n4 * 4;
-    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+    // 4 independent loads in flight per thread (the slabs are 9*Cpad*N floats apart; 8 measured slower)
+    float4 acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     int s = 0;
-    for (; s + 1 < a.S; s += 2) {
-      float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)s * sstride);
-      float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(s + 1) * sstride);
-      acc0.x += v0.x; acc0.y += v0.y; acc0.z += v0.z; acc0.w += v0.w;
-      acc1.x += v1.x; acc1.y += v1.y; acc1.z += v1.z; acc1.w += v1.w;
+    for (; s + 3 < a.S; s += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float4 v = *reinterpret_cast<const float4*>(p + (size_t)(s + u) * sstride);
+        acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+      }
     }
-    if (s < a.S) {
-      float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)s * sstride);
-      acc0.x += v0.x; acc0.y += v0.y; acc0.z += v0.z; acc0.w += v0.w;
+    for (; s < a.S; ++s) {
+      float4 v = *reinterpret_cast<const float4*>(p + (size_t)s * sstride);
+      acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+    }
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      acc0.x += acc[u].x; acc0.y += acc[u].y; acc0.z += acc[u].z; acc0.w += acc[u].w;
+      acc1.x += acc[u + 1].x; acc1.y += acc[u + 1].y; acc1.z += acc[u + 1].z; acc1.w += acc[u + 1].w;
     }
     float out[4] = {acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w};
 #pragma unroll

@@ -150,20 +150,29 @@ int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st) {
 
 // spectral attention Conv1d weights [C][C][K]: only tap K/2 is live on a length-1 sequence.
 // packed = [a1t | a2t | a1 | a2], each [C][C]; *t is input-major (a_t[i][o] = W[o][i][K/2]).
-__global__ void k_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C * C) return;
-  int o = i / C, in = i - o * C;
-  float v1 = w1[(size_t)i * K + K / 2], v2 = w2[(size_t)i * K + K / 2];
-  packed[in * C + o] = v1;
-  packed[C * C + in * C + o] = v2;
-  packed[2 * C * C + i] = v1;
-  packed[3 * C * C + i] = v2;
+__global__ void k_pack_spectral_att(SpecPackGroup gr) {
+  const int j = blockIdx.y, C = gr.C[j], K = gr.K[j];
+  const float* w1 = gr.w1[j]; const float* w2 = gr.w2[j];
+  float* packed = gr.packed[j];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * C; i += gridDim.x * blockDim.x) {
+    int o = i / C, in = i - o * C;
+    float v1 = w1[(size_t)i * K + K / 2], v2 = w2[(size_t)i * K + K / 2];
+    packed[in * C + o] = v1;
+    packed[C * C + in * C + o] = v2;
+    packed[2 * C * C + i] = v1;
+    packed[3 * C * C + i] = v2;
+  }
 }
-int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed, hipStream_t st) {
-  hipLaunchKernelGGL(k_pack_spectral_att, dim3((C * C + 255) / 256), dim3(256), 0, st, w1, w2, C, K, packed);
+int launch_pack_spectral_att_group(const SpecPackGroup& gr, hipStream_t st) {
+  if (gr.n == 0) return 0;
+  hipLaunchKernelGGL(k_pack_spectral_att, dim3(64, gr.n), dim3(256), 0, st, gr);
   DTA_CHECK_LAUNCH("k_pack_spectral_att");
   return 0;
+}
+int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed, hipStream_t st) {
+  SpecPackGroup gr;
+  gr.n = 1; gr.w1[0] = w1; gr.w2[0] = w2; gr.packed[0] = packed; gr.C[0] = C; gr.K[0] = K;
+  return launch_pack_spectral_att_group(gr, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -31,7 +31,9 @@ struct WgradReduceArgs {
   int G, S, N, C, Cpad, mode, nsplit;
 };
 template <typename T> int launch_pack_input(const float* x, void* out, int B, int C, int H, int W, hipStream_t st);
+struct PackWGroup { PackWArgs job[6]; void* dst[6]; int n = 0; };
 template <typename T> int launch_pack_conv_w(const PackWArgs& a, void* dst, hipStream_t st);
+template <typename T> int launch_pack_conv_w_group(const PackWGroup& gr, hipStream_t st);
 template <typename T> int launch_conv3x3(const ConvArgs& a, int G, hipStream_t st);
 template <typename T> int launch_conv_wgrad(const WgradArgs& a, int G, hipStream_t st);
 template <> int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st);       // conv_bf16.hip
@@ -127,6 +129,8 @@ struct ColsumArgs {
 };
 int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st);
 int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed, hipStream_t st);
+struct SpecPackGroup { const float* w1[6]; const float* w2[6]; float* packed[6]; int C[6], K[6]; int n = 0; };
+int launch_pack_spectral_att_group(const SpecPackGroup& gr, hipStream_t st);
 
 struct BlendArgs {
   const float* spec; const float* spat; const double* alpha; float* joint; int B, classes;

@@ -144,7 +144,6 @@ static size_t stage_lds_floats(const StageArgs& a, bool bwd) {
   int Hz = a.pool ? a.Hc / 2 : a.Hc, Wz = a.pool ? a.Wc / 2 : a.Wc;
   int HWz = Hz * Wz, ld = a.C + 1;
   size_t n = (size_t)HWz * ld;                 // Z
-  if (a.pool) n += (size_t)HWc * ld;            // R
   if (bwd) n += (size_t)HWz * ld;               // D
   n += (size_t)(bwd ? 8 : 4) * stage_vslot(a.C, Hz, Wz) + 512;   // vectors / padded maps + reduction scratch
   return n;
@@ -155,8 +154,10 @@ template <typename F>
 __device__ __forceinline__ void colreduce(int C, int n, float* scratch, float* out, float scale, F f) {
   const int t = threadIdx.x, c = t % C, sl = t / C, nsl = 256 / C;
   float acc = 0.f;
-  if (sl < nsl)
-    for (int i = sl; i < n; i += nsl) acc += f(c, i);
+  if (sl < nsl) {
+#pragma unroll 8
+    for (int i = sl; i < n; i += nsl) acc += f(c, i);   // unrolled: independent (global) loads overlap
+  }
   __syncthreads();
   scratch[t] = acc;
   __syncthreads();
@@ -166,6 +167,28 @@ __device__ __forceinline__ void colreduce(int C, int n, float* scratch, float* o
     out[t] = s * scale;
   }
   __syncthreads();
+}
+
+// Per-pixel reduction over channels, all 256 threads busy: LP = 2^k lanes (LP <= 64, LP * npix <= 256) share a
+// pixel, each sums channels c = l, l+LP, ..., then a butterfly over the LP lanes.  done(p, sum) runs on one lane.
+template <typename F, typename G>
+__device__ __forceinline__ void pixreduce(int npix, int C, F f, G done) {
+  int LP = 64;
+  while (LP > 1 && LP * npix > 256) LP >>= 1;
+  if (LP == 1) {
+    for (int p = threadIdx.x; p < npix; p += 256) {
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) acc += f(p, c);
+      done(p, acc);
+    }
+    return;
+  }
+  const int p = threadIdx.x / LP, l = threadIdx.x % LP;
+  float acc = 0.f;
+  if (p < npix)
+    for (int c = l; c < C; c += LP) acc += f(p, c);
+  for (int o = LP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (p < npix && l == 0) done(p, acc);
 }
 
 // k x k cross-correlation of a zero-padded single-channel map (radius r = k/2, row pitch Wp = Wz + 2r) at pixel
@@ -184,50 +207,61 @@ __device__ __forceinline__ float stencil_at(const float* mp, const float* kw, in
 }
 
 // Forward recompute shared by both kernels.  On return (all threads synced):
-//   Z [HWz][ld]  post BN/ReLU/pool activations,  R [HWc][ld] pre-pool (only if pool)
+//   Z [HWz][ld]  post BN/ReLU/pool activations (pooled straight from global memory: no pre-pool tile in LDS)
 //   spectral: v0 = pooled, v1 = h (post ReLU), v2 = gate
 //   spatial : v0 = m (post ReLU, zero-padded map), v1 = t1 (post ReLU, zero-padded map), v2 = s (gate, per pixel)
 template <typename CFG>
 __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeom& s, int g, int b, int kind,
-                                              float* Z, float* R, float* v0, float* v1, float* v2, float* scratch) {
+                                              float* Z, float* v0, float* v1, float* v2, float* scratch) {
   constexpr int CT = CFG::C;
   const bool pool = cfg_pool<CFG>(a);
   const int t = threadIdx.x, C = s.C, ld = s.ld;
   const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
   const float* coef = a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr;
-  float* dst = pool ? R : Z;
+  if (kind == KIND_SPATIAL) {   // zero the padded maps' borders (interiors are overwritten below)
+    for (int i = t; i < 2 * s.vslot; i += 256) v0[i] = 0.f;   // v0 and v1 are adjacent
+  }
   if (CT > 0) {
     // 256 % C == 0: every thread keeps one channel, its BN coefficients live in registers
     const int c = t % C, p0 = t / C, pstep = 256 / C;
     const float sc = a.apply_bn ? coef[c * 4 + 0] : 1.f, sh = a.apply_bn ? coef[c * 4 + 1] : 0.f;
-    for (int p = p0; p < s.HWc; p += pstep) {
-      float v = y[(size_t)p * a.y_rs + c] * sc + sh;
-      if (a.relu) v = fmaxf(v, 0.f);
-      dst[p * ld + c] = v;
+    if (!pool) {
+#pragma unroll 8
+      for (int p = p0; p < s.HWc; p += pstep) {      // unrolled: 8 independent global loads in flight per thread
+        float v = y[(size_t)p * a.y_rs + c] * sc + sh;
+        if (a.relu) v = fmaxf(v, 0.f);
+        Z[p * ld + c] = v;
+      }
+    } else {
+#pragma unroll 2
+      for (int pz = p0; pz < s.HWz; pz += pstep) {   // 2x2 max-pool straight from global memory (floor: last row/col dropped)
+        int hz = pz / s.Wz, wz = pz - hz * s.Wz;
+        const float* y0 = y + (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
+        float v0_ = y0[0] * sc + sh, v1_ = y0[a.y_rs] * sc + sh;
+        float v2_ = y0[(size_t)s.Wc * a.y_rs] * sc + sh, v3_ = y0[(size_t)(s.Wc + 1) * a.y_rs] * sc + sh;
+        float m = fmaxf(fmaxf(v0_, v1_), fmaxf(v2_, v3_));
+        if (a.relu) m = fmaxf(m, 0.f);
+        Z[pz * ld + c] = m;
+      }
     }
   } else {
-    for (int i = t; i < s.HWc * C; i += 256) {
+    const int n = pool ? s.HWz : s.HWc;
+    for (int i = t; i < n * C; i += 256) {
       int p = i / C, c = i - p * C;
-      float v = y[(size_t)p * a.y_rs + c];
-      if (a.apply_bn) v = v * coef[c * 4 + 0] + coef[c * 4 + 1];
+      const float sc = a.apply_bn ? coef[c * 4 + 0] : 1.f, sh = a.apply_bn ? coef[c * 4 + 1] : 0.f;
+      float v;
+      if (!pool) v = y[(size_t)p * a.y_rs + c] * sc + sh;
+      else {
+        int hz = p / s.Wz, wz = p - hz * s.Wz;
+        const float* y0 = y + (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
+        v = fmaxf(fmaxf(y0[0] * sc + sh, y0[a.y_rs] * sc + sh),
+                  fmaxf(y0[(size_t)s.Wc * a.y_rs] * sc + sh, y0[(size_t)(s.Wc + 1) * a.y_rs] * sc + sh));
+      }
       if (a.relu) v = fmaxf(v, 0.f);
-      dst[p * ld + c] = v;
+      Z[p * ld + c] = v;
     }
-  }
-  if (kind == KIND_SPATIAL) {   // zero the padded maps' borders (interiors are overwritten below)
-    for (int i = t; i < 2 * s.vslot; i += 256) v0[i] = 0.f;   // v0 and v1 are adjacent
   }
   __syncthreads();
-  if (pool) {
-    for (int i = t; i < s.HWz * C; i += 256) {
-      int pz = i / C, c = i - pz * C;
-      int hz = pz / s.Wz, wz = pz - hz * s.Wz;
-      const float* r0 = R + ((2 * hz) * s.Wc + 2 * wz) * ld + c;
-      float m = fmaxf(fmaxf(r0[0], r0[ld]), fmaxf(r0[s.Wc * ld], r0[(s.Wc + 1) * ld]));
-      Z[pz * ld + c] = m;
-    }
-    __syncthreads();
-  }
   if (kind == KIND_SPECTRAL) {
     const float* a1t = a.att[g].p[0]; const float* c1 = a.att[g].p[1];
     const float* a2t = a.att[g].p[2]; const float* c2 = a.att[g].p[3];
@@ -243,12 +277,11 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
     const float* k1 = a.att[g].p[2]; const float b1 = a.att[g].p[3][0];
     const float* k2 = a.att[g].p[4]; const float b2 = a.att[g].p[5][0];
     const int k = cfg_att_k<CFG>(a, g), r = k / 2, Wp = s.Wz + 2 * r;
-    for (int p = t; p < s.HWz; p += 256) {
-      float acc = bc;
-      for (int c = 0; c < C; ++c) acc += wc[c] * Z[p * ld + c];
-      int h = p / s.Wz, w = p - h * s.Wz;
-      v0[(h + r) * Wp + w + r] = fmaxf(acc, 0.f);
-    }
+    pixreduce(s.HWz, C, [&](int p, int c) { return wc[c] * Z[p * ld + c]; },
+              [&](int p, float acc) {
+                int h = p / s.Wz, w = p - h * s.Wz;
+                v0[(h + r) * Wp + w + r] = fmaxf(acc + bc, 0.f);
+              });
     __syncthreads();
     for (int p = t; p < s.HWz; p += 256) {
       int h = p / s.Wz, w = p - h * s.Wz;
@@ -274,11 +307,10 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
   const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = s.C, ld = s.ld;
   const int kind = a.kind[g];
   float* Z = sm;
-  float* R = Z + (size_t)s.HWz * ld;
-  float* v0 = R + (cfg_pool<CFG>(a) ? (size_t)s.HWc * ld : 0);
+  float* v0 = Z + (size_t)s.HWz * ld;
   float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
   float* scratch = v3 + s.vslot;
-  stage_forward<CFG>(a, s, g, b, kind, Z, R, v0, v1, v2, scratch);
+  stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch);
 
   // classifier features
   if (a.feat) {
@@ -383,15 +415,14 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
   const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = s.C, ld = s.ld;
   const int kind = a.kind[g];
   float* Z = sm;
-  float* R = Z + (size_t)s.HWz * ld;
-  float* D = R + (pool ? (size_t)s.HWc * ld : 0);
+  float* D = Z + (size_t)s.HWz * ld;
   float* v0 = D + (size_t)s.HWz * ld;
   float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
   float* v4 = v3 + s.vslot; float* v5 = v4 + s.vslot; float* v6 = v5 + s.vslot; float* v7 = v6 + s.vslot;
   float* scratch = v7 + s.vslot;
   if (kind == KIND_SPATIAL)
     for (int i = t; i < 2 * s.vslot; i += 256) v3[i] = 0.f;   // padded maps d2 (v3) and d1 (v4)
-  stage_forward<CFG>(a, s, g, b, kind, Z, R, v0, v1, v2, scratch);
+  stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch);
 
   // D = incoming gradient wrt the gated map
   if (ba.da) {
@@ -449,12 +480,11 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
       __syncthreads();
     }
     // ds -> d2 (v3, padded map)
-    for (int p = t; p < s.HWz; p += 256) {
-      float acc = 0.f;
-      for (int c = 0; c < C; ++c) acc += D[p * ld + c] * Z[p * ld + c];
-      int h = p / s.Wz, w = p - h * s.Wz;
-      v3[(h + r) * Wp + w + r] = acc * v2[p] * (1.f - v2[p]);
-    }
+    pixreduce(s.HWz, C, [&](int p, int c) { return D[p * ld + c] * Z[p * ld + c]; },
+              [&](int p, float acc) {
+                int h = p / s.Wz, w = p - h * s.Wz;
+                v3[(h + r) * Wp + w + r] = acc * v2[p] * (1.f - v2[p]);
+              });
     __syncthreads();
     // dt1 = transposed stencil of d2 with k2, masked by t1 > 0 -> d1 (v4, padded map)
     for (int p = t; p < s.HWz; p += 256) {
@@ -472,10 +502,11 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
     __syncthreads();
     if (vec) {
       // [dwc (C) | dbc | dK1 (kk) | db1 | dK2 (kk) | db2]
-      for (int i = t; i < C + 2 * kk + 3; i += 256) {
+      colreduce(C, s.HWz, scratch, v6, 1.f, [&](int c, int p) { return v5[p] * Z[p * ld + c]; });
+      if (t < C) vec[t] = v6[t];
+      for (int i = C + t; i < C + 2 * kk + 3; i += 256) {
         float acc = 0.f;
-        if (i < C) { for (int p = 0; p < s.HWz; ++p) acc += v5[p] * Z[p * ld + i]; }
-        else if (i == C) { for (int p = 0; p < s.HWz; ++p) acc += v5[p]; }
+        if (i == C) { for (int p = 0; p < s.HWz; ++p) acc += v5[p]; }
         else if (i == C + 1 + kk || i == C + 2 + 2 * kk) {
           const float* dd = (i == C + 1 + kk) ? v4 : v3;    // padded maps: borders are zero
           for (int q = 0; q < (s.Hz + 2 * r) * Wp; ++q) acc += dd[q];
@@ -513,28 +544,47 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
   const int c = t % C, sl = t / C, nsl = 256 / C;
   float s1 = 0.f, s2 = 0.f;
   if (sl < nsl) {
+    // xhat is recovered from the activation instead of re-reading the conv output: a non-zero gradient only
+    // survives where the ReLU output r is positive, and there r = gamma * xhat + beta  (gamma = scale / rstd)
     const float mean = a.apply_bn ? coef[c * 4 + 2] : 0.f, rstd = a.apply_bn ? coef[c * 4 + 3] : 0.f;
-    for (int p = sl; p < s.HWc; p += nsl) {
-      float d;
-      if (pool) {
-        int h = p / s.Wc, w = p - h * s.Wc, hz = h >> 1, wz = w >> 1;
-        d = 0.f;
-        if (hz < s.Hz && wz < s.Wz) {
-          float zv = Z[(hz * s.Wz + wz) * ld + c];
-          const float* r0 = R + ((2 * hz) * s.Wc + 2 * wz) * ld + c;
-          int first = (r0[0] == zv) ? 0 : (r0[ld] == zv) ? 1 : (r0[s.Wc * ld] == zv) ? 2 : 3;
-          int me = (h & 1) * 2 + (w & 1);
-          if (me == first) d = D[(hz * s.Wz + wz) * ld + c];
+    const float scale = a.apply_bn ? coef[c * 4 + 0] : 1.f, shift = a.apply_bn ? coef[c * 4 + 1] : 0.f;
+    const float gam = scale / (rstd != 0.f ? rstd : 1.f), bet = shift + mean * scale;
+    const bool recover = a.apply_bn && a.relu && gam != 0.f;
+    const float inv_gam = recover ? 1.f / gam : 0.f;
+    if (!pool) {
+      for (int p = sl; p < s.HWc; p += nsl) {
+        float d = D[p * ld + c], r = Z[p * ld + c];
+        if (a.relu && r <= 0.f) d = 0.f;
+        dv[(size_t)p * C + c] = d;
+        if (a.apply_bn) {
+          float xh = recover ? (r - bet) * inv_gam : (y[(size_t)p * a.y_rs + c] - mean) * rstd;
+          s1 += d; s2 += d * xh;
         }
-        if (a.relu && R[p * ld + c] <= 0.f) d = 0.f;
-      } else {
-        d = D[p * ld + c];
-        if (a.relu && Z[p * ld + c] <= 0.f) d = 0.f;
       }
-      dv[(size_t)p * C + c] = d;
-      if (a.apply_bn) {
-        float xh = (y[(size_t)p * a.y_rs + c] - mean) * rstd;
-        s1 += d; s2 += d * xh;
+    } else {
+      // one pooled element per iteration: re-read its 2x2 window, route the gradient to the first maximum
+      for (int pz = sl; pz < s.HWz; pz += nsl) {
+        int hz = pz / s.Wz, wz = pz - hz * s.Wz;
+        const int p00 = (2 * hz) * s.Wc + 2 * wz;
+        const int po[4] = {p00, p00 + 1, p00 + s.Wc, p00 + s.Wc + 1};
+        float yv[4], m = -3.4e38f;
+        int first = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          yv[k] = y[(size_t)po[k] * a.y_rs + c];
+          float v = yv[k] * scale + shift;
+          if (v > m) { m = v; first = k; }
+        }
+        float d = D[pz * ld + c];
+        if (a.relu && m <= 0.f) d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dv[(size_t)po[k] * C + c] = (k == first) ? d : 0.f;
+        if (a.apply_bn) { s1 += d; s2 += d * (yv[first] - mean) * rstd; }
+      }
+      // conv-resolution positions the floor pooling dropped get no gradient
+      for (int p = sl; p < s.HWc; p += nsl) {
+        int h = p / s.Wc, w = p - h * s.Wc;
+        if ((h >> 1) >= s.Hz || (w >> 1) >= s.Wz) dv[(size_t)p * C + c] = 0.f;
       }
     }
   }
