@@ -1,0 +1,82 @@
+"""Two ranks on ONE GPU (gloo backend moves the CUDA gradient buffers through the host) exercising the real
+data-parallel train step: backward phases 1/2, side-stream all-reduce, 1/world scaling in the Adam kernel.
+Expected result: the oracle's Adam step on the MEAN of the two shards' gradients (per-rank BatchNorm statistics,
+per-rank loss normalisation = DDP semantics)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+BANDS, CLASSES, B, SEED = 20, 7, 6, 13
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, overlap, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import hang2020_np as O
+    from oracle import prng
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    p = O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=SEED)
+    m = H.Hang2020(BANDS, CLASSES)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in p.items()})
+    if rank != 0:   # start-up broadcast must overwrite whatever a non-zero rank holds
+        with torch.no_grad():
+            for prm in m.parameters():
+                prm.add_(0.5)
+    m = m.to(dev).train()
+    tr = FusedTrainer(m, lr=1e-3, overlap_comm=overlap)
+    assert tr.world == world
+    x = prng.uniform01(100 + rank, 1, (B, BANDS, 11, 11))
+    y = prng.randint(100 + rank, 2, (B,), CLASSES)
+    tr.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    torch.cuda.synchronize()
+    out[rank] = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_rank_train_step_matches_oracle(overlap):
+    from conftest import rel_l2
+    from oracle import hang2020_np as O
+    from oracle import prng
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), overlap, out), nprocs=world, join=True)
+    p = O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=SEED)
+    grads, upds = [], []
+    for rank in range(world):
+        x = prng.uniform01(100 + rank, 1, (B, BANDS, 11, 11))
+        y = prng.randint(100 + rank, 2, (B,), CLASSES)
+        logits, cache, upd = O.hang2020_fwd(p, x, True, np.float64)
+        _, dl = O.weighted_cross_entropy(logits, y, np.ones(CLASSES, np.float32))
+        grads.append(O.hang2020_bwd(p, cache, dl, np.float64))
+        upds.append(upd)
+    mean_g = {k: (np.asarray(grads[0][k], np.float64) + np.asarray(grads[1][k], np.float64)) / 2 for k in grads[0]}
+    want = O.adam_step(p, mean_g, {}, lr=1e-3)
+    for k, v in want.items():
+        if O.is_buffer(k) or k.endswith("conv_layer.bias"):
+            continue
+        assert rel_l2(out[0][k], out[1][k]) < 1e-6, f"ranks diverged on {k}"      # replicas stay identical
+        assert rel_l2(out[0][k], v) < 2e-3, k                                      # Adam on the averaged gradient
+    for rank in range(world):   # BatchNorm buffers stay per-rank (no sync_batchnorm in the reference)
+        for k, v in upds[rank].items():
+            assert rel_l2(out[rank][k], v) < 2e-4, (rank, k)
