@@ -155,11 +155,20 @@ def main():
             avg_ms = sum(buf[i] for i in range(n)) / n
             flops = CONV1_FLOP_PER_PATCH * a.batch if a.site in ("fwd0", "wgrad0") else None
             if flops:
+                # HBM bytes per launch of this kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+                # profiles/r01_traffic.json); only valid for the configuration it was measured on
+                traffic = None
+                tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+                if os.path.exists(tpath):
+                    tj = json.load(open(tpath))
+                    if tj.get("batch") == a.batch and tj.get("precision") == a.precision and a.site in tj:
+                        traffic = tj[a.site]["hbm_bytes_per_launch"]
                 ach = flops / (avg_ms * 1e-3) / 1e12
                 roof = {"bound": "mfma", "kernel": {"fwd0": "k_conv3x3 (conv1, both branches)",
                                                     "wgrad0": "k_conv_wgrad (conv1, both branches)"}[a.site],
                         "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_TFLOPS[a.precision], 4), "traffic": None,
+                        "frac": round(ach / PEAK_TFLOPS[a.precision], 4), "traffic": traffic,
+                        "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes)",
                         "avg_launch_ms": round(avg_ms, 4), "launches": n,
                         "algorithmic_flop_per_launch": flops}
         total = a.steps * a.batch * world
