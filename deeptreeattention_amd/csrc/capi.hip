@@ -112,6 +112,7 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     // bf16 path: register-prefetch pipeline, 1 workgroup per CU; fp32 path: 2 workgroups per CU overlap each other
     int target = d->dtype == DTA_BF16 ? 256 : 512;
     int S = target / (p->cgroups[L] * launchG);   // floor: never spill into a second round of workgroups
+    if (S >= 8) S &= ~7;                           // multiple of 8: whole batch splits per XCD (see k_conv_wgrad_bf16)
     p->S[L] = S < 1 ? 1 : (S > B ? B : S);
   }
   Carver c;

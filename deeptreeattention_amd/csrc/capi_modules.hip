@@ -42,6 +42,7 @@ int cm_plan(const dta_conv_module_desc* d, CmPlan* p) {
   p->Cpad = p->NC * 16; p->cgroups = (p->Cpad + cpw - 1) / cpw;
   int target = d->dtype == DTA_BF16 ? 256 : 512;
   int S = target / p->cgroups;
+  if (S >= 8) S &= ~7;
   p->S = S < 1 ? 1 : (S > p->B ? p->B : S);
   Carver c;
   const size_t e = p->esz;

@@ -20,6 +20,12 @@ __device__ __forceinline__ bf16x8 lds_tr8(const unsigned char* base, int off) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+__device__ __forceinline__ bf16x8 lds_tr8w(const unsigned char* base, int off) {   // same, 32-byte rows
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(base + off));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(base + off + 4 * 32));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad conv
 // ------------------------------------------------------------------------------------------------
@@ -256,6 +262,9 @@ int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
 // weight gradient
 // ------------------------------------------------------------------------------------------------
 constexpr int WGB_PAD_ROWS = 16;
+constexpr int RW = 32;    // weight-gradient LDS rows stay compact (32 B): with chunk tiles 128 B (mod 256 B) apart the two
+                          // 16-lane groups of a ds_read_b64_tr_b16 half-wave hit disjoint banks for any row offset
+__host__ __device__ inline int wgrad_qp(int Q) { int qp = Q + WGB_PAD_ROWS; while ((qp & 7) != 4) ++qp; return qp; }
 
 // One patch: K runs over the haloed-grid rows in steps of 16; NTAP accumulators share each dY fragment.
 template <int NTAP>
@@ -263,11 +272,11 @@ __device__ __forceinline__ void wgrad_ksteps(const unsigned char* bx, const unsi
                                              int b_off, int nks, f32x16* acc) {
 #pragma unroll 1
   for (int ks = 0; ks < nks; ++ks) {
-    const int koff = ks * 16 * RB;
-    bf16x8 bfr = lds_tr8(by, b_off + koff);
+    const int koff = ks * 16 * RW;
+    bf16x8 bfr = lds_tr8w(by, b_off + koff);
     bf16x8 afr[NTAP];
 #pragma unroll
-    for (int j = 0; j < NTAP; ++j) afr[j] = lds_tr8(bx, a_tap[j] + koff);
+    for (int j = 0; j < NTAP; ++j) afr[j] = lds_tr8w(bx, a_tap[j] + koff);
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[j], bfr, acc[j], 0, 0, 0);
   }
@@ -280,11 +289,18 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   constexpr int CT = 4 / NTT;            // 32-channel input tiles per workgroup
   constexpr int N = NTT * 32;
   constexpr int XCH = CT * 2, YCH = NTT * 2;
-  const int Q = a.Q, Qp = Q + WGB_PAD_ROWS, W2 = a.W + 2;
-  const int xbytes = XCH * Qp * RB, stage = (XCH + YCH) * Qp * RB;   // stage = [XCH][Qp][48 B] | [YCH][Qp][48 B]
+  const int Q = a.Q, Qp = wgrad_qp(Q), W2 = a.W + 2;
+  const int xbytes = XCH * Qp * RW, stage = (XCH + YCH) * Qp * RW;   // stage = [XCH][Qp][48 B] | [YCH][Qp][48 B]
   const bool dbuf = a.dbuf != 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cg = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
+  // XCD-aware placement: workgroup id b runs on XCD b % 8 (observed dispatch rule, speed only); consecutive LOGICAL
+  // indices (the channel groups of one batch split, which all re-read the same dY tiles) are mapped to one XCD so
+  // that those re-reads hit its L2.
+  const int total = a.cgroups * a.S * a.G;
+  const int per_xcd = (total + 7) / 8;
+  const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (logical >= total) return;
+  const int cg = logical % a.cgroups, s = (logical / a.cgroups) % a.S, g = logical / (a.cgroups * a.S);
   const int tg = wave & 1, pair = wave >> 1;              // tap group (0: taps 0-4, 1: taps 5-8), (c-tile, n-tile)
   const int ct = pair / NTT, nt = pair % NTT;
   const int tap0 = tg ? 5 : 0, ntap = tg ? 4 : 5;
@@ -306,14 +322,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   const int q0 = a.W + 3, q1 = Q - a.W - 3;
   const int nks = (q1 - q0 + 15) / 16;
   const int gq = lane >> 4, li = lane & 15;
-  const int lane_off = (8 * (gq >> 1) + (li >> 2)) * RB + (li & 3) * 8;
-  const int b_off = ((nt * 2 + (gq & 1)) * Qp + q0) * RB + lane_off;
+  const int lane_off = (8 * (gq >> 1) + (li >> 2)) * RW + (li & 3) * 8;
+  const int b_off = ((nt * 2 + (gq & 1)) * Qp + q0) * RW + lane_off;
   int a_tap[5];
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     int tap = min(tap0 + j, 8);
     int shift = (tap / 3 - 1) * W2 + (tap % 3 - 1);
-    a_tap[j] = ((ct * 2 + (gq & 1)) * Qp + q0 + shift) * RB + lane_off;
+    a_tap[j] = ((ct * 2 + (gq & 1)) * Qp + q0 + shift) * RW + lane_off;
   }
 
   // ---- staging plan ----
@@ -330,14 +346,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     int v = min(tid + u * NTHR, max(nxv, 1) - 1);
     int ch = v / vpc, o = v - ch * vpc;
     xsrc[u] = (size_t)(chunk0 + ch) * Q * 16 + (size_t)o * 8;
-    xdst[u] = (ch * Qp + (o >> 1)) * RB + (o & 1) * 16;
+    xdst[u] = (ch * Qp + (o >> 1)) * RW + (o & 1) * 16;
   }
 #pragma unroll
   for (int u = 0; u < YV; ++u) {
     int v = min(tid + u * NTHR, nyv - 1);
     int ch = v / vpc, o = v - ch * vpc;
     ysrc[u] = (size_t)(a.ych0 + ch) * Q * 16 + (size_t)o * 8;
-    ydst[u] = (ch * Qp + (o >> 1)) * RB + (o & 1) * 16;
+    ydst[u] = (ch * Qp + (o >> 1)) * RW + (o & 1) * 16;
   }
   u32x4 rx[XV], ry[YV];
 #define DTA_FETCH(b_)                                                                                             \
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
 template <int NTT>
 static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream_t st) {
   constexpr int CT = 4 / NTT;
-  size_t stage = (size_t)(CT * 2 + NTT * 2) * (a.Q + WGB_PAD_ROWS) * RB;
+  size_t stage = (size_t)(CT * 2 + NTT * 2) * wgrad_qp(a.Q) * RW;
   WgradArgs a2 = a;
   a2.dbuf = 2 * stage <= 160 * 1024;
   size_t lds = (a2.dbuf ? 2 : 1) * stage;
@@ -409,7 +425,9 @@ static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream
     hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_conv_wgrad_bf16<NTT>), dim3(cgroups, a.S, G), dim3(512), lds, st, a2);
+  a2.cgroups = cgroups; a2.G = G;
+  const int total = cgroups * a.S * G;
+  hipLaunchKernelGGL((k_conv_wgrad_bf16<NTT>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
   DTA_CHECK_LAUNCH("k_conv_wgrad_bf16");
   return 0;
 }

@@ -24,7 +24,7 @@ struct WgradArgs {
   const void* x_tl; size_t x_gs; int NCx;
   const void* dy_tl; size_t dy_gs; int NCy, ych0;
   float* partial;                     // [G][S][9][Cpad][N]
-  int B, H, W, Q, N, Cpad, S, dbuf;
+  int B, H, W, Q, N, Cpad, S, dbuf, cgroups, G;
 };
 struct WgradReduceArgs {
   const float* partial; float* dst[2];
