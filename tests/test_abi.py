@@ -66,3 +66,19 @@ def test_load_from_backbone_roundtrip(tmp_path):
     twenty = H.load_from_backbone(state_dict=path, classes=20, bands=3)
     assert twenty.classifier3.fc1.weight.shape == (20, 128)
     assert torch.equal(twenty.conv1.conv_layer.weight, ten.spectral_network.conv1.conv_layer.weight)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No fallback: when libdta_hip.so is absent the product raises instead of computing some other way."""
+    from deeptreeattention_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdta_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    import glob
+    for f in glob.glob(os.path.join(REPO, "deeptreeattention_amd", "**", "*.py"), recursive=True):
+        src = open(f).read()
+        assert "import oracle" not in src and "from oracle" not in src, f
