@@ -423,28 +423,27 @@ template <> struct WFrag<bf16_t> {
   }
 };
 
-constexpr int WG_PAD_ROWS = 16;
-
 template <typename T, int NTT>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 1 : 2) void k_conv_wgrad(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CT = 4 / NTT;          // c-tiles (32 input channels each) per workgroup
   constexpr int N = NTT * 32;
   constexpr int XCH = CT * 2, YCH = NTT * 2;
-  const int Q = a.Q, Qp = Q + WG_PAD_ROWS, W2 = a.W + 2;
-  T* sx = (T*)smem;                    // [XCH][Qp][16]
-  T* sy = sx + (size_t)XCH * Qp * 16;  // [YCH][Qp][16]
+  // K is walked in bands of a.bl haloed-grid rows (a multiple of 16, so the row swizzle of the linear LDS copy is
+  // band independent); the LDS window of a band holds tile rows [band*bl, band*bl + WR).  See conv_bf16.hip.
+  const int Q = a.Q, WR = a.wr, W2 = a.W + 2;
+  T* sx = (T*)smem;                    // [XCH][WR][16]
+  T* sy = sx + (size_t)XCH * WR * 16;  // [YCH][WR][16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
   const int ct = wave / NTT, nt = wave % NTT;
   const int chunk0 = cg * XCH;
   const int nxch = max(0, min(XCH, a.NCx - chunk0));
 
-  // zero everything once: pad rows and absent chunks stay zero for the whole kernel
-  {
+  {  // zero everything once: absent chunks stay zero for the whole kernel
     u32x4 z = {0, 0, 0, 0};
     u32x4* d = reinterpret_cast<u32x4*>(smem);
-    int tot = (XCH + YCH) * Qp * 16 * (int)sizeof(T) / 16;
+    int tot = (XCH + YCH) * WR * 16 * (int)sizeof(T) / 16;
     for (int v = tid; v < tot; v += 256) d[v] = z;
   }
   f32x16 acc[9];
@@ -453,67 +452,42 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 1 : 2) void k_conv_wgrad(Wgra
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const int vpc = Q * 16 * (int)sizeof(T) / 16;  // vectors per chunk tile
+  constexpr int VPR = 16 * (int)sizeof(T) / 16;   // 16-byte vectors per row
+  const int vpc = WR * VPR;                       // vectors per chunk window
   const T* xg = (const T*)a.x_tl + (size_t)g * a.x_gs;
   const T* yg = (const T*)a.dy_tl + (size_t)g * a.dy_gs;
   const int q0 = a.W + 3, q1 = Q - a.W - 3;
-  const T* xt = sx + (size_t)ct * 2 * Qp * 16;
-  const T* yt = sy + (size_t)nt * 2 * Qp * 16;
+  const T* xt = sx + (size_t)ct * 2 * WR * 16;
+  const T* yt = sy + (size_t)nt * 2 * WR * 16;
+  const u32x4 zero4 = {0, 0, 0, 0};
 
-  constexpr bool PIPE = sizeof(T) == 2;
-  constexpr int XV = PIPE ? 6 : 1, YV = PIPE ? 6 : 1;
-  u32x4 rx[XV], ry[YV];
-  const int nxv = nxch * vpc, nyv = YCH * vpc;
-#define DTA_WGRAD_FETCH(b_)                                                                                  \
-  {                                                                                                          \
-    _Pragma("unroll") for (int u = 0; u < XV; ++u) {                                                         \
-      int v = min(tid + u * 256, max(nxv, 1) - 1);                                                           \
-      int ch = v / vpc, o = v - ch * vpc;                                                                    \
-      rx[u] = reinterpret_cast<const u32x4*>(xg + (((size_t)(b_) * a.NCx + chunk0 + ch) * Q) * 16)[o];       \
-    }                                                                                                        \
-    _Pragma("unroll") for (int u = 0; u < YV; ++u) {                                                         \
-      int v = min(tid + u * 256, nyv - 1);                                                                   \
-      int ch = v / vpc, o = v - ch * vpc;                                                                    \
-      ry[u] = reinterpret_cast<const u32x4*>(yg + (((size_t)(b_) * a.NCy + a.ych0 + ch) * Q) * 16)[o];       \
-    }                                                                                                        \
-  }
-  const bool pipe = PIPE && nxv <= XV * 256 && nyv <= YV * 256;
-  if (pipe && s < a.B) DTA_WGRAD_FETCH(s)
   for (int b = s; b < a.B; b += a.S) {
-    __syncthreads();
-    if (pipe) {
-#pragma unroll
-      for (int u = 0; u < XV; ++u) {
-        int v = tid + u * 256;
-        if (v < nxv) { int ch = v / vpc, o = v - ch * vpc; reinterpret_cast<u32x4*>(sx + (size_t)ch * Qp * 16)[o] = rx[u]; }
-      }
-#pragma unroll
-      for (int u = 0; u < YV; ++u) {
-        int v = tid + u * 256;
-        if (v < nyv) { int ch = v / vpc, o = v - ch * vpc; reinterpret_cast<u32x4*>(sy + (size_t)ch * Qp * 16)[o] = ry[u]; }
-      }
-    } else {
-      for (int v = tid; v < nxv; v += 256) {
+    for (int band = 0; band < a.nbands; ++band) {
+      const int r0 = band * a.bl;
+      __syncthreads();
+      for (int v = tid; v < nxch * vpc; v += 256) {
         int ch = v / vpc, o = v - ch * vpc;
-        reinterpret_cast<u32x4*>(sx + (size_t)ch * Qp * 16)[o] =
-            reinterpret_cast<const u32x4*>(xg + (((size_t)b * a.NCx + chunk0 + ch) * Q) * 16)[o];
+        const bool in = r0 + o / VPR < Q;
+        reinterpret_cast<u32x4*>(sx + (size_t)ch * WR * 16)[o] =
+            in ? reinterpret_cast<const u32x4*>(xg + (((size_t)b * a.NCx + chunk0 + ch) * Q + r0) * 16)[o] : zero4;
       }
-      for (int v = tid; v < nyv; v += 256) {
+      for (int v = tid; v < YCH * vpc; v += 256) {
         int ch = v / vpc, o = v - ch * vpc;
-        reinterpret_cast<u32x4*>(sy + (size_t)ch * Qp * 16)[o] =
-            reinterpret_cast<const u32x4*>(yg + (((size_t)b * a.NCy + a.ych0 + ch) * Q) * 16)[o];
+        const bool in = r0 + o / VPR < Q;
+        reinterpret_cast<u32x4*>(sy + (size_t)ch * WR * 16)[o] =
+            in ? reinterpret_cast<const u32x4*>(yg + (((size_t)b * a.NCy + a.ych0 + ch) * Q + r0) * 16)[o] : zero4;
       }
-    }
-    __syncthreads();
-    if (pipe && b + a.S < a.B) DTA_WGRAD_FETCH(b + a.S)
+      __syncthreads();
+      const int qend = q0 + min(a.bl, (q1 - q0) - r0);
 #pragma unroll 1
-    for (int q = q0; q < q1; q += WFrag<T>::KS) {
-      typename WFrag<T>::reg bf = WFrag<T>::load(yt, Qp, q, lane);
+      for (int q = q0; q < qend; q += WFrag<T>::KS) {
+        typename WFrag<T>::reg bf = WFrag<T>::load(yt, WR, q, lane);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int shift = (tap / 3 - 1) * W2 + (tap % 3 - 1);
-        typename WFrag<T>::reg af = WFrag<T>::load(xt, Qp, q + shift, lane);
-        acc[tap] = WFrag<T>::mfma(af, bf, acc[tap]);
+        for (int tap = 0; tap < 9; ++tap) {
+          const int shift = (tap / 3 - 1) * W2 + (tap % 3 - 1);
+          typename WFrag<T>::reg af = WFrag<T>::load(xt, WR, q + shift, lane);
+          acc[tap] = WFrag<T>::mfma(af, bf, acc[tap]);
+        }
       }
     }
   }
@@ -576,17 +550,32 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradReduceArgs a) {
 
 int wgrad_cpw(int N) { return (4 / (N / 32)) * 32; }
 
+void wgrad_band_plan(int Q, int W, int wr_max, int* bl, int* wr, int* nbands) {
+  const int span = Q - 2 * (W + 3);              // haloed-grid rows q0..q1
+  const int halo = 2 * (W + 3);
+  int b = (span + 15) / 16 * 16;
+  auto align = [](int r) { while ((r & 7) != 4) ++r; return r; };
+  while (b >= 16 && align(b + halo) > wr_max) b -= 16;
+  *bl = b;
+  *wr = b >= 16 ? align(b + halo) : 0;
+  *nbands = b >= 16 ? (span + b - 1) / b : 0;
+}
+
 template <typename T, int NTT>
 static int launch_wgrad_t(const WgradArgs& a, int G, int cgroups, hipStream_t st) {
-  constexpr int CT = 4 / NTT;
-  size_t lds = (size_t)(CT * 2 + NTT * 2) * (a.Q + WG_PAD_ROWS) * 16 * sizeof(T);
-  if (lds > 160 * 1024) { dta_set_error("conv_wgrad: LDS need %zu B exceeds 160 KiB", lds); return 1; }
+  constexpr int CT = 4 / NTT, NCH = CT * 2 + NTT * 2;
+  WgradArgs a2 = a;
+  int wr_max = (int)(160 * 1024 / ((size_t)NCH * 16 * sizeof(T)));
+  if (wr_max > 1024) wr_max = 1024;
+  wgrad_band_plan(a.Q, a.W, wr_max, &a2.bl, &a2.wr, &a2.nbands);
+  if (a2.bl < 16) { dta_set_error("conv_wgrad: %dx%d patch is too wide for the band plan", a.H, a.W); return 1; }
+  size_t lds = (size_t)NCH * a2.wr * 16 * sizeof(T);
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)k_conv_wgrad<T, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_conv_wgrad<T, NTT>), dim3(cgroups, a.S, G), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_conv_wgrad<T, NTT>), dim3(cgroups, a.S, G), dim3(256), lds, st, a2);
   DTA_CHECK_LAUNCH("k_conv_wgrad");
   return 0;
 }

@@ -264,7 +264,7 @@ int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
 constexpr int WGB_PAD_ROWS = 16;
 constexpr int RW = 32;    // weight-gradient LDS rows stay compact (32 B): with chunk tiles 128 B (mod 256 B) apart the two
                           // 16-lane groups of a ds_read_b64_tr_b16 half-wave hit disjoint banks for any row offset
-__host__ __device__ inline int wgrad_qp(int Q) { int qp = Q + WGB_PAD_ROWS; while ((qp & 7) != 4) ++qp; return qp; }
+
 
 // One patch: K runs over the haloed-grid rows in steps of 16; NTAP accumulators share each dY fragment.
 template <int NTAP>
@@ -289,8 +289,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   constexpr int CT = 4 / NTT;            // 32-channel input tiles per workgroup
   constexpr int N = NTT * 32;
   constexpr int XCH = CT * 2, YCH = NTT * 2;
-  const int Q = a.Q, Qp = wgrad_qp(Q), W2 = a.W + 2;
-  const int xbytes = XCH * Qp * RW, stage = (XCH + YCH) * Qp * RW;   // stage = [XCH][Qp][48 B] | [YCH][Qp][48 B]
+  // The K dimension (haloed-grid rows q0..q1 of a patch) is walked in bands of a.bl rows; a band's LDS window holds
+  // tile rows [band*bl, band*bl + WR) of the X and dY chunk tiles (WR = bl + 2*(W+3) covers the +-(W+3) tap shifts),
+  // so k-step addresses are the same for every band.  11x11 patches are a single band.
+  const int Q = a.Q, WR = a.wr, W2 = a.W + 2;
+  const int xbytes = XCH * WR * RW, stage = (XCH + YCH) * WR * RW;
   const bool dbuf = a.dbuf != 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware placement: workgroup id b runs on XCD b % 8 (observed dispatch rule, speed only); consecutive LOGICAL
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   const int chunk0 = cg * XCH;
   const int nxch = max(0, min(XCH, a.NCx - chunk0));
 
-  {  // zero everything once: pad rows, row padding and absent chunks stay zero for the whole kernel
+  {  // zero everything once: absent chunks stay zero for the whole kernel
     u32x4 z = {0, 0, 0, 0};
     u32x4* d = reinterpret_cast<u32x4*>(smem);
     int tot = (dbuf ? 2 : 1) * stage / 16;
@@ -320,81 +323,93 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int q0 = a.W + 3, q1 = Q - a.W - 3;
-  const int nks = (q1 - q0 + 15) / 16;
   const int gq = lane >> 4, li = lane & 15;
   const int lane_off = (8 * (gq >> 1) + (li >> 2)) * RW + (li & 3) * 8;
-  const int b_off = ((nt * 2 + (gq & 1)) * Qp + q0) * RW + lane_off;
+  const int b_off = ((nt * 2 + (gq & 1)) * WR + q0) * RW + lane_off;
   int a_tap[5];
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     int tap = min(tap0 + j, 8);
     int shift = (tap / 3 - 1) * W2 + (tap % 3 - 1);
-    a_tap[j] = ((ct * 2 + (gq & 1)) * Qp + q0 + shift) * RW + lane_off;
+    a_tap[j] = ((ct * 2 + (gq & 1)) * WR + q0 + shift) * RW + lane_off;
   }
 
-  // ---- staging plan ----
-  constexpr int XV = 3, YV = 3;
-  const int vpc = Q * 2;
+  // ---- staging plan (band independent): thread t owns window vectors t, t+512, ... of the X part and of the dY part
+  constexpr int XV = XCH, YV = YCH;            // one vector per chunk per thread covers windows of up to 256 rows
+  const int vpc = WR * 2;                      // 16-byte vectors per chunk window
   const int nxv = nxch * vpc, nyv = YCH * vpc;
   const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs;
   const bf16_t* yg = (const bf16_t*)a.dy_tl + (size_t)g * a.dy_gs;
   const size_t xpatch = (size_t)a.NCx * Q * 16, ypatch = (size_t)a.NCy * Q * 16;
   size_t xsrc[XV], ysrc[YV];
-  int xdst[XV], ydst[YV];
+  int xdst[XV], ydst[YV], xrow[XV], yrow[YV];
 #pragma unroll
   for (int u = 0; u < XV; ++u) {
     int v = min(tid + u * NTHR, max(nxv, 1) - 1);
     int ch = v / vpc, o = v - ch * vpc;
+    xrow[u] = (tid + u * NTHR < nxv) ? (o >> 1) : (1 << 30);    // window row of this vector (huge = not mine)
     xsrc[u] = (size_t)(chunk0 + ch) * Q * 16 + (size_t)o * 8;
-    xdst[u] = (ch * Qp + (o >> 1)) * RW + (o & 1) * 16;
+    xdst[u] = (ch * WR + (o >> 1)) * RW + (o & 1) * 16;
   }
 #pragma unroll
   for (int u = 0; u < YV; ++u) {
     int v = min(tid + u * NTHR, nyv - 1);
     int ch = v / vpc, o = v - ch * vpc;
+    yrow[u] = (tid + u * NTHR < nyv) ? (o >> 1) : (1 << 30);
     ysrc[u] = (size_t)(a.ych0 + ch) * Q * 16 + (size_t)o * 8;
-    ydst[u] = (ch * Qp + (o >> 1)) * RW + (o & 1) * 16;
+    ydst[u] = (ch * WR + (o >> 1)) * RW + (o & 1) * 16;
   }
   u32x4 rx[XV], ry[YV];
-#define DTA_FETCH(b_)                                                                                             \
+  const u32x4 zero4 = {0, 0, 0, 0};
+  // rows of the window that fall beyond the tile (last band) are staged as zeros
+#define DTA_FETCH(b_, band_)                                                                                      \
   {                                                                                                               \
-    if (nxv > 0) { _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                 \
-        rx[u] = *reinterpret_cast<const u32x4*>(xg + (size_t)(b_) * xpatch + xsrc[u]); }                          \
+    const int r0_ = (band_) * a.bl;                                                                               \
+    _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                                \
+        rx[u] = (xrow[u] + r0_ < Q) ? *reinterpret_cast<const u32x4*>(xg + (size_t)(b_) * xpatch + xsrc[u] + (size_t)r0_ * 16) : zero4; \
     _Pragma("unroll") for (int u = 0; u < YV; ++u)                                                                \
-        ry[u] = *reinterpret_cast<const u32x4*>(yg + (size_t)(b_) * ypatch + ysrc[u]);                            \
+        ry[u] = (yrow[u] + r0_ < Q) ? *reinterpret_cast<const u32x4*>(yg + (size_t)(b_) * ypatch + ysrc[u] + (size_t)r0_ * 16) : zero4; \
   }
 #define DTA_STORE(base_)                                                                                          \
   {                                                                                                               \
     _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                                \
-        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((base_) + xdst[u]) = rx[u];                           \
+        if (xrow[u] < WR) *reinterpret_cast<u32x4*>((base_) + xdst[u]) = rx[u];                                   \
     _Pragma("unroll") for (int u = 0; u < YV; ++u)                                                                \
-        if (tid + u * NTHR < nyv) *reinterpret_cast<u32x4*>((base_) + xbytes + ydst[u]) = ry[u];                  \
+        if (yrow[u] < WR) *reinterpret_cast<u32x4*>((base_) + xbytes + ydst[u]) = ry[u];                          \
   }
-  if (s < a.B) {
-    DTA_FETCH(s)
-    __syncthreads();                       // zero fill complete before the first tile lands
+  // flattened (patch, band) iteration space of this workgroup
+  const int npb = (a.B - s + a.S - 1) / a.S;
+  const int niter = npb * a.nbands;
+#define DTA_ITER_B(it_) (s + ((it_) / a.nbands) * a.S)
+#define DTA_ITER_BAND(it_) ((it_) % a.nbands)
+  if (niter > 0) {
+    DTA_FETCH(DTA_ITER_B(0), DTA_ITER_BAND(0))
+    __syncthreads();                       // zero fill complete before the first window lands
     DTA_STORE(smem)
-    if (s + a.S < a.B) DTA_FETCH(s + a.S)
+    if (niter > 1) DTA_FETCH(DTA_ITER_B(1), DTA_ITER_BAND(1))
   }
   __syncthreads();
-  int it = 0;
-  for (int b = s; b < a.B; b += a.S, ++it) {
+  for (int it = 0; it < niter; ++it) {
     unsigned char* cur = smem + ((dbuf && (it & 1)) ? stage : 0);
     unsigned char* nxt = smem + ((dbuf && !(it & 1)) ? stage : 0);
-    const bool more = b + a.S < a.B;
+    const bool more = it + 1 < niter;
     if (dbuf && more) {
       DTA_STORE(nxt)
-      if (b + 2 * a.S < a.B) DTA_FETCH(b + 2 * a.S)
+      if (it + 2 < niter) DTA_FETCH(DTA_ITER_B(it + 2), DTA_ITER_BAND(it + 2))
     }
+    const int rem = (q1 - q0) - DTA_ITER_BAND(it) * a.bl;
+    const int nks = (min(a.bl, rem) + 15) / 16;
     if (tg == 0) wgrad_ksteps<5>(cur, cur + xbytes, a_tap, b_off, nks, acc);
     else wgrad_ksteps<4>(cur, cur + xbytes, a_tap, b_off, nks, acc);
     __syncthreads();
     if (!dbuf && more) {
       DTA_STORE(nxt)
-      if (b + 2 * a.S < a.B) DTA_FETCH(b + 2 * a.S)
+      if (it + 2 < niter) DTA_FETCH(DTA_ITER_B(it + 2), DTA_ITER_BAND(it + 2))
       __syncthreads();
     }
   }
+#undef DTA_ITER_BAND
+#undef DTA_ITER_B
 #undef DTA_STORE
 #undef DTA_FETCH
   // partial[g][s][tap][c][n]
@@ -414,12 +429,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
 template <int NTT>
 static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream_t st) {
   constexpr int CT = 4 / NTT;
-  size_t stage = (size_t)(CT * 2 + NTT * 2) * wgrad_qp(a.Q) * RW;
   WgradArgs a2 = a;
+  // band plan: window rows WR = bl + 2*(W+3), WR == 4 (mod 8) (bank-disjoint chunk tiles), WR <= 252 (staging plan)
+  wgrad_band_plan(a.Q, a.W, 252, &a2.bl, &a2.wr, &a2.nbands);
+  if (a2.bl < 16 || a2.wr > 256) { dta_set_error("conv_wgrad(bf16): %dx%d patch is too wide for the band plan", a.H, a.W); return 1; }
+  size_t stage = (size_t)(CT * 2 + NTT * 2) * a2.wr * RW;
   a2.dbuf = 2 * stage <= 160 * 1024;
   size_t lds = (a2.dbuf ? 2 : 1) * stage;
   if (lds > 160 * 1024) { dta_set_error("conv_wgrad(bf16): LDS need %zu B exceeds 160 KiB", lds); return 1; }
-  if (4 * a.Q * 2 > 3 * 512) { dta_set_error("conv_wgrad(bf16): %dx%d tile exceeds the staging plan", a.H, a.W); return 1; }
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -25,7 +25,10 @@ struct WgradArgs {
   const void* dy_tl; size_t dy_gs; int NCy, ych0;
   float* partial;                     // [G][S][9][Cpad][N]
   int B, H, W, Q, N, Cpad, S, dbuf, cgroups, G;
+  int bl, wr, nbands;                 // K-band plan (rows per band, LDS window rows, bands per patch)
 };
+// bl = rows per band (multiple of 16), wr = bl + 2*(W+3) rounded up to 4 (mod 8), wr <= wr_max
+void wgrad_band_plan(int Q, int W, int wr_max, int* bl, int* wr, int* nbands);
 struct WgradReduceArgs {
   const float* partial; float* dst[2];
   int G, S, N, C, Cpad, mode, nsplit;
@@ -67,6 +70,7 @@ struct StageArgs {
   int B, C, Hc, Wc;                    // conv-resolution dims
   AttParams att[2];
   int att_k[2], att_pool[2];           // spatial stencil size / class-pool size
+  int vslot;                           // LDS vector slot (floats); filled by the launcher
   void* a_tl; size_t a_gs; int a_nc, a_ch0;      // gated map as tiles for the next conv (or null)
   float* a_nchw; size_t a_nchw_gs;     // gated map as fp32 NCHW (standalone modules) or null
   float* feat; size_t feat_gs; int F[2];         // [B][F]

@@ -125,7 +125,7 @@ __device__ __forceinline__ StageGeom stage_geom(const StageArgs& a) {
   s.Hc = CFG::fixed ? CFG::H : a.Hc; s.Wc = CFG::fixed ? CFG::W : a.Wc; s.HWc = s.Hc * s.Wc;
   const bool pool = CFG::fixed ? (CFG::P != 0) : (a.pool != 0);
   s.Hz = pool ? s.Hc / 2 : s.Hc; s.Wz = pool ? s.Wc / 2 : s.Wc; s.HWz = s.Hz * s.Wz;
-  s.vslot = stage_vslot(s.C, s.Hz, s.Wz);
+  s.vslot = a.vslot;
   return s;
 }
 // spatial-attention stencil size / class-pool size are functions of the channel count in the reference
@@ -139,13 +139,20 @@ template <typename CFG> __device__ __forceinline__ int cfg_att_pool(const StageA
 template <typename CFG> __device__ __forceinline__ bool cfg_pool(const StageArgs& a) {
   return CFG::fixed ? (CFG::P != 0) : (a.pool != 0);
 }
+// LDS vector slot size: padded single-channel maps only when a spatial-attention group is present
+int stage_vslot_for(const StageArgs& a, int G) {
+  int Hz = a.pool ? a.Hc / 2 : a.Hc, Wz = a.pool ? a.Wc / 2 : a.Wc;
+  bool spatial = false;
+  for (int g = 0; g < G; ++g) spatial |= a.kind[g] == KIND_SPATIAL;
+  return spatial ? stage_vslot(a.C, Hz, Wz) : a.C;
+}
 static size_t stage_lds_floats(const StageArgs& a, bool bwd) {
   int HWc = a.Hc * a.Wc;
   int Hz = a.pool ? a.Hc / 2 : a.Hc, Wz = a.pool ? a.Wc / 2 : a.Wc;
   int HWz = Hz * Wz, ld = a.C + 1;
   size_t n = (size_t)HWz * ld;                 // Z
   if (bwd) n += (size_t)HWz * ld;               // D
-  n += (size_t)(bwd ? 8 : 4) * stage_vslot(a.C, Hz, Wz) + 512;   // vectors / padded maps + reduction scratch
+  n += (size_t)(bwd ? 8 : 4) * a.vslot + 512;   // vectors / padded maps + reduction scratch
   return n;
 }
 
@@ -385,7 +392,9 @@ static bool stage_net_cfg(const StageArgs& a) {
 }
 
 template <typename T>
-int launch_stage_fwd(const StageArgs& a, int G, hipStream_t st) {
+int launch_stage_fwd(const StageArgs& a_in, int G, hipStream_t st) {
+  StageArgs a = a_in;
+  a.vslot = stage_vslot_for(a, G);
   size_t lds = stage_lds_floats(a, false) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_fwd: %dx%dx%d patch needs %zu B of LDS", a.Hc, a.Wc, a.C, lds); return 1; }
   // the three stages of the 11x11 network are fully specialised (stencils unroll, no index divisions)
@@ -613,7 +622,9 @@ static int launch_stage_bwd_c(const StageBwdArgs& a, int G, size_t lds, hipStrea
   return 0;
 }
 
-int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st) {
+int launch_stage_bwd(const StageBwdArgs& a_in, int G, hipStream_t st) {
+  StageBwdArgs a = a_in;
+  a.f.vslot = stage_vslot_for(a.f, G);
   size_t lds = stage_lds_floats(a.f, true) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_bwd: %dx%dx%d patch needs %zu B of LDS", a.f.Hc, a.f.Wc, a.f.C, lds); return 1; }
   const bool net = a.f.apply_bn && a.f.relu && stage_net_cfg(a.f);

@@ -138,3 +138,43 @@ def test_metadata_sensor_fusion_eval_matches_oracle_composition():
     ref = np.maximum(np.concatenate([meta, sensor], axis=1) @ w.T + b, 0)
     assert out.shape == (B, classes)
     assert rel_l2(out, ref) < TIGHT
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_spectral_network_24x24_crops(golden, precision):
+    """BASELINE config 5 geometry: spectral_network is size-agnostic (reference Hang2020.py:226-240); 24x24 crops take
+    the banded weight-gradient path and the large-map stage kernels.  fp32 against the reference's golden, bf16
+    against the oracle run with the same operand rounding."""
+    from deeptreeattention_amd import Hang2020 as H
+    g = golden("subnets.npz")
+    bands, classes, B, hw = 16, 7, 2, 24
+    p = O.init_params(O.subnet_spec("spectral", bands, classes), seed=51)
+    m = load(H.spectral_network(bands, classes, precision=precision), p)
+    xn = prng.uniform01(52, hw, (B, bands, hw, hw))
+    m.train()
+    s = m(torch.from_numpy(xn).to(dev()))
+    dsn = [prng.uniform(52, 10 + i, (B, classes), -1, 1) for i in range(3)]
+    sum((a * torch.from_numpy(b).to(dev())).sum() for a, b in zip(s, dsn)).backward()
+    if precision == "fp32":
+        for i in range(3):
+            assert rel_l2(s[i].detach().cpu().numpy(), g[f"spectral24/head{i + 1}"]) < TIGHT
+        for k, prm in m.named_parameters():
+            if not k.endswith("conv_layer.bias"):
+                assert rel_l2(prm.grad.cpu().numpy(), g[f"spectral24/g/{k}"]) < TOL, k
+        return
+    O.set_conv_operand_quantizer(O.bf16_round)
+    try:
+        rs, cache, _ = O.subnet_fwd(p, "", "spectral", xn, True, np.float64)
+        rg = O.subnet_bwd(p, "", cache, [d.astype(np.float64) for d in dsn], np.float64)
+    finally:
+        O.set_conv_operand_quantizer(None)
+    for i in range(3):
+        assert rel_l2(s[i].detach().cpu().numpy(), rs[i]) < 1e-3
+        assert rel_l2(s[i].detach().cpu().numpy(), g[f"spectral24/head{i + 1}"]) < 1e-2     # vs the exact reference
+    num = den = 0.0
+    for k, prm in m.named_parameters():
+        if k.endswith("conv_layer.bias"):
+            continue
+        num += float(((prm.grad.double().cpu().numpy() - rg[k]) ** 2).sum())
+        den += float((np.asarray(rg[k], np.float64) ** 2).sum())
+    assert np.sqrt(num / den) < 5e-2
