@@ -99,6 +99,8 @@ def lib():
         L.dta_linear_forward.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
         L.dta_linear_backward.restype = C.c_int
         L.dta_linear_backward.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+        L.dta_softmax_top2.restype = C.c_int
+        L.dta_softmax_top2.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
         L.dta_profile_enable.restype = C.c_int
         L.dta_profile_enable.argtypes = [C.c_int]
         L.dta_profile_collect.restype = C.c_int

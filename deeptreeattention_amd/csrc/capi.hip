@@ -555,6 +555,12 @@ int dta_weighted_ce(const float* logits, const long long* labels, const float* w
   return launch_weighted_ce(a, (hipStream_t)stream);
 }
 
+int dta_softmax_top2(const float* logits, int batch, int classes, float* probs, long long* top_idx, float* top_score,
+                     void* stream) {
+  if (!logits || !top_idx || !top_score || batch < 1 || classes < 2) { dta_set_error("dta_softmax_top2: bad argument"); return 1; }
+  return launch_softmax_top2(logits, batch, classes, probs, top_idx, top_score, (hipStream_t)stream);
+}
+
 int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double* alpha_p, const double* alpha_g,
                   double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
                   float grad_scale, void* stream) {

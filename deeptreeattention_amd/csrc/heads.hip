@@ -282,6 +282,58 @@ int launch_weighted_ce(const CeArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Inference epilogue: softmax over classes (reference multi_stage.py:302,315; main.py:190) plus the top-2 labels and
+// scores main.py:192-205 extracts on the host.  One wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_softmax_top2(const float* logits, int B, int classes, float* probs,
+                                                      long long* top_idx, float* top_score) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* z = logits + (size_t)row * classes;
+  float mx = -3.4e38f;
+  for (int n = lane; n < classes; n += 64) mx = fmaxf(mx, z[n]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int n = lane; n < classes; n += 64) se += __expf(z[n] - mx);
+  se = wave_sum(se);
+  const float inv = 1.f / se;
+  float b1 = -1.f, b2 = -1.f;
+  int i1 = -1, i2 = -1;
+  for (int n = lane; n < classes; n += 64) {
+    float pr = __expf(z[n] - mx) * inv;
+    if (probs) probs[(size_t)row * classes + n] = pr;
+    if (pr > b1) { b2 = b1; i2 = i1; b1 = pr; i1 = n; }
+    else if (pr > b2) { b2 = pr; i2 = n; }
+  }
+  // merge the per-lane (best, second) pairs across the wave; ties resolve to the lower class index (as torch.topk)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob1 = __shfl_xor(b1, o), ob2 = __shfl_xor(b2, o);
+    int oi1 = __shfl_xor(i1, o), oi2 = __shfl_xor(i2, o);
+    auto better = [](float a, int ia, float b, int ib) { return a > b || (a == b && ia >= 0 && (ib < 0 || ia < ib)); };
+    float n1, n2; int j1, j2;
+    if (better(b1, i1, ob1, oi1)) {
+      n1 = b1; j1 = i1;
+      if (better(b2, i2, ob1, oi1)) { n2 = b2; j2 = i2; } else { n2 = ob1; j2 = oi1; }
+    } else {
+      n1 = ob1; j1 = oi1;
+      if (better(b1, i1, ob2, oi2)) { n2 = b1; j2 = i1; } else { n2 = ob2; j2 = oi2; }
+    }
+    b1 = n1; i1 = j1; b2 = n2; i2 = j2;
+  }
+  if (lane == 0) {
+    top_idx[row * 2] = i1; top_idx[row * 2 + 1] = i2;
+    top_score[row * 2] = b1; top_score[row * 2 + 1] = b2;
+  }
+}
+int launch_softmax_top2(const float* logits, int B, int classes, float* probs, long long* top_idx, float* top_score,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(k_softmax_top2, dim3((B + 3) / 4), dim3(256), 0, st, logits, B, classes, probs, top_idx, top_score);
+  DTA_CHECK_LAUNCH("k_softmax_top2");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // torch.optim.Adam (defaults: no weight decay, no amsgrad) over one flat fp32 buffer + the fp64 alpha.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_adam(AdamArgs a) {

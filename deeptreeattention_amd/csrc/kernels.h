@@ -156,5 +156,7 @@ struct AdamArgs {
   float lr, beta1, beta2, eps, bc1, bc2; float grad_scale;
 };
 int launch_adam(const AdamArgs& a, hipStream_t st);
+int launch_softmax_top2(const float* logits, int B, int classes, float* probs, long long* top_idx, float* top_score,
+                        hipStream_t st);
 
 }  // namespace dta

@@ -188,3 +188,27 @@ class FusedTrainer:
                                      self.model._classes, _lib.ptr(self.loss), None, _lib.ptr(self.ce_scratch), st),
                    "dta_weighted_ce")
         return self.logits, self.loss
+
+
+def predict(model, images, return_probs=True):
+    """Inference step of the reference (`MultiStage.predict_step` / `TreeModel.predict_dataloader`): eval-mode forward,
+    softmax over classes and the top-2 labels/scores, all on the device.  Returns (probs or None, top_idx [B,2] int64,
+    top_score [B,2] float32)."""
+    L = _lib.lib()
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            logits = model(images)
+    finally:
+        model.train(was_training)
+    if isinstance(logits, (list, tuple)):
+        logits = logits[-1]
+    logits = logits.contiguous().float()
+    Bn, classes = logits.shape
+    probs = torch.empty_like(logits) if return_probs else None
+    idx = torch.empty(Bn, 2, dtype=torch.int64, device=logits.device)
+    score = torch.empty(Bn, 2, dtype=torch.float32, device=logits.device)
+    _lib.check(L.dta_softmax_top2(_lib.ptr(logits), Bn, classes, _lib.ptr(probs), _lib.ptr(idx), _lib.ptr(score),
+                                  _lib.current_stream_ptr()), "dta_softmax_top2")
+    return probs, idx, score

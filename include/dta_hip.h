@@ -88,6 +88,12 @@ int dta_net_backward(const dta_net_desc* d, const dta_subnet_params* nets, const
 int dta_weighted_ce(const float* logits, const long long* labels, const float* weight, int batch, int classes,
                     float* loss, float* dlogits, float* scratch, void* stream);
 
+/* Inference epilogue: replaces F.softmax(pred, dim=1) (src/models/multi_stage.py:302,315; src/main.py:190) and the
+ * top-1/top-2 label+score extraction of src/main.py:192-205.  probs [batch][classes] may be null.
+ * top_idx [batch][2] int64, top_score [batch][2] float32. */
+int dta_softmax_top2(const float* logits, int batch, int classes, float* probs, long long* top_idx, float* top_score,
+                     void* stream);
+
 /* Replaces torch.optim.Adam(params, lr).step() (src/main.py:136) over one flat fp32 buffer plus the float64
  * alpha (alpha_* may be null).  step = 1-based step count; grads are multiplied by grad_scale first. */
 int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double* alpha_p, const double* alpha_g,

@@ -178,3 +178,19 @@ def test_spectral_network_24x24_crops(golden, precision):
         num += float(((prm.grad.double().cpu().numpy() - rg[k]) ** 2).sum())
         den += float((np.asarray(rg[k], np.float64) ** 2).sum())
     assert np.sqrt(num / den) < 5e-2
+
+
+def test_predict_softmax_top2():
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import predict
+    torch.manual_seed(3)
+    m = H.Hang2020(bands=12, classes=37).to(dev())
+    x = torch.rand(50, 12, 11, 11, device=dev())
+    probs, idx, score = predict(m, x)
+    m.eval()
+    with torch.no_grad():
+        ref = torch.softmax(m(x), dim=1)
+    assert rel_l2(probs.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    tv, ti = torch.topk(ref, 2, dim=1)
+    assert torch.equal(ti.cpu(), idx.cpu())
+    assert rel_l2(score.cpu().numpy(), tv.cpu().numpy()) < 1e-5
