@@ -19,8 +19,8 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x,
                                                     int H, int W, int NC, int CG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int HW = H * W, Q = (H + 2) * (W + 2);
-  float* s = (float*)smem;                 // [CG*16][HW]
-  int* lut = (int*)(s + CG * 16 * HW);     // [Q] pixel index of haloed-grid row q, or -1 on the halo
+  int* lut = (int*)smem;                   // [Q] pixel index of haloed-grid row q, or -1 on the halo
+  float* sbase = (float*)(lut + ((Q + 3) & ~3));   // 16-byte aligned
   const int b = blockIdx.x, chunk0 = blockIdx.y * CG;
   const int nch = min(CG, NC - chunk0);
   const int c0 = chunk0 * 16;
@@ -30,7 +30,18 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x,
     int hh = q / (W + 2) - 1, ww = q % (W + 2) - 1;
     lut[q] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? hh * W + ww : -1;
   }
-  for (int i = threadIdx.x; i < nch * 16 * HW; i += 256) s[i] = (i < creal * HW) ? src[i] : 0.f;
+  // The patch's channel planes are one contiguous run of floats whose 16-byte phase depends on (b, c0): shift the LDS
+  // image by the same phase so that the body can move as aligned float4 (global AND LDS), with a scalar head/tail.
+  const size_t e0 = ((size_t)b * C + c0) * HW;
+  const int phase = (int)(e0 & 3);
+  float* s = sbase + phase;                // s[i] <-> src[i]; (s + i) is 16-byte aligned exactly when (src + i) is
+  const int nreal = creal * HW, ntot = nch * 16 * HW;
+  const int head = min(nreal, (4 - phase) & 3);
+  const int nvec = (nreal - head) / 4;
+  if (threadIdx.x < head) s[threadIdx.x] = src[threadIdx.x];
+  for (int k = threadIdx.x; k < nvec; k += 256)
+    *reinterpret_cast<float4*>(s + head + 4 * k) = *reinterpret_cast<const float4*>(src + head + 4 * k);
+  for (int i = head + 4 * nvec + threadIdx.x; i < ntot; i += 256) s[i] = (i < nreal) ? src[i] : 0.f;
   __syncthreads();
   constexpr int VW = TlVec<T>::VW, PARTS = 16 / VW;
   for (int ch = 0; ch < nch; ++ch) {
@@ -52,7 +63,7 @@ int launch_pack_input(const float* x, void* out, int B, int C, int H, int W, hip
   int NC = (C + 15) / 16, HW = H * W;
   int CG = 2;   // 2 chunks (32 channels) per workgroup measured best on MI355X (more resident workgroups)
   while (CG > 1 && (size_t)CG * 16 * HW * 4 > 65536) CG >>= 1;
-  size_t lds = (size_t)CG * 16 * HW * 4 + (size_t)(H + 2) * (W + 2) * 4;
+  size_t lds = (size_t)CG * 16 * HW * 4 + (size_t)(((H + 2) * (W + 2) + 3) & ~3) * 4 + 16;
   if (lds > 160 * 1024) { dta_set_error("pack_input: %dx%d patch does not fit LDS", H, W); return 1; }
   dim3 grid(B, (NC + CG - 1) / CG);
   hipLaunchKernelGGL(k_pack_input<T>, grid, dim3(256), lds, st, x, (T*)out, B, C, H, W, NC, CG);
