@@ -282,7 +282,7 @@ __device__ __forceinline__ void wgrad_ksteps(const unsigned char* bx, const unsi
   }
 }
 
-template <int NTT>
+template <int NTT, bool BIGW>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTHR = 512;
@@ -335,7 +335,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   }
 
   // ---- staging plan (band independent): thread t owns window vectors t, t+512, ... of the X part and of the dY part
-  constexpr int XV = XCH, YV = YCH;            // one vector per chunk per thread covers windows of up to 256 rows
+  // vectors per thread: a chunk window has 2*WR vectors; WR <= 192 (11x11 patches: 172) or <= 256 (BIGW)
+  constexpr int XV = BIGW ? XCH : (3 * XCH + 3) / 4, YV = BIGW ? YCH : (3 * YCH + 3) / 4;
   const int vpc = WR * 2;                      // 16-byte vectors per chunk window
   const int nxv = nxch * vpc, nyv = YCH * vpc;
   const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs;
@@ -439,12 +440,14 @@ static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream
   if (lds > 160 * 1024) { dta_set_error("conv_wgrad(bf16): LDS need %zu B exceeds 160 KiB", lds); return 1; }
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<NTT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<NTT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   a2.cgroups = cgroups; a2.G = G;
   const int total = cgroups * a.S * G;
-  hipLaunchKernelGGL((k_conv_wgrad_bf16<NTT>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
+  if (a2.wr <= 192) hipLaunchKernelGGL((k_conv_wgrad_bf16<NTT, false>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
+  else hipLaunchKernelGGL((k_conv_wgrad_bf16<NTT, true>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
   DTA_CHECK_LAUNCH("k_conv_wgrad_bf16");
   return 0;
 }
