@@ -292,7 +292,9 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
       }
     }
   }
+  prof_begin(DTA_SITE_GEMM, st);
   if (launch_gemm_group(heads, st)) return 1;   // all classifier heads of all branches in one launch
+  prof_end(DTA_SITE_GEMM, st);
   if (d->kind == DTA_NET_HANG2020) {
     if (!(d->heads_mask & 4) || !joint || !alpha) { dta_set_error("Hang2020 forward needs head 3, alpha and a joint output"); return 1; }
     BlendArgs ba;
@@ -396,7 +398,9 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
         if (!deferred.add(ga)) { if (launch_gemm_group(deferred, st)) return 1; deferred.n = 0; deferred.add(ga); }
       }
     }
+    if (any_head) prof_begin(DTA_SITE_GEMM + 1, st);
     if (launch_gemm_group(dfeat_grp, st)) return 1;
+    if (any_head) prof_end(DTA_SITE_GEMM + 1, st);
     // ---- attention + pool + ReLU backward ----
     StageBwdArgs sb;
     memset(&sb, 0, sizeof(sb));
@@ -459,7 +463,11 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     else { ap.dy_gs = (size_t)B * (C / 16) * p.Qin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
     if (launch_bn_bwd_apply<T>(ap, G, st)) return 1;
     // ---- conv weight gradient ----
-    if (L == 0 && launch_gemm_group(deferred, st)) return 1;   // end of phase 1: flush the deferred GEMMs
+    if (L == 0) {   // end of phase 1: flush the deferred GEMMs
+      prof_begin(DTA_SITE_GEMM + 2, st);
+      if (launch_gemm_group(deferred, st)) return 1;
+      prof_end(DTA_SITE_GEMM + 2, st);
+    }
     if (L > 0 || (phases & 2))
       if (conv_wgrad_layer<T>(p, d, grads, ws, L, st)) return 1;
     // ---- conv input gradient (feeds the previous stage's gated map) ----

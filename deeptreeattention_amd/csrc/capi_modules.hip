@@ -291,7 +291,8 @@ int dta_linear_forward(const float* x, const float* w, const float* b, int batch
   ga.A = x; ga.sa_m = in_features; ga.sa_k = 1;
   ga.Bm = w; ga.sb_k = 1; ga.sb_n = in_features;
   ga.C = out; ga.sc_m = out_features; ga.sc_n = 1; ga.bias = b;
-  ga.M = batch; ga.N = out_features; ga.K = in_features; ga.ksplit = 1;
+  ga.M = batch; ga.N = out_features; ga.K = in_features; ga.ksplit = gemm_auto_ksplit(batch, out_features, in_features);
+  if (ga.ksplit > 1) hipMemsetAsync(out, 0, (size_t)batch * out_features * 4, (hipStream_t)stream);
   return launch_gemm(ga, (hipStream_t)stream);
 }
 
@@ -305,7 +306,8 @@ int dta_linear_backward(const float* x, const float* w, const float* dout, int b
     ga.A = dout; ga.sa_m = out_features; ga.sa_k = 1;
     ga.Bm = w; ga.sb_k = in_features; ga.sb_n = 1;
     ga.C = dx; ga.sc_m = in_features; ga.sc_n = 1;
-    ga.M = batch; ga.N = in_features; ga.K = out_features; ga.ksplit = 1;
+    ga.M = batch; ga.N = in_features; ga.K = out_features; ga.ksplit = gemm_auto_ksplit(batch, in_features, out_features);
+    if (ga.ksplit > 1) hipMemsetAsync(dx, 0, (size_t)batch * in_features * 4, st);
     if (launch_gemm(ga, st)) return 1;
   }
   if (gw) {   // gw / gb arrive zero-filled

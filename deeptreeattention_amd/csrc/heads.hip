@@ -10,47 +10,130 @@ namespace dta {
 // 64x64 output tile per workgroup, wave w -> 32x32 quadrant, K chunk 32 staged in LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int GK = 32;
-__device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, int bz, float (*As)[GK + 1], float (*Bs)[64]) {
+constexpr int GP = 36;   // LDS row pitch (floats): 16-byte aligned rows, conflict-free b128 operand reads
+
+// Both operands live in LDS as [row][kperm] (row = m for A, n for B) with kperm(k) = (k & 1) * 16 + (k >> 1): the
+// 16 k values one lane feeds to the 16 MFMAs of a chunk (k = 2j + lane/32) are contiguous -> four ds_read_b128.
+enum { LD_SCALAR = 0, LD_VEC_K = 1, LD_VEC_ROW = 2, LD_RUNTIME = 3 };
+
+__device__ __forceinline__ int gemm_load_mode(const float* p, int rows, int K, long s_row, long s_k) {
+  const bool al = (((size_t)p) & 15) == 0;
+  if (s_k == 1 && al && (s_row & 3) == 0 && (K & 3) == 0) return LD_VEC_K;
+  if (s_row == 1 && al && (s_k & 3) == 0 && (rows & 3) == 0) return LD_VEC_ROW;
+  return LD_SCALAR;
+}
+
+// one 64 x GK operand tile -> 8 floats per thread
+__device__ __forceinline__ void gemm_load(float (&r)[8], const float* p, int mode, int rows, int r0, long s_row, long s_k,
+                                          int k0, int kend, int t) {
+  if (mode == LD_VEC_K) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = t + u * 256, row = i >> 3, k = (i & 7) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + row < rows && k0 + k < kend) v = *(const f32x4*)(p + (size_t)(r0 + row) * s_row + (k0 + k));
+      r[4 * u] = v[0]; r[4 * u + 1] = v[1]; r[4 * u + 2] = v[2]; r[4 * u + 3] = v[3];
+    }
+  } else if (mode == LD_VEC_ROW) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = t + u * 256, k = i >> 4, row = (i & 15) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + row < rows && k0 + k < kend) v = *(const f32x4*)(p + (size_t)(k0 + k) * s_k + (r0 + row));
+      r[4 * u] = v[0]; r[4 * u + 1] = v[1]; r[4 * u + 2] = v[2]; r[4 * u + 3] = v[3];
+    }
+  } else {
+    const bool rowfast = s_row == 1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = t + u * 256;
+      const int row = rowfast ? (i & 63) : (i >> 5), k = rowfast ? (i >> 6) : (i & 31);
+      r[u] = (r0 + row < rows && k0 + k < kend) ? p[(size_t)(r0 + row) * s_row + (size_t)(k0 + k) * s_k] : 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ int kperm(int k) { return (k & 1) * 16 + (k >> 1); }
+
+// LDS image of one operand tile.  k-fast operands: [row][GP] with permuted k (above).  row-fast operands (the
+// transposed gradients GEMMs): [k][64] exactly as the float4 global loads deliver it; the MFMA feed is then 16
+// conflict-free ds_read_b32 (32 consecutive rows per half-wave).
+__device__ __forceinline__ void gemm_store(float* S, const float (&r)[8], int mode, bool rowfast, int t) {
+  if (mode == LD_VEC_K) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = t + u * 256, row = i >> 3, k = (i & 7) * 4;   // k, k+2 -> even half; k+1, k+3 -> odd half
+      *(f32x2*)&S[row * GP + (k >> 1)] = f32x2{r[4 * u], r[4 * u + 2]};
+      *(f32x2*)&S[row * GP + 16 + (k >> 1)] = f32x2{r[4 * u + 1], r[4 * u + 3]};
+    }
+  } else if (mode == LD_VEC_ROW) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = t + u * 256, k = i >> 4, row = (i & 15) * 4;
+      *(f32x4*)&S[k * 64 + row] = f32x4{r[4 * u], r[4 * u + 1], r[4 * u + 2], r[4 * u + 3]};
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = t + u * 256;
+      if (rowfast) S[(i >> 6) * 64 + (i & 63)] = r[u];
+      else S[(i >> 5) * GP + kperm(i & 31)] = r[u];
+    }
+  }
+}
+
+// the 16 k-values lane (row, h = lane / 32) feeds to the chunk's MFMAs: k = 2j + h
+__device__ __forceinline__ void gemm_fetch(float (&v)[16], const float* S, bool rowfast, int row, int h) {
+  if (rowfast) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = S[(2 * j + h) * 64 + row];
+  } else {
+    const f32x4* p = (const f32x4*)&S[row * GP + h * 16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f32x4 q = p[j]; v[4 * j] = q[0]; v[4 * j + 1] = q[1]; v[4 * j + 2] = q[2]; v[4 * j + 3] = q[3]; }
+  }
+}
+
+// AM / BM: compile-time load mode of each operand (straight-line code: the loads of both operands stay in flight
+// together and under the MFMAs), or LD_RUNTIME for the generic any-stride path.
+template <int AM, int BM>
+__device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, int bz, float* As, float* Bs) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m0 = bx * 64, n0 = by * 64;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  const int kper = (a.K + a.ksplit - 1) / a.ksplit;
+  const int kper = ((a.K + a.ksplit - 1) / a.ksplit + GK - 1) / GK * GK;
   const int kbeg = bz * kper, kend = min(a.K, kbeg + kper);
+  if (bz > 0 && kbeg >= kend) return;   // K rounded up to whole chunks can leave trailing slices empty
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float rsum = 0.f;   // row sums of A over this block's K range (bias gradients), first column-tile only
-  const bool a_kfast = a.sa_k == 1, b_nfast = a.sb_n == 1;
+  const int amode = AM == LD_RUNTIME ? gemm_load_mode(a.A, a.M, a.K, a.sa_m, a.sa_k) : AM;
+  const int bmode = BM == LD_RUNTIME ? gemm_load_mode(a.Bm, a.N, a.K, a.sb_n, a.sb_k) : BM;
+  const bool arow = AM == LD_RUNTIME ? a.sa_m == 1 : AM == LD_VEC_ROW, brow = BM == LD_RUNTIME ? a.sb_n == 1 : BM == LD_VEC_ROW;
+  float ra[8], rb[8];
+  if (kbeg < kend) {
+    gemm_load(ra, a.A, amode, a.M, m0, a.sa_m, a.sa_k, kbeg, kend, t);
+    gemm_load(rb, a.Bm, bmode, a.N, n0, a.sb_n, a.sb_k, kbeg, kend, t);
+  }
   for (int k0 = kbeg; k0 < kend; k0 += GK) {
-    float ra[8], rb[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      int i = t + u * 256;
-      int m = a_kfast ? i / GK : i % 64, k = a_kfast ? i % GK : i / 64;
-      ra[u] = (m0 + m < a.M && k0 + k < kend) ? a.A[(size_t)(m0 + m) * a.sa_m + (size_t)(k0 + k) * a.sa_k] : 0.f;
-      int n = b_nfast ? i % 64 : i / GK, kb = b_nfast ? i / 64 : i % GK;
-      rb[u] = (n0 + n < a.N && k0 + kb < kend) ? a.Bm[(size_t)(k0 + kb) * a.sb_k + (size_t)(n0 + n) * a.sb_n] : 0.f;
-    }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      int i = t + u * 256;
-      int m = a_kfast ? i / GK : i % 64, k = a_kfast ? i % GK : i / 64;
-      As[m][k] = ra[u];
-      int n = b_nfast ? i % 64 : i / GK, kb = b_nfast ? i / 64 : i % GK;
-      Bs[kb][n] = rb[u];
-    }
+    gemm_store(As, ra, amode, arow, t);
+    gemm_store(Bs, rb, bmode, brow, t);
     __syncthreads();
+    if (k0 + GK < kend) {   // next chunk's global loads fly under this chunk's MFMAs
+      gemm_load(ra, a.A, amode, a.M, m0, a.sa_m, a.sa_k, k0 + GK, kend, t);
+      gemm_load(rb, a.Bm, bmode, a.N, n0, a.sb_n, a.sb_k, k0 + GK, kend, t);
+    }
     if (a.rowsum_out && by == 0 && t < 64) {
 #pragma unroll
-      for (int k = 0; k < GK; ++k) rsum += As[t][k];
+      for (int k = 0; k < GK; ++k) rsum += arow ? As[k * 64 + t] : As[t * GP + k];
     }
+    float av[16], bv[16];
+    gemm_fetch(av, As, arow, wm + (lane & 31), lane >> 5);
+    gemm_fetch(bv, Bs, brow, wn + (lane & 31), lane >> 5);
 #pragma unroll
-    for (int kk = 0; kk < GK; kk += 2) {
-      float av = As[wm + (lane & 31)][kk + (lane >> 5)];
-      float bv = Bs[kk + (lane >> 5)][wn + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
+    for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
   }
   if (a.rowsum_out && by == 0 && t < 64 && m0 + t < a.M) atomicAdd(a.rowsum_out + m0 + t, rsum);
   const int n = n0 + wn + (lane & 31);
@@ -70,8 +153,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, in
 
 // Several independent small GEMMs in one launch: block -> (problem, m-tile, n-tile, k-slice).
 __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup gg) {
-  __shared__ float As[64][GK + 1];
-  __shared__ float Bs[GK][64];
+  __shared__ __attribute__((aligned(16))) float As[64 * GP];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * GP];
   int pi = 0;
   while (pi + 1 < gg.n && (int)blockIdx.x >= gg.start[pi + 1]) ++pi;
   const GemmArgs& a = gg.g[pi];
@@ -80,13 +163,20 @@ __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup gg) {
   const int bx = local % tm; local /= tm;
   const int by = local % tn;
   const int bz = local / tn;
-  gemm_block(a, bx, by, bz, As, Bs);
+  const int am = gemm_load_mode(a.A, a.M, a.K, a.sa_m, a.sa_k), bm = gemm_load_mode(a.Bm, a.N, a.K, a.sb_n, a.sb_k);
+  if (am == LD_VEC_K && bm == LD_VEC_K) gemm_block<LD_VEC_K, LD_VEC_K>(a, bx, by, bz, As, Bs);              // x W^T
+  else if (am == LD_VEC_K && bm == LD_VEC_ROW) gemm_block<LD_VEC_K, LD_VEC_ROW>(a, bx, by, bz, As, Bs);     // dy W
+  else if (am == LD_VEC_ROW && bm == LD_VEC_ROW) gemm_block<LD_VEC_ROW, LD_VEC_ROW>(a, bx, by, bz, As, Bs); // dy^T x
+  else gemm_block<LD_RUNTIME, LD_RUNTIME>(a, bx, by, bz, As, Bs);
 }
 
 int gemm_auto_ksplit(int M, int N, int K) {
   int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  int ks = (128 + tiles - 1) / tiles;
-  int kmax = (K + 63) / 64;
+  // measured on MI355X: beyond ~128 workgroups or K slices under 128 the same-address atomic chains cost more
+  // than the shorter K loop saves
+  constexpr int target = 128, kgran = 128;
+  int ks = (target + tiles - 1) / tiles;
+  int kmax = (K + kgran - 1) / kgran;
   if (ks > kmax) ks = kmax;
   return ks < 1 ? 1 : ks;
 }

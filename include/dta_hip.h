@@ -147,7 +147,8 @@ int dta_linear_backward(const float* x, const float* w, const float* dout, int b
  * stream the kernel is launched on.  site = DTA_SITE_* + layer (0..2); -1 disables.  dta_profile_collect waits
  * for the recorded events, writes up to `max` durations in milliseconds (HOST pointer) and returns the count. */
 enum { DTA_SITE_CONV_FWD = 0, DTA_SITE_CONV_WGRAD = 3, DTA_SITE_CONV_DGRAD = 6, DTA_SITE_STAGE_FWD = 9,
-       DTA_SITE_STAGE_BWD = 12 };
+       DTA_SITE_STAGE_BWD = 12,
+       DTA_SITE_GEMM = 15 /* +0 classifier heads forward, +1 head input gradients, +2 parameter-gradient group */ };
 int dta_profile_enable(int site);
 int dta_profile_collect(float* ms, int max);
 
