@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
   unsigned u = __float_as_uint(f);

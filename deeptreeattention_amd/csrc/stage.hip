@@ -738,8 +738,80 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
   }
 }
 
+// Same transform, patch image assembled in LDS: pixel-major float4 reads of dv / y (fully coalesced), the tile-layout
+// image of the patch (halo included) built in LDS, then one linear 16-byte-per-lane copy to HBM.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_apply[];
+  const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = a.C;
+  const int W2 = a.W + 2, Q = (a.H + 2) * W2, HW = a.H * a.W, nch = C / 16, C4 = C / 4;
+  float* sk = (float*)smem_apply;                       // [3][C]
+  T* img = (T*)(smem_apply + ((3 * C * 4 + 15) & ~15)); // [nch][Q][16]
+  const float* dv = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
+  const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs;
+  const float* coef = a.coef + (size_t)g * a.coef_gs;
+  const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
+  for (int c = t; c < C; c += 256) {
+    float A = bc[c * 4 + 0], Bc = bc[c * 4 + 1], Cc = bc[c * 4 + 2], mean = coef[c * 4 + 2], rstd = coef[c * 4 + 3];
+    sk[c] = A;
+    sk[C + c] = -A * Cc * rstd;
+    sk[2 * C + c] = A * (Cc * rstd * mean - Bc);
+  }
+  const int nvec = nch * Q * 16 * (int)sizeof(T) / 16;
+  u32x4* img4 = (u32x4*)img;
+  for (int i = t; i < nvec; i += 256) img4[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  const int total = HW * C4;
+  constexpr int UB = 4;
+  for (int i0 = t; i0 < total; i0 += 256 * UB) {
+    f32x4 yv[UB], dvv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int i = i0 + u * 256;
+      if (i < total) {
+        const int pix = i / C4, c4 = (i - pix * C4) * 4;
+        yv[u] = *(const f32x4*)(y + (size_t)pix * a.y_rs + c4);
+        dvv[u] = *(const f32x4*)(dv + (size_t)pix * C + c4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int i = i0 + u * 256;
+      if (i < total) {
+        const int pix = i / C4, c4 = (i - pix * C4) * 4;
+        const int hh = pix / a.W, ww = pix - hh * a.W, q = (hh + 1) * W2 + ww + 1;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sk[c4 + j] * dvv[u][j] + sk[C + c4 + j] * yv[u][j] + sk[2 * C + c4 + j];
+        T* row = img + ((size_t)(c4 >> 4) * Q + q) * 16;
+        if constexpr (sizeof(T) == 2) {
+          u32x2 pk = {(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+          *(u32x2*)(row + (c4 & 15)) = pk;
+        } else {
+          // stored position of channel c is (c & 15) ^ (q & 15): an aligned group of 4 stays an aligned group
+          const int s = q & 15, grp = ((c4 & 15) ^ s) & ~3, sw = s & 3;
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = v[j ^ sw];
+          *(f32x4*)((float*)row + grp) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  u32x4* dst = (u32x4*)((T*)a.dy_tl + (size_t)g * a.dy_gs + ((size_t)b * a.dy_nc + a.dy_ch0) * Q * 16);
+  for (int i = t; i < nvec; i += 256) dst[i] = img4[i];
+}
+
 template <typename T>
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st) {
+  const int Q = (a.H + 2) * (a.W + 2);
+  const size_t lds = ((3 * a.C * 4 + 15) & ~15) + (size_t)(a.C / 16) * Q * 16 * sizeof(T);
+  if (lds <= 48 * 1024) {
+    hipLaunchKernelGGL(k_bn_bwd_apply_lds<T>, dim3(a.B, G), dim3(256), lds, st, a);
+    DTA_CHECK_LAUNCH("k_bn_bwd_apply_lds");
+    return 0;
+  }
   hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(a.B, G), dim3(256), 0, st, a);
   DTA_CHECK_LAUNCH("k_bn_bwd_apply");
   return 0;
