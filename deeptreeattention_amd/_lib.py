@@ -81,6 +81,8 @@ def lib():
         L.dta_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_void_p]
+        L.dta_adam_step_zero_grad.restype = C.c_int
+        L.dta_adam_step_zero_grad.argtypes = L.dta_adam_step.argtypes
         vp = C.c_void_p
         L.dta_conv_module_workspace_bytes.restype = C.c_size_t
         L.dta_conv_module_workspace_bytes.argtypes = [C.POINTER(ConvModuleDesc)]

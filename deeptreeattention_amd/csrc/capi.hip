@@ -55,6 +55,7 @@ struct Plan {
   int S[3], cgroups[3], CpadW[3];
   size_t x_tl, wp[3], wd[3], y[3], stats[3], coef[3], a_tl[3], feat[3], attpk[2][3], scores[2][3];
   size_t dsc[2], dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart, rowtmp;
+  size_t attsave[3]; int attsave_ld[3];
   size_t scores_all, scores_bytes, dfeat_all, dfeat_bytes;
   size_t total;
 };
@@ -144,6 +145,11 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     p->bcoef[L] = c.take((size_t)G * CH[L] * 4 * 4);
     p->dy_tl[L] = c.take((size_t)G * B * (CH[L] / 16) * p->Qin[L] * 16 * e);
     p->vec[L] = c.take((size_t)G * B * p->vec_ld[L] * 4);
+    {   // attention intermediates kept from the forward: 3 vector slots per patch (padded maps for stencil radius <= 3)
+      const int pm = (p->Hz[L] + 6) * (p->Wz[L] + 6);
+      p->attsave_ld[L] = 3 * (CH[L] > pm ? CH[L] : pm);
+      p->attsave[L] = c.take((size_t)G * B * p->attsave_ld[L] * 4);
+    }
     if (L > 0) {
       p->wd[L] = c.take((size_t)G * (CH[L] / 16) * 9 * CH[L - 1] * 16 * e);
       p->da[L] = c.take((size_t)G * B * p->HWc[L] * CH[L - 1] * 4);   // grad wrt the conv's input map
@@ -192,6 +198,7 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
     s.a_nc = C / 16; s.a_ch0 = 0;
     s.a_gs = (size_t)B * (C / 16) * p.Qin[L + 1] * 16;
   }
+  s.attsave = at<float>(ws, p.attsave[L]); s.attsave_ld = p.attsave_ld[L];
   s.feat = at<float>(ws, p.feat[L]);
   s.feat_gs = (size_t)B * (p.Fmax[L] > 0 ? p.Fmax[L] : 1);
   // per-group row length of feat is F[g] (rows packed per group)
@@ -365,7 +372,6 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     dsc[0][2] = djoint ? djoint : dsc[0][2];
   }
 
-  hipMemsetAsync(at<char>(ws, p.dfeat_all), 0, p.dfeat_bytes, st);   // split-K GEMM targets
   GemmGroup deferred;   // parameter-gradient GEMMs nothing downstream waits for: one grouped launch at the end
   for (int L = 2; L >= 0; --L) {
     const int C = CH[L];
@@ -380,12 +386,15 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       const int F = p.F[g][L];
       if (!dsc[g][L] || F == 0) continue;
       any_head = true;
+      for (int g2 = 0; g2 < G; ++g2)   // a branch without a score gradient at this stage contributes zeros
+        if (!dsc[g2][L] && p.F[g2][L] > 0)
+          hipMemsetAsync(at<float>(ws, p.dfeat[L]) + (size_t)g2 * fgs, 0, (size_t)B * p.F[g2][L] * 4, st);
       GemmArgs ga;
       memset(&ga, 0, sizeof(ga));
       ga.A = dsc[g][L]; ga.sa_m = p.classes; ga.sa_k = 1;
       ga.Bm = nets[g].fc_w[L]; ga.sb_k = F; ga.sb_n = 1;
       ga.C = at<float>(ws, p.dfeat[L]) + (size_t)g * fgs; ga.sc_m = F; ga.sc_n = 1;
-      ga.M = B; ga.N = F; ga.K = p.classes; ga.ksplit = gemm_auto_ksplit(B, F, p.classes);
+      ga.M = B; ga.N = F; ga.K = p.classes; ga.ksplit = 1;   // plain stores: dfeat needs no clearing
       dfeat_grp.add(ga);
       if (grads[g].fc_w[L]) {
         memset(&ga, 0, sizeof(ga));
@@ -414,6 +423,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     if (launch_stage_bwd(sb, G, st)) return 1;
     prof_end(DTA_SITE_STAGE_BWD + L, st);
     // ---- attention parameter gradients (batch reductions) ----
+    ColsumArgs cs_jobs[2]; int ncs_jobs = 0;   // column sums ride in the BatchNorm-finalize launch below
     for (int g = 0; g < G; ++g) {
       const float* vec = at<float>(ws, p.vec[L]) + (size_t)g * sb.vec_gs;
       const int ld = p.vec_ld[L];
@@ -439,7 +449,8 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
         int offs[6] = {0, C, C + 1, C + 1 + kk, C + 2 + kk, C + 2 + 2 * kk};
         int lens[6] = {C, 1, kk, 1, kk, 1};
         for (int i = 0; i < 6; ++i) { cs.off[i] = offs[i]; cs.len[i] = lens[i]; cs.dst[i] = grads[g].att[L][i]; cs.dst_stride[i] = 1; }
-        if (launch_colsum_scatter(cs, st)) return 1;
+        if (ncs_jobs < 2) cs_jobs[ncs_jobs++] = cs;
+        else if (launch_colsum_scatter(cs, st)) return 1;
       }
     }
     // ---- BatchNorm backward ----
@@ -452,7 +463,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       bf.dconvbias[g] = grads[g].conv_b[L];
     }
     bf.bcoef = at<float>(ws, p.bcoef[L]); bf.bcoef_gs = C * 4; bf.training = d->training;
-    if (launch_bn_bwd_finalize(bf, G, st)) return 1;
+    if (launch_bn_bwd_finalize_colsum(bf, G, cs_jobs, ncs_jobs, st)) return 1;
     BnBwdApplyArgs ap;
     memset(&ap, 0, sizeof(ap));
     ap.dv = sb.dv; ap.dv_gs = sb.dv_gs; ap.y = sa.y; ap.y_gs = sa.y_gs; ap.y_rs = sa.y_rs;
@@ -569,18 +580,32 @@ int dta_softmax_top2(const float* logits, int batch, int classes, float* probs, 
   return launch_softmax_top2(logits, batch, classes, probs, top_idx, top_score, (hipStream_t)stream);
 }
 
-int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double* alpha_p, const double* alpha_g,
-                  double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
-                  float grad_scale, void* stream) {
+static int adam_step_impl(float* p, const float* g, float* gz, float* m, float* v, size_t n, double* alpha_p,
+                          const double* alpha_g, double* alpha_gz, double* alpha_m, double* alpha_v, int step, float lr,
+                          float beta1, float beta2, float eps, float grad_scale, void* stream) {
   if (step < 1 || (n && (!p || !g || !m || !v))) { dta_set_error("dta_adam_step: bad argument"); return 1; }
   AdamArgs a;
-  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.gz = gz; a.alpha_gz = alpha_gz;
   a.alpha_p = alpha_p; a.alpha_g = alpha_g; a.alpha_m = alpha_m; a.alpha_v = alpha_v;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
   double b1 = 1.0, b2 = 1.0;
   for (int i = 0; i < step; ++i) { b1 *= (double)beta1; b2 *= (double)beta2; }
   a.bc1 = (float)(1.0 - b1); a.bc2 = (float)(1.0 - b2);
   return launch_adam(a, (hipStream_t)stream);
+}
+
+int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double* alpha_p, const double* alpha_g,
+                  double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
+                  float grad_scale, void* stream) {
+  return adam_step_impl(p, g, nullptr, m, v, n, alpha_p, alpha_g, nullptr, alpha_m, alpha_v, step, lr, beta1, beta2, eps,
+                        grad_scale, stream);
+}
+
+int dta_adam_step_zero_grad(float* p, float* g, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,
+                            double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
+                            float grad_scale, void* stream) {
+  return adam_step_impl(p, g, g, m, v, n, alpha_p, alpha_g, alpha_g, alpha_m, alpha_v, step, lr, beta1, beta2, eps,
+                        grad_scale, stream);
 }
 
 }  // extern "C"

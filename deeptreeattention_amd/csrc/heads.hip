@@ -206,30 +206,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_colsum_scatter(ColsumArgs a) {
   __shared__ float sc[32][33];
-  const int t = threadIdx.x, jl = t & 31, sl = t >> 5, j = blockIdx.x * 32 + jl;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-  if (j < a.cols) {
-    int r = sl;
-    for (; r + 96 < a.rows; r += 128) {
-      acc0 += a.A[(size_t)r * a.lda + j];
-      acc1 += a.A[(size_t)(r + 32) * a.lda + j];
-      acc2 += a.A[(size_t)(r + 64) * a.lda + j];
-      acc3 += a.A[(size_t)(r + 96) * a.lda + j];
-    }
-    for (; r < a.rows; r += 32) acc0 += a.A[(size_t)r * a.lda + j];
-  }
-  sc[sl][jl] = (acc0 + acc1) + (acc2 + acc3);
-  __syncthreads();
-  if (t < 32 && j < a.cols) {
-    float v = 0.f;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) v += sc[s][t];
-    for (int s = 0; s < a.nseg; ++s)
-      if (j >= a.off[s] && j < a.off[s] + a.len[s]) {
-        if (a.dst[s]) a.dst[s][(size_t)(j - a.off[s]) * a.dst_stride[s]] = v;
-        break;
-      }
-  }
+  colsum_scatter_block(a, blockIdx.x, sc);
 }
 
 int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st) {
@@ -434,6 +411,7 @@ __global__ void k_adam(AdamArgs a) {
     float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
     a.m[i] = m; a.v[i] = v;
     a.p[i] -= ss * (m / (sqrtf(v) * rbc2 + a.eps));
+    if (a.gz) a.gz[i] = 0.f;
   }
   if (a.alpha_p && blockIdx.x == 0 && threadIdx.x == 0) {
     double g = a.alpha_g[0] * (double)a.grad_scale;
@@ -441,6 +419,7 @@ __global__ void k_adam(AdamArgs a) {
     double v = (double)a.beta2 * a.alpha_v[0] + (1.0 - (double)a.beta2) * g * g;
     a.alpha_m[0] = m; a.alpha_v[0] = v;
     a.alpha_p[0] -= ((double)a.lr / (double)a.bc1) * (m / (sqrt(v) / sqrt((double)a.bc2) + (double)a.eps));
+    if (a.alpha_gz) a.alpha_gz[0] = 0.0;
   }
 }
 int launch_adam(const AdamArgs& a, hipStream_t st) {

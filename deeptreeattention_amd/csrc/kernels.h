@@ -74,6 +74,9 @@ struct StageArgs {
   void* a_tl; size_t a_gs; int a_nc, a_ch0;      // gated map as tiles for the next conv (or null)
   float* a_nchw; size_t a_nchw_gs;     // gated map as fp32 NCHW (standalone modules) or null
   float* feat; size_t feat_gs; int F[2];         // [B][F]
+  // attention intermediates of every patch ([G][B][attsave_ld] floats, >= 3 * vslot): written by the forward,
+  // read back by the backward instead of recomputing the attention; null = backward recomputes
+  float* attsave; int attsave_ld;
 };
 template <typename T> int launch_stage_fwd(const StageArgs& a, int G, hipStream_t st);
 
@@ -131,7 +134,39 @@ struct ColsumArgs {
   const float* A; int rows, cols; long lda;
   int nseg; int off[8], len[8]; float* dst[8]; long dst_stride[8];
 };
+#if defined(__HIPCC__)
+// one 1024-thread block: 32 columns x 32 row slices of A, partial sums through sc[32][33]
+__device__ __forceinline__ void colsum_scatter_block(const ColsumArgs& a, int bx, float (*sc)[33]) {
+  const int t = threadIdx.x, jl = t & 31, sl = t >> 5, j = bx * 32 + jl;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  if (j < a.cols) {
+    int r = sl;
+    for (; r + 96 < a.rows; r += 128) {
+      acc0 += a.A[(size_t)r * a.lda + j];
+      acc1 += a.A[(size_t)(r + 32) * a.lda + j];
+      acc2 += a.A[(size_t)(r + 64) * a.lda + j];
+      acc3 += a.A[(size_t)(r + 96) * a.lda + j];
+    }
+    for (; r < a.rows; r += 32) acc0 += a.A[(size_t)r * a.lda + j];
+  }
+  sc[sl][jl] = (acc0 + acc1) + (acc2 + acc3);
+  __syncthreads();
+  if (t < 32 && j < a.cols) {
+    float v = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) v += sc[s][t];
+    for (int s = 0; s < a.nseg; ++s)
+      if (j >= a.off[s] && j < a.off[s] + a.len[s]) {
+        if (a.dst[s]) a.dst[s][(size_t)(j - a.off[s]) * a.dst_stride[s]] = v;
+        break;
+      }
+  }
+}
+#endif
 int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st);
+// BatchNorm-backward finalize and up to two batch column-sum jobs (spatial-attention parameter gradients) in one
+// launch: both are [batch] reductions over per-patch partials that the same stage-backward kernel produced.
+int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const ColsumArgs* cs, int ncs, hipStream_t st);
 int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed, hipStream_t st);
 struct SpecPackGroup { const float* w1[6]; const float* w2[6]; float* packed[6]; int C[6], K[6]; int n = 0; };
 int launch_pack_spectral_att_group(const SpecPackGroup& gr, hipStream_t st);
@@ -154,6 +189,7 @@ struct AdamArgs {
   float* p; const float* g; float* m; float* v; size_t n;
   double* alpha_p; const double* alpha_g; double* alpha_m; double* alpha_v;
   float lr, beta1, beta2, eps, bc1, bc2; float grad_scale;
+  float* gz; double* alpha_gz;         // non-null: gradients are cleared after use (step + zero_grad in one pass)
 };
 int launch_adam(const AdamArgs& a, hipStream_t st);
 int launch_softmax_top2(const float* logits, int B, int classes, float* probs, long long* top_idx, float* top_score,

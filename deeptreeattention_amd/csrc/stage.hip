@@ -219,28 +219,41 @@ __device__ __forceinline__ float stencil_at(const float* mp, const float* kw, in
 //   spatial : v0 = m (post ReLU, zero-padded map), v1 = t1 (post ReLU, zero-padded map), v2 = s (gate, per pixel)
 template <typename CFG>
 __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeom& s, int g, int b, int kind,
-                                              float* Z, float* v0, float* v1, float* v2, float* scratch) {
+                                              float* Z, float* v0, float* v1, float* v2, float* scratch,
+                                              bool use_saved = false, const float* da = nullptr, float* D = nullptr) {
   constexpr int CT = CFG::C;
   const bool pool = cfg_pool<CFG>(a);
   const int t = threadIdx.x, C = s.C, ld = s.ld;
   const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
   const float* coef = a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr;
-  if (kind == KIND_SPATIAL) {   // zero the padded maps' borders (interiors are overwritten below)
+  if (use_saved) {   // v0 | v1 | v2 as the forward kernel left them (padded maps include their zero borders)
+    const float* src = a.attsave + ((size_t)g * a.B + b) * a.attsave_ld;
+    for (int i = t; i < 3 * s.vslot; i += 256) v0[i] = src[i];
+  } else if (kind == KIND_SPATIAL) {   // zero the padded maps' borders (interiors are overwritten below)
     for (int i = t; i < 2 * s.vslot; i += 256) v0[i] = 0.f;   // v0 and v1 are adjacent
+  }
+  // backward of a specialised stage: the incoming gradient ([HWz][C], contiguous) is fetched into registers ahead
+  // of the activations so both sets of global loads are in flight together; it lands in D once Z is built
+  constexpr int HZT = CFG::fixed ? (CFG::P ? CFG::H / 2 : CFG::H) * (CFG::P ? CFG::W / 2 : CFG::W) : 0;
+  constexpr int ND = CFG::fixed ? (HZT * CT + 255) / 256 : 1;
+  float rd[ND];
+  if (CFG::fixed && da) {
+#pragma unroll
+    for (int u = 0; u < ND; ++u) { const int i = t + u * 256; rd[u] = i < HZT * CT ? da[i] : 0.f; }
   }
   if (CT > 0) {
     // 256 % C == 0: every thread keeps one channel, its BN coefficients live in registers
     const int c = t % C, p0 = t / C, pstep = 256 / C;
     const float sc = a.apply_bn ? coef[c * 4 + 0] : 1.f, sh = a.apply_bn ? coef[c * 4 + 1] : 0.f;
     if (!pool) {
-#pragma unroll 8
-      for (int p = p0; p < s.HWc; p += pstep) {      // unrolled: 8 independent global loads in flight per thread
+#pragma unroll 16
+      for (int p = p0; p < s.HWc; p += pstep) {      // unrolled: independent global loads in flight per thread
         float v = y[(size_t)p * a.y_rs + c] * sc + sh;
         if (a.relu) v = fmaxf(v, 0.f);
         Z[p * ld + c] = v;
       }
     } else {
-#pragma unroll 2
+#pragma unroll 4
       for (int pz = p0; pz < s.HWz; pz += pstep) {   // 2x2 max-pool straight from global memory (floor: last row/col dropped)
         int hz = pz / s.Wz, wz = pz - hz * s.Wz;
         const float* y0 = y + (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
@@ -268,7 +281,15 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
       Z[p * ld + c] = v;
     }
   }
+  if (CFG::fixed && da) {
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = t + u * 256;
+      if (i < HZT * CT) { const int p = i / (CT > 0 ? CT : 1), c = i - p * CT; D[p * ld + c] = rd[u]; }
+    }
+  }
   __syncthreads();
+  if (use_saved) return;
   if (kind == KIND_SPECTRAL) {
     const float* a1t = a.att[g].p[0]; const float* c1 = a.att[g].p[1];
     const float* a2t = a.att[g].p[2]; const float* c2 = a.att[g].p[3];
@@ -318,6 +339,10 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
   float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
   float* scratch = v3 + s.vslot;
   stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch);
+  if (a.attsave) {
+    float* dst = a.attsave + ((size_t)g * a.B + b) * a.attsave_ld;
+    for (int i = t; i < 3 * s.vslot; i += 256) dst[i] = v0[i];
+  }
 
   // classifier features
   if (a.feat) {
@@ -415,6 +440,12 @@ template int launch_stage_fwd<bf16_t>(const StageArgs&, int, hipStream_t);
 // ------------------------------------------------------------------------------------------------
 // Backward of one stage for one patch.
 // ------------------------------------------------------------------------------------------------
+#ifdef DTA_TICKS
+__device__ long long g_ticks[2][32];
+#define TICK(i) do { if (threadIdx.x == 0 && blockIdx.x == 700) g_ticks[blockIdx.y][i] = clock64(); } while (0)
+#else
+#define TICK(i)
+#endif
 template <typename CFG>
 __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -431,19 +462,22 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
   float* scratch = v7 + s.vslot;
   if (kind == KIND_SPATIAL)
     for (int i = t; i < 2 * s.vslot; i += 256) v3[i] = 0.f;   // padded maps d2 (v3) and d1 (v4)
-  stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch);
-
-  // D = incoming gradient wrt the gated map
+  TICK(0);
+  // D = incoming gradient wrt the gated map (issued first: its loads fly together with the activations')
+  const float* da_pre = nullptr;
   if (ba.da) {
     const float* da = ba.da + (size_t)g * ba.da_gs + (size_t)b * s.HWz * C;
-    for (int i = t; i < s.HWz * C; i += 256) { int p = i / C, c = i - p * C; D[p * ld + c] = da[i]; }
+    if (CFG::fixed) da_pre = da;
+    else for (int i = t; i < s.HWz * C; i += 256) { int p = i / C, c = i - p * C; D[p * ld + c] = da[i]; }
   } else if (ba.da_nchw) {
     const float* da = ba.da_nchw + (size_t)g * ba.da_nchw_gs + (size_t)b * C * s.HWz;
     for (int i = t; i < s.HWz * C; i += 256) { int c = i / s.HWz, p = i - c * s.HWz; D[p * ld + c] = da[i]; }
   } else {
     for (int i = t; i < s.HWz * ld; i += 256) D[i] = 0.f;
   }
-  __syncthreads();
+  TICK(1);
+  stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch, a.attsave != nullptr, da_pre, D);
+  TICK(2);
   const float* df = ba.dfeat ? ba.dfeat + (size_t)g * ba.dfeat_gs + (size_t)b * a.F[g] : nullptr;
   float* vec = ba.vec ? ba.vec + (size_t)g * ba.vec_gs + (size_t)b * ba.vec_ld : nullptr;
 
@@ -495,6 +529,7 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
                 v3[(h + r) * Wp + w + r] = acc * v2[p] * (1.f - v2[p]);
               });
     __syncthreads();
+    TICK(6);
     // dt1 = transposed stencil of d2 with k2, masked by t1 > 0 -> d1 (v4, padded map)
     for (int p = t; p < s.HWz; p += 256) {
       int h = p / s.Wz, w = p - h * s.Wz, pi = (h + r) * Wp + w + r;
@@ -509,31 +544,44 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
       v5[p] = v0[pi] > 0.f ? acc : 0.f;
     }
     __syncthreads();
+    TICK(7);
     if (vec) {
       // [dwc (C) | dbc | dK1 (kk) | db1 | dK2 (kk) | db2]
       colreduce(C, s.HWz, scratch, v6, 1.f, [&](int c, int p) { return v5[p] * Z[p * ld + c]; });
       if (t < C) vec[t] = v6[t];
-      for (int i = C + t; i < C + 2 * kk + 3; i += 256) {
-        float acc = 0.f;
-        if (i == C) { for (int p = 0; p < s.HWz; ++p) acc += v5[p]; }
-        else if (i == C + 1 + kk || i == C + 2 + 2 * kk) {
-          const float* dd = (i == C + 1 + kk) ? v4 : v3;    // padded maps: borders are zero
-          for (int q = 0; q < (s.Hz + 2 * r) * Wp; ++q) acc += dd[q];
-        } else {
-          const bool first = i < C + 1 + kk;
-          const int j = first ? i - (C + 1) : i - (C + 2 + kk);
-          const int ky = j / k, kx = j - ky * k;
-          const float* src = first ? v0 : v1;   // conv input map (m for K1, t1 for K2), padded
-          const float* dd = first ? v4 : v3;    // grad wrt the conv output, padded
-          for (int h = 0; h < s.Hz; ++h) {
-            const float* sr = src + (h + ky) * Wp + kx;
-            const float* dr = dd + (h + r) * Wp + r;
-            for (int w = 0; w < s.Wz; ++w) acc += sr[w] * dr[w];
-          }
+      // bias gradients: dbc = sum dm, db1 = sum d1, db2 = sum d2 (padded maps: borders are zero)
+      {
+        const int npad = (s.Hz + 2 * r) * Wp;
+        float sA = 0.f, sB = 0.f, sC = 0.f;
+        for (int p = t; p < s.HWz; p += 256) sA += v5[p];
+        for (int q = t; q < npad; q += 256) { sB += v4[q]; sC += v3[q]; }
+        sA = wave_sum(sA); sB = wave_sum(sB); sC = wave_sum(sC);
+        if ((t & 63) == 0) { scratch[(t >> 6) * 3] = sA; scratch[(t >> 6) * 3 + 1] = sB; scratch[(t >> 6) * 3 + 2] = sC; }
+        __syncthreads();
+        if (t < 3) {
+          const float tot = scratch[t] + scratch[3 + t] + scratch[6 + t] + scratch[9 + t];
+          vec[t == 0 ? C : (t == 1 ? C + 1 + kk : C + 2 + 2 * kk)] = tot;
         }
-        vec[i] = acc;
+      }
+      // stencil-weight gradients: one (kernel, tap) task per lane pair, the pair splits the rows
+      for (int task = t >> 1; task < 2 * kk; task += 128) {
+        const int half = t & 1;
+        const bool first = task < kk;
+        const int j = first ? task : task - kk;
+        const int ky = j / k, kx = j - ky * k;
+        const float* src = first ? v0 : v1;   // conv input map (m for K1, t1 for K2), padded
+        const float* dd = first ? v4 : v3;    // grad wrt the conv output, padded
+        float acc = 0.f;
+        for (int h = half; h < s.Hz; h += 2) {
+          const float* sr = src + (h + ky) * Wp + kx;
+          const float* dr = dd + (h + r) * Wp + r;
+          for (int w = 0; w < s.Wz; ++w) acc += sr[w] * dr[w];
+        }
+        acc += __shfl_xor(acc, 1);
+        if (!half) vec[first ? C + 1 + j : C + 2 + kk + j] = acc;
       }
     }
+    TICK(8);
     for (int i = t; i < s.HWz * C; i += 256) {
       int p = i / C, c = i - p * C;
       D[p * ld + c] = D[p * ld + c] * v2[p] + v5[p] * wc[c];
@@ -546,6 +594,7 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
     }
   }
 
+  TICK(3);
   // pool + ReLU backward, write dv and the per-patch BatchNorm-backward partial sums
   float* dv = ba.dv + (size_t)g * ba.dv_gs + (size_t)b * s.HWc * C;
   const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
@@ -597,6 +646,7 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
       }
     }
   }
+  TICK(4);
   if (ba.bnpart) {
     __syncthreads();
     scratch[t] = s1; scratch[256 + t] = s2;
@@ -608,7 +658,11 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
       o[0] = q1; o[1] = q2;
     }
   }
+  TICK(5);
 }
+#ifdef DTA_TICKS
+extern "C" int dta_debug_ticks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ticks), sizeof(long long) * 64); }
+#endif
 
 template <typename CFG>
 static int launch_stage_bwd_c(const StageBwdArgs& a, int G, size_t lds, hipStream_t st) {
@@ -642,11 +696,10 @@ int launch_stage_bwd(const StageBwdArgs& a_in, int G, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // BatchNorm backward: reduce per-patch partials -> dgamma, dbeta and the apply coefficients.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(BnBwdFinalizeArgs a) {
-  // block = 32 channels x 32 batch slices; grid = (C/32, G)
-  __shared__ float s1[32][33], s2[32][33];
-  const int g = blockIdx.y, t = threadIdx.x, C = a.C;
-  const int cl = t & 31, sl = t >> 5, c = blockIdx.x * 32 + cl;
+__device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdFinalizeArgs& a, int bx, int g, float (*s1)[33], float (*s2)[33]) {
+  // block = 32 channels x 32 batch slices
+  const int t = threadIdx.x, C = a.C;
+  const int cl = t & 31, sl = t >> 5, c = bx * 32 + cl;
   const float* part = a.bnpart + (size_t)g * a.bnpart_gs;
   float q1 = 0.f, q2 = 0.f, r1 = 0.f, r2 = 0.f;
   if (c < C) {
@@ -682,9 +735,37 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(BnBwdFinalizeArgs a) {
   }
 }
 
+__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(BnBwdFinalizeArgs a) {
+  __shared__ float s1[32][33], s2[32][33];
+  bn_bwd_finalize_block(a, blockIdx.x, blockIdx.y, s1, s2);   // grid = (C/32, G)
+}
+
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, int G, hipStream_t st) {
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((a.C + 31) / 32, G), dim3(1024), 0, st, a);
   DTA_CHECK_LAUNCH("k_bn_bwd_finalize");
+  return 0;
+}
+
+// blocks [0, nbn): BatchNorm finalize (block -> (channel tile, group)); then the column-sum jobs
+struct ColsumPair { ColsumArgs cs[2]; int nblk[2]; };
+__global__ __launch_bounds__(1024) void k_bn_bwd_finalize_colsum(BnBwdFinalizeArgs a, int nbx, int nbn, ColsumPair cp) {
+  __shared__ float s1[32][33], s2[32][33];
+  int bx = blockIdx.x;
+  if (bx < nbn) { bn_bwd_finalize_block(a, bx % nbx, bx / nbx, s1, s2); return; }
+  bx -= nbn;
+  if (bx < cp.nblk[0]) { colsum_scatter_block(cp.cs[0], bx, s1); return; }
+  colsum_scatter_block(cp.cs[1], bx - cp.nblk[0], s1);
+}
+
+int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const ColsumArgs* cs, int ncs, hipStream_t st) {
+  if (ncs <= 0) return launch_bn_bwd_finalize(a, G, st);
+  if (ncs > 2) { dta_set_error("bn_bwd_finalize_colsum: at most two column-sum jobs"); return 1; }
+  ColsumPair cp = {};
+  int extra = 0;
+  for (int i = 0; i < ncs; ++i) { cp.cs[i] = cs[i]; cp.nblk[i] = (cs[i].cols + 31) / 32; extra += cp.nblk[i]; }
+  const int nbx = (a.C + 31) / 32, nbn = nbx * G;
+  hipLaunchKernelGGL(k_bn_bwd_finalize_colsum, dim3(nbn + extra), dim3(1024), 0, st, a, nbx, nbn, cp);
+  DTA_CHECK_LAUNCH("k_bn_bwd_finalize_colsum");
   return 0;
 }
 

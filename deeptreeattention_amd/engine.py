@@ -26,12 +26,13 @@ class FusedTrainer:
     """
 
     def __init__(self, model, lr, loss_weight=None, betas=(0.9, 0.999), eps=1e-8, process_group=None,
-                 overlap_comm=True):
+                 overlap_comm=True, keep_grads=False):
         if not isinstance(model, H._Net):
             raise TypeError("FusedTrainer needs a deeptreeattention_amd network module")
         self.model = model
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         self.step_count = 0
+        self.keep_grads = bool(keep_grads)   # True: gradients stay readable (grad_of) after train_step
         self.pg = process_group
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -54,6 +55,7 @@ class FusedTrainer:
         self.split = n - sum(p.numel() for p in first)
         self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._grads_clear = True       # flat_g / alpha_g hold zeros (kept so by dta_adam_step_zero_grad)
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
         self._gview = {}
@@ -85,7 +87,9 @@ class FusedTrainer:
         self.sync.broadcast([self.flat_p] + ([self.alpha.data] if self.hang else []) + list(self.model.buffers()), src)
 
     def grad_of(self, param):
-        """Gradient view (inside the flat gradient buffer) of one of the model's fp32 parameters."""
+        """Gradient view (inside the flat gradient buffer) of one of the model's fp32 parameters.  After train_step
+        it holds the step's gradient only when the trainer was built with keep_grads=True (by default the optimizer
+        pass clears the buffer, as optimizer.zero_grad() would)."""
         return self._gview[id(param)]
 
     def _structs(self):
@@ -149,7 +153,8 @@ class FusedTrainer:
                                      m._classes, _lib.ptr(self.loss), _lib.ptr(self.dlogits), _lib.ptr(self.ce_scratch),
                                      st), "dta_weighted_ce")
         dalpha = _lib.ptr(self.alpha_g) if self.hang else None
-        self.flat_g.zero_()            # C-ABI contract: gradient buffers arrive zero-filled
+        if not self._grads_clear:      # C-ABI contract: gradient buffers arrive zero-filled
+            self.flat_g.zero_()
         if self.world == 1:
             _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table),
                                           _lib.ptr(self.dlogits), self.grads, dalpha, 3, st), "dta_net_backward")
@@ -164,14 +169,17 @@ class FusedTrainer:
             self.sync.reduce_late(self.flat_g[self.split:])
             self.sync.finish()
         self.step_count += 1
-        _lib.check(L.dta_adam_step(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m),
-                                   _lib.ptr(self.flat_v), self.n,
-                                   _lib.ptr(self.alpha) if self.hang else None,
-                                   _lib.ptr(self.alpha_g) if self.hang else None,
-                                   _lib.ptr(self.alpha_m) if self.hang else None,
-                                   _lib.ptr(self.alpha_v) if self.hang else None,
-                                   self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
-                                   self.sync.grad_scale, st), "dta_adam_step")
+        # default: step + zero_grad in one pass, so the next backward finds its gradient buffers already cleared
+        adam = L.dta_adam_step if self.keep_grads else L.dta_adam_step_zero_grad
+        _lib.check(adam(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v),
+                        self.n,
+                        _lib.ptr(self.alpha) if self.hang else None,
+                        _lib.ptr(self.alpha_g) if self.hang else None,
+                        _lib.ptr(self.alpha_m) if self.hang else None,
+                        _lib.ptr(self.alpha_v) if self.hang else None,
+                        self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                        self.sync.grad_scale, st), "dta_adam_step")
+        self._grads_clear = not self.keep_grads
         return self.loss
 
     def forward_loss(self, x, y):

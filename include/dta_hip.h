@@ -100,6 +100,12 @@ int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double
                   double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
                   float grad_scale, void* stream);
 
+/* optimizer.step() followed by optimizer.zero_grad() (the Lightning loop of src/main.py does both every batch) in one
+ * pass: same update as dta_adam_step, then g and alpha_g are cleared, which is the state dta_net_backward expects. */
+int dta_adam_step_zero_grad(float* p, float* g, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,
+                            double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
+                            float grad_scale, void* stream);
+
 /* ---- stand-alone building blocks (same kernels as the network-level path) ------------------------------------ */
 
 typedef struct dta_conv_module_desc {

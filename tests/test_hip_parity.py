@@ -235,7 +235,7 @@ def test_fused_trainer_matches_oracle_adam_loop():
     y = prng.randint(32, 2, (B,), classes)
     w = (0.1 + (np.arange(classes) % 7)).astype(np.float32)
     m.train()
-    tr = FusedTrainer(m, lr=1e-3, loss_weight=torch.from_numpy(w))
+    tr = FusedTrainer(m, lr=1e-3, loss_weight=torch.from_numpy(w), keep_grads=True)
     xt, yt = torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev())
     state = {}
     for step in range(3):
@@ -256,6 +256,30 @@ def test_fused_trainer_matches_oracle_adam_loop():
             continue   # conv biases under BN: noise-signed Adam updates (see test_oracle_golden)
         assert rel_l2(sd[k].cpu().numpy(), v) < 2e-3, k
     assert int(sd["spectral_network.conv1.bn1.num_batches_tracked"]) == 3
+
+
+def test_fused_trainer_zero_grad_pass_is_equivalent():
+    """Default trainer (optimizer pass also clears the gradients) == keep_grads trainer (separate clear)."""
+    from deeptreeattention_amd.engine import FusedTrainer
+    bands, classes, B = 20, 7, 9
+    x = torch.from_numpy(prng.uniform01(77, 1, (B, bands, 11, 11))).to(dev())
+    y = torch.from_numpy(prng.randint(77, 2, (B,), classes)).to(dev())
+    out = []
+    for keep in (False, True):
+        m, _ = make("hang", bands, classes, 13)
+        m.train()
+        tr = FusedTrainer(m, lr=1e-3, keep_grads=keep)
+        losses = [tr.train_step(x, y).item() for _ in range(3)]
+        if not keep:
+            assert float(tr.flat_g.abs().max()) == 0.0 and float(tr.alpha_g) == 0.0
+        else:
+            assert float(tr.flat_g.abs().max()) > 0.0
+        out.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
+    # not bit-for-bit: split-K partial sums meet through atomics, so two runs differ in the last ulps
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-5)
+    for k in out[0][1]:
+        a, b = out[0][1][k].double(), out[1][1][k].double()
+        assert float((a - b).norm()) <= 1e-4 * max(float(b.norm()), 1e-12), k
 
 
 @pytest.mark.parametrize("bands,classes,B,seed", [(369, 200, 16, 31), (20, 7, 9, 5)])
