@@ -228,7 +228,11 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
   const float* coef = a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr;
   if (use_saved) {   // v0 | v1 | v2 as the forward kernel left them (padded maps include their zero borders)
     const float* src = a.attsave + ((size_t)g * a.B + b) * a.attsave_ld;
-    for (int i = t; i < 3 * s.vslot; i += 256) v0[i] = src[i];
+    if (kind == KIND_SPECTRAL) {   // three C-vectors, stored packed
+      for (int i = t; i < 3 * C; i += 256) { const int k = i / C; v0[k * s.vslot + (i - k * C)] = src[i]; }
+    } else if (kind == KIND_SPATIAL) {
+      for (int i = t; i < 3 * s.vslot; i += 256) v0[i] = src[i];
+    }
   } else if (kind == KIND_SPATIAL) {   // zero the padded maps' borders (interiors are overwritten below)
     for (int i = t; i < 2 * s.vslot; i += 256) v0[i] = 0.f;   // v0 and v1 are adjacent
   }
@@ -246,14 +250,14 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
     const int c = t % C, p0 = t / C, pstep = 256 / C;
     const float sc = a.apply_bn ? coef[c * 4 + 0] : 1.f, sh = a.apply_bn ? coef[c * 4 + 1] : 0.f;
     if (!pool) {
-#pragma unroll 16
+#pragma unroll 8
       for (int p = p0; p < s.HWc; p += pstep) {      // unrolled: independent global loads in flight per thread
         float v = y[(size_t)p * a.y_rs + c] * sc + sh;
         if (a.relu) v = fmaxf(v, 0.f);
         Z[p * ld + c] = v;
       }
     } else {
-#pragma unroll 4
+#pragma unroll 2
       for (int pz = p0; pz < s.HWz; pz += pstep) {   // 2x2 max-pool straight from global memory (floor: last row/col dropped)
         int hz = pz / s.Wz, wz = pz - hz * s.Wz;
         const float* y0 = y + (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
@@ -341,7 +345,11 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
   stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch);
   if (a.attsave) {
     float* dst = a.attsave + ((size_t)g * a.B + b) * a.attsave_ld;
-    for (int i = t; i < 3 * s.vslot; i += 256) dst[i] = v0[i];
+    if (kind == KIND_SPECTRAL) {
+      for (int i = t; i < 3 * C; i += 256) { const int k = i / C; dst[i] = v0[k * s.vslot + (i - k * C)]; }
+    } else if (kind == KIND_SPATIAL) {
+      for (int i = t; i < 3 * s.vslot; i += 256) dst[i] = v0[i];
+    }
   }
 
   // classifier features
