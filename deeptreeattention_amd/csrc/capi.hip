@@ -54,7 +54,7 @@ struct Plan {
   int nwg[3], MWG[3];
   int S[3], cgroups[3], CpadW[3];
   size_t x_tl, wp[3], wd[3], y[3], stats[3], coef[3], a_tl[3], feat[3], attpk[2][3], scores[2][3];
-  size_t dsc[2], dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart, rowtmp;
+  size_t dsc[2], dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart[3], rowtmp;
   size_t attsave[3]; int attsave_ld[3];
   size_t scores_all, scores_bytes, dfeat_all, dfeat_bytes;
   size_t total;
@@ -155,14 +155,11 @@ int build_plan(const dta_net_desc* d, Plan* p) {
       p->da[L] = c.take((size_t)G * B * p->HWc[L] * CH[L - 1] * 4);   // grad wrt the conv's input map
     }
   }
-  size_t wpmax = 0;
-  for (int L = 0; L < 3; ++L) {
+  for (int L = 0; L < 3; ++L) {   // split-K slabs of every layer stay live until the one grouped reduction
     int Nconv = L == 0 ? 32 * G : CH[L];
     int launchG = L == 0 ? 1 : G;
-    size_t w = (size_t)launchG * p->S[L] * 9 * p->CpadW[L] * Nconv * 4;
-    if (w > wpmax) wpmax = w;
+    p->wpart[L] = c.take((size_t)launchG * p->S[L] * 9 * p->CpadW[L] * Nconv * 4);
   }
-  p->wpart = c.take(wpmax);
   p->rowtmp = c.take((size_t)(B + 1) * 4);
   p->total = c.off;
   return 0;
@@ -209,8 +206,6 @@ template <typename T>
 int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const float* x,
               void* ws, float* const scores[2][3], float* joint, hipStream_t st) {
   const int G = p.G, B = p.B;
-  if (d->heads_mask) hipMemsetAsync(at<char>(ws, p.scores_all), 0, p.scores_bytes, st);   // split-K GEMM targets
-  if (launch_pack_input<T>(x, at<char>(ws, p.x_tl), B, p.bands, p.H, p.W, st)) return 1;
   GemmGroup heads;
   // ---- all weight re-layouts of the step in two launches (forward forms, and when training the transposed
   //      forms the input-gradient convs will need) ----
@@ -239,8 +234,13 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
         spacks.packed[j] = at<float>(ws, p.attpk[g][L]); spacks.C[j] = C; spacks.K[j] = SPEC_K[L];
       }
   }
-  if (launch_pack_conv_w_group<T>(packs, st)) return 1;
-  if (launch_pack_spectral_att_group(spacks, st)) return 1;
+  {
+    PrepArgs pa = {};
+    pa.x = x; pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
+    pa.packs = packs; pa.spacks = spacks;
+    if (d->heads_mask) { pa.zero = at<float>(ws, p.scores_all); pa.zero_n4 = (p.scores_bytes + 15) / 16; }   // split-K GEMM targets
+    if (launch_forward_prep<T>(pa, st)) return 1;
+  }
   for (int L = 0; L < 3; ++L) {
     const int C = CH[L];
     const int Nconv = L == 0 ? 32 * G : C;
@@ -314,7 +314,8 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
 }
 
 template <typename T>
-int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grads* grads, void* ws, int L, hipStream_t st) {
+int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grads* grads, void* ws, int L,
+                     WgradReduceGroup& reduces, hipStream_t st) {
   const int G = p.G, B = p.B, C = CH[L];
   const int Nconv = L == 0 ? 32 * G : C;
   const int launchG = L == 0 ? 1 : G;
@@ -329,7 +330,7 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
   wa.dy_tl = at<char>(ws, p.dy_tl[L]);
   wa.dy_gs = L == 0 ? 0 : (size_t)B * (C / 16) * p.Qin[L] * 16;
   wa.NCy = Nconv / 16; wa.ych0 = 0;
-  wa.partial = at<float>(ws, p.wpart);
+  wa.partial = at<float>(ws, p.wpart[L]);
   wa.B = B; wa.H = p.Hc[L]; wa.W = p.Wc[L]; wa.Q = p.Qin[L]; wa.N = Nconv; wa.Cpad = p.CpadW[L]; wa.S = p.S[L];
   prof_begin(DTA_SITE_CONV_WGRAD + L, st);
   if (launch_conv_wgrad<T>(wa, launchG, st)) return 1;
@@ -339,7 +340,8 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
   wr.partial = wa.partial; wr.G = launchG; wr.S = p.S[L]; wr.N = Nconv; wr.C = p.Cin[L]; wr.Cpad = p.CpadW[L];
   wr.mode = (L == 0 && G == 2) ? 1 : 0; wr.nsplit = 32;
   wr.dst[0] = grads[0].conv_w[L]; wr.dst[1] = G == 2 ? grads[1].conv_w[L] : nullptr;
-  return launch_wgrad_reduce(wr, st);
+  reduces.job[reduces.n++] = wr;   // reduced (and laid out as torch weights) by the caller's grouped launch
+  return 0;
 }
 
 template <typename T>
@@ -349,7 +351,9 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
   const int G = p.G, B = p.B;
   if (!(phases & 1)) {
     // phase 2 only: the first layer's weight gradient from tensors phase 1 left in the workspace
-    return conv_wgrad_layer<T>(p, d, grads, ws, 0, st);
+    WgradReduceGroup reduces;
+    if (conv_wgrad_layer<T>(p, d, grads, ws, 0, reduces, st)) return 1;
+    return launch_wgrad_reduce_group(reduces, st);
   }
   const float* dsc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   if (dscores)
@@ -373,6 +377,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
   }
 
   GemmGroup deferred;   // parameter-gradient GEMMs nothing downstream waits for: one grouped launch at the end
+  WgradReduceGroup reduces;   // likewise the split-K reductions of the conv weight gradients
   for (int L = 2; L >= 0; --L) {
     const int C = CH[L];
     const int Nconv = L == 0 ? 32 * G : C;
@@ -480,7 +485,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       prof_end(DTA_SITE_GEMM + 2, st);
     }
     if (L > 0 || (phases & 2))
-      if (conv_wgrad_layer<T>(p, d, grads, ws, L, st)) return 1;
+      if (conv_wgrad_layer<T>(p, d, grads, ws, L, reduces, st)) return 1;
     // ---- conv input gradient (feeds the previous stage's gated map) ----
     if (L > 0) {
       PackWArgs pw;
@@ -499,7 +504,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       prof_end(DTA_SITE_CONV_DGRAD + L, st);
     }
   }
-  return 0;
+  return launch_wgrad_reduce_group(reduces, st);
 }
 
 }  // namespace

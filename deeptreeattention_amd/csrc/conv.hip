@@ -15,13 +15,12 @@ namespace dta {
 // pack input
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x, T* __restrict__ out, int B, int C,
-                                                    int H, int W, int NC, int CG) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void pack_input_block(const float* __restrict__ x, T* __restrict__ out, int B, int C, int H,
+                                                 int W, int NC, int CG, int b, int ycg, unsigned char* smem) {
   const int HW = H * W, Q = (H + 2) * (W + 2);
   int* lut = (int*)smem;                   // [Q] pixel index of haloed-grid row q, or -1 on the halo
   float* sbase = (float*)(lut + ((Q + 3) & ~3));   // 16-byte aligned
-  const int b = blockIdx.x, chunk0 = blockIdx.y * CG;
+  const int chunk0 = ycg * CG;
   const int nch = min(CG, NC - chunk0);
   const int c0 = chunk0 * 16;
   const int creal = max(0, min(nch * 16, C - c0));
@@ -59,12 +58,26 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x,
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x, T* __restrict__ out, int B, int C,
+                                                    int H, int W, int NC, int CG) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  pack_input_block<T>(x, out, B, C, H, W, NC, CG, blockIdx.x, blockIdx.y, smem);
+}
+
+static int pack_input_plan(int C, int H, int W, int* NC, int* CG, size_t* lds) {
+  const int HW = H * W;
+  *NC = (C + 15) / 16;
+  *CG = 2;   // 2 chunks (32 channels) per workgroup measured best on MI355X (more resident workgroups)
+  while (*CG > 1 && (size_t)*CG * 16 * HW * 4 > 65536) *CG >>= 1;
+  *lds = (size_t)*CG * 16 * HW * 4 + (size_t)(((H + 2) * (W + 2) + 3) & ~3) * 4 + 16;
+  if (*lds > 160 * 1024) { dta_set_error("pack_input: %dx%d patch does not fit LDS", H, W); return 1; }
+  return 0;
+}
+
+template <typename T>
 int launch_pack_input(const float* x, void* out, int B, int C, int H, int W, hipStream_t st) {
-  int NC = (C + 15) / 16, HW = H * W;
-  int CG = 2;   // 2 chunks (32 channels) per workgroup measured best on MI355X (more resident workgroups)
-  while (CG > 1 && (size_t)CG * 16 * HW * 4 > 65536) CG >>= 1;
-  size_t lds = (size_t)CG * 16 * HW * 4 + (size_t)(((H + 2) * (W + 2) + 3) & ~3) * 4 + 16;
-  if (lds > 160 * 1024) { dta_set_error("pack_input: %dx%d patch does not fit LDS", H, W); return 1; }
+  int NC, CG; size_t lds;
+  if (pack_input_plan(C, H, W, &NC, &CG, &lds)) return 1;
   dim3 grid(B, (NC + CG - 1) / CG);
   hipLaunchKernelGGL(k_pack_input<T>, grid, dim3(256), lds, st, x, (T*)out, B, C, H, W, NC, CG);
   DTA_CHECK_LAUNCH("k_pack_input");
@@ -134,6 +147,40 @@ int launch_pack_conv_w(const PackWArgs& a, void* dst, hipStream_t st) {
 }
 template int launch_pack_conv_w<float>(const PackWArgs&, void*, hipStream_t);
 template int launch_pack_conv_w<bf16_t>(const PackWArgs&, void*, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// Everything the forward needs before its first conv, in ONE launch (each of these is a few microseconds of work
+// and none depends on another): input patches -> tiles, conv weights -> MFMA operand images, spectral-attention
+// centre taps -> dense matrices, and the clearing of the split-K targets.  blockIdx.y selects the job.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_forward_prep(PrepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int y = blockIdx.y;
+  if (y < a.ncg) { pack_input_block<T>(a.x, (T*)a.x_tl, a.B, a.C, a.H, a.W, a.NC, a.CG, blockIdx.x, y, smem); return; }
+  y -= a.ncg;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x, tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (y < a.packs.n) { pack_conv_w_job<T>(a.packs.job[y], (T*)a.packs.dst[y], tid, nthreads); return; }
+  y -= a.packs.n;
+  if (y < a.spacks.n) { pack_spectral_att_job(a.spacks, y, tid, nthreads); return; }
+  if (a.zero) {
+    float4* z = (float4*)a.zero;   // workspace regions are 256-byte aligned and padded
+    for (size_t i = tid; i < a.zero_n4; i += nthreads) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <typename T>
+int launch_forward_prep(PrepArgs a, hipStream_t st) {
+  size_t lds;
+  if (pack_input_plan(a.C, a.H, a.W, &a.NC, &a.CG, &lds)) return 1;
+  a.ncg = (a.NC + a.CG - 1) / a.CG;
+  dim3 grid(a.B, a.ncg + a.packs.n + a.spacks.n + (a.zero ? 1 : 0));
+  hipLaunchKernelGGL(k_forward_prep<T>, grid, dim3(256), lds, st, a);
+  DTA_CHECK_LAUNCH("k_forward_prep");
+  return 0;
+}
+template int launch_forward_prep<float>(PrepArgs, hipStream_t);
+template int launch_forward_prep<bf16_t>(PrepArgs, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 // MFMA fragment helpers.  A 32x32 output tile per MFMA; K step = 2 (fp32, exact) or 16 (bf16).
@@ -514,11 +561,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
 }
 
 // out_g[n][c][tap] (torch layout) = sum_s partial[g][s][tap][c][n]; each thread sums 4 consecutive n.
-__global__ __launch_bounds__(256) void k_wgrad_reduce(WgradReduceArgs a) {
+__device__ __forceinline__ void wgrad_reduce_blocks(const WgradReduceArgs& a, int bx, int nblocks) {
   const int N = a.N, N4 = N / 4;
   size_t total = (size_t)a.G * 9 * a.C * N4;
   const size_t sstride = (size_t)9 * a.Cpad * N;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = bx * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)nblocks * blockDim.x) {
     int n4 = i % N4;
     size_t r = i / N4;
     int c = r % a.C; r /= a.C;
@@ -557,6 +604,13 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradReduceArgs a) {
       if (dst) dst[((size_t)nn * a.C + c) * 9 + tap] = out[k];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(WgradReduceArgs a) { wgrad_reduce_blocks(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void k_wgrad_reduce_group(WgradReduceGroup gr) {
+  int j = 0;
+  while (j + 1 < gr.n && (int)blockIdx.x >= gr.start[j + 1]) ++j;
+  wgrad_reduce_blocks(gr.job[j], blockIdx.x - gr.start[j], gr.start[j + 1] - gr.start[j]);
 }
 
 int wgrad_cpw(int N) { return (4 / (N / 32)) * 32; }
@@ -605,11 +659,23 @@ int launch_conv_wgrad(const WgradArgs& a, int G, hipStream_t st) {
 }
 template int launch_conv_wgrad<float>(const WgradArgs&, int, hipStream_t);   // bf16: conv_bf16.hip
 
-int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {
+static int wgrad_reduce_nblocks(const WgradReduceArgs& a) {
   size_t total = (size_t)a.G * 9 * a.C * (a.N / 4);
-  int blocks = (int)min((size_t)4096, (total + 255) / 256);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, a);
+  return (int)min((size_t)4096, (total + 255) / 256);
+}
+int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(wgrad_reduce_nblocks(a)), dim3(256), 0, st, a);
   DTA_CHECK_LAUNCH("k_wgrad_reduce");
+  return 0;
+}
+int launch_wgrad_reduce_group(WgradReduceGroup& gr, hipStream_t st) {
+  if (gr.n == 0) return 0;
+  if (gr.n == 1) return launch_wgrad_reduce(gr.job[0], st);
+  int total = 0;
+  for (int j = 0; j < gr.n; ++j) { gr.start[j] = total; total += wgrad_reduce_nblocks(gr.job[j]); }
+  gr.start[gr.n] = total;
+  hipLaunchKernelGGL(k_wgrad_reduce_group, dim3(total), dim3(256), 0, st, gr);
+  DTA_CHECK_LAUNCH("k_wgrad_reduce_group");
   return 0;
 }
 

@@ -218,17 +218,7 @@ int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st) {
 // spectral attention Conv1d weights [C][C][K]: only tap K/2 is live on a length-1 sequence.
 // packed = [a1t | a2t | a1 | a2], each [C][C]; *t is input-major (a_t[i][o] = W[o][i][K/2]).
 __global__ void k_pack_spectral_att(SpecPackGroup gr) {
-  const int j = blockIdx.y, C = gr.C[j], K = gr.K[j];
-  const float* w1 = gr.w1[j]; const float* w2 = gr.w2[j];
-  float* packed = gr.packed[j];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * C; i += gridDim.x * blockDim.x) {
-    int o = i / C, in = i - o * C;
-    float v1 = w1[(size_t)i * K + K / 2], v2 = w2[(size_t)i * K + K / 2];
-    packed[in * C + o] = v1;
-    packed[C * C + in * C + o] = v2;
-    packed[2 * C * C + i] = v1;
-    packed[3 * C * C + i] = v2;
-  }
+  pack_spectral_att_job(gr, blockIdx.y, blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 int launch_pack_spectral_att_group(const SpecPackGroup& gr, hipStream_t st) {
   if (gr.n == 0) return 0;

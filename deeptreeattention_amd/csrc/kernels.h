@@ -42,6 +42,9 @@ template <typename T> int launch_conv_wgrad(const WgradArgs& a, int G, hipStream
 template <> int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st);       // conv_bf16.hip
 template <> int launch_conv_wgrad<bf16_t>(const WgradArgs& a, int G, hipStream_t st);   // conv_bf16.hip
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st);
+// several layers' split-K reductions in one launch (block ranges -> jobs)
+struct WgradReduceGroup { WgradReduceArgs job[3]; int start[4]; int n = 0; };
+int launch_wgrad_reduce_group(WgradReduceGroup& gr, hipStream_t st);
 void conv_geometry(int HW, int MWG, int B, int* ppw, int* spp, int* nwg);
 int conv_mwg(int N);
 int wgrad_cpw(int N);
@@ -170,6 +173,29 @@ int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const Colsu
 int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed, hipStream_t st);
 struct SpecPackGroup { const float* w1[6]; const float* w2[6]; float* packed[6]; int C[6], K[6]; int n = 0; };
 int launch_pack_spectral_att_group(const SpecPackGroup& gr, hipStream_t st);
+#if defined(__HIPCC__)
+// packed = [a1t | a2t | a1 | a2], each [C][C]; *t is input-major (a_t[i][o] = W[o][i][K/2])
+__device__ __forceinline__ void pack_spectral_att_job(const SpecPackGroup& gr, int j, size_t i0, size_t stride) {
+  const int C = gr.C[j], K = gr.K[j];
+  const float* w1 = gr.w1[j]; const float* w2 = gr.w2[j];
+  float* packed = gr.packed[j];
+  for (size_t i = i0; i < (size_t)C * C; i += stride) {
+    int o = (int)(i / C), in = (int)(i - (size_t)o * C);
+    float v1 = w1[i * K + K / 2], v2 = w2[i * K + K / 2];
+    packed[in * C + o] = v1;
+    packed[C * C + in * C + o] = v2;
+    packed[2 * C * C + i] = v1;
+    packed[3 * C * C + i] = v2;
+  }
+}
+#endif
+// one launch for everything the forward needs before its first conv (conv.hip)
+struct PrepArgs {
+  const float* x; void* x_tl; int B, C, H, W, NC, CG, ncg;
+  PackWGroup packs; SpecPackGroup spacks;
+  float* zero; size_t zero_n4;         // float4 count to clear, or zero == null
+};
+template <typename T> int launch_forward_prep(PrepArgs a, hipStream_t st);
 
 struct BlendArgs {
   const float* spec; const float* spat; const double* alpha; float* joint; int B, classes;
