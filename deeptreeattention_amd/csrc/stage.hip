@@ -152,7 +152,8 @@ static size_t stage_lds_floats(const StageArgs& a, bool bwd) {
   int HWz = Hz * Wz, ld = a.C + 1;
   size_t n = (size_t)HWz * ld;                 // Z
   if (bwd) n += (size_t)HWz * ld;               // D
-  n += (size_t)(bwd ? 8 : 4) * a.vslot + 512;   // vectors / padded maps + reduction scratch
+  // vectors / padded maps + reduction scratch.  backward: v0..v4 full slots, v5 per-pixel-or-channel, v6 per-channel
+  n += bwd ? (size_t)5 * a.vslot + (HWz > a.C ? HWz : a.C) + a.C + 512 : (size_t)4 * a.vslot + 512;
   return n;
 }
 
@@ -466,8 +467,8 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
   float* D = Z + (size_t)s.HWz * ld;
   float* v0 = D + (size_t)s.HWz * ld;
   float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
-  float* v4 = v3 + s.vslot; float* v5 = v4 + s.vslot; float* v6 = v5 + s.vslot; float* v7 = v6 + s.vslot;
-  float* scratch = v7 + s.vslot;
+  float* v4 = v3 + s.vslot; float* v5 = v4 + s.vslot; float* v6 = v5 + (s.HWz > C ? s.HWz : C);
+  float* scratch = v6 + C;   // (the slot plan keeps the 11x11x32 stage at 4 workgroups per CU)
   if (kind == KIND_SPATIAL)
     for (int i = t; i < 2 * s.vslot; i += 256) v3[i] = 0.f;   // padded maps d2 (v3) and d1 (v4)
   TICK(0);
