@@ -266,22 +266,50 @@ constexpr int RW = 32;    // weight-gradient LDS rows stay compact (32 B): with 
                           // 16-lane groups of a ds_read_b64_tr_b16 half-wave hit disjoint banks for any row offset
 
 
-// One patch: K runs over the haloed-grid rows in steps of 16; NTAP accumulators share each dY fragment.
-template <int NTAP>
-__device__ __forceinline__ void wgrad_ksteps(const unsigned char* bx, const unsigned char* by, const int* a_tap,
-                                             int b_off, int nks, f32x16* acc) {
-#pragma unroll 1
-  for (int ks = 0; ks < nks; ++ks) {
-    const int koff = ks * 16 * RW;
-    bf16x8 bfr = lds_tr8w(by, b_off + koff);
-    bf16x8 afr[NTAP];
+// One k-step (16 window rows) of all nine taps of a (32 input channels x 32 output columns) tile.
+// The three taps of one kernel row read the same X rows shifted by one: their A fragments (8 consecutive rows per
+// lane) are cut out of ONE 12-row transposing read (3 x ds_read_b64_tr_b16: rows r-1 .. r+10) with 16-bit funnel
+// shifts, and the dY fragment is shared by all nine MFMAs -> 11 LDS reads per 9 MFMAs (the per-tap scheme needed 20).
+__device__ __forceinline__ u32x2 lds_tr4w(const unsigned char* base, int off) {
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(base + off));
+  return __builtin_bit_cast(u32x2, v);
+}
+struct WgradFrags { bf16x8 b; u32x2 r[3][3]; };
+__device__ __forceinline__ void wgrad_kstep9_load(WgradFrags& f, const unsigned char* bx, const unsigned char* by,
+                                                  const int (&a_dy)[3], int b_off, int koff) {
+  f.b = lds_tr8w(by, b_off + koff);
 #pragma unroll
-    for (int j = 0; j < NTAP; ++j) afr[j] = lds_tr8w(bx, a_tap[j] + koff);
+  for (int d = 0; d < 3; ++d)
 #pragma unroll
-    for (int j = 0; j < NTAP; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[j], bfr, acc[j], 0, 0, 0);
+    for (int h = 0; h < 3; ++h) f.r[d][h] = lds_tr4w(bx, a_dy[d] + koff + h * 4 * RW);
+}
+__device__ __forceinline__ void wgrad_kstep9_mma(const WgradFrags& f, f32x16 (&acc)[9]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const unsigned R0 = f.r[d][0][0], R1 = f.r[d][0][1], R2 = f.r[d][1][0], R3 = f.r[d][1][1], R4 = f.r[d][2][0];
+    const u32x4 fm = {R0, R1, R2, R3};                                     // rows r-1 .. r+6   (dx = -1)
+    const u32x4 fz = {__builtin_amdgcn_alignbit(R1, R0, 16), __builtin_amdgcn_alignbit(R2, R1, 16),
+                      __builtin_amdgcn_alignbit(R3, R2, 16), __builtin_amdgcn_alignbit(R4, R3, 16)};   // r .. r+7
+    const u32x4 fp = {R1, R2, R3, R4};                                     // rows r+1 .. r+8   (dx = +1)
+    acc[d * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fm), f.b, acc[d * 3 + 0], 0, 0, 0);
+    acc[d * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fz), f.b, acc[d * 3 + 1], 0, 0, 0);
+    acc[d * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fp), f.b, acc[d * 3 + 2], 0, 0, 0);
   }
 }
 
+// developer instrumentation (-DDTA_TICKS): per-wave cycle totals of the staging / k-step / barrier phases
+#ifdef DTA_TICKS
+__device__ long long g_wticks[64];
+extern "C" int dta_debug_wticks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wticks), sizeof(long long) * 64); }
+#define WTICK_DECL long long wt_[5] = {0, 0, 0, 0, 0}, wacc_[4] = {0, 0, 0, 0}; const long long wt0_ = clock64();
+#define WTICK(i) wt_[i] = clock64(); if (i == 4) { wacc_[0] += wt_[1] - wt_[0]; wacc_[1] += wt_[2] - wt_[1]; wacc_[2] += wt_[3] - wt_[2]; wacc_[3] += wt_[4] - wt_[3]; }
+#define WTICK_DUMP if (blockIdx.x == 17 && lane == 0 && a.N == 64 && a.NCx > 8) { long long* o_ = g_wticks + wave * 8; \
+    o_[0] = wacc_[0]; o_[1] = wacc_[1]; o_[2] = wacc_[2]; o_[3] = clock64() - wt0_; o_[4] = niter; o_[5] = wacc_[3]; }
+#else
+#define WTICK_DECL
+#define WTICK(i)
+#define WTICK_DUMP
+#endif
 template <int NTT, bool BIGW>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -304,9 +332,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (logical >= total) return;
   const int cg = logical % a.cgroups, s = (logical / a.cgroups) % a.S, g = logical / (a.cgroups * a.S);
-  const int tg = wave & 1, pair = wave >> 1;              // tap group (0: taps 0-4, 1: taps 5-8), (c-tile, n-tile)
+  // wave = ((c-tile, n-tile) pair, k half): the two waves of a pair split the k-steps (even / odd) and hold partial
+  // sums of the same nine tap tiles; waves w and w+4 share a SIMD, so every SIMD carries one wave of each half
+  const int pair = wave & 3, khalf = wave >> 2;
   const int ct = pair / NTT, nt = pair % NTT;
-  const int tap0 = tg ? 5 : 0, ntap = tg ? 4 : 5;
   const int chunk0 = cg * XCH;
   const int nxch = max(0, min(XCH, a.NCx - chunk0));
 
@@ -316,9 +345,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     int tot = (dbuf ? 2 : 1) * stage / 16;
     for (int v = tid; v < tot; v += NTHR) d[v] = z;
   }
-  f32x16 acc[5];
+  f32x16 acc[9];
 #pragma unroll
-  for (int t = 0; t < 5; ++t)
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -326,13 +355,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   const int gq = lane >> 4, li = lane & 15;
   const int lane_off = (8 * (gq >> 1) + (li >> 2)) * RW + (li & 3) * 8;
   const int b_off = ((nt * 2 + (gq & 1)) * WR + q0) * RW + lane_off;
-  int a_tap[5];
+  int a_dy[3];   // first row of the 12-row read of kernel row dy: q0 + dy*W2 - 1  (>= 0: q0 = W2 + 1)
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    int tap = min(tap0 + j, 8);
-    int shift = (tap / 3 - 1) * W2 + (tap % 3 - 1);
-    a_tap[j] = ((ct * 2 + (gq & 1)) * WR + q0 + shift) * RW + lane_off;
-  }
+  for (int d = 0; d < 3; ++d) a_dy[d] = ((ct * 2 + (gq & 1)) * WR + q0 + (d - 1) * W2 - 1) * RW + lane_off;
 
   // ---- staging plan (band independent): thread t owns window vectors t, t+512, ... of the X part and of the dY part
   // vectors per thread: a chunk window has 2*WR vectors; WR <= 192 (11x11 patches: 172) or <= 256 (BIGW)
@@ -342,41 +367,47 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs;
   const bf16_t* yg = (const bf16_t*)a.dy_tl + (size_t)g * a.dy_gs;
   const size_t xpatch = (size_t)a.NCx * Q * 16, ypatch = (size_t)a.NCy * Q * 16;
-  size_t xsrc[XV], ysrc[YV];
-  int xdst[XV], ydst[YV], xrow[XV], yrow[YV];
+  // per vector: element offset inside the patch's tile and window row.  (The LDS image is linear: vector v of a part
+  // lives at byte 16*v.)  Vectors past the end of the part are not stored; their loads are pointed at a valid row.
+  int xsrc[XV], ysrc[YV], xrow[XV], yrow[YV];
 #pragma unroll
   for (int u = 0; u < XV; ++u) {
     int v = min(tid + u * NTHR, max(nxv, 1) - 1);
     int ch = v / vpc, o = v - ch * vpc;
-    xrow[u] = (tid + u * NTHR < nxv) ? (o >> 1) : (1 << 30);    // window row of this vector (huge = not mine)
-    xsrc[u] = (size_t)(chunk0 + ch) * Q * 16 + (size_t)o * 8;
-    xdst[u] = (ch * WR + (o >> 1)) * RW + (o & 1) * 16;
+    xrow[u] = o >> 1;
+    xsrc[u] = ((nxch > 0 ? chunk0 : 0) + ch) * Q * 16 + o * 8;
   }
 #pragma unroll
   for (int u = 0; u < YV; ++u) {
     int v = min(tid + u * NTHR, nyv - 1);
     int ch = v / vpc, o = v - ch * vpc;
-    yrow[u] = (tid + u * NTHR < nyv) ? (o >> 1) : (1 << 30);
-    ysrc[u] = (size_t)(a.ych0 + ch) * Q * 16 + (size_t)o * 8;
-    ydst[u] = (ch * WR + (o >> 1)) * RW + (o & 1) * 16;
+    yrow[u] = o >> 1;
+    ysrc[u] = (a.ych0 + ch) * Q * 16 + o * 8;
   }
   u32x4 rx[XV], ry[YV];
-  const u32x4 zero4 = {0, 0, 0, 0};
-  // rows of the window that fall beyond the tile (last band) are staged as zeros
+  // Branch-free fetch: wave-uniform base (patch, band) + per-lane 32-bit offset.  A window row that falls beyond the
+  // tile (last band; rows Q..WR-1 of an 11x11 patch) is redirected to row 0 of its chunk, a halo row, i.e. zeros.
+  // (LDS-DMA staging was measured slower here: its LDS writes stall the transposing fragment reads.)
 #define DTA_FETCH(b_, band_)                                                                                      \
   {                                                                                                               \
     const int r0_ = (band_) * a.bl;                                                                               \
-    _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                                \
-        rx[u] = (xrow[u] + r0_ < Q) ? *reinterpret_cast<const u32x4*>(xg + (size_t)(b_) * xpatch + xsrc[u] + (size_t)r0_ * 16) : zero4; \
-    _Pragma("unroll") for (int u = 0; u < YV; ++u)                                                                \
-        ry[u] = (yrow[u] + r0_ < Q) ? *reinterpret_cast<const u32x4*>(yg + (size_t)(b_) * ypatch + ysrc[u] + (size_t)r0_ * 16) : zero4; \
+    const bf16_t* xb_ = xg + (size_t)(b_) * xpatch + (size_t)r0_ * 16;                                            \
+    const bf16_t* yb_ = yg + (size_t)(b_) * ypatch + (size_t)r0_ * 16;                                            \
+    _Pragma("unroll") for (int u = 0; u < XV; ++u) {                                                              \
+      const int off_ = (xrow[u] + r0_ < Q) ? xsrc[u] : xsrc[u] - (xrow[u] + r0_) * 16;                            \
+      rx[u] = *reinterpret_cast<const u32x4*>(xb_ + off_);                                                        \
+    }                                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < YV; ++u) {                                                              \
+      const int off_ = (yrow[u] + r0_ < Q) ? ysrc[u] : ysrc[u] - (yrow[u] + r0_) * 16;                            \
+      ry[u] = *reinterpret_cast<const u32x4*>(yb_ + off_);                                                        \
+    }                                                                                                             \
   }
 #define DTA_STORE(base_)                                                                                          \
   {                                                                                                               \
     _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                                \
-        if (xrow[u] < WR) *reinterpret_cast<u32x4*>((base_) + xdst[u]) = rx[u];                                   \
+        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((base_) + (tid + u * NTHR) * 16) = rx[u];             \
     _Pragma("unroll") for (int u = 0; u < YV; ++u)                                                                \
-        if (yrow[u] < WR) *reinterpret_cast<u32x4*>((base_) + xbytes + ydst[u]) = ry[u];                          \
+        if (tid + u * NTHR < nyv) *reinterpret_cast<u32x4*>((base_) + xbytes + (tid + u * NTHR) * 16) = ry[u];    \
   }
   // flattened (patch, band) iteration space of this workgroup
   const int npb = (a.B - s + a.S - 1) / a.S;
@@ -390,19 +421,36 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     if (niter > 1) DTA_FETCH(DTA_ITER_B(1), DTA_ITER_BAND(1))
   }
   __syncthreads();
+  WTICK_DECL
   for (int it = 0; it < niter; ++it) {
     unsigned char* cur = smem + ((dbuf && (it & 1)) ? stage : 0);
     unsigned char* nxt = smem + ((dbuf && !(it & 1)) ? stage : 0);
     const bool more = it + 1 < niter;
-    if (dbuf && more) {
+    WTICK(0)
+    const int rem = (q1 - q0) - DTA_ITER_BAND(it) * a.bl;
+    const int nks = (min(a.bl, rem) + 15) / 16;
+    // The two waves of a SIMD (k halves 0 and 1) run their phases in opposite order: while one issues its LDS
+    // writes and global loads for the next window, the other keeps the matrix core busy.
+    const bool stage_now = dbuf && more;
+    if (khalf == 1 && stage_now) {
       DTA_STORE(nxt)
       if (it + 2 < niter) DTA_FETCH(DTA_ITER_B(it + 2), DTA_ITER_BAND(it + 2))
     }
-    const int rem = (q1 - q0) - DTA_ITER_BAND(it) * a.bl;
-    const int nks = (min(a.bl, rem) + 15) / 16;
-    if (tg == 0) wgrad_ksteps<5>(cur, cur + xbytes, a_tap, b_off, nks, acc);
-    else wgrad_ksteps<4>(cur, cur + xbytes, a_tap, b_off, nks, acc);
+    WTICK(1)
+#pragma unroll 1
+    for (int ks = khalf; ks < nks; ks += 2) {
+      WgradFrags f;
+      wgrad_kstep9_load(f, cur, cur + xbytes, a_dy, b_off, ks * 16 * RW);
+      wgrad_kstep9_mma(f, acc);
+    }
+    WTICK(2)
+    if (khalf == 0 && stage_now) {
+      DTA_STORE(nxt)
+      if (it + 2 < niter) DTA_FETCH(DTA_ITER_B(it + 2), DTA_ITER_BAND(it + 2))
+    }
+    WTICK(3)
     __syncthreads();
+    WTICK(4)
     if (!dbuf && more) {
       DTA_STORE(nxt)
       if (it + 2 < niter) DTA_FETCH(DTA_ITER_B(it + 2), DTA_ITER_BAND(it + 2))
@@ -413,16 +461,40 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
 #undef DTA_ITER_B
 #undef DTA_STORE
 #undef DTA_FETCH
+  WTICK_DUMP
+  // the odd-k waves hand their partial sums to their even-k partners through LDS (the staging buffers are free now:
+  // the loop ended on a barrier), two tap tiles per pass
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j0 = 0; j0 < 9; j0 += 2) {
+    if (khalf == 1) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        if (j0 + jj < 9) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((pair * 2 + jj) * 16 + r) * 64 + lane] = acc[j0 + jj][r];
+        }
+    }
+    __syncthreads();
+    if (khalf == 0) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        if (j0 + jj < 9) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j0 + jj][r] += red[((pair * 2 + jj) * 16 + r) * 64 + lane];
+        }
+    }
+    __syncthreads();
+  }
+  if (khalf != 0) return;
   // partial[g][s][tap][c][n]
   float* out = a.partial + ((size_t)(g * a.S + s) * 9) * a.Cpad * N;
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    if (j < ntap) {
+  for (int j = 0; j < 9; ++j) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int c = cg * CT * 32 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (c < a.Cpad) out[((size_t)(tap0 + j) * a.Cpad + c) * N + nt * 32 + (lane & 31)] = acc[j][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      int c = cg * CT * 32 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (c < a.Cpad) out[((size_t)j * a.Cpad + c) * N + nt * 32 + (lane & 31)] = acc[j][r];
     }
   }
 }
@@ -437,6 +509,7 @@ static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream
   size_t stage = (size_t)(CT * 2 + NTT * 2) * a2.wr * RW;
   a2.dbuf = 2 * stage <= 160 * 1024;
   size_t lds = (a2.dbuf ? 2 : 1) * stage;
+  if (lds < 32 * 1024) lds = 32 * 1024;   // the final pair reduction passes 4 x 2 tiles (8 KiB each) through LDS
   if (lds > 160 * 1024) { dta_set_error("conv_wgrad(bf16): LDS need %zu B exceeds 160 KiB", lds); return 1; }
   static bool attr_done = false;
   if (!attr_done) {
