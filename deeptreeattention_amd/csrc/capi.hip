@@ -356,6 +356,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     return launch_wgrad_reduce_group(reduces, st);
   }
   const float* dsc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  BlendBwdArgs blend_fin = {}; bool blend_fin_pending = false;
   if (dscores)
     for (int g = 0; g < G; ++g)
       for (int L = 0; L < 3; ++L) dsc[g][L] = dscores[g][L];
@@ -370,7 +371,8 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     bb.dalpha = dalpha ? dalpha : at<double>(ws, p.rowtmp);  // discard into scratch when not wanted
     bb.rowtmp = at<float>(ws, p.rowtmp); bb.B = B; bb.classes = p.classes;
     if (dalpha == nullptr) { dta_set_error("Hang2020 backward needs a dalpha destination"); return 1; }
-    if (launch_blend_bwd(bb, st)) return 1;
+    if (launch_blend_bwd_rows(bb, st)) return 1;   // d(alpha) is finished by a block of the first GEMM group below
+    blend_fin = bb; blend_fin_pending = true;
     dsc[0][2] = bb.dspec; dsc[1][2] = bb.dspat;
   } else if (d->kind == DTA_NET_VANILLA) {
     dsc[0][2] = djoint ? djoint : dsc[0][2];
@@ -413,7 +415,10 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       }
     }
     if (any_head) prof_begin(DTA_SITE_GEMM + 1, st);
-    if (launch_gemm_group(dfeat_grp, st)) return 1;
+    if (blend_fin_pending) {
+      if (launch_gemm_group_with_blend_fin(dfeat_grp, blend_fin, st)) return 1;
+      blend_fin_pending = false;
+    } else if (launch_gemm_group(dfeat_grp, st)) return 1;
     if (any_head) prof_end(DTA_SITE_GEMM + 1, st);
     // ---- attention + pool + ReLU backward ----
     StageBwdArgs sb;

@@ -152,9 +152,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, in
 }
 
 // Several independent small GEMMs in one launch: block -> (problem, m-tile, n-tile, k-slice).
-__global__ __launch_bounds__(256) void k_gemm_group(GemmGroup gg) {
-  __shared__ __attribute__((aligned(16))) float As[64 * GP];
-  __shared__ __attribute__((aligned(16))) float Bs[64 * GP];
+__device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, float* As, float* Bs) {
   int pi = 0;
   while (pi + 1 < gg.n && (int)blockIdx.x >= gg.start[pi + 1]) ++pi;
   const GemmArgs& a = gg.g[pi];
@@ -168,6 +166,11 @@ __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup gg) {
   else if (am == LD_VEC_K && bm == LD_VEC_ROW) gemm_block<LD_VEC_K, LD_VEC_ROW>(a, bx, by, bz, As, Bs);     // dy W
   else if (am == LD_VEC_ROW && bm == LD_VEC_ROW) gemm_block<LD_VEC_ROW, LD_VEC_ROW>(a, bx, by, bz, As, Bs); // dy^T x
   else gemm_block<LD_RUNTIME, LD_RUNTIME>(a, bx, by, bz, As, Bs);
+}
+__global__ __launch_bounds__(256) void k_gemm_group(GemmGroup gg) {
+  __shared__ __attribute__((aligned(16))) float As[64 * GP];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * GP];
+  gemm_group_block(gg, As, Bs);
 }
 
 int gemm_auto_ksplit(int M, int N, int K) {
@@ -265,8 +268,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd_rows(BlendBwdArgs a) {
   acc = wave_sum(acc);
   if (lane == 0) a.rowtmp[row] = acc;
 }
-__global__ __launch_bounds__(256) void k_blend_bwd_fin(BlendBwdArgs a) {
-  __shared__ double sd[256];
+__device__ __forceinline__ void blend_bwd_fin_block(const BlendBwdArgs& a, double* sd) {
   double acc = 0;
   for (int r = threadIdx.x; r < a.B; r += 256) acc += a.rowtmp[r];
   sd[threadIdx.x] = acc;
@@ -276,6 +278,38 @@ __global__ __launch_bounds__(256) void k_blend_bwd_fin(BlendBwdArgs a) {
     const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
     a.dalpha[0] = sd[0] * wd * (1.0 - wd);
   }
+}
+__global__ __launch_bounds__(256) void k_blend_bwd_fin(BlendBwdArgs a) {
+  __shared__ double sd[256];
+  blend_bwd_fin_block(a, sd);
+}
+// grouped GEMMs + one trailing block that finishes the blend backward (both only wait for k_blend_bwd_rows)
+__global__ __launch_bounds__(256) void k_gemm_group_fin(GemmGroup gg, BlendBwdArgs fin, int ngemm) {
+  __shared__ __attribute__((aligned(16))) float As[64 * GP];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * GP];
+  if ((int)blockIdx.x >= ngemm) { blend_bwd_fin_block(fin, reinterpret_cast<double*>(As)); return; }
+  gemm_group_block(gg, As, Bs);
+}
+int launch_blend_bwd_rows(const BlendBwdArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_blend_bwd_rows, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_blend_bwd_rows");
+  return 0;
+}
+int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hipStream_t st) {
+  if (gg.n == 0) {
+    hipLaunchKernelGGL(k_blend_bwd_fin, dim3(1), dim3(256), 0, st, fin);
+    DTA_CHECK_LAUNCH("k_blend_bwd_fin");
+    return 0;
+  }
+  int total = 0;
+  for (int i = 0; i < gg.n; ++i) {
+    gg.start[i] = total;
+    total += ((gg.g[i].M + 63) / 64) * ((gg.g[i].N + 63) / 64) * gg.g[i].ksplit;
+  }
+  gg.start[gg.n] = total;
+  hipLaunchKernelGGL(k_gemm_group_fin, dim3(total + 1), dim3(256), 0, st, gg, fin, total);
+  DTA_CHECK_LAUNCH("k_gemm_group_fin");
+  return 0;
 }
 int launch_blend_bwd(const BlendBwdArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_blend_bwd_rows, dim3((a.B + 3) / 4), dim3(256), 0, st, a);

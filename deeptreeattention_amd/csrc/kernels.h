@@ -206,6 +206,9 @@ struct BlendBwdArgs {
   float* dspec; float* dspat; double* dalpha; float* rowtmp; int B, classes;
 };
 int launch_blend_bwd(const BlendBwdArgs& a, hipStream_t st);
+// rows pass only; the scalar d(alpha) reduction then rides as one extra block of the next grouped GEMM launch
+int launch_blend_bwd_rows(const BlendBwdArgs& a, hipStream_t st);
+int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hipStream_t st);
 struct CeArgs {
   const float* logits; const long long* labels; const float* weight;  // weight may be null (= ones)
   float* dlogits; float* loss; float* rowtmp; int B, classes;
