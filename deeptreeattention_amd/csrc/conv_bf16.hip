@@ -233,7 +233,9 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   int nwg;
   conv_geometry(a.HW, MWG, a.B, &a.ppw, &a.spp, &nwg);
   size_t tab = (size_t)MWG * 8 + (size_t)9 * N * 4, stage = ((size_t)a.ppw * a.Q + (size_t)9 * N) * RB;
-  a.dbuf = tab + 2 * stage <= 160 * 1024;
+  // few chunks (the 32- and 64-channel layers): one LDS stage, so that two or three workgroups share a CU and overlap
+  // each other's prologue / epilogue instead of double-buffering a two-iteration loop
+  a.dbuf = tab + 2 * stage <= 160 * 1024 && a.NC > 4;   // measured: conv2's input-gradient conv 28 -> 22 us
   size_t lds = tab + (a.dbuf ? 2 : 1) * stage;
   if (lds > 160 * 1024) { dta_set_error("conv3x3(bf16): LDS need %zu B exceeds 160 KiB (H=%d W=%d)", lds, a.H, a.W); return 1; }
   if (a.ppw * a.Q * 2 > 4 * 512) { dta_set_error("conv3x3(bf16): %dx%d tile exceeds the staging plan", a.H, a.W); return 1; }
