@@ -253,7 +253,14 @@ template <>
 int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
   switch (a.N) {     // workgroup rows must match conv_mwg(N): 512 for N<=64, 256 for N=128
     case 32: return launch_conv_bf16_t<2, 1>(a, G, st);
-    case 64: return launch_conv_bf16_t<2, 2>(a, G, st);
+    case 64: {
+      // an input-gradient conv (no BN partials, so the plan's workgroup geometry is not binding) over few rows:
+      // 256-row workgroups double the number of busy CUs
+      int ppw, spp, nwg;
+      conv_geometry(a.HW, 512, a.B, &ppw, &spp, &nwg);
+      if (a.stats == nullptr && nwg * G <= 128) return launch_conv_bf16_t<1, 2>(a, G, st);
+      return launch_conv_bf16_t<2, 2>(a, G, st);
+    }
     case 128: return launch_conv_bf16_t<1, 4>(a, G, st);
   }
   dta_set_error("conv3x3: unsupported output width %d", a.N);
