@@ -357,6 +357,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
   }
   const float* dsc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   BlendBwdArgs blend_fin = {}; bool blend_fin_pending = false;
+  int dsc_mode[2] = {0, 0};   // Hang2020: scale mode of the last-head score gradient of each branch
   if (dscores)
     for (int g = 0; g < G; ++g)
       for (int L = 0; L < 3; ++L) dsc[g][L] = dscores[g][L];
@@ -364,16 +365,15 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     if (!djoint || !alpha) { dta_set_error("Hang2020 backward needs djoint and alpha"); return 1; }
     // the forward kept both branch scores in the workspace unless the caller supplied its own buffers; the
     // Python binding always lets the workspace hold them
-    BlendBwdArgs bb;
+    // d(joint)/d(branch score) = sigmoid(alpha) / 1 - sigmoid(alpha): folded into the head GEMMs as an output scale
+    // (GemmArgs::sig_mode); d(alpha) is reduced by one extra block of the first GEMM launch below
+    BlendBwdArgs bb = {};
     bb.spec = at<float>(ws, p.scores[0][2]); bb.spat = at<float>(ws, p.scores[1][2]);
-    bb.alpha = alpha; bb.djoint = djoint;
-    bb.dspec = at<float>(ws, p.dsc[0]); bb.dspat = at<float>(ws, p.dsc[1]);
-    bb.dalpha = dalpha ? dalpha : at<double>(ws, p.rowtmp);  // discard into scratch when not wanted
-    bb.rowtmp = at<float>(ws, p.rowtmp); bb.B = B; bb.classes = p.classes;
+    bb.alpha = alpha; bb.djoint = djoint; bb.dalpha = dalpha; bb.rowtmp = nullptr; bb.B = B; bb.classes = p.classes;
     if (dalpha == nullptr) { dta_set_error("Hang2020 backward needs a dalpha destination"); return 1; }
-    if (launch_blend_bwd_rows(bb, st)) return 1;   // d(alpha) is finished by a block of the first GEMM group below
     blend_fin = bb; blend_fin_pending = true;
-    dsc[0][2] = bb.dspec; dsc[1][2] = bb.dspat;
+    dsc[0][2] = djoint; dsc[1][2] = djoint;
+    dsc_mode[0] = 1; dsc_mode[1] = 2;
   } else if (d->kind == DTA_NET_VANILLA) {
     dsc[0][2] = djoint ? djoint : dsc[0][2];
   }
@@ -402,6 +402,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       ga.Bm = nets[g].fc_w[L]; ga.sb_k = F; ga.sb_n = 1;
       ga.C = at<float>(ws, p.dfeat[L]) + (size_t)g * fgs; ga.sc_m = F; ga.sc_n = 1;
       ga.M = B; ga.N = F; ga.K = p.classes; ga.ksplit = 1;   // plain stores: dfeat needs no clearing
+      if (L == 2 && dsc_mode[g]) { ga.sig_alpha = alpha; ga.sig_mode = dsc_mode[g]; }
       dfeat_grp.add(ga);
       if (grads[g].fc_w[L]) {
         memset(&ga, 0, sizeof(ga));
@@ -411,6 +412,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
         ga.M = p.classes; ga.N = F; ga.K = B;
         ga.ksplit = gemm_auto_ksplit(p.classes, F, B);
         ga.rowsum_out = grads[g].fc_b[L];      // db[n] = sum_b dscore[b][n]
+        if (L == 2 && dsc_mode[g]) { ga.sig_alpha = alpha; ga.sig_mode = dsc_mode[g]; }
         if (!deferred.add(ga)) { if (launch_gemm_group(deferred, st)) return 1; deferred.n = 0; deferred.add(ga); }
       }
     }

@@ -135,7 +135,12 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, in
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
   }
-  if (a.rowsum_out && by == 0 && t < 64 && m0 + t < a.M) atomicAdd(a.rowsum_out + m0 + t, rsum);
+  float osc = 1.f;
+  if (a.sig_mode) {
+    const double wd = 1.0 / (1.0 + exp(-a.sig_alpha[0]));
+    osc = a.sig_mode == 1 ? (float)wd : (float)(1.0 - wd);
+  }
+  if (a.rowsum_out && by == 0 && t < 64 && m0 + t < a.M) atomicAdd(a.rowsum_out + m0 + t, rsum * osc);
   const int n = n0 + wn + (lane & 31);
   if (n >= a.N) return;
   const float bias = (a.bias && bz == 0) ? a.bias[n] : 0.f;
@@ -144,7 +149,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, in
     int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (m >= a.M) continue;
     float* c = a.C + (size_t)m * a.sc_m + (size_t)n * a.sc_n;
-    float v = acc[r] + bias;
+    float v = acc[r] * osc + bias;
     if (a.ksplit > 1) atomicAdd(c, v);
     else if (a.accumulate) *c += v;
     else *c = v;
@@ -268,26 +273,47 @@ __global__ __launch_bounds__(256) void k_blend_bwd_rows(BlendBwdArgs a) {
   acc = wave_sum(acc);
   if (lane == 0) a.rowtmp[row] = acc;
 }
-__device__ __forceinline__ void blend_bwd_fin_block(const BlendBwdArgs& a, double* sd) {
+constexpr int BLEND_FIN_BLOCKS = 32;
+// d(alpha) = w (1 - w) * sum_{b,n} djoint * (spec - spat).  Either one block sums the row partials k_blend_bwd_rows
+// left (rowtmp != null, part 0 of 1), or BLEND_FIN_BLOCKS blocks each reduce a slice of the (B, classes) slab and add
+// it to dalpha, which then must arrive zeroed like every other gradient buffer.
+__device__ __forceinline__ void blend_bwd_fin_block(const BlendBwdArgs& a, double* sd, int part, int nparts) {
   double acc = 0;
-  for (int r = threadIdx.x; r < a.B; r += 256) acc += a.rowtmp[r];
+  if (a.rowtmp) {
+    for (int r = threadIdx.x; r < a.B; r += 256) acc += a.rowtmp[r];
+  } else {
+    const size_t n4 = (size_t)a.B * a.classes / 4, per = (n4 + nparts - 1) / nparts;
+    const size_t beg = part * per, end = min(n4, beg + per);
+    const f32x4* dj = (const f32x4*)a.djoint; const f32x4* sp = (const f32x4*)a.spec; const f32x4* st = (const f32x4*)a.spat;
+    float f0 = 0.f, f1 = 0.f;
+#pragma unroll 4
+    for (size_t i = beg + threadIdx.x; i < end; i += 256) {
+      const f32x4 d = dj[i], x = sp[i], y = st[i];
+      f0 += d[0] * (x[0] - y[0]) + d[1] * (x[1] - y[1]);
+      f1 += d[2] * (x[2] - y[2]) + d[3] * (x[3] - y[3]);
+    }
+    acc = (double)f0 + (double)f1;
+    if (part == 0)   // tail when B * classes is not a multiple of 4
+      for (size_t i = n4 * 4 + threadIdx.x; i < (size_t)a.B * a.classes; i += 256) acc += (double)(a.djoint[i] * (a.spec[i] - a.spat[i]));
+  }
   sd[threadIdx.x] = acc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) {
     const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
-    a.dalpha[0] = sd[0] * wd * (1.0 - wd);
+    if (a.rowtmp) a.dalpha[0] = sd[0] * wd * (1.0 - wd);
+    else atomicAdd(a.dalpha, sd[0] * wd * (1.0 - wd));
   }
 }
 __global__ __launch_bounds__(256) void k_blend_bwd_fin(BlendBwdArgs a) {
   __shared__ double sd[256];
-  blend_bwd_fin_block(a, sd);
+  blend_bwd_fin_block(a, sd, blockIdx.x, gridDim.x);
 }
 // grouped GEMMs + one trailing block that finishes the blend backward (both only wait for k_blend_bwd_rows)
 __global__ __launch_bounds__(256) void k_gemm_group_fin(GemmGroup gg, BlendBwdArgs fin, int ngemm) {
   __shared__ __attribute__((aligned(16))) float As[64 * GP];
   __shared__ __attribute__((aligned(16))) float Bs[64 * GP];
-  if ((int)blockIdx.x >= ngemm) { blend_bwd_fin_block(fin, reinterpret_cast<double*>(As)); return; }
+  if ((int)blockIdx.x >= ngemm) { blend_bwd_fin_block(fin, reinterpret_cast<double*>(As), blockIdx.x - ngemm, gridDim.x - ngemm); return; }
   gemm_group_block(gg, As, Bs);
 }
 int launch_blend_bwd_rows(const BlendBwdArgs& a, hipStream_t st) {
@@ -296,8 +322,9 @@ int launch_blend_bwd_rows(const BlendBwdArgs& a, hipStream_t st) {
   return 0;
 }
 int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hipStream_t st) {
+  const int nfin = fin.rowtmp ? 1 : BLEND_FIN_BLOCKS;
   if (gg.n == 0) {
-    hipLaunchKernelGGL(k_blend_bwd_fin, dim3(1), dim3(256), 0, st, fin);
+    hipLaunchKernelGGL(k_blend_bwd_fin, dim3(nfin), dim3(256), 0, st, fin);
     DTA_CHECK_LAUNCH("k_blend_bwd_fin");
     return 0;
   }
@@ -307,7 +334,7 @@ int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hip
     total += ((gg.g[i].M + 63) / 64) * ((gg.g[i].N + 63) / 64) * gg.g[i].ksplit;
   }
   gg.start[gg.n] = total;
-  hipLaunchKernelGGL(k_gemm_group_fin, dim3(total + 1), dim3(256), 0, st, gg, fin, total);
+  hipLaunchKernelGGL(k_gemm_group_fin, dim3(total + nfin), dim3(256), 0, st, gg, fin, total);
   DTA_CHECK_LAUNCH("k_gemm_group_fin");
   return 0;
 }

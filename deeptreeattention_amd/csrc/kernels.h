@@ -122,6 +122,9 @@ struct GemmArgs {
   const float* bias;
   float* rowsum_out;                  // optional: rowsum_out[m] += sum_k A(m,k) (atomic; must be pre-zeroed)
   int M, N, K, ksplit, accumulate;    // ksplit > 1: atomic accumulation into a pre-zeroed C
+  // Hang2020 blend folded into the GEMM: results (and row sums) are multiplied by sigmoid(alpha) (mode 1) or
+  // 1 - sigmoid(alpha) (mode 2) -- d(joint)/d(branch score) -- so the branch gradients are never materialised
+  const double* sig_alpha; int sig_mode;
 };
 constexpr int GEMM_GROUP_MAX = 12;
 struct GemmGroup {

@@ -153,8 +153,10 @@ class FusedTrainer:
                                      m._classes, _lib.ptr(self.loss), _lib.ptr(self.dlogits), _lib.ptr(self.ce_scratch),
                                      st), "dta_weighted_ce")
         dalpha = _lib.ptr(self.alpha_g) if self.hang else None
-        if not self._grads_clear:      # C-ABI contract: gradient buffers arrive zero-filled
+        if not self._grads_clear:      # C-ABI contract: gradient buffers (and dalpha) arrive zero-filled
             self.flat_g.zero_()
+            if self.hang:
+                self.alpha_g.zero_()
         if self.world == 1:
             _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table),
                                           _lib.ptr(self.dlogits), self.grads, dalpha, 3, st), "dta_net_backward")

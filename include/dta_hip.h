@@ -74,8 +74,8 @@ int dta_net_forward(const dta_net_desc* d, const dta_subnet_params* nets, const 
 
 /* Replaces autograd's backward through the module above.  `workspace` is the blob the matching training (or eval)
  * forward filled.  dscores[net][L] / djoint: gradients wrt the forward outputs (null = that output unused; for
- * HANG2020 pass djoint, for the others dscores).  Every non-null gradient buffer in `grads` must arrive ZERO-FILLED
- * (split-K partial sums are accumulated with atomics); on return it holds the gradient.
+ * HANG2020 pass djoint, for the others dscores).  Every non-null gradient buffer in `grads`, and `dalpha`, must arrive
+ * ZERO-FILLED (split-K partial sums are accumulated with atomics); on return it holds the gradient.
  * phases: bit 0 = everything except the first conv's weight gradient, bit 1 = the first conv's weight gradient
  * (the largest and last piece); 3 = all.  Two calls (1, then 2) let the caller start the gradient all-reduce of
  * the rest (RCCL on a side stream) while the first conv's weight gradient is still being computed. */
