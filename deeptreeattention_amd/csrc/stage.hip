@@ -455,23 +455,19 @@ __device__ long long g_ticks[2][32];
 #else
 #define TICK(i)
 #endif
+// Backward of one patch (b, g).  tiles_ready: Z, D and the saved attention state (v0..v2) are already in LDS.
 template <typename CFG>
-__global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const StageGeom& s, int b, int g, bool tiles_ready,
+                                                float* Z, float* D, float* v0, float* v1, float* v2, float* v3,
+                                                float* v4, float* v5, float* v6, float* scratch) {
   const StageArgs& a = ba.f;
-  const StageGeom s = stage_geom<CFG>(a);
   const bool pool = cfg_pool<CFG>(a);
-  const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = s.C, ld = s.ld;
+  const int t = threadIdx.x, C = s.C, ld = s.ld;
   const int kind = a.kind[g];
-  float* Z = sm;
-  float* D = Z + (size_t)s.HWz * ld;
-  float* v0 = D + (size_t)s.HWz * ld;
-  float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
-  float* v4 = v3 + s.vslot; float* v5 = v4 + s.vslot; float* v6 = v5 + (s.HWz > C ? s.HWz : C);
-  float* scratch = v6 + C;   // (the slot plan keeps the 11x11x32 stage at 4 workgroups per CU)
   if (kind == KIND_SPATIAL)
     for (int i = t; i < 2 * s.vslot; i += 256) v3[i] = 0.f;   // padded maps d2 (v3) and d1 (v4)
   TICK(0);
+  if (!tiles_ready) {
   // D = incoming gradient wrt the gated map (issued first: its loads fly together with the activations')
   const float* da_pre = nullptr;
   if (ba.da) {
@@ -486,6 +482,7 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
   }
   TICK(1);
   stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch, a.attsave != nullptr, da_pre, D);
+  }
   TICK(2);
   const float* df = ba.dfeat ? ba.dfeat + (size_t)g * ba.dfeat_gs + (size_t)b * a.F[g] : nullptr;
   float* vec = ba.vec ? ba.vec + (size_t)g * ba.vec_gs + (size_t)b * ba.vec_ld : nullptr;
@@ -669,6 +666,75 @@ __global__ __launch_bounds__(256) void k_stage_bwd(StageBwdArgs ba) {
   }
   TICK(5);
 }
+
+template <typename CFG>
+__global__ __launch_bounds__(256, (CFG::fixed && CFG::P == 0) ? 4 : 1) void k_stage_bwd(StageBwdArgs ba) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const StageArgs& a = ba.f;
+  const StageGeom s = stage_geom<CFG>(a);
+  const int g = blockIdx.y, t = threadIdx.x, C = s.C, ld = s.ld;
+  const int kind = a.kind[g];
+  float* Z = sm;
+  float* D = Z + (size_t)s.HWz * ld;
+  float* v0 = D + (size_t)s.HWz * ld;
+  float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
+  float* v4 = v3 + s.vslot; float* v5 = v4 + s.vslot; float* v6 = v5 + (s.HWz > C ? s.HWz : C);
+  float* scratch = v6 + C;   // (the slot plan keeps the 11x11x32 stage at 4 workgroups per CU)
+  // Un-pooled network stage (11x11x32) launched with half a grid: every workgroup owns TWO patches (b, b + gridDim.x).
+  // All workgroups are then resident at once, and the second patch's conv output and incoming gradient are fetched
+  // into registers while the first patch is processed: its HBM latency (every workgroup bursting at once) is hidden.
+  constexpr bool PIPE = CFG::fixed && CFG::P == 0;
+  if (PIPE && (int)gridDim.x < a.B) {
+    constexpr int NQ = PIPE ? (CFG::H * CFG::W * CFG::C + 255) / 256 : 1;
+    constexpr int CQ = PIPE ? CFG::C : 1, NEL = PIPE ? CFG::H * CFG::W * CFG::C : 0;
+    float ry[NQ], rq[NQ];
+    const float* coef = a.coef + (size_t)g * a.coef_gs;
+    const float psc = coef[(t % CQ) * 4 + 0], psh = coef[(t % CQ) * 4 + 1];
+#define DTA_STAGE_ISSUE(b_)                                                                          \
+    {                                                                                                \
+      const float* y_ = a.y + (size_t)g * a.y_gs + (size_t)(b_) * s.HWc * a.y_rs;                    \
+      const float* d_ = ba.da + (size_t)g * ba.da_gs + (size_t)(b_) * s.HWz * C;                     \
+      _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                                               \
+        const int i = t + u * 256;                                                                   \
+        if (i < NEL) { ry[u] = y_[(size_t)(i / CQ) * a.y_rs + (i % CQ)]; rq[u] = d_[i]; }            \
+      }                                                                                              \
+    }
+#define DTA_STAGE_LAND(b_)                                                                           \
+    {                                                                                                \
+      if (kind == KIND_SPATIAL)                                                                      \
+        for (int i = t; i < 2 * s.vslot; i += 256) v3[i] = 0.f;                                      \
+      _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                                               \
+        const int i = t + u * 256;                                                                   \
+        if (i < NEL) {                                                                               \
+          const int p = i / CQ, c = i % CQ;                                                          \
+          Z[p * ld + c] = fmaxf(ry[u] * psc + psh, 0.f);                                             \
+          D[p * ld + c] = rq[u];                                                                     \
+        }                                                                                            \
+      }                                                                                              \
+      const float* src = a.attsave + ((size_t)g * a.B + (b_)) * a.attsave_ld;                        \
+      if (kind == KIND_SPECTRAL) {                                                                   \
+        for (int i = t; i < 3 * C; i += 256) { const int k = i / C; v0[k * s.vslot + (i - k * C)] = src[i]; } \
+      } else if (kind == KIND_SPATIAL) {                                                             \
+        for (int i = t; i < 3 * s.vslot; i += 256) v0[i] = src[i];                                   \
+      }                                                                                              \
+      __syncthreads();                                                                               \
+    }
+    const int b0 = blockIdx.x, b1 = blockIdx.x + gridDim.x;
+    DTA_STAGE_ISSUE(b0)
+    DTA_STAGE_LAND(b0)
+    if (b1 < a.B) DTA_STAGE_ISSUE(b1)
+    stage_bwd_patch<CFG>(ba, s, b0, g, true, Z, D, v0, v1, v2, v3, v4, v5, v6, scratch);
+    if (b1 < a.B) {
+      __syncthreads();   // the second patch reuses the LDS tiles
+      DTA_STAGE_LAND(b1)
+      stage_bwd_patch<CFG>(ba, s, b1, g, true, Z, D, v0, v1, v2, v3, v4, v5, v6, scratch);
+    }
+#undef DTA_STAGE_LAND
+#undef DTA_STAGE_ISSUE
+    return;
+  }
+  stage_bwd_patch<CFG>(ba, s, blockIdx.x, g, false, Z, D, v0, v1, v2, v3, v4, v5, v6, scratch);
+}
 #ifdef DTA_TICKS
 extern "C" int dta_debug_ticks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ticks), sizeof(long long) * 64); }
 #endif
@@ -680,7 +746,9 @@ static int launch_stage_bwd_c(const StageBwdArgs& a, int G, size_t lds, hipStrea
     hipFuncSetAttribute((const void*)k_stage_bwd<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_stage_bwd<CFG>), dim3(a.f.B, G), dim3(256), lds, st, a);
+  // (11x11x32 network stage with saved attention state: two patches per workgroup, see the kernel)
+  const bool pipe = CFG::fixed && CFG::P == 0 && a.da && a.f.attsave && a.f.apply_bn && a.f.relu && a.f.B >= 512;
+  hipLaunchKernelGGL((k_stage_bwd<CFG>), dim3(pipe ? (a.f.B + 1) / 2 : a.f.B, G), dim3(256), lds, st, a);
   DTA_CHECK_LAUNCH("k_stage_bwd");
   return 0;
 }
