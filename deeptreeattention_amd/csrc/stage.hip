@@ -221,7 +221,8 @@ __device__ __forceinline__ float stencil_at(const float* mp, const float* kw, in
 template <typename CFG>
 __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeom& s, int g, int b, int kind,
                                               float* Z, float* v0, float* v1, float* v2, float* scratch,
-                                              bool use_saved = false, const float* da = nullptr, float* D = nullptr) {
+                                              bool use_saved = false, const float* da = nullptr, float* D = nullptr,
+                                              bool z_ready = false) {
   constexpr int CT = CFG::C;
   const bool pool = cfg_pool<CFG>(a);
   const int t = threadIdx.x, C = s.C, ld = s.ld;
@@ -246,7 +247,9 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
 #pragma unroll
     for (int u = 0; u < ND; ++u) { const int i = t + u * 256; rd[u] = i < HZT * CT ? da[i] : 0.f; }
   }
-  if (CT > 0) {
+  if (z_ready) {
+    // the caller already built Z from prefetched registers
+  } else if (CT > 0) {
     // 256 % C == 0: every thread keeps one channel, its BN coefficients live in registers
     const int c = t % C, p0 = t / C, pstep = 256 / C;
     const float sc = a.apply_bn ? coef[c * 4 + 0] : 1.f, sh = a.apply_bn ? coef[c * 4 + 1] : 0.f;
@@ -333,17 +336,13 @@ __device__ __forceinline__ float gate_of(int kind, const float* v2, int p, int c
   return kind == KIND_SPECTRAL ? v2[c] : (kind == KIND_SPATIAL ? v2[p] : 1.f);
 }
 
+// Forward of one patch (b, g).  z_ready: the caller already built Z (BN + ReLU of the conv output) in LDS.
 template <typename T, typename CFG>
-__global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const StageGeom s = stage_geom<CFG>(a);
-  const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = s.C, ld = s.ld;
+__device__ __forceinline__ void stage_fwd_patch(const StageArgs& a, const StageGeom& s, int b, int g, bool z_ready,
+                                                float* Z, float* v0, float* v1, float* v2, float* scratch) {
+  const int t = threadIdx.x, C = s.C, ld = s.ld;
   const int kind = a.kind[g];
-  float* Z = sm;
-  float* v0 = Z + (size_t)s.HWz * ld;
-  float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
-  float* scratch = v3 + s.vslot;
-  stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch);
+  stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch, false, nullptr, nullptr, z_ready);
   if (a.attsave) {
     float* dst = a.attsave + ((size_t)g * a.B + b) * a.attsave_ld;
     if (kind == KIND_SPECTRAL) {
@@ -403,13 +402,62 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
 }
 
 template <typename T, typename CFG>
+__global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const StageGeom s = stage_geom<CFG>(a);
+  const int g = blockIdx.y, t = threadIdx.x, ld = s.ld;
+  float* Z = sm;
+  float* v0 = Z + (size_t)s.HWz * ld;
+  float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
+  float* scratch = v3 + s.vslot;
+  // Un-pooled network stage launched with half a grid: two patches per workgroup, the second one's conv output is
+  // fetched into registers while the first is processed (see k_stage_bwd).
+  constexpr bool PIPE = CFG::fixed && CFG::P == 0;
+  if (PIPE && (int)gridDim.x < a.B) {
+    constexpr int NQ = PIPE ? (CFG::H * CFG::W * CFG::C + 255) / 256 : 1;
+    constexpr int CQ = PIPE ? CFG::C : 1, NEL = PIPE ? CFG::H * CFG::W * CFG::C : 0;
+    float ry[NQ];
+    const float* coef = a.coef + (size_t)g * a.coef_gs;
+    const float psc = coef[(t % CQ) * 4 + 0], psh = coef[(t % CQ) * 4 + 1];
+#define DTA_STAGE_ISSUE(b_)                                                                          \
+    {                                                                                                \
+      const float* y_ = a.y + (size_t)g * a.y_gs + (size_t)(b_) * s.HWc * a.y_rs;                    \
+      _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                                               \
+        const int i = t + u * 256;                                                                   \
+        if (i < NEL) ry[u] = y_[(size_t)(i / CQ) * a.y_rs + (i % CQ)];                               \
+      }                                                                                              \
+    }
+#define DTA_STAGE_LAND()                                                                             \
+    _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                                                 \
+      const int i = t + u * 256;                                                                     \
+      if (i < NEL) Z[(i / CQ) * ld + (i % CQ)] = fmaxf(ry[u] * psc + psh, 0.f);                      \
+    }
+    const int b0 = blockIdx.x, b1 = blockIdx.x + gridDim.x;
+    DTA_STAGE_ISSUE(b0)
+    DTA_STAGE_LAND()
+    if (b1 < a.B) DTA_STAGE_ISSUE(b1)
+    stage_fwd_patch<T, CFG>(a, s, b0, g, true, Z, v0, v1, v2, scratch);
+    if (b1 < a.B) {
+      __syncthreads();   // the second patch reuses the LDS tiles
+      DTA_STAGE_LAND()
+      stage_fwd_patch<T, CFG>(a, s, b1, g, true, Z, v0, v1, v2, scratch);
+    }
+#undef DTA_STAGE_LAND
+#undef DTA_STAGE_ISSUE
+    return;
+  }
+  stage_fwd_patch<T, CFG>(a, s, blockIdx.x, g, false, Z, v0, v1, v2, scratch);
+}
+
+template <typename T, typename CFG>
 static int launch_stage_fwd_c(const StageArgs& a, int G, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)k_stage_fwd<T, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_stage_fwd<T, CFG>), dim3(a.B, G), dim3(256), lds, st, a);
+  const bool pipe = CFG::fixed && CFG::P == 0 && a.apply_bn && a.relu && a.B >= 512;   // two patches per workgroup
+  hipLaunchKernelGGL((k_stage_fwd<T, CFG>), dim3(pipe ? (a.B + 1) / 2 : a.B, G), dim3(256), lds, st, a);
   DTA_CHECK_LAUNCH("k_stage_fwd");
   return 0;
 }
