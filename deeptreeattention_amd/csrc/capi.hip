@@ -429,6 +429,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     if (L < 2) { sb.da = at<float>(ws, p.da[L + 1]); sb.da_gs = (size_t)B * p.HWz[L] * C; }
     sb.dfeat = any_head ? at<float>(ws, p.dfeat[L]) : nullptr; sb.dfeat_gs = fgs;
     sb.dv = at<float>(ws, p.dv[L]); sb.dv_gs = (size_t)B * p.HWc[L] * C;
+    sb.dv_compact = L > 0 && bn_bwd_apply_uses_lds(C, p.Hc[L], p.Wc[L], p.esz);   // pooled stages: 3/4 of dv is zeros
     sb.bnpart = at<float>(ws, p.bnpart[L]); sb.bnpart_gs = (size_t)B * C * 2;
     sb.vec = at<float>(ws, p.vec[L]); sb.vec_gs = (size_t)B * p.vec_ld[L]; sb.vec_ld = p.vec_ld[L];
     prof_begin(DTA_SITE_STAGE_BWD + L, st);
@@ -481,6 +482,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     ap.dv = sb.dv; ap.dv_gs = sb.dv_gs; ap.y = sa.y; ap.y_gs = sa.y_gs; ap.y_rs = sa.y_rs;
     ap.coef = sa.coef; ap.coef_gs = sa.coef_gs; ap.bcoef = bf.bcoef; ap.bcoef_gs = bf.bcoef_gs;
     ap.B = B; ap.C = C; ap.H = p.Hc[L]; ap.W = p.Wc[L];
+    ap.dv_compact = sb.dv_compact; ap.Hz = p.Hz[L]; ap.Wz = p.Wz[L];
     ap.dy_tl = at<char>(ws, p.dy_tl[L]);
     if (L == 0) { ap.dy_gs = (size_t)2 * p.Qin[0] * 16; ap.dy_nc = 2 * G; ap.dy_ch0 = 0; }   // group g -> chunks [2g, 2g+2)
     else { ap.dy_gs = (size_t)B * (C / 16) * p.Qin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }

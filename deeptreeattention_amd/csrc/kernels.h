@@ -91,6 +91,10 @@ struct StageBwdArgs {
   float* dv; size_t dv_gs;             // out: grad wrt BN output (pre-ReLU), fp32 [B][HWc][C]
   float* bnpart; size_t bnpart_gs;     // out: [B][C][2] per-patch (sum dv, sum dv*xhat)
   float* vec; size_t vec_gs; int vec_ld;         // out: per-patch attention-gradient vectors [B][vec_ld]
+  // pooled stages: dv is 3/4 zeros (only each 2x2 window's maximum gets a gradient).  dv_compact: write per patch
+  // [HWz][C] gradient values followed by [HWz][C] window positions (1 byte) instead of the dense [HWc][C] map;
+  // k_bn_bwd_apply_lds expands it on the fly (same per-patch stride)
+  int dv_compact;
 };
 int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st);
 
@@ -110,7 +114,9 @@ struct BnBwdApplyArgs {
   const float* coef; int coef_gs; const float* bcoef; int bcoef_gs;
   int B, C, H, W;
   void* dy_tl; size_t dy_gs; int dy_nc, dy_ch0;
+  int dv_compact, Hz, Wz;              // see StageBwdArgs::dv_compact
 };
+bool bn_bwd_apply_uses_lds(int C, int H, int W, size_t elem_bytes);
 template <typename T> int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st);
 
 // ---- heads.hip -----------------------------------------------------------------------------------

@@ -675,6 +675,7 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
       }
     } else {
       // one pooled element per iteration: re-read its 2x2 window, route the gradient to the first maximum
+      unsigned char* fpos = reinterpret_cast<unsigned char*>(dv + (size_t)s.HWz * C);   // compact form: positions
       for (int pz = sl; pz < s.HWz; pz += nsl) {
         int hz = pz / s.Wz, wz = pz - hz * s.Wz;
         const int p00 = (2 * hz) * s.Wc + 2 * wz;
@@ -689,15 +690,19 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
         }
         float d = D[pz * ld + c];
         if (a.relu && m <= 0.f) d = 0.f;
+        if (ba.dv_compact) { dv[(size_t)pz * C + c] = d; fpos[(size_t)pz * C + c] = (unsigned char)first; }
+        else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dv[(size_t)po[k] * C + c] = (k == first) ? d : 0.f;
+          for (int k = 0; k < 4; ++k) dv[(size_t)po[k] * C + c] = (k == first) ? d : 0.f;
+        }
         if (a.apply_bn) { s1 += d; s2 += d * (yv[first] - mean) * rstd; }
       }
       // conv-resolution positions the floor pooling dropped get no gradient
-      for (int p = sl; p < s.HWc; p += nsl) {
-        int h = p / s.Wc, w = p - h * s.Wc;
-        if ((h >> 1) >= s.Hz || (w >> 1) >= s.Wz) dv[(size_t)p * C + c] = 0.f;
-      }
+      if (!ba.dv_compact)
+        for (int p = sl; p < s.HWc; p += nsl) {
+          int h = p / s.Wc, w = p - h * s.Wc;
+          if ((h >> 1) >= s.Hz || (w >> 1) >= s.Wz) dv[(size_t)p * C + c] = 0.f;
+        }
     }
   }
   TICK(4);
@@ -955,6 +960,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   T* img = (T*)(smem_apply + ((3 * C * 4 + 15) & ~15)); // [nch][Q][16]
   const float* dv = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
   const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs;
+  const unsigned char* fpos = reinterpret_cast<const unsigned char*>(dv + (size_t)a.Hz * a.Wz * C);   // compact form only
   const float* coef = a.coef + (size_t)g * a.coef_gs;
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
   for (int c = t; c < C; c += 256) {
@@ -977,7 +983,20 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
       if (i < total) {
         const int pix = i / C4, c4 = (i - pix * C4) * 4;
         yv[u] = *(const f32x4*)(y + (size_t)pix * a.y_rs + c4);
-        dvv[u] = *(const f32x4*)(dv + (size_t)pix * C + c4);
+        if (!a.dv_compact) dvv[u] = *(const f32x4*)(dv + (size_t)pix * C + c4);
+        else {
+          // expand the pooled stage's compact gradient: the value lands on the window position the forward chose
+          const int hh = pix / a.W, ww = pix - hh * a.W, hz = hh >> 1, wz = ww >> 1;
+          f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+          if (hz < a.Hz && wz < a.Wz) {
+            const int pz = hz * a.Wz + wz, k = (hh & 1) * 2 + (ww & 1);
+            const f32x4 dc = *(const f32x4*)(dv + (size_t)pz * C + c4);
+            const unsigned fb = *(const unsigned*)(fpos + (size_t)pz * C + c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dz[j] = (int)((fb >> (8 * j)) & 0xFFu) == k ? dc[j] : 0.f;
+          }
+          dvv[u] = dz;
+        }
       }
     }
 #pragma unroll
@@ -1009,10 +1028,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   for (int i = t; i < nvec; i += 256) dst[i] = img4[i];
 }
 
+static size_t bn_bwd_apply_lds_bytes(int C, int H, int W, size_t esz) {
+  return ((3 * C * 4 + 15) & ~15) + (size_t)(C / 16) * (H + 2) * (W + 2) * 16 * esz;
+}
+bool bn_bwd_apply_uses_lds(int C, int H, int W, size_t esz) { return bn_bwd_apply_lds_bytes(C, H, W, esz) <= 48 * 1024; }
+
 template <typename T>
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st) {
-  const int Q = (a.H + 2) * (a.W + 2);
-  const size_t lds = ((3 * a.C * 4 + 15) & ~15) + (size_t)(a.C / 16) * Q * 16 * sizeof(T);
+  const size_t lds = bn_bwd_apply_lds_bytes(a.C, a.H, a.W, sizeof(T));
+  if (a.dv_compact && lds > 48 * 1024) { dta_set_error("bn_bwd_apply: compact dv needs the LDS-image kernel"); return 1; }
   if (lds <= 48 * 1024) {
     hipLaunchKernelGGL(k_bn_bwd_apply_lds<T>, dim3(a.B, G), dim3(256), lds, st, a);
     DTA_CHECK_LAUNCH("k_bn_bwd_apply_lds");
