@@ -956,8 +956,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_apply[];
   const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = a.C;
   const int W2 = a.W + 2, Q = (a.H + 2) * W2, HW = a.H * a.W, nch = C / 16, C4 = C / 4;
+  const int c4sh = 31 - __clz(C4);                      // C is a power of two (32 / 64 / 128)
   float* sk = (float*)smem_apply;                       // [3][C]
-  T* img = (T*)(smem_apply + ((3 * C * 4 + 15) & ~15)); // [nch][Q][16]
+  int* lut = (int*)(smem_apply + 3 * C * 4);            // [HW] pixel -> haloed row q | pooled element << 10 | window position << 20 | in-window << 22
+  T* img = (T*)(smem_apply + ((3 * C * 4 + HW * 4 + 15) & ~15)); // [nch][Q][16]
   const float* dv = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
   const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs;
   const unsigned char* fpos = reinterpret_cast<const unsigned char*>(dv + (size_t)a.Hz * a.Wz * C);   // compact form only
@@ -969,6 +971,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
     sk[C + c] = -A * Cc * rstd;
     sk[2 * C + c] = A * (Cc * rstd * mean - Bc);
   }
+  for (int pix = t; pix < HW; pix += 256) {
+    const int hh = pix / a.W, ww = pix - hh * a.W, hz = hh >> 1, wz = ww >> 1;
+    const int inw = (a.dv_compact && hz < a.Hz && wz < a.Wz) ? 1 : 0;
+    lut[pix] = ((hh + 1) * W2 + ww + 1) | ((inw ? hz * a.Wz + wz : 0) << 10) | ((((hh & 1) << 1) | (ww & 1)) << 20) | (inw << 22);
+  }
   const int nvec = nch * Q * 16 * (int)sizeof(T) / 16;
   u32x4* img4 = (u32x4*)img;
   for (int i = t; i < nvec; i += 256) img4[i] = u32x4{0u, 0u, 0u, 0u};
@@ -977,19 +984,21 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   constexpr int UB = 4;
   for (int i0 = t; i0 < total; i0 += 256 * UB) {
     f32x4 yv[UB], dvv[UB];
+    int lq[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int i = i0 + u * 256;
       if (i < total) {
-        const int pix = i / C4, c4 = (i - pix * C4) * 4;
+        const int pix = i >> c4sh, c4 = (i - (pix << c4sh)) * 4;
         yv[u] = *(const f32x4*)(y + (size_t)pix * a.y_rs + c4);
+        const int l = lut[pix];
+        lq[u] = l;
         if (!a.dv_compact) dvv[u] = *(const f32x4*)(dv + (size_t)pix * C + c4);
         else {
           // expand the pooled stage's compact gradient: the value lands on the window position the forward chose
-          const int hh = pix / a.W, ww = pix - hh * a.W, hz = hh >> 1, wz = ww >> 1;
           f32x4 dz = {0.f, 0.f, 0.f, 0.f};
-          if (hz < a.Hz && wz < a.Wz) {
-            const int pz = hz * a.Wz + wz, k = (hh & 1) * 2 + (ww & 1);
+          if (l >> 22) {
+            const int pz = (l >> 10) & 1023, k = (l >> 20) & 3;
             const f32x4 dc = *(const f32x4*)(dv + (size_t)pz * C + c4);
             const unsigned fb = *(const unsigned*)(fpos + (size_t)pz * C + c4);
 #pragma unroll
@@ -1003,8 +1012,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
     for (int u = 0; u < UB; ++u) {
       const int i = i0 + u * 256;
       if (i < total) {
-        const int pix = i / C4, c4 = (i - pix * C4) * 4;
-        const int hh = pix / a.W, ww = pix - hh * a.W, q = (hh + 1) * W2 + ww + 1;
+        const int pix = i >> c4sh, c4 = (i - (pix << c4sh)) * 4;
+        const int q = lq[u] & 1023;
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = sk[c4 + j] * dvv[u][j] + sk[C + c4 + j] * yv[u][j] + sk[2 * C + c4 + j];
@@ -1029,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
 }
 
 static size_t bn_bwd_apply_lds_bytes(int C, int H, int W, size_t esz) {
-  return ((3 * C * 4 + 15) & ~15) + (size_t)(C / 16) * (H + 2) * (W + 2) * 16 * esz;
+  return ((3 * C * 4 + H * W * 4 + 15) & ~15) + (size_t)(C / 16) * (H + 2) * (W + 2) * 16 * esz;
 }
 bool bn_bwd_apply_uses_lds(int C, int H, int W, size_t esz) { return bn_bwd_apply_lds_bytes(C, H, W, esz) <= 48 * 1024; }
 
