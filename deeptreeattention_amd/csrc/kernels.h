@@ -115,6 +115,7 @@ struct BnBwdApplyArgs {
   int B, C, H, W;
   void* dy_tl; size_t dy_gs; int dy_nc, dy_ch0;
   int dv_compact, Hz, Wz;              // see StageBwdArgs::dv_compact
+  int cslice;                          // channels per workgroup (filled by the launcher)
 };
 bool bn_bwd_apply_uses_lds(int C, int H, int W, size_t elem_bytes);
 template <typename T> int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st);

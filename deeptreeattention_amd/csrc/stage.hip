@@ -954,22 +954,25 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_apply[];
-  const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = a.C;
-  const int W2 = a.W + 2, Q = (a.H + 2) * W2, HW = a.H * a.W, nch = C / 16, C4 = C / 4;
+  // a workgroup = one patch x one slice of CS channels (blockIdx.z): small LDS images keep 8 workgroups on a CU
+  const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = a.C, CS = a.cslice, c0 = blockIdx.z * CS;
+  const int W2 = a.W + 2, Q = (a.H + 2) * W2, HW = a.H * a.W, nch = CS / 16, C4 = CS / 4;
   const int c4sh = 31 - __clz(C4);                      // C is a power of two (32 / 64 / 128)
-  float* sk = (float*)smem_apply;                       // [3][C]
-  int* lut = (int*)(smem_apply + 3 * C * 4);            // [HW] pixel -> haloed row q | pooled element << 10 | window position << 20 | in-window << 22
-  T* img = (T*)(smem_apply + ((3 * C * 4 + HW * 4 + 15) & ~15)); // [nch][Q][16]
-  const float* dv = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
-  const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs;
-  const unsigned char* fpos = reinterpret_cast<const unsigned char*>(dv + (size_t)a.Hz * a.Wz * C);   // compact form only
+  float* sk = (float*)smem_apply;                       // [3][CS]
+  int* lut = (int*)(smem_apply + 3 * CS * 4);            // [HW] pixel -> haloed row q | pooled element << 10 | window position << 20 | in-window << 22
+  T* img = (T*)(smem_apply + ((3 * CS * 4 + HW * 4 + 15) & ~15)); // [nch][Q][16]
+  const float* dvp = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
+  const float* dv = dvp + c0;
+  const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs + c0;
+  const unsigned char* fpos = reinterpret_cast<const unsigned char*>(dvp + (size_t)a.Hz * a.Wz * C) + c0;   // compact form only
   const float* coef = a.coef + (size_t)g * a.coef_gs;
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
-  for (int c = t; c < C; c += 256) {
-    float A = bc[c * 4 + 0], Bc = bc[c * 4 + 1], Cc = bc[c * 4 + 2], mean = coef[c * 4 + 2], rstd = coef[c * 4 + 3];
+  for (int c = t; c < CS; c += 256) {
+    const int cc = c0 + c;
+    float A = bc[cc * 4 + 0], Bc = bc[cc * 4 + 1], Cc = bc[cc * 4 + 2], mean = coef[cc * 4 + 2], rstd = coef[cc * 4 + 3];
     sk[c] = A;
-    sk[C + c] = -A * Cc * rstd;
-    sk[2 * C + c] = A * (Cc * rstd * mean - Bc);
+    sk[CS + c] = -A * Cc * rstd;
+    sk[2 * CS + c] = A * (Cc * rstd * mean - Bc);
   }
   for (int pix = t; pix < HW; pix += 256) {
     const int hh = pix / a.W, ww = pix - hh * a.W, hz = hh >> 1, wz = ww >> 1;
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
         const int q = lq[u] & 1023;
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = sk[c4 + j] * dvv[u][j] + sk[C + c4 + j] * yv[u][j] + sk[2 * C + c4 + j];
+        for (int j = 0; j < 4; ++j) v[j] = sk[c4 + j] * dvv[u][j] + sk[CS + c4 + j] * yv[u][j] + sk[2 * CS + c4 + j];
         T* row = img + ((size_t)(c4 >> 4) * Q + q) * 16;
         if constexpr (sizeof(T) == 2) {
           u32x2 pk = {(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
@@ -1033,21 +1036,29 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
     }
   }
   __syncthreads();
-  u32x4* dst = (u32x4*)((T*)a.dy_tl + (size_t)g * a.dy_gs + ((size_t)b * a.dy_nc + a.dy_ch0) * Q * 16);
+  u32x4* dst = (u32x4*)((T*)a.dy_tl + (size_t)g * a.dy_gs + ((size_t)b * a.dy_nc + a.dy_ch0 + c0 / 16) * Q * 16);
   for (int i = t; i < nvec; i += 256) dst[i] = img4[i];
 }
 
-static size_t bn_bwd_apply_lds_bytes(int C, int H, int W, size_t esz) {
-  return ((3 * C * 4 + H * W * 4 + 15) & ~15) + (size_t)(C / 16) * (H + 2) * (W + 2) * 16 * esz;
+static size_t bn_bwd_apply_lds_bytes(int CS, int H, int W, size_t esz) {
+  return ((3 * CS * 4 + H * W * 4 + 15) & ~15) + (size_t)(CS / 16) * (H + 2) * (W + 2) * 16 * esz;
 }
-bool bn_bwd_apply_uses_lds(int C, int H, int W, size_t esz) { return bn_bwd_apply_lds_bytes(C, H, W, esz) <= 48 * 1024; }
+// channels per workgroup of the LDS-image kernel: whole patch if its image is small, else 32-channel slices
+static int bn_bwd_apply_cslice(int C, int H, int W, size_t esz) {
+  return (C > 32 && bn_bwd_apply_lds_bytes(C, H, W, esz) > 20 * 1024) ? 32 : C;
+}
+bool bn_bwd_apply_uses_lds(int C, int H, int W, size_t esz) {
+  return bn_bwd_apply_lds_bytes(bn_bwd_apply_cslice(C, H, W, esz), H, W, esz) <= 48 * 1024;
+}
 
 template <typename T>
-int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st) {
-  const size_t lds = bn_bwd_apply_lds_bytes(a.C, a.H, a.W, sizeof(T));
+int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st) {
+  BnBwdApplyArgs a = a_in;
+  a.cslice = bn_bwd_apply_cslice(a.C, a.H, a.W, sizeof(T));
+  const size_t lds = bn_bwd_apply_lds_bytes(a.cslice, a.H, a.W, sizeof(T));
   if (a.dv_compact && lds > 48 * 1024) { dta_set_error("bn_bwd_apply: compact dv needs the LDS-image kernel"); return 1; }
   if (lds <= 48 * 1024) {
-    hipLaunchKernelGGL(k_bn_bwd_apply_lds<T>, dim3(a.B, G), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_bn_bwd_apply_lds<T>, dim3(a.B, G, a.C / a.cslice), dim3(256), lds, st, a);
     DTA_CHECK_LAUNCH("k_bn_bwd_apply_lds");
     return 0;
   }
