@@ -98,11 +98,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("DTA_BENCH_BACKEND", "nccl") != "nccl":
+        local = local % torch.cuda.device_count()   # development only: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" is RCCL on ROCm.  DTA_BENCH_BACKEND=gloo exists only to exercise this multi-rank code path with
+        # several ranks sharing ONE GPU (development boxes); it is never a measured configuration.
+        backend = os.environ.get("DTA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from deeptreeattention_amd import Hang2020 as H
     from deeptreeattention_amd import _lib
