@@ -319,11 +319,14 @@ extern "C" int dta_debug_wticks(long long* out) { return (int)hipMemcpyFromSymbo
 #define WTICK(i)
 #define WTICK_DUMP
 #endif
-template <int NTT, bool BIGW>
+template <int CT, int NTT, bool BIGW>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTHR = 512;
-  constexpr int CT = 4 / NTT;            // 32-channel input tiles per workgroup
+  // CT 32-channel input tiles x NTT 32-column tiles per workgroup = PAIRS wave tiles; the 8 waves are PAIRS tiles x
+  // KS k-slices (KS = 2 for the usual 4 tiles; 4 when the layer has only 32 input channels: CT = 1, NTT = 2)
+  constexpr int PAIRS = CT * NTT, KS = 8 / PAIRS;
+  static_assert(PAIRS == 2 || PAIRS == 4, "8 waves = tiles x k-slices");
   constexpr int N = NTT * 32;
   constexpr int XCH = CT * 2, YCH = NTT * 2;
   // The K dimension (haloed-grid rows q0..q1 of a patch) is walked in bands of a.bl rows; a band's LDS window holds
@@ -341,9 +344,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (logical >= total) return;
   const int cg = logical % a.cgroups, s = (logical / a.cgroups) % a.S, g = logical / (a.cgroups * a.S);
-  // wave = ((c-tile, n-tile) pair, k half): the two waves of a pair split the k-steps (even / odd) and hold partial
-  // sums of the same nine tap tiles; waves w and w+4 share a SIMD, so every SIMD carries one wave of each half
-  const int pair = wave & 3, khalf = wave >> 2;
+  // wave = ((c-tile, n-tile) pair, k slice): the KS waves of a pair split the k-steps (ks = slice, slice + KS, ...) and
+  // hold partial sums of the same nine tap tiles; waves w and w+4 share a SIMD and belong to different slices
+  const int pair = wave % PAIRS, khalf = wave / PAIRS;   // khalf: k-slice index 0 .. KS-1
   const int ct = pair / NTT, nt = pair % NTT;
   const int chunk0 = cg * XCH;
   const int nxch = max(0, min(XCH, a.NCx - chunk0));
@@ -441,19 +444,19 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     // The two waves of a SIMD (k halves 0 and 1) run their phases in opposite order: while one issues its LDS
     // writes and global loads for the next window, the other keeps the matrix core busy.
     const bool stage_now = dbuf && more;
-    if (khalf == 1 && stage_now) {
+    if ((khalf & 1) == 1 && stage_now) {
       DTA_STORE(nxt)
       if (it + 2 < niter) DTA_FETCH(DTA_ITER_B(it + 2), DTA_ITER_BAND(it + 2))
     }
     WTICK(1)
 #pragma unroll 1
-    for (int ks = khalf; ks < nks; ks += 2) {
+    for (int ks = khalf; ks < nks; ks += KS) {
       WgradFrags f;
       wgrad_kstep9_load(f, cur, cur + xbytes, a_dy, b_off, ks * 16 * RW);
       wgrad_kstep9_mma(f, acc);
     }
     WTICK(2)
-    if (khalf == 0 && stage_now) {
+    if ((khalf & 1) == 0 && stage_now) {
       DTA_STORE(nxt)
       if (it + 2 < niter) DTA_FETCH(DTA_ITER_B(it + 2), DTA_ITER_BAND(it + 2))
     }
@@ -476,12 +479,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int j0 = 0; j0 < 9; j0 += 2) {
-    if (khalf == 1) {
+    if (khalf != 0) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
         if (j0 + jj < 9) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) red[((pair * 2 + jj) * 16 + r) * 64 + lane] = acc[j0 + jj][r];
+          for (int r = 0; r < 16; ++r) red[(((pair * (KS - 1) + khalf - 1) * 2 + jj) * 16 + r) * 64 + lane] = acc[j0 + jj][r];
         }
     }
     __syncthreads();
@@ -490,7 +493,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
       for (int jj = 0; jj < 2; ++jj)
         if (j0 + jj < 9) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[j0 + jj][r] += red[((pair * 2 + jj) * 16 + r) * 64 + lane];
+          for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j0 + jj][r] += red[(((pair * (KS - 1) + q) * 2 + jj) * 16 + r) * 64 + lane];
         }
     }
     __syncthreads();
@@ -508,9 +513,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   }
 }
 
-template <int NTT>
+template <int CT, int NTT>
 static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream_t st) {
-  constexpr int CT = 4 / NTT;
   WgradArgs a2 = a;
   // band plan: window rows WR = bl + 2*(W+3), WR == 4 (mod 8) (bank-disjoint chunk tiles), WR <= 252 (staging plan)
   wgrad_band_plan(a.Q, a.W, 252, &a2.bl, &a2.wr, &a2.nbands);
@@ -518,18 +522,18 @@ static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream
   size_t stage = (size_t)(CT * 2 + NTT * 2) * a2.wr * RW;
   a2.dbuf = 2 * stage <= 160 * 1024;
   size_t lds = (a2.dbuf ? 2 : 1) * stage;
-  if (lds < 32 * 1024) lds = 32 * 1024;   // the final pair reduction passes 4 x 2 tiles (8 KiB each) through LDS
+  if (lds < 48 * 1024) lds = 48 * 1024;   // the final reduction passes up to 6 x 2 tiles (8 KiB each) through LDS
   if (lds > 160 * 1024) { dta_set_error("conv_wgrad(bf16): LDS need %zu B exceeds 160 KiB", lds); return 1; }
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<NTT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<NTT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   a2.cgroups = cgroups; a2.G = G;
   const int total = cgroups * a.S * G;
-  if (a2.wr <= 192) hipLaunchKernelGGL((k_conv_wgrad_bf16<NTT, false>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
-  else hipLaunchKernelGGL((k_conv_wgrad_bf16<NTT, true>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
+  if (a2.wr <= 192) hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
+  else hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, true>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
   DTA_CHECK_LAUNCH("k_conv_wgrad_bf16");
   return 0;
 }
@@ -539,9 +543,12 @@ int launch_conv_wgrad<bf16_t>(const WgradArgs& a, int G, hipStream_t st) {
   int cpw = wgrad_cpw(a.N);
   int cgroups = (a.Cpad + cpw - 1) / cpw;
   switch (a.N) {
-    case 32: return launch_wgrad_bf16_t<1>(a, G, cgroups, st);
-    case 64: return launch_wgrad_bf16_t<2>(a, G, cgroups, st);
-    case 128: return launch_wgrad_bf16_t<4>(a, G, cgroups, st);
+    case 32: return launch_wgrad_bf16_t<4, 1>(a, G, cgroups, st);
+    case 64:
+      // a 32-channel input (conv2) fills only one of the two c-tiles: run one tile pair-wise over four k-slices
+      if (a.Cpad <= 32 && cgroups == 1) return launch_wgrad_bf16_t<1, 2>(a, G, cgroups, st);
+      return launch_wgrad_bf16_t<2, 2>(a, G, cgroups, st);
+    case 128: return launch_wgrad_bf16_t<1, 4>(a, G, cgroups, st);
   }
   dta_set_error("conv_wgrad: unsupported width %d", a.N);
   return 1;
