@@ -54,7 +54,7 @@ struct Plan {
   int nwg[3], MWG[3];
   int S[3], cgroups[3], CpadW[3];
   size_t x_tl, wp[3], wd[3], y[3], stats[3], coef[3], a_tl[3], feat[3], attpk[2][3], scores[2][3];
-  size_t dsc[2], dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart[3], rowtmp;
+  size_t dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart[3];
   size_t attsave[3]; int attsave_ld[3];
   size_t scores_all, scores_bytes, dfeat_all, dfeat_bytes;
   size_t total;
@@ -135,7 +135,6 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     for (int L = 0; L < 3; ++L) p->scores[g][L] = c.take((size_t)B * p->classes * 4);
   p->scores_bytes = c.off - p->scores_all;
   // backward
-  for (int g = 0; g < 2; ++g) p->dsc[g] = c.take((size_t)B * p->classes * 4);
   p->dfeat_all = c.off;
   for (int L = 0; L < 3; ++L) p->dfeat[L] = c.take((size_t)G * B * (p->Fmax[L] > 0 ? p->Fmax[L] : 1) * 4);
   p->dfeat_bytes = c.off - p->dfeat_all;
@@ -160,7 +159,6 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     int launchG = L == 0 ? 1 : G;
     p->wpart[L] = c.take((size_t)launchG * p->S[L] * 9 * p->CpadW[L] * Nconv * 4);
   }
-  p->rowtmp = c.take((size_t)(B + 1) * 4);
   p->total = c.off;
   return 0;
 }
@@ -369,7 +367,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     // (GemmArgs::sig_mode); d(alpha) is reduced by one extra block of the first GEMM launch below
     BlendBwdArgs bb = {};
     bb.spec = at<float>(ws, p.scores[0][2]); bb.spat = at<float>(ws, p.scores[1][2]);
-    bb.alpha = alpha; bb.djoint = djoint; bb.dalpha = dalpha; bb.rowtmp = nullptr; bb.B = B; bb.classes = p.classes;
+    bb.alpha = alpha; bb.djoint = djoint; bb.dalpha = dalpha; bb.B = B; bb.classes = p.classes;
     if (dalpha == nullptr) { dta_set_error("Hang2020 backward needs a dalpha destination"); return 1; }
     blend_fin = bb; blend_fin_pending = true;
     dsc[0][2] = djoint; dsc[1][2] = djoint;

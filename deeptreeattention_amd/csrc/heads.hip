@@ -257,31 +257,12 @@ int launch_blend(const BlendArgs& a, hipStream_t st) {
   return 0;
 }
 
-__global__ __launch_bounds__(256) void k_blend_bwd_rows(BlendBwdArgs a) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.B) return;
-  const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
-  const float w = (float)wd, w1 = (float)(1.0 - wd);
-  float acc = 0.f;
-  for (int n = lane; n < a.classes; n += 64) {
-    size_t i = (size_t)row * a.classes + n;
-    float d = a.djoint[i];
-    a.dspec[i] = d * w;
-    a.dspat[i] = d * w1;
-    acc += d * (a.spec[i] - a.spat[i]);
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) a.rowtmp[row] = acc;
-}
 constexpr int BLEND_FIN_BLOCKS = 32;
-// d(alpha) = w (1 - w) * sum_{b,n} djoint * (spec - spat).  Either one block sums the row partials k_blend_bwd_rows
-// left (rowtmp != null, part 0 of 1), or BLEND_FIN_BLOCKS blocks each reduce a slice of the (B, classes) slab and add
-// it to dalpha, which then must arrive zeroed like every other gradient buffer.
+// d(alpha) = w (1 - w) * sum_{b,n} djoint * (spec - spat): BLEND_FIN_BLOCKS blocks each reduce a slice of the
+// (B, classes) slab and add it to dalpha, which must arrive zeroed like every other gradient buffer.
 __device__ __forceinline__ void blend_bwd_fin_block(const BlendBwdArgs& a, double* sd, int part, int nparts) {
   double acc = 0;
-  if (a.rowtmp) {
-    for (int r = threadIdx.x; r < a.B; r += 256) acc += a.rowtmp[r];
-  } else {
+  {
     const size_t n4 = (size_t)a.B * a.classes / 4, per = (n4 + nparts - 1) / nparts;
     const size_t beg = part * per, end = min(n4, beg + per);
     const f32x4* dj = (const f32x4*)a.djoint; const f32x4* sp = (const f32x4*)a.spec; const f32x4* st = (const f32x4*)a.spat;
@@ -301,28 +282,22 @@ __device__ __forceinline__ void blend_bwd_fin_block(const BlendBwdArgs& a, doubl
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) {
     const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
-    if (a.rowtmp) a.dalpha[0] = sd[0] * wd * (1.0 - wd);
-    else atomicAdd(a.dalpha, sd[0] * wd * (1.0 - wd));
+    atomicAdd(a.dalpha, sd[0] * wd * (1.0 - wd));
   }
 }
 __global__ __launch_bounds__(256) void k_blend_bwd_fin(BlendBwdArgs a) {
   __shared__ double sd[256];
   blend_bwd_fin_block(a, sd, blockIdx.x, gridDim.x);
 }
-// grouped GEMMs + one trailing block that finishes the blend backward (both only wait for k_blend_bwd_rows)
+// grouped GEMMs + trailing blocks that reduce the blend's d(alpha) (independent of the GEMMs)
 __global__ __launch_bounds__(256) void k_gemm_group_fin(GemmGroup gg, BlendBwdArgs fin, int ngemm) {
   __shared__ __attribute__((aligned(16))) float As[64 * GP];
   __shared__ __attribute__((aligned(16))) float Bs[64 * GP];
   if ((int)blockIdx.x >= ngemm) { blend_bwd_fin_block(fin, reinterpret_cast<double*>(As), blockIdx.x - ngemm, gridDim.x - ngemm); return; }
   gemm_group_block(gg, As, Bs);
 }
-int launch_blend_bwd_rows(const BlendBwdArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_blend_bwd_rows, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
-  DTA_CHECK_LAUNCH("k_blend_bwd_rows");
-  return 0;
-}
 int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hipStream_t st) {
-  const int nfin = fin.rowtmp ? 1 : BLEND_FIN_BLOCKS;
+  const int nfin = BLEND_FIN_BLOCKS;
   if (gg.n == 0) {
     hipLaunchKernelGGL(k_blend_bwd_fin, dim3(nfin), dim3(256), 0, st, fin);
     DTA_CHECK_LAUNCH("k_blend_bwd_fin");
@@ -338,14 +313,6 @@ int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hip
   DTA_CHECK_LAUNCH("k_gemm_group_fin");
   return 0;
 }
-int launch_blend_bwd(const BlendBwdArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_blend_bwd_rows, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
-  DTA_CHECK_LAUNCH("k_blend_bwd_rows");
-  hipLaunchKernelGGL(k_blend_bwd_fin, dim3(1), dim3(256), 0, st, a);
-  DTA_CHECK_LAUNCH("k_blend_bwd_fin");
-  return 0;
-}
-
 // ------------------------------------------------------------------------------------------------
 // F.cross_entropy(logits, y, weight=w): loss = sum_i w[y_i] * nll_i / sum_i w[y_i], plus dlogits.
 // Labels outside [0, classes) are ignored (torch's ignore_index behaviour).

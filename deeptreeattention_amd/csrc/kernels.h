@@ -213,11 +213,10 @@ struct BlendArgs {
 int launch_blend(const BlendArgs& a, hipStream_t st);
 struct BlendBwdArgs {
   const float* spec; const float* spat; const double* alpha; const float* djoint;
-  float* dspec; float* dspat; double* dalpha; float* rowtmp; int B, classes;
+  double* dalpha; int B, classes;
 };
-int launch_blend_bwd(const BlendBwdArgs& a, hipStream_t st);
-// rows pass only; the scalar d(alpha) reduction then rides as one extra block of the next grouped GEMM launch
-int launch_blend_bwd_rows(const BlendBwdArgs& a, hipStream_t st);
+// the blend's backward lives inside the head GEMMs (GemmArgs::sig_mode); its d(alpha) reduction rides as extra blocks
+// of a grouped GEMM launch
 int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hipStream_t st);
 struct CeArgs {
   const float* logits; const long long* labels; const float* weight;  // weight may be null (= ones)
