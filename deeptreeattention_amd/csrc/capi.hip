@@ -380,8 +380,6 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
   WgradReduceGroup reduces;   // likewise the split-K reductions of the conv weight gradients
   for (int L = 2; L >= 0; --L) {
     const int C = CH[L];
-    const int Nconv = L == 0 ? 32 * G : C;
-    const int launchG = L == 0 ? 1 : G;
     StageArgs sa = stage_args(p, d, nets, ws, L);
     const size_t fgs = sa.feat_gs;
     // ---- classifier backward -> dfeat, dW, db (gradient buffers arrive zeroed: split-K accumulates) ----

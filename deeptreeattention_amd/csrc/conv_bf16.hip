@@ -270,7 +270,6 @@ int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------
-constexpr int WGB_PAD_ROWS = 16;
 constexpr int RW = 32;    // weight-gradient LDS rows stay compact (32 B): with chunk tiles 128 B (mod 256 B) apart the two
                           // 16-lane groups of a ds_read_b64_tr_b16 half-wave hit disjoint banks for any row offset
 

@@ -42,11 +42,11 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(BnFinK a) {
   }
   const float* st = a.stats + (size_t)g * a.stats_goff;
   // pass 1: grand mean = sum n_i mean_i / sum n_i
-  double sn = 0, sm = 0;
+  double sm = 0;
   if (c < C)
     for (int wg = sl; wg < a.nwg; wg += 32) {
       double nb = conv_wg_count(wg, a.HW, a.MWG, a.B);
-      sn += nb; sm += nb * (double)st[((size_t)wg * a.stats_ld + c) * 2];
+      sm += nb * (double)st[((size_t)wg * a.stats_ld + c) * 2];
     }
   red[sl][cl] = sm;
   __syncthreads();
@@ -147,7 +147,6 @@ int stage_vslot_for(const StageArgs& a, int G) {
   return spatial ? stage_vslot(a.C, Hz, Wz) : a.C;
 }
 static size_t stage_lds_floats(const StageArgs& a, bool bwd) {
-  int HWc = a.Hc * a.Wc;
   int Hz = a.pool ? a.Hc / 2 : a.Hc, Wz = a.pool ? a.Wc / 2 : a.Wc;
   int HWz = Hz * Wz, ld = a.C + 1;
   size_t n = (size_t)HWz * ld;                 // Z
