@@ -56,6 +56,7 @@ struct Plan {
   size_t x_tl, wp[3], wd[3], y[3], stats[3], coef[3], a_tl[3], feat[3], attpk[2][3], scores[2][3];
   size_t dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart[3];
   size_t attsave[3]; int attsave_ld[3];
+  int x_compact;   // bf16, 11x11-class patches: the network-input tiles are stored without their halo rows
   size_t scores_all, scores_bytes, dfeat_all, dfeat_bytes;
   size_t total;
 };
@@ -115,6 +116,11 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     int S = target / (p->cgroups[L] * launchG);   // floor: never spill into a second round of workgroups
     if (S >= 8) S &= ~7;                           // multiple of 8: whole batch splits per XCD (see k_conv_wgrad_bf16)
     p->S[L] = S < 1 ? 1 : (S > B ? B : S);
+  }
+  {   // halo-free input tiles need the single-window weight-gradient plan (and the bf16 kernels)
+    int bl, wr, nb;
+    wgrad_band_plan(p->Qin[0], p->Wc[0], 252, &bl, &wr, &nb);
+    p->x_compact = d->dtype == DTA_BF16 && nb == 1 && bl >= 16 && wr <= 256;
   }
   Carver c;
   const size_t e = p->esz;
@@ -235,6 +241,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
   {
     PrepArgs pa = {};
     pa.x = x; pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
+    pa.x_compact = p.x_compact;
     pa.packs = packs; pa.spacks = spacks;
     if (d->heads_mask) { pa.zero = at<float>(ws, p.scores_all); pa.zero_n4 = (p.scores_bytes + 15) / 16; }   // split-K GEMM targets
     if (launch_forward_prep<T>(pa, st)) return 1;
@@ -246,7 +253,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     // conv
     ConvArgs ca;
     memset(&ca, 0, sizeof(ca));
-    if (L == 0) { ca.x_tl = at<char>(ws, p.x_tl); ca.x_gs = 0; }
+    if (L == 0) { ca.x_tl = at<char>(ws, p.x_tl); ca.x_gs = 0; ca.x_compact = p.x_compact; }
     else { ca.x_tl = at<char>(ws, p.a_tl[L - 1]); ca.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
     ca.wp = at<char>(ws, p.wp[L]);
     ca.bias[0] = nets[0].conv_b[L]; ca.bias[1] = G == 2 ? nets[1].conv_b[L] : nullptr;
@@ -322,7 +329,7 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
   if (!want_w) return 0;
   WgradArgs wa;
   memset(&wa, 0, sizeof(wa));
-  if (L == 0) { wa.x_tl = at<char>(ws, p.x_tl); wa.x_gs = 0; }
+  if (L == 0) { wa.x_tl = at<char>(ws, p.x_tl); wa.x_gs = 0; wa.x_compact = p.x_compact; }
   else { wa.x_tl = at<char>(ws, p.a_tl[L - 1]); wa.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
   wa.NCx = p.NCin[L];
   wa.dy_tl = at<char>(ws, p.dy_tl[L]);

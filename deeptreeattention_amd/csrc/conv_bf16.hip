@@ -80,19 +80,31 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
 
   // ---- staging plan: 16-byte vectors; thread t owns vectors t, t+512, ... (fixed per thread for all chunks) ----
   constexpr int XV = 4, WV = (9 * N * 2 + NTHR - 1) / NTHR;
-  const int vpp = Q * 2;                      // vectors per patch tile
+  // input tiles in HBM: haloed [q][16] rows, or (x_compact, the network input) halo-free [pixel][16] rows whose zero
+  // halo exists only in LDS (zeroed once below, never overwritten)
+  const bool xc = a.x_compact != 0;
+  const int trows = xc ? HW : Q;              // tile rows in HBM
+  const int vpp = trows * 2;                  // vectors per patch tile
   const int nxv = npatch * vpp, wvec = 9 * N * 2;
   const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs;
   const bf16_t* wg = (const bf16_t*)a.wp + (size_t)g * a.NC * 9 * N * 16;
-  const size_t xchunk = (size_t)Q * 16;       // elements between consecutive chunks of one patch
+  const size_t xchunk = (size_t)trows * 16;   // elements between consecutive chunks of one patch
   size_t xsrc[XV];
   int xdst[XV], wdst[WV];
 #pragma unroll
   for (int u = 0; u < XV; ++u) {
     int v = min(tid + u * NTHR, max(nxv, 1) - 1);
     int pl = v / vpp, o = v - pl * vpp;
+    int row = o >> 1;
+    if (xc) { const int hh = row / a.W; row = (hh + 1) * W2 + (row - hh * a.W) + 1; }   // pixel -> haloed-grid row
     xsrc[u] = ((size_t)(b0 + pl) * a.NC) * xchunk + (size_t)o * 8;
-    xdst[u] = (pl * Q + (o >> 1)) * RB + (o & 1) * 16;
+    xdst[u] = (pl * Q + row) * RB + (o & 1) * 16;
+  }
+  if (xc) {   // the halo rows of both LDS stages
+    u32x4* z = reinterpret_cast<u32x4*>(sbuf);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < xbytes / 16; i += NTHR) { z[i] = zero; if (dbuf) z[i + stage / 16] = zero; }
+    __syncthreads();
   }
 #pragma unroll
   for (int u = 0; u < WV; ++u) {
@@ -374,19 +386,27 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   // vectors per thread: a chunk window has 2*WR vectors; WR <= 192 (11x11 patches: 172) or <= 256 (BIGW)
   constexpr int XV = BIGW ? XCH : (3 * XCH + 3) / 4, YV = BIGW ? YCH : (3 * YCH + 3) / 4;
   const int vpc = WR * 2;                      // 16-byte vectors per chunk window
-  const int nxv = nxch * vpc, nyv = YCH * vpc;
+  // X tiles may be halo-free in HBM (x_compact: the network input, single band): HW rows per chunk, scattered to their
+  // haloed-grid rows of the LDS window; the halo rows stay zero from the initial fill
+  const bool xc = a.x_compact != 0;
+  const int HWp = a.H * a.W;
+  const int vpcx = xc ? HWp * 2 : vpc, xtrows = xc ? HWp : Q;
+  const int nxv = nxch * vpcx, nyv = YCH * vpc;
   const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs;
   const bf16_t* yg = (const bf16_t*)a.dy_tl + (size_t)g * a.dy_gs;
-  const size_t xpatch = (size_t)a.NCx * Q * 16, ypatch = (size_t)a.NCy * Q * 16;
+  const size_t xpatch = (size_t)a.NCx * xtrows * 16, ypatch = (size_t)a.NCy * Q * 16;
   // per vector: element offset inside the patch's tile and window row.  (The LDS image is linear: vector v of a part
   // lives at byte 16*v.)  Vectors past the end of the part are not stored; their loads are pointed at a valid row.
-  int xsrc[XV], ysrc[YV], xrow[XV], yrow[YV];
+  int xsrc[XV], ysrc[YV], xrow[XV], yrow[YV], xdst[XV];
 #pragma unroll
   for (int u = 0; u < XV; ++u) {
     int v = min(tid + u * NTHR, max(nxv, 1) - 1);
-    int ch = v / vpc, o = v - ch * vpc;
-    xrow[u] = o >> 1;
-    xsrc[u] = ((nxch > 0 ? chunk0 : 0) + ch) * Q * 16 + o * 8;
+    int ch = v / vpcx, o = v - ch * vpcx;
+    int row = o >> 1;
+    xsrc[u] = ((nxch > 0 ? chunk0 : 0) + ch) * xtrows * 16 + o * 8;
+    if (xc) { const int hh = row / a.W; row = (hh + 1) * W2 + (row - hh * a.W) + 1; }   // pixel -> haloed-grid row
+    xrow[u] = xc ? 0 : row;                    // compact rows always exist
+    xdst[u] = (ch * WR + row) * RW + (o & 1) * 16;
   }
 #pragma unroll
   for (int u = 0; u < YV; ++u) {
@@ -416,7 +436,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
 #define DTA_STORE(base_)                                                                                          \
   {                                                                                                               \
     _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                                \
-        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((base_) + (tid + u * NTHR) * 16) = rx[u];             \
+        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((base_) + xdst[u]) = rx[u];                           \
     _Pragma("unroll") for (int u = 0; u < YV; ++u)                                                                \
         if (tid + u * NTHR < nyv) *reinterpret_cast<u32x4*>((base_) + xbytes + (tid + u * NTHR) * 16) = ry[u];    \
   }

@@ -19,6 +19,7 @@ struct ConvArgs {
   float* y; size_t y_gs; int y_rs;    // fp32 output rows [row][y_rs], group offset y_gs
   float* stats;                       // [G][nwg][N][2] (mean, M2) or null
   int B, H, W, NC, N, Q, HW, ppw, spp, dbuf;
+  int x_compact;                      // bf16: input tiles are halo-free [patch][chunk][pixel][16] (network input only)
 };
 struct WgradArgs {
   const void* x_tl; size_t x_gs; int NCx;
@@ -26,6 +27,7 @@ struct WgradArgs {
   float* partial;                     // [G][S][9][Cpad][N]
   int B, H, W, Q, N, Cpad, S, dbuf, cgroups, G;
   int bl, wr, nbands;                 // K-band plan (rows per band, LDS window rows, bands per patch)
+  int x_compact;                      // bf16, single band: X tiles are halo-free [patch][chunk][pixel][16]
 };
 // bl = rows per band (multiple of 16), wr = bl + 2*(W+3) rounded up to 4 (mod 8), wr <= wr_max
 void wgrad_band_plan(int Q, int W, int wr_max, int* bl, int* wr, int* nbands);
@@ -201,7 +203,7 @@ __device__ __forceinline__ void pack_spectral_att_job(const SpecPackGroup& gr, i
 #endif
 // one launch for everything the forward needs before its first conv (conv.hip)
 struct PrepArgs {
-  const float* x; void* x_tl; int B, C, H, W, NC, CG, ncg;
+  const float* x; void* x_tl; int B, C, H, W, NC, CG, ncg, x_compact;
   PackWGroup packs; SpecPackGroup spacks;
   float* zero; size_t zero_n4;         // float4 count to clear, or zero == null
 };
