@@ -566,25 +566,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
       }
     }
   }
-  // partial[g][s][tap][c][n]
-  float* out = a.partial + ((size_t)(g * a.S + s) * 9) * a.Cpad * N;
+  // partial[g][tap][c][s][n]: the S partial sums of one output row are contiguous for the reduction
+  float* out = a.partial + (size_t)g * 9 * a.Cpad * a.S * N + (size_t)s * N;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int c = cg * CT * 32 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (c < a.Cpad) out[((size_t)tap * a.Cpad + c) * N + nt * 32 + (lane & 31)] = acc[tap][r];
+      if (c < a.Cpad) out[((size_t)tap * a.Cpad + c) * a.S * N + nt * 32 + (lane & 31)] = acc[tap][r];
     }
 }
 
-// out_g[n][c][tap] (torch layout) = sum_s partial[g][s][tap][c][n]; each thread sums 4 consecutive n.
+// out_g[n][c][tap] (torch layout) = sum_s partial[g][tap][c][s][n]
 __device__ __forceinline__ void wgrad_reduce_blocks(const WgradReduceArgs& a, int bx, int nblocks) {
   // item = (group, tap, channel, 4 consecutive n); FOUR lanes share an item and each sums every fourth slab, then the
   // four partial sums meet through two shuffles: this is a pure streaming read of S slabs, bound by the bytes in
   // flight, and four times as many threads keep four times as many loads outstanding
   const int N = a.N, N4 = N / 4;
   const size_t total = (size_t)a.G * 9 * a.C * N4;
-  const size_t sstride = (size_t)9 * a.Cpad * N;
+  const size_t sstride = (size_t)N;              // the S partial rows of an item are adjacent
   const int part = threadIdx.x & 3;
   const size_t first = (bx * (size_t)blockDim.x + threadIdx.x) >> 2, step = ((size_t)nblocks * blockDim.x) >> 2;
   const size_t iters = (total + step - 1) / step;   // all lanes of a quad iterate together (shuffles below)
@@ -597,7 +597,7 @@ __device__ __forceinline__ void wgrad_reduce_blocks(const WgradReduceArgs& a, in
     int c = r % a.C; r /= a.C;
     int tap = r % 9;
     int g = r / 9;
-    const float* p = a.partial + ((size_t)g * a.S * 9 + tap) * a.Cpad * N + (size_t)c * N + n4 * 4;
+    const float* p = a.partial + (((size_t)g * 9 + tap) * a.Cpad + c) * a.S * N + n4 * 4;
     float4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);

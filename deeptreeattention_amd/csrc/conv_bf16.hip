@@ -520,14 +520,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     __syncthreads();
   }
   if (khalf != 0) return;
-  // partial[g][s][tap][c][n]
-  float* out = a.partial + ((size_t)(g * a.S + s) * 9) * a.Cpad * N;
+  // partial[g][tap][c][s][n]: the S partial sums of one output row are contiguous for the reduction
+  float* out = a.partial + (size_t)g * 9 * a.Cpad * a.S * N + (size_t)s * N;
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int c = cg * CT * 32 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (c < a.Cpad) out[((size_t)j * a.Cpad + c) * N + nt * 32 + (lane & 31)] = acc[j][r];
+      if (c < a.Cpad) out[((size_t)j * a.Cpad + c) * a.S * N + nt * 32 + (lane & 31)] = acc[j][r];
     }
   }
 }

@@ -24,7 +24,7 @@ struct ConvArgs {
 struct WgradArgs {
   const void* x_tl; size_t x_gs; int NCx;
   const void* dy_tl; size_t dy_gs; int NCy, ych0;
-  float* partial;                     // [G][S][9][Cpad][N]
+  float* partial;                     // [G][9][Cpad][S][N]
   int B, H, W, Q, N, Cpad, S, dbuf, cgroups, G;
   int bl, wr, nbands;                 // K-band plan (rows per band, LDS window rows, bands per patch)
   int x_compact;                      // bf16, single band: X tiles are halo-free [patch][chunk][pixel][16]
