@@ -74,6 +74,29 @@ def test_eval_gradients_are_additive_over_the_batch(setup):
         assert rel_l2(gf[k].cpu().numpy(), want.cpu().numpy()) < 1e-3, k
 
 
+def test_eval_gradients_additive_over_an_uneven_split(setup):
+    """Same property with an odd split (513 + 511): 513 takes the two-patches-per-workgroup stage kernels with an odd
+    count (the last workgroup owns a single patch), 511 the one-patch kernels; both must agree with the full batch."""
+    m, x, y = setup
+    m.eval()
+
+    def grads(xs, ys):
+        m.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(m(xs), ys)
+        loss.backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, loss.item()
+
+    gf, lf = grads(x, y)
+    g1, l1 = grads(x[:513].contiguous(), y[:513].contiguous())
+    g2, l2 = grads(x[513:].contiguous(), y[513:].contiguous())
+    assert abs(lf - (513 * l1 + 511 * l2) / 1024) / lf < 1e-5
+    for k in gf:
+        want = (513 * g1[k].double() + 511 * g2[k].double()) / 1024
+        if float(want.norm()) == 0:
+            continue
+        assert rel_l2(gf[k].cpu().numpy(), want.cpu().numpy()) < 1e-3, k
+
+
 def test_bf16_close_to_fp32_at_full_size(setup):
     m, x, y = setup
     mb = copy.deepcopy(m)
