@@ -511,8 +511,10 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
   const bool pool = cfg_pool<CFG>(a);
   const int t = threadIdx.x, C = s.C, ld = s.ld;
   const int kind = a.kind[g];
-  if (kind == KIND_SPATIAL)
-    for (int i = t; i < 2 * s.vslot; i += 256) v3[i] = 0.f;   // padded maps d2 (v3) and d1 (v4)
+  // padded maps d2 (v3) and d1 (v4).  With tiles_ready the caller has already cleared them BEFORE its barrier:
+  // clearing here would race with the first writes into v3 below when no head gradient adds a barrier in between.
+  if (kind == KIND_SPATIAL && !tiles_ready)
+    for (int i = t; i < 2 * s.vslot; i += 256) v3[i] = 0.f;
   TICK(0);
   if (!tiles_ready) {
   // D = incoming gradient wrt the gated map (issued first: its loads fly together with the activations')
