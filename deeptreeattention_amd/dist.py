@@ -58,3 +58,12 @@ class GradSync:
     def broadcast(self, tensors, src=0):
         for t in tensors:
             dist.broadcast(t, src, group=self.group)
+
+
+def kept_anywhere(local, group=None, device="cpu"):
+    """Year-ensemble step under data parallelism: `local[i]` says whether THIS rank's shard of year i is non-zero;
+    returns, identically on every rank, whether ANY rank kept year i (those years are stepped everywhere; ranks
+    that skipped one contribute zero gradients, as DDP does for unused parameters)."""
+    flags = torch.tensor([1.0 if k else 0.0 for k in local], device=device)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+    return [f > 0 for f in flags.tolist()]

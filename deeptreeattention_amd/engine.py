@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from . import Hang2020 as H
-from .dist import GradSync
+from .dist import GradSync, kept_anywhere
 
 
 class FusedTrainer:
@@ -26,7 +26,7 @@ class FusedTrainer:
     """
 
     def __init__(self, model, lr, loss_weight=None, betas=(0.9, 0.999), eps=1e-8, process_group=None,
-                 overlap_comm=True, keep_grads=False):
+                 overlap_comm=True, keep_grads=False, last_head_only=False):
         if not isinstance(model, H._Net):
             raise TypeError("FusedTrainer needs a deeptreeattention_amd network module")
         self.model = model
@@ -39,6 +39,9 @@ class FusedTrainer:
             self.world = torch.distributed.get_world_size(process_group)
         self.overlap = overlap_comm and self.world > 1
         self.hang = model._net_code == _lib.NET_HANG2020
+        self.single_score = model._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
+        # a spectral/spatial network whose caller keeps only the last head's scores (year ensemble, year.py:30)
+        self.last_head_only = bool(last_head_only) and not self.single_score
         plist = model._param_list()
         dev = plist[-1].device
         if dev.type != "cuda":
@@ -101,8 +104,8 @@ class FusedTrainer:
             tensors = {n: H._get(mod, n) for n in names}
             gt = {}
             for n in names:
-                if self.hang and ("classifier1" in n or "classifier2" in n):
-                    continue   # Hang2020.forward keeps only the last heads (reference :256-257): no gradient
+                if (self.hang or self.last_head_only) and ("classifier1" in n or "classifier2" in n):
+                    continue   # only the last heads reach the loss (reference Hang2020.py:256-257, year.py:30)
                 gt[n] = self._gview[id(tensors[n])]
             for Lv in (1, 2, 3):
                 bn = H._get(mod, f"conv{Lv}.bn1")
@@ -120,7 +123,7 @@ class FusedTrainer:
         if key != self._ws_key:
             L = _lib.lib()
             self.desc = _lib.NetDesc(B, bands, Hh, Ww, m._classes, m._net_code, _lib.dtype_code(m.precision),
-                                     1 if m.training else 0, 4 if m._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA) else 7,
+                                     1 if m.training else 0, 4 if (self.single_score or self.last_head_only) else 7,
                                      H.BN_MOMENTUM, H.BN_EPS)
             nbytes = L.dta_net_workspace_bytes(C.byref(self.desc))
             if nbytes == 0:
@@ -132,44 +135,80 @@ class FusedTrainer:
             self.nets, self.grads = self._structs()
             self._ws_key = key
 
-    def train_step(self, x, y):
-        """One optimisation step on the batch (x: float32 NCHW on the device, y: int64 labels).  Returns the loss
-        as a 0-d device tensor (no host sync)."""
+    def _forward_scores(self, x):
+        """Enqueue the network forward; the (B, classes) scores the loss consumes land in self.logits."""
         L = _lib.lib()
-        m = self.model
-        if m._net_code not in (_lib.NET_HANG2020, _lib.NET_VANILLA):
-            raise RuntimeError("train_step supports Hang2020 and vanilla_CNN (single-score models)")
         x = H._check_input(x)
-        if y.dtype != torch.int64 or not y.is_cuda:
-            y = y.to(self.device, torch.int64)
         self._prepare(x)
+        table = _lib.ScoreTable()
+        joint = _lib.ptr(self.logits)
+        if not self.single_score:
+            if not self.last_head_only:
+                raise RuntimeError("the fused step needs a single-score model (Hang2020, vanilla_CNN) or a "
+                                   "spectral/spatial network built with last_head_only=True")
+            table[0][2] = self.logits.data_ptr()
+            joint = None
+        _lib.check(L.dta_net_forward(C.byref(self.desc), self.nets, _lib.ptr(self.alpha) if self.hang else None,
+                                     _lib.ptr(x), _lib.ptr(self._ws), C.byref(table), joint,
+                                     _lib.current_stream_ptr()), "dta_net_forward")
+        return self.logits
+
+    def _loss(self, logits, y, want_grad):
+        L = _lib.lib()
+        _lib.check(L.dta_weighted_ce(_lib.ptr(logits), _lib.ptr(y), _lib.ptr(self.loss_weight), logits.shape[0],
+                                     logits.shape[1], _lib.ptr(self.loss),
+                                     _lib.ptr(self.dlogits) if want_grad else None, _lib.ptr(self.ce_scratch),
+                                     _lib.current_stream_ptr()), "dta_weighted_ce")
+        return self.loss
+
+    def _backward(self, dlogits):
+        """Enqueue the backward of the last forward from d(loss)/d(scores); gradients land in the flat buffer
+        (summed over ranks when data-parallel)."""
+        L = _lib.lib()
         st = _lib.current_stream_ptr()
         d = C.byref(self.desc)
         alpha = _lib.ptr(self.alpha) if self.hang else None
-        table = _lib.ScoreTable()
-        _lib.check(L.dta_net_forward(d, self.nets, alpha, _lib.ptr(x), _lib.ptr(self._ws), C.byref(table),
-                                     _lib.ptr(self.logits), st), "dta_net_forward")
-        _lib.check(L.dta_weighted_ce(_lib.ptr(self.logits), _lib.ptr(y), _lib.ptr(self.loss_weight), x.shape[0],
-                                     m._classes, _lib.ptr(self.loss), _lib.ptr(self.dlogits), _lib.ptr(self.ce_scratch),
-                                     st), "dta_weighted_ce")
         dalpha = _lib.ptr(self.alpha_g) if self.hang else None
-        if not self._grads_clear:      # C-ABI contract: gradient buffers (and dalpha) arrive zero-filled
-            self.flat_g.zero_()
-            if self.hang:
-                self.alpha_g.zero_()
+        table = _lib.ScoreTable()
+        djoint = _lib.ptr(dlogits)
+        if not self.single_score:
+            table[0][2] = dlogits.data_ptr()
+            djoint = None
+        self._zero_grads()             # C-ABI contract: gradient buffers (and dalpha) arrive zero-filled
         if self.world == 1:
-            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table),
-                                          _lib.ptr(self.dlogits), self.grads, dalpha, 3, st), "dta_net_backward")
+            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table), djoint, self.grads,
+                                          dalpha, 3, st), "dta_net_backward")
         else:
             # phase 1: everything but the first conv's weight gradient; its all-reduce (side stream when overlap is
             # on) runs while phase 2, the first conv's weight gradient, is computed
-            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table),
-                                          _lib.ptr(self.dlogits), self.grads, dalpha, 1, st), "dta_net_backward")
+            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table), djoint, self.grads,
+                                          dalpha, 1, st), "dta_net_backward")
             self.sync.reduce_early(self.flat_g[:self.split], self.alpha_g if self.hang else None)
-            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table),
-                                          _lib.ptr(self.dlogits), self.grads, dalpha, 2, st), "dta_net_backward")
+            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table), djoint, self.grads,
+                                          dalpha, 2, st), "dta_net_backward")
             self.sync.reduce_late(self.flat_g[self.split:])
             self.sync.finish()
+        self._grads_clear = False
+
+    def _reduce_zero_grads(self):
+        """Data-parallel step in which THIS rank skipped the network (all-zero year) while another rank did not:
+        take part in the same all-reduces with the (zero) gradient buffer."""
+        if self.world > 1:
+            self._zero_grads()
+            self.sync.reduce_early(self.flat_g[:self.split], self.alpha_g if self.hang else None)
+            self.sync.reduce_late(self.flat_g[self.split:])
+            self.sync.finish()
+            self._grads_clear = False
+
+    def _zero_grads(self):
+        if not self._grads_clear:
+            self.flat_g.zero_()
+            if self.hang:
+                self.alpha_g.zero_()
+            self._grads_clear = True
+
+    def _adam(self):
+        L = _lib.lib()
         self.step_count += 1
         # default: step + zero_grad in one pass, so the next backward finds its gradient buffers already cleared
         adam = L.dta_adam_step if self.keep_grads else L.dta_adam_step_zero_grad
@@ -180,24 +219,172 @@ class FusedTrainer:
                         _lib.ptr(self.alpha_m) if self.hang else None,
                         _lib.ptr(self.alpha_v) if self.hang else None,
                         self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
-                        self.sync.grad_scale, st), "dta_adam_step")
+                        self.sync.grad_scale, _lib.current_stream_ptr()), "dta_adam_step")
         self._grads_clear = not self.keep_grads
+
+    def _labels(self, y):
+        if y.dtype != torch.int64 or not y.is_cuda:
+            y = y.to(self.device, torch.int64)
+        return y
+
+    def train_step(self, x, y):
+        """One optimisation step on the batch (x: float32 NCHW on the device, y: int64 labels).  Returns the loss
+        as a 0-d device tensor (no host sync)."""
+        if not self.single_score:
+            raise RuntimeError("train_step supports Hang2020 and vanilla_CNN (single-score models); a year ensemble "
+                               "of spectral networks trains through EnsembleTrainer")
+        y = self._labels(y)
+        logits = self._forward_scores(x)
+        self._loss(logits, y, True)
+        self._backward(self.dlogits)
+        self._adam()
         return self.loss
+
+    def training_step(self, batch, batch_idx=0):
+        """The reference's TreeModel.training_step unpacking (src/main.py:71-80): batch = (individual, inputs, y),
+        images = inputs["HSI"]; runs the whole optimisation step and returns the loss."""
+        individual, inputs, y = batch
+        return self.train_step(inputs["HSI"], y)
+
+    def validation_step(self, batch, batch_idx=0):
+        """TreeModel.validation_step (src/main.py:82-94): forward + weighted CE, no update."""
+        individual, inputs, y = batch
+        return self.forward_loss(inputs["HSI"], y)[1]
 
     def forward_loss(self, x, y):
         """Forward + loss only (validation_step, reference src/main.py:82-94); returns (logits, loss)."""
+        logits = self._forward_scores(x)
+        return logits, self._loss(logits, self._labels(y), False)
+
+
+class EnsembleTrainer:
+    """Fused train step of the year ensemble (reference src/models/year.py:9-33) as the reference's MultiStage loop
+    drives one level of it (src/models/multi_stage.py:277-288 training_step, :258-275 one Adam per level):
+    scores = mean over the kept years of each year's last-head scores, loss = weighted CE, backward, Adam.
+
+    Every year's spectral_network owns flat parameter / gradient / moment buffers (a FusedTrainer restricted to the
+    last head).  A year whose whole batch tensor sums to zero is skipped exactly as the reference skips it: no
+    forward (BatchNorm running statistics and num_batches_tracked untouched), no gradient, and -- since torch's Adam
+    passes over parameters whose grad is None -- no moment decay and no step-count advance for that year.  The
+    zero-year test costs ONE host transfer per step (the reference: one blocking comparison per year); callers that
+    know which years are present (the reference's dataset zero-fills missing years, src/data.py) pass `present`
+    and the step enqueues without any host synchronisation.
+
+    Data-parallel: a year is stepped when any rank kept it; ranks that skipped it contribute zero gradients to the
+    same all-reduces (what DDP does for unused parameters)."""
+
+    def __init__(self, model, lr, loss_weight=None, betas=(0.9, 0.999), eps=1e-8, process_group=None,
+                 overlap_comm=True, keep_grads=False):
+        from .year import learned_ensemble
+        if not isinstance(model, learned_ensemble):
+            raise TypeError("EnsembleTrainer needs a deeptreeattention_amd.year.learned_ensemble")
+        self.model = model
+        self.years = [FusedTrainer(m, lr, loss_weight, betas, eps, process_group, overlap_comm, keep_grads,
+                                   last_head_only=True) for m in model.year_models]
+        first = self.years[0]
+        self.device, self.world, self.pg = first.device, first.world, first.pg
+        self.loss_weight = first.loss_weight
+        self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
+        self._shape = None
+
+    @property
+    def lr(self):
+        return self.years[0].lr
+
+    @lr.setter
+    def lr(self, value):       # ReduceLROnPlateau-style schedulers set one rate per level
+        for t in self.years:
+            t.lr = float(value)
+
+    def grad_of(self, param):
+        for t in self.years:
+            if id(param) in t._gview:
+                return t._gview[id(param)]
+        raise KeyError("not a parameter of this ensemble")
+
+    def _kept(self, images, present):
+        if len(images) != len(self.years):
+            raise ValueError("expected one image tensor per year ({}), got {}".format(len(self.years), len(images)))
+        if present is None:
+            # reference year.py:27 (`x.sum() == 0`), all years in one host transfer
+            present = (torch.stack([x.sum() for x in images]) != 0).tolist()
+        local = [bool(k) for k in present]
+        if not any(local):
+            raise RuntimeError("every year of the batch is all-zero: the reference has nothing to average (year.py:33)")
+        anywhere = local
+        if self.world > 1:
+            anywhere = kept_anywhere(local, self.pg, self.device)
+        return local, anywhere
+
+    def _buffers(self, B, classes):
+        if self._shape != (B, classes):
+            self.scores = torch.empty(B, classes, dtype=torch.float32, device=self.device)
+            self.dscores = torch.empty_like(self.scores)
+            self.ce_scratch = torch.empty(B + 1, dtype=torch.float32, device=self.device)
+            self._shape = (B, classes)
+
+    def _forward(self, images, local):
+        kept = [i for i, k in enumerate(local) if k]
+        per_year = [self.years[i]._forward_scores(images[i]) for i in kept]
+        B, classes = per_year[0].shape
+        self._buffers(B, classes)
+        torch.mean(torch.stack(per_year, dim=1), dim=1, out=self.scores)        # year.py:33
+        return kept
+
+    def _ce(self, y, want_grad):
         L = _lib.lib()
-        x = H._check_input(x)
-        self._prepare(x)
-        st = _lib.current_stream_ptr()
-        table = _lib.ScoreTable()
-        _lib.check(L.dta_net_forward(C.byref(self.desc), self.nets, _lib.ptr(self.alpha) if self.hang else None,
-                                     _lib.ptr(x), _lib.ptr(self._ws), C.byref(table), _lib.ptr(self.logits), st),
-                   "dta_net_forward")
-        _lib.check(L.dta_weighted_ce(_lib.ptr(self.logits), _lib.ptr(y), _lib.ptr(self.loss_weight), x.shape[0],
-                                     self.model._classes, _lib.ptr(self.loss), None, _lib.ptr(self.ce_scratch), st),
-                   "dta_weighted_ce")
-        return self.logits, self.loss
+        _lib.check(L.dta_weighted_ce(_lib.ptr(self.scores), _lib.ptr(y), _lib.ptr(self.loss_weight),
+                                     self.scores.shape[0], self.scores.shape[1], _lib.ptr(self.loss),
+                                     _lib.ptr(self.dscores) if want_grad else None, _lib.ptr(self.ce_scratch),
+                                     _lib.current_stream_ptr()), "dta_weighted_ce")
+
+    def train_step(self, images, y, present=None):
+        """images: list of (B, bands, H, W) float32 device tensors, one per year; y: int64 labels.  Returns the loss
+        as a 0-d device tensor."""
+        local, anywhere = self._kept(images, present)
+        y = self.years[0]._labels(y)
+        kept = self._forward(images, local)
+        self._ce(y, True)
+        self.dscores.mul_(1.0 / len(kept))      # d(mean over kept years)/d(year score)
+        for i, t in enumerate(self.years):
+            if local[i]:
+                t._backward(self.dscores)
+            elif anywhere[i]:
+                t._reduce_zero_grads()
+            else:
+                t._zero_grads()                 # skipped everywhere: grad None in the reference
+        for i, t in enumerate(self.years):
+            if anywhere[i]:
+                t._adam()
+        return self.loss
+
+    def forward_loss(self, images, y, present=None):
+        """validation_step of the level (multi_stage.py:290-304): ensemble scores + weighted CE, no update."""
+        local, _ = self._kept(images, present)
+        self._forward(images, local)
+        self._ce(self.years[0]._labels(y), False)
+        return self.scores, self.loss
+
+
+class MultiStageTrainer:
+    """Step driver of the reference's hierarchical model (src/models/multi_stage.py): one year ensemble, one class
+    weight vector, one Adam and one learning rate per level, selected by Lightning's optimizer_idx /
+    dataloader_idx.  Batches keep the reference's structure: (individual, {"HSI": [year tensors]}, labels)."""
+
+    def __init__(self, models, lrs, loss_weights=None, **kwargs):
+        loss_weights = loss_weights or [None] * len(models)
+        self.levels = [EnsembleTrainer(m, lr, w, **kwargs) for m, lr, w in zip(models, lrs, loss_weights)]
+
+    def training_step(self, batch, batch_idx, optimizer_idx, present=None):
+        """multi_stage.py:277-288: the level's batch is batch[optimizer_idx]."""
+        individual, inputs, y = batch[optimizer_idx]
+        return self.levels[optimizer_idx].train_step(inputs["HSI"], y, present)
+
+    def validation_step(self, batch, batch_idx, dataloader_idx, present=None):
+        """multi_stage.py:290-304: returns the level's softmax scores with the loss."""
+        individual, inputs, y = batch
+        scores, loss = self.levels[dataloader_idx].forward_loss(inputs["HSI"], y, present)
+        return {"individual": individual, "yhat": torch.softmax(scores, dim=1), "label": y, "val_loss": loss}
 
 
 def predict(model, images, return_probs=True):

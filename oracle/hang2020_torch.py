@@ -89,3 +89,33 @@ class TrainStep:
         loss.backward()
         self.opt.step()
         return logits.detach(), loss.detach()
+
+
+def learned_ensemble(p, images, training=True, pre=""):
+    """src/models/year.py:24-33: one spectral_network per year; a year whose whole batch tensor sums to zero is
+    skipped (:27); the kept years' last-head scores are averaged (:30, :33)."""
+    scores = []
+    for i, x in enumerate(images):
+        if x.sum() == 0:
+            continue
+        scores.append(subnet(p, f"{pre}year_models.{i}.", "spectral", x, training)[-1])
+    return torch.stack(scores, dim=1).mean(dim=1)
+
+
+class EnsembleTrainStep:
+    """One level of the reference's MultiStage loop on stock torch ops: src/models/multi_stage.py:277-288
+    (training_step: weighted CE of the ensemble's scores) and :258-275 (one Adam per level).  Parameters of a
+    skipped year keep grad None, so torch's Adam leaves them, their moments and their step counts untouched."""
+
+    def __init__(self, params, lr, loss_weight=None):
+        self.p = params
+        self.w = loss_weight
+        self.opt = torch.optim.Adam([t for t in params.values() if t.requires_grad], lr=lr)
+
+    def __call__(self, images, y):
+        self.opt.zero_grad(set_to_none=True)
+        scores = learned_ensemble(self.p, images, True)
+        loss = F.cross_entropy(scores, y, weight=self.w)
+        loss.backward()
+        self.opt.step()
+        return scores.detach(), loss.detach()

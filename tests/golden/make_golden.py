@@ -251,8 +251,53 @@ def case_subnets():
     print("subnets.npz", len(out))
 
 
+def case_ensemble_steps():
+    """Year-ensemble train steps as MultiStage drives them (reference src/models/multi_stage.py:258-288: per-level
+    Adam over models[level].parameters(), loss = F.cross_entropy(model(images), y, weight=loss_weight)), with the
+    reference's learned_ensemble.  Step 2 has an all-zero year: its sub-network is skipped (year.py:27), gets no
+    gradient and is left untouched by Adam (its per-parameter step count does not advance)."""
+    out = {}
+    years, bands, classes, B, lr = 3, 16, 7, 6, 1e-3
+    p = O.init_params(O.learned_ensemble_spec(years, bands, classes), seed=81)
+    m = RY.learned_ensemble(years=years, classes=classes, config={"pretrain_state_dict": None, "bands": bands})
+    load(m, p)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    w = torch.from_numpy((0.1 + (np.arange(classes) % 7)).astype(np.float32))
+    for step in range(4):
+        imgs = [prng.uniform01(82 + step, yy, (B, bands, 11, 11)) for yy in range(years)]
+        if step == 1:
+            imgs[2] = np.zeros_like(imgs[2])
+        if step == 2:
+            imgs[0] = np.zeros_like(imgs[0])
+        y = torch.from_numpy(prng.randint(82 + step, 7, (B,), classes))
+        opt.zero_grad(set_to_none=True)
+        s = m([torch.from_numpy(a) for a in imgs])
+        loss = F.cross_entropy(s, y, weight=w)
+        loss.backward()
+        opt.step()
+        out[f"step{step}/score"] = s.detach().numpy()
+        out[f"step{step}/loss"] = np.float64(loss.item())
+        for k, prm in m.named_parameters():
+            a = prm.detach().numpy()
+            out[f"step{step}/pnorm/{k}"] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+            if a.size <= 4096:
+                out[f"step{step}/pfull/{k}"] = a.copy()
+            else:
+                out[f"step{step}/psamp/{k}"] = a.reshape(-1)[sample_idx(a.size)].copy()
+        for k, b in m.named_buffers():
+            out[f"step{step}/buf/{k}"] = b.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "ensemble_steps.npz"), **out)
+    print("ensemble_steps.npz", len(out))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:      # regenerate only the named cases, e.g. `make_golden.py case_ensemble_steps`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     case_modules()
     case_hang_small()
     case_subnets()
+    case_ensemble_steps()
     case_hang_full()

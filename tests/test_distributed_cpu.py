@@ -67,3 +67,32 @@ def test_flat_layout_puts_first_conv_last():
     order, split, total = flat_layout(sizes, late=lambda k: k.endswith("conv1.conv_layer.weight"))
     assert total == 191 and split == 41
     assert [k for k, _ in order[-2:]] == ["a.conv1.conv_layer.weight", "b.conv1.conv_layer.weight"]
+
+
+def _ensemble_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deeptreeattention_amd.dist import GradSync, kept_anywhere
+    # year 0 kept by both ranks, year 1 only by rank 1, year 2 by nobody
+    local = [True, rank == 1, False]
+    anywhere = kept_anywhere(local)
+    sync = GradSync(world=world)
+    # the year only rank 1 kept: rank 0 joins the same two-phase reduction with its zero-filled buffer
+    g = torch.full((10,), 3.0) if local[1] else torch.zeros(10)
+    sync.reduce_early(g[:6])
+    sync.reduce_late(g[6:])
+    sync.finish()
+    out[rank] = (anywhere, g.tolist(), sync.grad_scale)
+    dist.destroy_process_group()
+
+
+def test_ensemble_year_flags_and_zero_gradient_participation_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ensemble_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        anywhere, g, scale = out[r]
+        assert anywhere == [True, True, False]
+        assert g == [3.0] * 10 and scale == 0.5     # averaged gradient 1.5 on both ranks

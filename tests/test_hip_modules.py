@@ -194,3 +194,57 @@ def test_predict_softmax_top2():
     tv, ti = torch.topk(ref, 2, dim=1)
     assert torch.equal(ti.cpu(), idx.cpu())
     assert rel_l2(score.cpu().numpy(), tv.cpu().numpy()) < 1e-5
+
+
+def _ensemble_step_inputs(step, years, B, bands, classes):
+    imgs = [prng.uniform01(82 + step, yy, (B, bands, 11, 11)) for yy in range(years)]
+    if step == 1:
+        imgs[2] = np.zeros_like(imgs[2])
+    if step == 2:
+        imgs[0] = np.zeros_like(imgs[0])
+    return imgs, prng.randint(82 + step, 7, (B,), classes)
+
+
+@pytest.mark.parametrize("use_present", [False, True])
+def test_ensemble_trainer_steps_vs_reference_golden(golden, use_present):
+    """Year-ensemble train steps as the reference's MultiStage loop runs one level (multi_stage.py:258-288), two
+    of the four steps with an all-zero year: scores, loss, every parameter and every BatchNorm buffer after each
+    step against the reference's learned_ensemble + F.cross_entropy + torch Adam."""
+    from deeptreeattention_amd.year import learned_ensemble
+    from deeptreeattention_amd.engine import EnsembleTrainer, MultiStageTrainer
+    g = golden("ensemble_steps.npz")
+    years, bands, classes, B, lr = 3, 16, 7, 6, 1e-3
+    p = O.init_params(O.learned_ensemble_spec(years, bands, classes), seed=81)
+    m = load(learned_ensemble(years=years, classes=classes, config={"pretrain_state_dict": None, "bands": bands}), p)
+    m.train()
+    w = torch.from_numpy((0.1 + (np.arange(classes) % 7)).astype(np.float32))
+    driver = MultiStageTrainer([m], [lr], [w])
+    tr = driver.levels[0]
+    assert isinstance(tr, EnsembleTrainer)
+    for step in range(4):
+        imgs, y = _ensemble_step_inputs(step, years, B, bands, classes)
+        present = [bool(a.any()) for a in imgs] if use_present else None
+        batch = [(["id"] * B, {"HSI": [torch.from_numpy(a).to(dev()) for a in imgs]}, torch.from_numpy(y).to(dev()))]
+        loss = driver.training_step(batch, step, 0, present)
+        assert rel_l2(tr.scores.cpu().numpy(), g[f"step{step}/score"]) < TIGHT, step
+        ref = float(g[f"step{step}/loss"])
+        assert abs(float(loss) - ref) < TIGHT * abs(ref), step
+        for k, prm in m.named_parameters():
+            if k.endswith("conv_layer.bias"):
+                continue   # conv biases under BN: gradient is rounding noise, Adam turns its sign into +-lr steps
+            a = prm.detach().cpu().numpy()
+            ref = float(g[f"step{step}/pnorm/{k}"])
+            assert abs(np.sqrt((a.astype(np.float64) ** 2).sum()) - ref) <= 1e-3 * ref, (step, k)
+            if f"step{step}/pfull/{k}" in g:
+                assert rel_l2(a, g[f"step{step}/pfull/{k}"]) < 2e-3, (step, k)
+            else:
+                idx = (prng.hash_u64(7, 99, 256) % np.uint64(a.size)).astype(np.int64)
+                assert rel_l2(a.reshape(-1)[idx], g[f"step{step}/psamp/{k}"]) < 2e-3, (step, k)
+        for k, b in m.named_buffers():
+            # running means carry the conv bias (noise-signed +-lr Adam steps, see above): looser bound
+            tol = 2e-3 if k.endswith("running_mean") else TIGHT
+            assert rel_l2(b.cpu().numpy(), g[f"step{step}/buf/{k}"]) < tol, (step, k)
+    # the skipped years' optimizer step counts did not advance (torch's Adam passes over grad-None parameters)
+    assert [t.step_count for t in tr.years] == [3, 4, 3]
+    out = driver.validation_step(batch[0], 0, 0, present)
+    assert out["yhat"].shape == (B, classes) and abs(float(out["yhat"].sum()) - B) < 1e-4

@@ -228,3 +228,36 @@ def test_torch_port_matches_reference_golden(golden):
         a = t.detach().numpy().reshape(-1)
         s = a[(prng.hash_u64(7, 99, 64) % np.uint64(a.size)).astype(np.int64)] if a.size > 64 else a
         assert rel_l2(s, g[f"p3_samp/{k}"]) < 2e-3, k
+
+
+def _ensemble_step_inputs(step, years, B, bands, classes):
+    imgs = [prng.uniform01(82 + step, yy, (B, bands, 11, 11)) for yy in range(years)]
+    if step == 1:
+        imgs[2] = np.zeros_like(imgs[2])
+    if step == 2:
+        imgs[0] = np.zeros_like(imgs[0])
+    return imgs, prng.randint(82 + step, 7, (B,), classes)
+
+
+def test_torch_oracle_ensemble_steps_match_reference_golden(golden):
+    """Year-ensemble train steps (MultiStage recipe) incl. two steps with an all-zero year: the torch restatement
+    against the reference's learned_ensemble + F.cross_entropy + Adam."""
+    import torch
+    from oracle import hang2020_torch as OT
+    g = golden("ensemble_steps.npz")
+    years, bands, classes, B, lr = 3, 16, 7, 6, 1e-3
+    p = OT.to_tensors(O.init_params(O.learned_ensemble_spec(years, bands, classes), seed=81))
+    w = torch.from_numpy((0.1 + (np.arange(classes) % 7)).astype(np.float32))
+    step_fn = OT.EnsembleTrainStep(p, lr, w)
+    for step in range(4):
+        imgs, y = _ensemble_step_inputs(step, years, B, bands, classes)
+        s, loss = step_fn([torch.from_numpy(a) for a in imgs], torch.from_numpy(y))
+        assert rel_l2(s.numpy(), g[f"step{step}/score"]) < 1e-4, step
+        assert abs(float(loss) - float(g[f"step{step}/loss"])) < 1e-4 * abs(float(g[f"step{step}/loss"]))
+        for k, t in p.items():
+            if not t.requires_grad:
+                assert rel_l2(t.numpy(), g[f"step{step}/buf/{k}"]) < 1e-4, (step, k)
+                continue
+            a = t.detach().numpy()
+            assert abs(np.sqrt((a.astype(np.float64) ** 2).sum()) - float(g[f"step{step}/pnorm/{k}"])) \
+                <= 1e-5 * float(g[f"step{step}/pnorm/{k}"]), (step, k)
