@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdta_hip.so")
 
 DTA_F32, DTA_BF16 = 0, 1
+MAX_YEARS = 4   # DTA_MAX_YEARS
 NET_HANG2020, NET_SPECTRAL, NET_SPATIAL, NET_VANILLA = 0, 1, 2, 3
 SITE_CONV_FWD, SITE_CONV_WGRAD, SITE_CONV_DGRAD, SITE_STAGE_FWD, SITE_STAGE_BWD, SITE_GEMM = 0, 3, 6, 9, 12, 15
 _DTYPES = {"fp32": DTA_F32, "f32": DTA_F32, "float32": DTA_F32, "bf16": DTA_BF16, "bfloat16": DTA_BF16}
@@ -74,6 +75,14 @@ def lib():
         L.dta_net_backward.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p,
                                        C.POINTER(ScoreTable), C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p,
                                        C.c_int, C.c_void_p]
+        L.dta_ensemble_workspace_bytes.restype = C.c_size_t
+        L.dta_ensemble_workspace_bytes.argtypes = [C.POINTER(NetDesc), C.c_int]
+        L.dta_ensemble_forward.restype = C.c_int
+        L.dta_ensemble_forward.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams),
+                                           C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_ensemble_backward.restype = C.c_int
+        L.dta_ensemble_backward.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams), C.c_void_p,
+                                            C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p]
         L.dta_weighted_ce.restype = C.c_int
         L.dta_weighted_ce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]

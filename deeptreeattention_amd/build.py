@@ -34,12 +34,16 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     objs, procs = [], []
+    extra = os.environ.get("DTA_EXTRA_HIPCC_FLAGS", "").split()
+    stamp = os.path.join(objdir, "flags.txt")   # objects built with other flags (developer -D switches) are stale
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(FLAGS + extra):
+        force = True
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + os.environ.get("DTA_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -51,6 +55,8 @@ def build(force=False, verbose=True):
             sys.stderr.write(f"--- {src} failed ---\n{out}\n")
     if failed:
         raise RuntimeError("hipcc failed")
+    with open(stamp, "w") as f:
+        f.write(" ".join(FLAGS + extra))
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

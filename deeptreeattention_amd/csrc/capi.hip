@@ -46,14 +46,16 @@ struct Carver {
 // All workspace offsets for one network description (identical in forward and backward).
 struct Plan {
   int G, B, bands, H, W, classes, esz;
-  int kinds[2];
+  int kinds[MAXG];
+  int shared_x;   // Hang2020: both branches read the same input, so the first conv is ONE launch over [branch0|branch1] columns
+  size_t x_tl_gs;  // bytes between the groups' network-input tiles (0 when shared)
   int NC0;
   int Hc[3], Wc[3], Hz[3], Wz[3], HWc[3], HWz[3], Qin[3];  // conv-res dims, post-pool dims, haloed grid of conv input
   int Cin[3], NCin[3];
-  int F[2][3], Fmax[3], vec_ld[3];
+  int F[MAXG][3], Fmax[3], vec_ld[3];
   int nwg[3], MWG[3];
   int S[3], cgroups[3], CpadW[3];
-  size_t x_tl, wp[3], wd[3], y[3], stats[3], coef[3], a_tl[3], feat[3], attpk[2][3], scores[2][3];
+  size_t x_tl, wp[3], wd[3], y[3], stats[3], coef[3], a_tl[3], feat[3], attpk[MAXG][3], scores[MAXG][3];
   size_t dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart[3];
   size_t attsave[3]; int attsave_ld[3];
   int x_compact;   // bf16, 11x11-class patches: the network-input tiles are stored without their halo rows
@@ -61,7 +63,7 @@ struct Plan {
   size_t total;
 };
 
-int build_plan(const dta_net_desc* d, Plan* p) {
+int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
   memset(p, 0, sizeof(*p));
   if (d->batch < 1 || d->bands < 1 || d->height < 4 || d->width < 4 || d->classes < 1) {
     dta_set_error("bad descriptor: batch=%d bands=%d H=%d W=%d classes=%d", d->batch, d->bands, d->height, d->width, d->classes);
@@ -69,6 +71,7 @@ int build_plan(const dta_net_desc* d, Plan* p) {
   }
   if (d->height + 2 > 255 || (d->height + 2) * (d->width + 2) > 65535) { dta_set_error("patch too large"); return 1; }
   p->G = d->kind == DTA_NET_HANG2020 ? 2 : 1;
+  p->shared_x = d->kind == DTA_NET_HANG2020;
   p->B = d->batch; p->bands = d->bands; p->H = d->height; p->W = d->width; p->classes = d->classes;
   p->esz = d->dtype == DTA_BF16 ? 2 : 4;
   switch (d->kind) {
@@ -77,6 +80,11 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     case DTA_NET_SPATIAL: p->kinds[0] = KIND_SPATIAL; break;
     case DTA_NET_VANILLA: p->kinds[0] = KIND_PLAIN; break;
     default: dta_set_error("unknown network kind %d", d->kind); return 1;
+  }
+  if (years > 0) {   // year ensemble: `years` spectral networks, each on its own input
+    if (d->kind != DTA_NET_SPECTRAL || years > MAXG) { dta_set_error("an ensemble is 1..%d spectral networks", MAXG); return 1; }
+    p->G = years;
+    for (int g = 0; g < years; ++g) p->kinds[g] = KIND_SPECTRAL;
   }
   const int G = p->G, B = p->B;
   p->NC0 = (d->bands + 15) / 16;
@@ -102,7 +110,7 @@ int build_plan(const dta_net_desc* d, Plan* p) {
       if (f > p->Fmax[L]) p->Fmax[L] = f;
       if (vl > p->vec_ld[L]) p->vec_ld[L] = vl;
     }
-    int Nconv = L == 0 ? 32 * G : CH[L];
+    int Nconv = (L == 0 && p->shared_x) ? 32 * G : CH[L];
     p->MWG[L] = conv_mwg(Nconv);
     int ppw, spp;
     conv_geometry(p->HWc[L], p->MWG[L], B, &ppw, &spp, &p->nwg[L]);
@@ -110,7 +118,7 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     int cpw = wgrad_cpw(Nconv);
     p->CpadW[L] = p->NCin[L] * 16;
     p->cgroups[L] = (p->CpadW[L] + cpw - 1) / cpw;
-    int launchG = L == 0 ? 1 : G;
+    int launchG = (L == 0 && p->shared_x) ? 1 : G;
     // bf16 path: register-prefetch pipeline, 1 workgroup per CU; fp32 path: 2 workgroups per CU overlap each other
     int target = d->dtype == DTA_BF16 ? 256 : 512;
     int S = target / (p->cgroups[L] * launchG);   // floor: never spill into a second round of workgroups
@@ -124,10 +132,14 @@ int build_plan(const dta_net_desc* d, Plan* p) {
   }
   Carver c;
   const size_t e = p->esz;
-  p->x_tl = c.take((size_t)B * p->NC0 * p->Qin[0] * 16 * e);
+  {
+    const size_t one = ((size_t)B * p->NC0 * p->Qin[0] * 16 * e + 255) & ~(size_t)255;
+    p->x_tl_gs = p->shared_x ? 0 : one;
+    p->x_tl = c.take(one * (p->shared_x ? 1 : G));
+  }
   for (int L = 0; L < 3; ++L) {
-    int Nconv = L == 0 ? 32 * G : CH[L];
-    int gw = L == 0 ? 1 : G;
+    int Nconv = (L == 0 && p->shared_x) ? 32 * G : CH[L];
+    int gw = (L == 0 && p->shared_x) ? 1 : G;
     p->wp[L] = c.take((size_t)gw * p->NCin[L] * 9 * Nconv * 16 * e);
     p->y[L] = c.take((size_t)G * B * p->HWc[L] * CH[L] * 4);
     p->stats[L] = c.take((size_t)gw * p->nwg[L] * Nconv * 2 * 4);
@@ -161,8 +173,8 @@ int build_plan(const dta_net_desc* d, Plan* p) {
     }
   }
   for (int L = 0; L < 3; ++L) {   // split-K slabs of every layer stay live until the one grouped reduction
-    int Nconv = L == 0 ? 32 * G : CH[L];
-    int launchG = L == 0 ? 1 : G;
+    int Nconv = (L == 0 && p->shared_x) ? 32 * G : CH[L];
+    int launchG = (L == 0 && p->shared_x) ? 1 : G;
     p->wpart[L] = c.take((size_t)launchG * p->S[L] * 9 * p->CpadW[L] * Nconv * 4);
   }
   p->total = c.off;
@@ -189,7 +201,7 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
     }
   }
   s.y = at<float>(ws, p.y[L]);
-  if (L == 0) { s.y_gs = 32; s.y_rs = 32 * G; }
+  if (L == 0 && p.shared_x) { s.y_gs = 32; s.y_rs = 32 * G; }
   else { s.y_gs = (size_t)B * p.HWc[L] * C; s.y_rs = C; }
   s.coef = at<float>(ws, p.coef[L]); s.coef_gs = C * 4;
   s.apply_bn = 1; s.relu = 1; s.pool = L > 0;
@@ -207,8 +219,8 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
 }
 
 template <typename T>
-int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const float* x,
-              void* ws, float* const scores[2][3], float* joint, hipStream_t st) {
+int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha,
+              const float* const* xs, void* ws, float* const (*scores)[3], float* joint, hipStream_t st) {
   const int G = p.G, B = p.B;
   GemmGroup heads;
   // ---- all weight re-layouts of the step in two launches (forward forms, and when training the transposed
@@ -220,15 +232,16 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     const int C = CH[L];
     PackWArgs pw;
     memset(&pw, 0, sizeof(pw));
-    pw.G = L == 0 ? 1 : G; pw.NC = p.NCin[L]; pw.N = L == 0 ? 32 * G : C; pw.K = p.Cin[L];
-    pw.src[0] = nets[0].conv_w[L]; pw.src[1] = G == 2 ? nets[1].conv_w[L] : nullptr;
-    pw.mode = (L == 0 && G == 2) ? 1 : 0; pw.nsplit = 32;
+    const bool cat = L == 0 && p.shared_x;   // one launch over the concatenated branch columns
+    pw.G = cat ? 1 : G; pw.NC = p.NCin[L]; pw.N = cat ? 32 * G : C; pw.K = p.Cin[L];
+    for (int g = 0; g < G; ++g) pw.src[g] = nets[g].conv_w[L];
+    pw.mode = (cat && G == 2) ? 1 : 0; pw.nsplit = 32;
     pack_mode[L] = pw.mode;
     packs.job[packs.n] = pw; packs.dst[packs.n++] = at<char>(ws, p.wp[L]);
     if (L > 0 && d->training) {
       memset(&pw, 0, sizeof(pw));
       pw.G = G; pw.NC = C / 16; pw.N = CH[L - 1]; pw.K = C; pw.mode = 2;
-      pw.src[0] = nets[0].conv_w[L]; pw.src[1] = G == 2 ? nets[1].conv_w[L] : nullptr;
+      for (int g = 0; g < G; ++g) pw.src[g] = nets[g].conv_w[L];
       packs.job[packs.n] = pw; packs.dst[packs.n++] = at<char>(ws, p.wd[L]);
     }
     for (int g = 0; g < G; ++g)
@@ -240,7 +253,9 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
   }
   {
     PrepArgs pa = {};
-    pa.x = x; pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
+    pa.nx = p.shared_x ? 1 : G; pa.x_tl_gs = p.x_tl_gs;
+    for (int g = 0; g < pa.nx; ++g) pa.x[g] = xs[g];
+    pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
     pa.x_compact = p.x_compact;
     pa.packs = packs; pa.spacks = spacks;
     if (d->heads_mask) { pa.zero = at<float>(ws, p.scores_all); pa.zero_n4 = (p.scores_bytes + 15) / 16; }   // split-K GEMM targets
@@ -248,18 +263,19 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
   }
   for (int L = 0; L < 3; ++L) {
     const int C = CH[L];
-    const int Nconv = L == 0 ? 32 * G : C;
-    const int launchG = L == 0 ? 1 : G;
+    const bool cat = L == 0 && p.shared_x;
+    const int Nconv = cat ? 32 * G : C;
+    const int launchG = cat ? 1 : G;
     // conv
     ConvArgs ca;
     memset(&ca, 0, sizeof(ca));
-    if (L == 0) { ca.x_tl = at<char>(ws, p.x_tl); ca.x_gs = 0; ca.x_compact = p.x_compact; }
+    if (L == 0) { ca.x_tl = at<char>(ws, p.x_tl); ca.x_gs = p.x_tl_gs / p.esz; ca.x_compact = p.x_compact; }
     else { ca.x_tl = at<char>(ws, p.a_tl[L - 1]); ca.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
     ca.wp = at<char>(ws, p.wp[L]);
-    ca.bias[0] = nets[0].conv_b[L]; ca.bias[1] = G == 2 ? nets[1].conv_b[L] : nullptr;
+    for (int g = 0; g < G; ++g) ca.bias[g] = nets[g].conv_b[L];
     ca.bias_mode = pack_mode[L]; ca.bias_split = 32;
     ca.y = at<float>(ws, p.y[L]);
-    if (L == 0) { ca.y_gs = 0; ca.y_rs = Nconv; } else { ca.y_gs = (size_t)B * p.HWc[L] * C; ca.y_rs = C; }
+    if (cat) { ca.y_gs = 0; ca.y_rs = Nconv; } else { ca.y_gs = (size_t)B * p.HWc[L] * C; ca.y_rs = C; }
     ca.stats = d->training ? at<float>(ws, p.stats[L]) : nullptr;
     ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
     prof_begin(DTA_SITE_CONV_FWD + L, st);
@@ -273,7 +289,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
       bf.gamma[g] = nets[g].bn_w[L]; bf.beta[g] = nets[g].bn_b[L];
       bf.rmean[g] = nets[g].bn_rm[L]; bf.rvar[g] = nets[g].bn_rv[L]; bf.nbt[g] = nets[g].bn_nbt[L];
     }
-    bf.cat_mode = (L == 0 && G == 2); bf.nsplit = 32;
+    bf.cat_mode = (cat && G == 2); bf.nsplit = 32;
     bf.coef = at<float>(ws, p.coef[L]); bf.training = d->training; bf.momentum = d->bn_momentum; bf.eps = d->bn_eps;
     if (launch_bn_finalize(bf, G, st)) return 1;
     // BN + ReLU + pool + attention
@@ -324,18 +340,19 @@ template <typename T>
 int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grads* grads, void* ws, int L,
                      WgradReduceGroup& reduces, hipStream_t st) {
   const int G = p.G, B = p.B, C = CH[L];
-  const int Nconv = L == 0 ? 32 * G : C;
-  const int launchG = L == 0 ? 1 : G;
+  const bool cat = L == 0 && p.shared_x;
+  const int Nconv = cat ? 32 * G : C;
+  const int launchG = cat ? 1 : G;
   bool want_w = false;
   for (int g = 0; g < G; ++g) want_w |= grads[g].conv_w[L] != nullptr;
   if (!want_w) return 0;
   WgradArgs wa;
   memset(&wa, 0, sizeof(wa));
-  if (L == 0) { wa.x_tl = at<char>(ws, p.x_tl); wa.x_gs = 0; wa.x_compact = p.x_compact; }
+  if (L == 0) { wa.x_tl = at<char>(ws, p.x_tl); wa.x_gs = p.x_tl_gs / p.esz; wa.x_compact = p.x_compact; }
   else { wa.x_tl = at<char>(ws, p.a_tl[L - 1]); wa.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
   wa.NCx = p.NCin[L];
   wa.dy_tl = at<char>(ws, p.dy_tl[L]);
-  wa.dy_gs = L == 0 ? 0 : (size_t)B * (C / 16) * p.Qin[L] * 16;
+  wa.dy_gs = cat ? 0 : (size_t)B * (C / 16) * p.Qin[L] * 16;
   wa.NCy = Nconv / 16; wa.ych0 = 0;
   wa.partial = at<float>(ws, p.wpart[L]);
   wa.B = B; wa.H = p.Hc[L]; wa.W = p.Wc[L]; wa.Q = p.Qin[L]; wa.N = Nconv; wa.Cpad = p.CpadW[L]; wa.S = p.S[L];
@@ -345,15 +362,15 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
   WgradReduceArgs wr;
   memset(&wr, 0, sizeof(wr));
   wr.partial = wa.partial; wr.G = launchG; wr.S = p.S[L]; wr.N = Nconv; wr.C = p.Cin[L]; wr.Cpad = p.CpadW[L];
-  wr.mode = (L == 0 && G == 2) ? 1 : 0; wr.nsplit = 32;
-  wr.dst[0] = grads[0].conv_w[L]; wr.dst[1] = G == 2 ? grads[1].conv_w[L] : nullptr;
+  wr.mode = (cat && G == 2) ? 1 : 0; wr.nsplit = 32;
+  for (int g = 0; g < G; ++g) wr.dst[g] = grads[g].conv_w[L];
   reduces.job[reduces.n++] = wr;   // reduced (and laid out as torch weights) by the caller's grouped launch
   return 0;
 }
 
 template <typename T>
 int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, void* ws,
-               const float* const dscores[2][3], const float* djoint, const dta_subnet_grads* grads, double* dalpha,
+               const float* const (*dscores)[3], const float* djoint, const dta_subnet_grads* grads, double* dalpha,
                int phases, hipStream_t st) {
   const int G = p.G, B = p.B;
   if (!(phases & 1)) {
@@ -362,9 +379,9 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     if (conv_wgrad_layer<T>(p, d, grads, ws, 0, reduces, st)) return 1;
     return launch_wgrad_reduce_group(reduces, st);
   }
-  const float* dsc[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  const float* dsc[MAXG][3] = {};
   BlendBwdArgs blend_fin = {}; bool blend_fin_pending = false;
-  int dsc_mode[2] = {0, 0};   // Hang2020: scale mode of the last-head score gradient of each branch
+  int dsc_mode[MAXG] = {};   // Hang2020: scale mode of the last-head score gradient of each branch
   if (dscores)
     for (int g = 0; g < G; ++g)
       for (int L = 0; L < 3; ++L) dsc[g][L] = dscores[g][L];
@@ -489,7 +506,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     ap.B = B; ap.C = C; ap.H = p.Hc[L]; ap.W = p.Wc[L];
     ap.dv_compact = sb.dv_compact; ap.Hz = p.Hz[L]; ap.Wz = p.Wz[L];
     ap.dy_tl = at<char>(ws, p.dy_tl[L]);
-    if (L == 0) { ap.dy_gs = (size_t)2 * p.Qin[0] * 16; ap.dy_nc = 2 * G; ap.dy_ch0 = 0; }   // group g -> chunks [2g, 2g+2)
+    if (L == 0 && p.shared_x) { ap.dy_gs = (size_t)2 * p.Qin[0] * 16; ap.dy_nc = 2 * G; ap.dy_ch0 = 0; }   // group g -> chunks [2g, 2g+2)
     else { ap.dy_gs = (size_t)B * (C / 16) * p.Qin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
     if (launch_bn_bwd_apply<T>(ap, G, st)) return 1;
     // ---- conv weight gradient ----
@@ -505,7 +522,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       PackWArgs pw;
       memset(&pw, 0, sizeof(pw));
       pw.G = G; pw.NC = C / 16; pw.N = CH[L - 1]; pw.K = C; pw.mode = 2;
-      pw.src[0] = nets[0].conv_w[L]; pw.src[1] = G == 2 ? nets[1].conv_w[L] : nullptr;
+      for (int g = 0; g < G; ++g) pw.src[g] = nets[g].conv_w[L];
       if (!d->training)   // a training forward already packed the transposed weights into the workspace
         if (launch_pack_conv_w<T>(pw, at<char>(ws, p.wd[L]), st)) return 1;
       ConvArgs ca;
@@ -565,9 +582,58 @@ int dta_net_forward(const dta_net_desc* d, const dta_subnet_params* nets, const 
   if (!d || !nets || !x || !workspace) { dta_set_error("dta_net_forward: null argument"); return 1; }
   if (build_plan(d, &p)) return 1;
   hipStream_t st = (hipStream_t)stream;
-  if (d->dtype == DTA_BF16) return forward_t<bf16_t>(p, d, nets, alpha, x, workspace, scores, joint, st);
-  if (d->dtype == DTA_F32) return forward_t<float>(p, d, nets, alpha, x, workspace, scores, joint, st);
+  const float* xs[MAXG] = {x, x, x, x};
+  if (d->dtype == DTA_BF16) return forward_t<bf16_t>(p, d, nets, alpha, xs, workspace, scores, joint, st);
+  if (d->dtype == DTA_F32) return forward_t<float>(p, d, nets, alpha, xs, workspace, scores, joint, st);
   dta_set_error("unknown dtype %d", d->dtype);
+  return 1;
+}
+
+// ---- year ensemble: `years` spectral networks as the groups of ONE set of launches ----
+static int ensemble_desc(const dta_net_desc* d, int years, dta_net_desc* out, Plan* p, const char* who) {
+  if (!d || years < 1 || years > MAXG) { dta_set_error("%s: 1..%d years", who, MAXG); return 1; }
+  if (d->kind != DTA_NET_SPECTRAL) { dta_set_error("%s: the descriptor's kind must be DTA_NET_SPECTRAL", who); return 1; }
+  *out = *d;
+  out->heads_mask = 4;   // the ensemble keeps each year's last head only (reference year.py:30)
+  return build_plan(out, p, years);
+}
+
+size_t dta_ensemble_workspace_bytes(const dta_net_desc* d, int years) {
+  Plan p; dta_net_desc dd;
+  if (ensemble_desc(d, years, &dd, &p, "dta_ensemble_workspace_bytes")) return 0;
+  return p.total;
+}
+
+int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
+                         void* workspace, float* mean_scores, void* stream) {
+  Plan p; dta_net_desc dd;
+  if (!nets || !x || !workspace || !mean_scores) { dta_set_error("dta_ensemble_forward: null argument"); return 1; }
+  if (ensemble_desc(d, years, &dd, &p, "dta_ensemble_forward")) return 1;
+  for (int g = 0; g < years; ++g)
+    if (!x[g]) { dta_set_error("dta_ensemble_forward: null input for year %d", g); return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (dd.dtype == DTA_BF16) rc = forward_t<bf16_t>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st);
+  else if (dd.dtype == DTA_F32) rc = forward_t<float>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st);
+  else { dta_set_error("unknown dtype %d", dd.dtype); return 1; }
+  if (rc) return rc;
+  MeanArgs ma = {};
+  for (int g = 0; g < years; ++g) ma.src[g] = at<float>(workspace, p.scores[g][2]);
+  ma.n = years; ma.dst = mean_scores; ma.count = (size_t)p.B * p.classes;
+  return launch_mean_scores(ma, st);
+}
+
+int dta_ensemble_backward(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
+                          const float* dscore, const dta_subnet_grads* grads, void* stream) {
+  Plan p; dta_net_desc dd;
+  if (!nets || !workspace || !dscore || !grads) { dta_set_error("dta_ensemble_backward: null argument"); return 1; }
+  if (ensemble_desc(d, years, &dd, &p, "dta_ensemble_backward")) return 1;
+  const float* dsc[MAXG][3] = {};
+  for (int g = 0; g < years; ++g) dsc[g][2] = dscore;   // d(mean)/d(year score) is the same 1/years for every year
+  hipStream_t st = (hipStream_t)stream;
+  if (dd.dtype == DTA_BF16) return backward_t<bf16_t>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, 3, st);
+  if (dd.dtype == DTA_F32) return backward_t<float>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, 3, st);
+  dta_set_error("unknown dtype %d", dd.dtype);
   return 1;
 }
 

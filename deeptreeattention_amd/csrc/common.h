@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 (MI355X) kernels of the Hang2020 hot path.
 // Written for CDNA4 only: 64-lane wavefronts, MFMA 32x32 tiles, 160 KiB LDS per CU.
 #pragma once
+#include <stdio.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -88,8 +89,14 @@ __device__ __forceinline__ float block_sum256(float v, float* scratch) {
 // Error plumbing: kernels launch asynchronously on the caller's stream; launch errors are caught here
 // and surfaced through dta_last_error() (no exceptions cross the C ABI).
 void dta_set_error(const char* fmt, ...);
+#ifdef DTA_TRACE_LAUNCHES   /* developer build: name every launch on stderr and wait for it */
+#define DTA_TRACE_LAUNCH_(name) do { fprintf(stderr, "[dta] %s\n", name); fflush(stderr); hipDeviceSynchronize(); } while (0)
+#else
+#define DTA_TRACE_LAUNCH_(name) do { } while (0)
+#endif
 #define DTA_CHECK_LAUNCH(name)                                                      \
   do {                                                                              \
+    DTA_TRACE_LAUNCH_(name);                                                        \
     hipError_t e_ = hipGetLastError();                                              \
     if (e_ != hipSuccess) {                                                         \
       dta_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));          \

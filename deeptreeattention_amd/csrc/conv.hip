@@ -174,8 +174,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_forward_prep(PrepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int y = blockIdx.y;
-  if (y < a.ncg) { pack_input_block<T>(a.x, (T*)a.x_tl, a.B, a.C, a.H, a.W, a.NC, a.CG, blockIdx.x, y, smem, a.x_compact != 0); return; }
-  y -= a.ncg;
+  if (y < a.ncg * a.nx) {
+    const int gi = y / a.ncg;
+    pack_input_block<T>(a.x[gi], (T*)((char*)a.x_tl + (size_t)gi * a.x_tl_gs), a.B, a.C, a.H, a.W, a.NC, a.CG, blockIdx.x,
+                        y - gi * a.ncg, smem, a.x_compact != 0);
+    return;
+  }
+  y -= a.ncg * a.nx;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x, tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (y < a.packs.n) { pack_conv_w_job<T>(a.packs.job[y], (T*)a.packs.dst[y], tid, nthreads); return; }
   y -= a.packs.n;
@@ -191,7 +196,7 @@ int launch_forward_prep(PrepArgs a, hipStream_t st) {
   size_t lds;
   if (pack_input_plan(a.C, a.H, a.W, &a.NC, &a.CG, &lds)) return 1;
   a.ncg = (a.NC + a.CG - 1) / a.CG;
-  dim3 grid(a.B, a.ncg + a.packs.n + a.spacks.n + (a.zero ? 1 : 0));
+  dim3 grid(a.B, a.ncg * a.nx + a.packs.n + a.spacks.n + (a.zero ? 1 : 0));
   hipLaunchKernelGGL(k_forward_prep<T>, grid, dim3(256), lds, st, a);
   DTA_CHECK_LAUNCH("k_forward_prep");
   return 0;

@@ -257,6 +257,23 @@ int launch_blend(const BlendArgs& a, hipStream_t st) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Year ensemble: scores = mean over the years' last-head scores (reference src/models/year.py:33).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mean_scores(MeanArgs a) {
+  const float inv = 1.f / (float)a.n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.count; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = a.src[0][i];
+    for (int k = 1; k < a.n; ++k) acc += a.src[k][i];
+    a.dst[i] = acc * inv;
+  }
+}
+int launch_mean_scores(const MeanArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_mean_scores, dim3((unsigned)min((size_t)1024, (a.count + 255) / 256)), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_mean_scores");
+  return 0;
+}
+
 constexpr int BLEND_FIN_BLOCKS = 32;
 // d(alpha) = w (1 - w) * sum_{b,n} djoint * (spec - spat): BLEND_FIN_BLOCKS blocks each reduce a slice of the
 // (B, classes) slab and add it to dalpha, which must arrive zeroed like every other gradient buffer.

@@ -5,17 +5,18 @@
 namespace dta {
 
 enum { KIND_SPECTRAL = 0, KIND_SPATIAL = 1, KIND_PLAIN = 2 };
+constexpr int MAXG = 4;   // groups per launch: Hang2020's two branches, or up to four years of an ensemble
 
 // ---- conv.hip ----------------------------------------------------------------------------------
 struct PackWArgs {
-  const float* src[2];
+  const float* src[MAXG];
   int G, NC, N, K;   // K = real size of the contraction-channel dim (Cin for fwd, Cout for dgrad)
   int mode, nsplit;
 };
 struct ConvArgs {
   const void* x_tl; size_t x_gs;      // input tiles, group stride in elements (0 = shared by groups)
   const void* wp;                     // [G][NC][9][N][16]
-  const float* bias[2]; int bias_mode, bias_split;
+  const float* bias[MAXG]; int bias_mode, bias_split;
   float* y; size_t y_gs; int y_rs;    // fp32 output rows [row][y_rs], group offset y_gs
   float* stats;                       // [G][nwg][N][2] (mean, M2) or null
   int B, H, W, NC, N, Q, HW, ppw, spp, dbuf;
@@ -32,7 +33,7 @@ struct WgradArgs {
 // bl = rows per band (multiple of 16), wr = bl + 2*(W+3) rounded up to 4 (mod 8), wr <= wr_max
 void wgrad_band_plan(int Q, int W, int wr_max, int* bl, int* wr, int* nbands);
 struct WgradReduceArgs {
-  const float* partial; float* dst[2];
+  const float* partial; float* dst[MAXG];
   int G, S, N, C, Cpad, mode, nsplit;
 };
 template <typename T> int launch_pack_input(const float* x, void* out, int B, int C, int H, int W, hipStream_t st);
@@ -54,8 +55,8 @@ int wgrad_cpw(int N);
 // ---- stage.hip (BatchNorm + ReLU + pool + attention, forward and backward) ------------------------
 struct BnFinalizeArgs {
   const float* stats; int nwg, N, HW, MWG, B;          // partials of one conv launch (per group)
-  const float* gamma[2]; const float* beta[2];         // per group (bias_mode 1: concatenated columns)
-  float* rmean[2]; float* rvar[2]; long long* nbt[2];
+  const float* gamma[MAXG]; const float* beta[MAXG];   // per group (bias_mode 1: concatenated columns)
+  float* rmean[MAXG]; float* rvar[MAXG]; long long* nbt[MAXG];
   int cat_mode, nsplit;                                // 1: G==1 launch whose columns are [branch0|branch1]
   float* coef;                                         // [G][N][4] = scale, shift, mean, rstd
   int training; float momentum, eps;
@@ -68,17 +69,17 @@ struct AttParams {          // forward-side attention parameters of one branch/s
   const float* p[6];
 };
 struct StageArgs {
-  int kind[2];                         // per group
+  int kind[MAXG];                      // per group
   const float* y; size_t y_gs; int y_rs;        // conv output (or raw activations when !apply_bn)
   const float* coef; int coef_gs;      // [..][C][4]
   int apply_bn, relu, pool;            // pool: 2x2 floor max-pool after ReLU
   int B, C, Hc, Wc;                    // conv-resolution dims
-  AttParams att[2];
-  int att_k[2], att_pool[2];           // spatial stencil size / class-pool size
+  AttParams att[MAXG];
+  int att_k[MAXG], att_pool[MAXG];           // spatial stencil size / class-pool size
   int vslot;                           // LDS vector slot (floats); filled by the launcher
   void* a_tl; size_t a_gs; int a_nc, a_ch0;      // gated map as tiles for the next conv (or null)
   float* a_nchw; size_t a_nchw_gs;     // gated map as fp32 NCHW (standalone modules) or null
-  float* feat; size_t feat_gs; int F[2];         // [B][F]
+  float* feat; size_t feat_gs; int F[MAXG];      // [B][F]
   // attention intermediates of every patch ([G][B][attsave_ld] floats, >= 3 * vslot): written by the forward,
   // read back by the backward instead of recomputing the attention; null = backward recomputes
   float* attsave; int attsave_ld;
@@ -103,8 +104,8 @@ int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st);
 struct BnBwdFinalizeArgs {
   const float* bnpart; size_t bnpart_gs; int B, C, HW;
   const float* coef; int coef_gs;
-  const float* gamma[2];
-  float* dgamma[2]; float* dbeta[2]; float* dconvbias[2];
+  const float* gamma[MAXG];
+  float* dgamma[MAXG]; float* dbeta[MAXG]; float* dconvbias[MAXG];
   int cat_mode, nsplit;                // G==1 launch with concatenated branch columns
   float* bcoef; int bcoef_gs;          // out [..][C][4] = A (gamma*rstd), Bc (dbeta/n), Cc (dgamma/n), 0
   int training;
@@ -183,7 +184,7 @@ int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st);
 // launch: both are [batch] reductions over per-patch partials that the same stage-backward kernel produced.
 int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const ColsumArgs* cs, int ncs, hipStream_t st);
 int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed, hipStream_t st);
-struct SpecPackGroup { const float* w1[6]; const float* w2[6]; float* packed[6]; int C[6], K[6]; int n = 0; };
+struct SpecPackGroup { const float* w1[3 * MAXG]; const float* w2[3 * MAXG]; float* packed[3 * MAXG]; int C[3 * MAXG], K[3 * MAXG]; int n = 0; };
 int launch_pack_spectral_att_group(const SpecPackGroup& gr, hipStream_t st);
 #if defined(__HIPCC__)
 // packed = [a1t | a2t | a1 | a2], each [C][C]; *t is input-major (a_t[i][o] = W[o][i][K/2])
@@ -203,7 +204,8 @@ __device__ __forceinline__ void pack_spectral_att_job(const SpecPackGroup& gr, i
 #endif
 // one launch for everything the forward needs before its first conv (conv.hip)
 struct PrepArgs {
-  const float* x; void* x_tl; int B, C, H, W, NC, CG, ncg, x_compact;
+  const float* x[MAXG]; int nx; size_t x_tl_gs;   // nx inputs (one per group with its own input), tile group stride in bytes
+  void* x_tl; int B, C, H, W, NC, CG, ncg, x_compact;
   PackWGroup packs; SpecPackGroup spacks;
   float* zero; size_t zero_n4;         // float4 count to clear, or zero == null
 };
@@ -213,6 +215,8 @@ struct BlendArgs {
   const float* spec; const float* spat; const double* alpha; float* joint; int B, classes;
 };
 int launch_blend(const BlendArgs& a, hipStream_t st);
+struct MeanArgs { const float* src[MAXG]; int n; float* dst; size_t count; };
+int launch_mean_scores(const MeanArgs& a, hipStream_t st);
 struct BlendBwdArgs {
   const float* spec; const float* spat; const double* alpha; const float* djoint;
   double* dalpha; int B, classes;

@@ -14,8 +14,8 @@ namespace dta {
 struct BnFinK {
   const float* stats; size_t stats_goff; int stats_ld;
   int nwg, C, HW, MWG, B;
-  const float* gamma[2]; const float* beta[2];
-  float* rmean[2]; float* rvar[2]; long long* nbt[2];
+  const float* gamma[MAXG]; const float* beta[MAXG];
+  float* rmean[MAXG]; float* rvar[MAXG]; long long* nbt[MAXG];
   float* coef; int training; float momentum, eps;
 };
 
@@ -89,7 +89,7 @@ int launch_bn_finalize(const BnFinalizeArgs& b, int G, hipStream_t st) {
   a.stats = b.stats; a.nwg = b.nwg; a.HW = b.HW; a.MWG = b.MWG; a.B = b.B;
   if (b.cat_mode) { a.C = b.nsplit; a.stats_goff = (size_t)b.nsplit * 2; a.stats_ld = b.N; }
   else { a.C = b.N; a.stats_goff = (size_t)b.nwg * b.N * 2; a.stats_ld = b.N; }
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < MAXG; ++g) {
     a.gamma[g] = b.gamma[g]; a.beta[g] = b.beta[g]; a.rmean[g] = b.rmean[g]; a.rvar[g] = b.rvar[g]; a.nbt[g] = b.nbt[g];
   }
   a.coef = b.coef; a.training = b.training; a.momentum = b.momentum; a.eps = b.eps;
@@ -467,7 +467,7 @@ static bool stage_net_cfg(const StageArgs& a) {
   if (lvl < 0) return false;
   const int H[3] = {11, 11, 5}, P[3] = {0, 1, 1}, K[3] = {7, 5, 3}, CP[3] = {4, 2, 1};
   if (a.Hc != H[lvl] || a.Wc != H[lvl] || (a.pool != 0) != (P[lvl] != 0)) return false;
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < MAXG; ++g)
     if (a.kind[g] == KIND_SPATIAL && (a.att_k[g] != K[lvl] || a.att_pool[g] != CP[lvl])) return false;
   return true;
 }

@@ -79,6 +79,7 @@ class FusedTrainer:
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self._ws = None
         self._ws_key = None
+        self._desc_key = None
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self.sync = GradSync(self.world, self.pg, self._side)
         if self.world > 1:
@@ -116,15 +117,25 @@ class FusedTrainer:
             H._fill_struct(grads[i], kind, gt, True)
         return nets, grads
 
-    def _prepare(self, x):
+    def _describe(self, x):
+        """Descriptor + parameter / gradient pointer structs for this input shape (no device allocation)."""
         B, bands, Hh, Ww = x.shape
         m = self.model
         key = (B, bands, Hh, Ww, m.precision, m.training)
-        if key != self._ws_key:
-            L = _lib.lib()
+        if key != self._desc_key:
             self.desc = _lib.NetDesc(B, bands, Hh, Ww, m._classes, m._net_code, _lib.dtype_code(m.precision),
                                      1 if m.training else 0, 4 if (self.single_score or self.last_head_only) else 7,
                                      H.BN_MOMENTUM, H.BN_EPS)
+            self.nets, self.grads = self._structs()
+            self._desc_key = key
+        return key
+
+    def _prepare(self, x):
+        B = x.shape[0]
+        m = self.model
+        key = self._describe(x)
+        if key != self._ws_key:
+            L = _lib.lib()
             nbytes = L.dta_net_workspace_bytes(C.byref(self.desc))
             if nbytes == 0:
                 raise RuntimeError("dta_net_workspace_bytes: " + L.dta_last_error().decode())
@@ -132,7 +143,6 @@ class FusedTrainer:
             self.logits = torch.empty(B, m._classes, dtype=torch.float32, device=self.device)
             self.dlogits = torch.empty_like(self.logits)
             self.ce_scratch = torch.empty(B + 1, dtype=torch.float32, device=self.device)
-            self.nets, self.grads = self._structs()
             self._ws_key = key
 
     def _forward_scores(self, x):
@@ -286,6 +296,8 @@ class EnsembleTrainer:
         self.loss_weight = first.loss_weight
         self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self._shape = None
+        self._ws = None
+        self._ws_key = None
 
     @property
     def lr(self):
@@ -324,12 +336,48 @@ class EnsembleTrainer:
             self._shape = (B, classes)
 
     def _forward(self, images, local):
+        """All kept years as the groups of one set of launches (dta_ensemble_forward); self.scores = their mean."""
+        L = _lib.lib()
         kept = [i for i, k in enumerate(local) if k]
-        per_year = [self.years[i]._forward_scores(images[i]) for i in kept]
-        B, classes = per_year[0].shape
+        if len(kept) > _lib.MAX_YEARS:
+            raise RuntimeError("at most {} years per grouped launch".format(_lib.MAX_YEARS))
+        xs = [H._check_input(images[i]) for i in kept]
+        if any(x.shape != xs[0].shape for x in xs):
+            raise ValueError("all years of a batch must have the same shape")
+        keys = [self.years[i]._describe(x) for i, x in zip(kept, xs)]
+        B, classes = xs[0].shape[0], self.model.year_models[0]._classes
         self._buffers(B, classes)
-        torch.mean(torch.stack(per_year, dim=1), dim=1, out=self.scores)        # year.py:33
+        n = len(kept)
+        self._nets = (_lib.SubnetParams * n)(*[self.years[i].nets[0] for i in kept])
+        self._grads = (_lib.SubnetGrads * n)(*[self.years[i].grads[0] for i in kept])
+        self._xptr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        self._desc = self.years[kept[0]].desc
+        ws_key = (n,) + keys[0]
+        if ws_key != self._ws_key:
+            nbytes = L.dta_ensemble_workspace_bytes(C.byref(self._desc), n)
+            if nbytes == 0:
+                raise RuntimeError("dta_ensemble_workspace_bytes: " + L.dta_last_error().decode())
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_key = ws_key
+        _lib.check(L.dta_ensemble_forward(C.byref(self._desc), n, self._nets, self._xptr, _lib.ptr(self._ws),
+                                          _lib.ptr(self.scores), _lib.current_stream_ptr()), "dta_ensemble_forward")
+        self._live = xs     # inputs stay referenced until the step's launches are enqueued
         return kept
+
+    def _backward(self, kept):
+        L = _lib.lib()
+        for i in kept:
+            self.years[i]._zero_grads()          # C-ABI contract: gradient buffers arrive zero-filled
+        _lib.check(L.dta_ensemble_backward(C.byref(self._desc), len(kept), self._nets, _lib.ptr(self._ws),
+                                           _lib.ptr(self.dscores), self._grads, _lib.current_stream_ptr()),
+                   "dta_ensemble_backward")
+        for i in kept:
+            t = self.years[i]
+            t._grads_clear = False
+            if t.world > 1:
+                t.sync.reduce_early(t.flat_g[:t.split])
+                t.sync.reduce_late(t.flat_g[t.split:])
+                t.sync.finish()
 
     def _ce(self, y, want_grad):
         L = _lib.lib()
@@ -346,10 +394,11 @@ class EnsembleTrainer:
         kept = self._forward(images, local)
         self._ce(y, True)
         self.dscores.mul_(1.0 / len(kept))      # d(mean over kept years)/d(year score)
+        self._backward(kept)
         for i, t in enumerate(self.years):
             if local[i]:
-                t._backward(self.dscores)
-            elif anywhere[i]:
+                continue
+            if anywhere[i]:
                 t._reduce_zero_grads()
             else:
                 t._zero_grads()                 # skipped everywhere: grad None in the reference

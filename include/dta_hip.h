@@ -83,6 +83,24 @@ int dta_net_backward(const dta_net_desc* d, const dta_subnet_params* nets, const
                      const float* const dscores[2][3], const float* djoint, const dta_subnet_grads* grads,
                      double* dalpha, int phases, void* stream);
 
+/* ---- Year ensemble (reference src/models/year.py:9-33): `years` (1..DTA_MAX_YEARS) spectral_networks, each on its own
+ * input, run as the groups of ONE set of launches (a third of the launches of `years` separate dta_net_* calls);
+ * the returned scores are the mean over the years of each year's last-head scores (year.py:30,33).
+ * The reference skips a year whose whole batch tensor sums to zero (year.py:27): the caller passes only the years it
+ * keeps (their params / inputs / grads, in any order), so a skipped year's BatchNorm state and gradients stay untouched.
+ *  d      : kind DTA_NET_SPECTRAL; heads_mask is ignored (only the last head is evaluated)
+ *  nets   : `years` entries;  x : `years` device pointers, each float32 NCHW [batch][bands][height][width]
+ *  mean_scores : float32 [batch][classes] */
+#define DTA_MAX_YEARS 4
+size_t dta_ensemble_workspace_bytes(const dta_net_desc* d, int years);
+int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
+                         void* workspace, float* mean_scores, void* stream);
+/* Backward of the above.  dscore: d(loss)/d(one year's scores) = d(loss)/d(mean_scores) / years, float32
+ * [batch][classes], shared by all years.  grads: `years` entries, every non-null buffer ZERO-FILLED on entry;
+ * classifier1/2 gradients are not produced (those heads never reach the loss). */
+int dta_ensemble_backward(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
+                          const float* dscore, const dta_subnet_grads* grads, void* stream);
+
 /* Replaces F.cross_entropy(logits, y, weight=w) forward+backward (src/main.py:78, multi_stage.py:285).
  * weight may be null (= ones, metadata.py:61).  scratch: batch+1 floats.  dlogits may be null. */
 int dta_weighted_ce(const float* logits, const long long* labels, const float* weight, int batch, int classes,

@@ -21,7 +21,8 @@ def test_every_declared_symbol_is_exported(lib):
     hdr = open(os.path.join(REPO, "include", "dta_hip.h")).read()
     names = set(re.findall(r"\b(dta_[a-z_0-9]+)\s*\(", hdr))
     assert {"dta_net_forward", "dta_net_backward", "dta_weighted_ce", "dta_adam_step", "dta_net_workspace_bytes",
-            "dta_last_error", "dta_abi_version", "dta_profile_enable", "dta_profile_collect"} <= names
+            "dta_last_error", "dta_abi_version", "dta_profile_enable", "dta_profile_collect",
+            "dta_ensemble_workspace_bytes", "dta_ensemble_forward", "dta_ensemble_backward"} <= names
     for n in names:
         assert hasattr(lib, n), n
 
@@ -38,6 +39,13 @@ def test_workspace_bytes_and_errors(lib):
     assert b"bad descriptor" in lib.dta_last_error()
     tiny = _lib.NetDesc(4, 3, 3, 3, 10, _lib.NET_SPECTRAL, _lib.DTA_F32, 1, 7, 0.1, 1e-5)
     assert lib.dta_net_workspace_bytes(C.byref(tiny)) == 0      # too small for two 2x2 pools: refused, not UB
+    # year ensemble: spectral networks only, 1..DTA_MAX_YEARS groups; the workspace grows with the number of years
+    spec = _lib.NetDesc(64, 369, 11, 11, 200, _lib.NET_SPECTRAL, _lib.DTA_BF16, 1, 4, 0.1, 1e-5)
+    one, three = lib.dta_ensemble_workspace_bytes(C.byref(spec), 1), lib.dta_ensemble_workspace_bytes(C.byref(spec), 3)
+    assert 0 < one < three
+    assert lib.dta_ensemble_workspace_bytes(C.byref(spec), _lib.MAX_YEARS + 1) == 0
+    assert lib.dta_ensemble_workspace_bytes(C.byref(ok), 3) == 0 and b"DTA_NET_SPECTRAL" in lib.dta_last_error()
+    assert lib.dta_ensemble_forward(C.byref(spec), 3, None, None, None, None, None) != 0
     # null arguments are reported, not dereferenced
     assert lib.dta_net_forward(None, None, None, None, None, None, None, None) != 0
     assert lib.dta_adam_step(None, None, None, None, 10, None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, None) != 0

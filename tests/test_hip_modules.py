@@ -248,3 +248,43 @@ def test_ensemble_trainer_steps_vs_reference_golden(golden, use_present):
     assert [t.step_count for t in tr.years] == [3, 4, 3]
     out = driver.validation_step(batch[0], 0, 0, present)
     assert out["yhat"].shape == (B, classes) and abs(float(out["yhat"].sum()) - B) < 1e-4
+
+
+@pytest.mark.parametrize("years,hw,bands,prec", [(5, 11, 16, "fp32"), (3, 24, 20, "fp32"), (3, 11, 369, "bf16")])
+def test_grouped_ensemble_equals_independent_networks(years, hw, bands, prec):
+    """The grouped launch (all kept years as the groups of one set of kernels; five years = a group of four + one)
+    against the same spectral_networks run one by one: scores and every gradient."""
+    from deeptreeattention_amd.year import learned_ensemble
+    from deeptreeattention_amd import Hang2020 as H
+    classes, B = 9, 10
+    torch.manual_seed(3)
+    m = learned_ensemble(years=years, classes=classes, config={"pretrain_state_dict": None, "bands": bands}).to(dev())
+    for net in m.year_models:
+        net.precision = prec
+    m.train()
+    imgs = [torch.rand(B, bands, hw, hw, device=dev()) for _ in range(years)]
+    imgs[1].zero_()
+    d = torch.randn(B, classes, device=dev())
+    (m(imgs) * d).sum().backward()
+    got = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    buf = {k: b.clone() for k, b in m.named_buffers()}
+    s_grouped = m(imgs).detach()
+    # one by one, from the same starting state
+    m.zero_grad(set_to_none=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.reset_running_stats()
+    kept = [i for i in range(years) if i != 1]
+    s = torch.stack([m.year_models[i](imgs[i])[-1] for i in kept], dim=1).mean(dim=1)
+    (s * d).sum().backward()
+    tol = 1e-5 if prec == "fp32" else 2e-3
+    assert rel_l2(s_grouped.cpu().numpy(), s.detach().cpu().numpy()) < tol
+    for k, p in m.named_parameters():
+        if k.startswith("year_models.1.") or "classifier1" in k or "classifier2" in k:
+            assert k not in got
+            continue
+        if k.endswith("conv_layer.bias"):
+            continue
+        assert rel_l2(got[k].cpu().numpy(), p.grad.cpu().numpy()) < max(tol, 2e-5), k
+    assert int(buf["year_models.1.conv1.bn1.num_batches_tracked"]) == 0      # the skipped year was not touched
+    assert int(buf["year_models.0.conv1.bn1.num_batches_tracked"]) == 1
