@@ -26,6 +26,14 @@ class NetDesc(C.Structure):
                 ("heads_mask", C.c_int), ("bn_momentum", C.c_float), ("bn_eps", C.c_float)]
 
 
+class CropDesc(C.Structure):      # mirrors dta_crop_desc
+    _fields_ = [(n, C.c_int) for n in ("batch", "bands_raw", "clip", "size", "flip", "layout", "dtype")]
+
+
+CROP_F32, CROP_I16, CROP_U8 = 0, 1, 2
+CROP_CHW, CROP_HWC = 0, 1
+
+
 class SubnetParams(C.Structure):
     _fields_ = [("conv_w", C.c_void_p * 3), ("conv_b", C.c_void_p * 3), ("bn_w", C.c_void_p * 3),
                 ("bn_b", C.c_void_p * 3), ("bn_rm", C.c_void_p * 3), ("bn_rv", C.c_void_p * 3),
@@ -83,6 +91,11 @@ def lib():
         L.dta_ensemble_backward.restype = C.c_int
         L.dta_ensemble_backward.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams), C.c_void_p,
                                             C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p]
+        L.dta_preprocess_out_bands.restype = C.c_int
+        L.dta_preprocess_out_bands.argtypes = [C.c_int, C.c_int]
+        L.dta_preprocess_crops.restype = C.c_int
+        L.dta_preprocess_crops.argtypes = [C.POINTER(CropDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]
         L.dta_weighted_ce.restype = C.c_int
         L.dta_weighted_ce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]

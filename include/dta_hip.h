@@ -101,6 +101,26 @@ int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_para
 int dta_ensemble_backward(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
                           const float* dscore, const dta_subnet_grads* grads, void* stream);
 
+/* ---- Crop preprocessing on the device: replaces load_image / preprocess_image (src/utils.py:36-79: drop the first and
+ * last `clip` bands when there are more than 3, float32, per-pixel min-max over the bands as
+ * sklearn.preprocessing.minmax_scale(axis=1) computes it, NEAREST resize to size x size) plus the training flips
+ * (src/augmentation.py:13-14: horizontal then vertical, both p=1) for a whole batch of ragged crops in one launch.
+ * Output is bit-identical to the reference's CPU path.
+ *  raw     : all crops of the batch back to back (device memory), element type `dtype`
+ *  offsets : [batch] int64 element offset of each crop inside raw;  heights/widths : [batch] int32 (device)
+ *            a crop with height or width 0 is a missing year: its output is all zeros (src/data.py:295-296)
+ *  layout  : DTA_CROP_CHW = band-first [bands_raw][h][w] (what rasterio's read() / np.load return),
+ *            DTA_CROP_HWC = pixel-interleaved [h][w][bands_raw] (how the crops lie on disk: TIFF PlanarConfiguration 1)
+ *  out     : float32 [batch][dta_preprocess_out_bands(bands_raw, clip)][size][size] */
+enum { DTA_CROP_F32 = 0, DTA_CROP_I16 = 1, DTA_CROP_U8 = 2 };
+enum { DTA_CROP_CHW = 0, DTA_CROP_HWC = 1 };
+typedef struct {
+  int batch, bands_raw, clip, size, flip, layout, dtype;
+} dta_crop_desc;
+int dta_preprocess_out_bands(int bands_raw, int clip);
+int dta_preprocess_crops(const dta_crop_desc* d, const void* raw, const long long* offsets, const int* heights,
+                         const int* widths, float* out, void* stream);
+
 /* Replaces F.cross_entropy(logits, y, weight=w) forward+backward (src/main.py:78, multi_stage.py:285).
  * weight may be null (= ones, metadata.py:61).  scratch: batch+1 floats.  dlogits may be null. */
 int dta_weighted_ce(const float* logits, const long long* labels, const float* weight, int batch, int classes,

@@ -291,6 +291,76 @@ def case_ensemble_steps():
     print("ensemble_steps.npz", len(out))
 
 
+def _read_strip_tiff(path):
+    """Minimal reader for the reference's test crops (uncompressed, strip-organised, pixel-interleaved TIFF): returns
+    the band-first array rasterio's `.read()` gives.  rasterio itself is not installed here."""
+    import struct
+    f = open(path, "rb").read()
+    bo = "<" if f[:2] == b"II" else ">"
+    off = struct.unpack(bo + "I", f[4:8])[0]
+    n = struct.unpack(bo + "H", f[off:off + 2])[0]
+    size = {1: 1, 3: 2, 4: 4}
+    fmt = {1: "B", 3: "H", 4: "I"}
+    tags = {}
+    for i in range(n):
+        tag, typ, cnt = struct.unpack(bo + "HHI", f[off + 2 + 12 * i:off + 10 + 12 * i])
+        raw = f[off + 10 + 12 * i:off + 14 + 12 * i]
+        if typ not in size:
+            continue
+        if size[typ] * cnt > 4:
+            q = struct.unpack(bo + "I", raw)[0]
+            raw = f[q:q + size[typ] * cnt]
+        tags[tag] = struct.unpack(bo + fmt[typ] * cnt, raw[:size[typ] * cnt])
+    W, H, spp = tags[256][0], tags[257][0], tags[277][0]
+    assert tags[259][0] == 1 and tags.get(284, (1,))[0] == 1, "uncompressed, pixel-interleaved only"
+    bits, sf = tags[258][0], tags.get(339, (1,))[0]
+    dt = {(16, 2): "i2", (16, 1): "u2", (8, 1): "u1", (32, 3): "f4"}[(bits, sf)]
+    data = b"".join(f[o:o + c] for o, c in zip(tags[273], tags[279]))
+    hwc = np.frombuffer(data, dtype=np.dtype(dt).newbyteorder(bo)).reshape(H, W, spp)
+    return np.ascontiguousarray(np.moveaxis(hwc, 2, 0)).astype(dt)
+
+
+def case_preprocess():
+    """Crop preprocessing (src/utils.py:36-79) on the reference's own test crops: raw pixels in, the reference's
+    preprocess_image output and the 11x11 / 24x24 NEAREST resizes out.  torchvision is absent, so the resize is
+    torch.nn.functional.interpolate(mode="nearest"), the routine torchvision's tensor resize dispatches to."""
+    import glob
+    import types as _t
+    tv = _t.ModuleType("torchvision")
+    tv.transforms = _t.ModuleType("torchvision.transforms")
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tv.transforms)
+    sys.modules.setdefault("rasterio", _t.ModuleType("rasterio"))
+    from src import utils as RU  # the reference's data utils (preprocess_image needs numpy + sklearn only)
+    out = {}
+    paths = sorted(glob.glob(os.path.join(REF, "tests/data/110ac77ae89043898f618466359c2a2e/*.tif")))[:5]
+    names = []
+    for path in paths:
+        name = os.path.basename(path)[:-4]
+        names.append(name)
+        raw = _read_strip_tiff(path)                       # (369, H, W) int16, as rio.open(path).read()
+        out[f"{name}/raw"] = raw
+        pre = RU.preprocess_image(raw, channel_is_first=True)
+        out[f"{name}/pre"] = pre.numpy()
+        for size in ((11, 24) if len(names) == 1 else (11,)):
+            r = F.interpolate(pre[None], size=(size, size), mode="nearest")[0]
+            out[f"{name}/resized{size}"] = r.numpy()
+    # synthetic float crops: constant pixels (zero range), near-constant pixels, a 3-band crop (no band clipping)
+    rng = np.random.RandomState(5)
+    syn = rng.rand(40, 9, 13).astype(np.float32) * 5000 - 100
+    syn[:, 2, 3] = 7.0
+    syn[:, 4, 4] = 1.0
+    syn[11, 4, 4] = np.float32(1.0) + np.float32(5e-7)
+    out["syn/raw"] = syn
+    out["syn/pre"] = RU.preprocess_image(syn, channel_is_first=True).numpy()
+    rgb = (rng.rand(3, 6, 5) * 255).astype(np.uint8)
+    out["rgb/raw"] = rgb
+    out["rgb/pre"] = RU.preprocess_image(rgb, channel_is_first=True).numpy()
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "preprocess.npz"), **out)
+    print("preprocess.npz", len(out), names)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:      # regenerate only the named cases, e.g. `make_golden.py case_ensemble_steps`
         for name in sys.argv[1:]:
@@ -300,4 +370,5 @@ if __name__ == "__main__":
     case_hang_small()
     case_subnets()
     case_ensemble_steps()
+    case_preprocess()
     case_hang_full()

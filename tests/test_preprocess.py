@@ -1,0 +1,113 @@
+"""Crop preprocessing (reference src/utils.py:36-79, src/augmentation.py:13-14).
+CPU: the NumPy oracle against outputs of the reference's own preprocess_image on the reference's own test crops
+(bit-exact) and against torch's nearest interpolation.  GPU: the HIP kernel against the oracle, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import preprocess_np as P
+
+
+def test_oracle_matches_reference_preprocess_bit_exact(golden):
+    g = golden("preprocess.npz")
+    names = list(g["names"]) + ["syn", "rgb"]
+    for name in names:
+        raw = g[f"{name}/raw"]
+        want = g[f"{name}/pre"]
+        got = P.preprocess_image(raw, True)
+        assert got.dtype == np.float32 and got.shape == want.shape
+        assert np.array_equal(got, want), name
+    assert g["rgb/pre"].shape[0] == 3 and g["syn/pre"].shape[0] == 20      # 3 bands: no clipping; 40 -> 20
+    name = names[0]
+    for size in (11, 24):
+        assert np.array_equal(P.resize_nearest(g[f"{name}/pre"], size), g[f"{name}/resized{size}"])
+    for name in names[1:-2]:
+        assert np.array_equal(P.load_crop(g[f"{name}/raw"], 11), g[f"{name}/resized11"])
+    # constant pixel -> zeros (zero range counts as scale 1); near-constant pixel (range < 10 eps) likewise
+    assert not g["syn/pre"][:, 2, 3].any()
+    assert g["syn/pre"][:, 4, 4].max() < 1e-6
+
+
+def test_nearest_index_matches_torch_interpolate():
+    for out_size in (11, 24, 7, 32):
+        for in_size in list(range(1, 70)) + [100, 127, 255]:
+            src = torch.arange(in_size, dtype=torch.float32).reshape(1, 1, in_size, 1)
+            want = torch.nn.functional.interpolate(src, size=(out_size, 1), mode="nearest").reshape(-1).numpy().astype(np.int64)
+            assert np.array_equal(P.nearest_index(out_size, in_size), want), (out_size, in_size)
+
+
+def test_training_flip_is_both_flips():
+    x = np.arange(2 * 5 * 7, dtype=np.int16).reshape(2, 5, 7)
+    a = P.load_crop(x, 4, train=False)
+    b = P.load_crop(x, 4, train=True)
+    assert np.array_equal(b, a[:, ::-1, ::-1])
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+def _dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+def test_hip_preprocess_reference_crops_bit_exact(golden):
+    """The reference's own int16 test crops, band-first (rasterio order) and pixel-interleaved (on-disk order),
+    against the outputs of the reference's preprocess_image + NEAREST resize: bit-identical."""
+    from deeptreeattention_amd import preprocess as PP
+    g = golden("preprocess.npz")
+    names = list(g["names"])
+    raws = [g[f"{n}/raw"] for n in names]
+    want = np.stack([g[f"{n}/resized11"] for n in names])
+    got = PP.preprocess_batch(raws, 11, train=False).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    hwc = [np.ascontiguousarray(np.moveaxis(r, 0, 2)) for r in raws]
+    got = PP.preprocess_batch(hwc, 11, train=False, pixel_interleaved=True).cpu().numpy()
+    assert np.array_equal(got, want)
+    got = PP.preprocess_batch(hwc, 11, train=True, pixel_interleaved=True).cpu().numpy()
+    assert np.array_equal(got, want[:, :, ::-1, ::-1])
+    assert np.array_equal(PP.load_image(raws[0], 24).cpu().numpy(), g[f"{names[0]}/resized24"])
+    for n in ("syn", "rgb"):      # float32 with constant / near-constant pixels; 3 uint8 bands (no band clipping)
+        assert np.array_equal(PP.preprocess_image(g[f"{n}/raw"], channel_is_first=True).cpu().numpy(), g[f"{n}/pre"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.int16, np.uint8])
+@pytest.mark.parametrize("size", [11, 24])
+def test_hip_preprocess_ragged_batch_vs_oracle(dtype, size):
+    """Ragged crops (1x1 up to 40x33), a missing year, both raw layouts, both flip settings: bit-exact vs the oracle."""
+    from deeptreeattention_amd import preprocess as PP
+    rng = np.random.RandomState(9)
+    bands = 369 if dtype != np.uint8 else 30
+    shapes = [(1, 1), (5, 7), (11, 11), (12, 9), (23, 40), (40, 33), (2, 30), (17, 3)]
+    crops = []
+    for h, w in shapes:
+        a = rng.randint(-300, 12000, size=(bands, h, w)) if dtype != np.uint8 else rng.randint(0, 256, size=(bands, h, w))
+        a = a.astype(dtype)
+        if dtype == np.float32:
+            a = (a * np.float32(0.37)).astype(np.float32)
+        crops.append(a)
+    crops[3][:, 0, 0] = 5            # a constant pixel
+    crops.insert(2, None)            # a missing year
+    for train in (False, True):
+        want = np.stack([np.zeros((bands - 20, size, size), np.float32) if c is None else P.load_crop(c, size, train)
+                         for c in crops])
+        got = PP.preprocess_batch(crops, size, train=train).cpu().numpy()
+        assert np.array_equal(got, want), ("chw", train)
+        hwc = [None if c is None else np.ascontiguousarray(np.moveaxis(c, 0, 2)) for c in crops]
+        got = PP.preprocess_batch(hwc, size, train=train, pixel_interleaved=True).cpu().numpy()
+        assert np.array_equal(got, want), ("hwc", train)
+
+
+@pytest.mark.gpu
+def test_hip_preprocess_feeds_the_network():
+    """End to end: raw int16 crops -> device preprocessing -> Hang2020 forward, equal to feeding the oracle's batch."""
+    from deeptreeattention_amd import preprocess as PP, Hang2020 as H
+    rng = np.random.RandomState(2)
+    crops = [rng.randint(0, 9000, size=(389, rng.randint(6, 30), rng.randint(6, 30))).astype(np.int16) for _ in range(16)]
+    x = PP.preprocess_batch(crops, 11, train=True)
+    assert x.shape == (16, 369, 11, 11) and float(x.min()) == 0.0 and abs(float(x.max()) - 1.0) < 3e-7
+    want = torch.from_numpy(np.stack([P.load_crop(c, 11, True) for c in crops])).to(_dev())
+    torch.manual_seed(0)
+    m = H.Hang2020(369, 12).to(_dev()).eval()
+    assert torch.equal(x, want)
+    with torch.no_grad():
+        assert torch.isfinite(m(x)).all()
