@@ -5,6 +5,7 @@ import os
 import re
 
 import pytest
+import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -90,3 +91,33 @@ def test_product_never_imports_the_oracle():
     for f in glob.glob(os.path.join(REPO, "deeptreeattention_amd", "**", "*.py"), recursive=True):
         src = open(f).read()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_multistage_and_treemodel_checkpoint_key_mapping(tmp_path, golden):
+    """Reference LightningModule checkpoints: MultiStage keys `models.{level}.model.year_models.{y}.<key>` (+
+    `loss_weight_{level}`), TreeModel keys `model.<key>`; round trip through a file and a Lightning-style dict."""
+    from deeptreeattention_amd import checkpoint as CK, Hang2020 as H
+    from deeptreeattention_amd.year import learned_ensemble
+    cfg = {"pretrain_state_dict": None, "bands": 6}
+    torch.manual_seed(1)
+    src = [learned_ensemble(2, c, cfg) for c in (3, 5)]
+    sd = CK.multistage_state_dict(src, {0: torch.ones(3), 1: torch.arange(5.0)})
+    assert "models.1.model.year_models.0.conv1.conv_layer.weight" in sd
+    assert "models.0.model.year_models.1.attention_3.attention_conv2.bias" in sd
+    assert "models.1.model.year_models.1.conv3.bn1.num_batches_tracked" in sd and "loss_weight_1" in sd
+    path = str(tmp_path / "multistage.pt")
+    torch.save({"state_dict": sd, "epoch": 3}, path)            # a Lightning checkpoint wraps the state_dict
+    dst = [learned_ensemble(2, c, cfg) for c in (3, 5)]
+    weights = CK.load_multistage(path, dst)
+    for a, b in zip(src, dst):
+        for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb)
+    assert torch.equal(weights[1], torch.arange(5.0))
+    with pytest.raises(KeyError):
+        CK.load_multistage({"state_dict": {}}, dst)
+    # TreeModel: the golden key list is the reference Hang2020's own
+    m = H.Hang2020(3, 10)
+    tm = {"model." + k: v.clone() + 1 for k, v in m.state_dict().items()}
+    assert [k[len("model."):] for k in tm] == list(golden("hang2020_3_10.npz")["keys"])
+    CK.load_treemodel({"state_dict": tm}, m)
+    assert torch.equal(m.state_dict()["spectral_network.conv1.conv_layer.weight"], tm["model.spectral_network.conv1.conv_layer.weight"])
