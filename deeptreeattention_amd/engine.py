@@ -436,25 +436,123 @@ class MultiStageTrainer:
         return {"individual": individual, "yhat": torch.softmax(scores, dim=1), "label": y, "val_loss": loss}
 
 
+class Predictor:
+    """Inference step of the reference (`MultiStage.predict_step` src/models/multi_stage.py:306-318,
+    `TreeModel.predict_dataloader` src/main.py:165-205): eval-mode forward, softmax over the classes and the top-2
+    labels / scores, all on the device, with the descriptor, pointer tables, workspace and output buffers cached
+    across calls (two C-ABI calls per batch, no per-call Python walk over the module tree).
+
+    model: a network of this package (Hang2020, vanilla_CNN; spectral/spatial_network -> last head) or a
+    year.learned_ensemble (zero years are skipped as in training: one host transfer per call, or pass `present`).
+    The pointer tables are rebuilt when the batch shape changes; call refresh() after replacing parameter tensors
+    (in-place updates, e.g. by FusedTrainer or load_state_dict, need nothing)."""
+
+    def __init__(self, model):
+        from .year import learned_ensemble
+        self.model = model
+        self.ensemble = isinstance(model, learned_ensemble)
+        nets = list(model.year_models) if self.ensemble else [model]
+        if not all(isinstance(n, H._Net) for n in nets):
+            raise TypeError("Predictor needs a deeptreeattention_amd network or learned_ensemble")
+        self.nets_mod = nets
+        self.device = next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("Predictor needs the model on a ROCm device (model.cuda()); there is no CPU path")
+        self._key = None
+
+    def refresh(self):
+        self._key = None
+
+    def _tables(self, mods):
+        out = []
+        for m in mods:
+            subnets = m._subnets()
+            arr = (_lib.SubnetParams * len(subnets))()
+            for i, (kind, mod, names) in enumerate(subnets):
+                tensors = {n: H._get(mod, n) for n in names}
+                for Lv in (1, 2, 3):
+                    bn = H._get(mod, f"conv{Lv}.bn1")
+                    tensors[f"conv{Lv}.bn1.running_mean"] = bn.running_mean
+                    tensors[f"conv{Lv}.bn1.running_var"] = bn.running_var
+                    tensors[f"conv{Lv}.bn1.num_batches_tracked"] = bn.num_batches_tracked
+                H._fill_struct(arr[i], kind, tensors, False)
+            out.append(arr)
+        return out
+
+    def _prepare(self, shape, kept):
+        L = _lib.lib()
+        m0 = self.nets_mod[0]
+        key = (tuple(shape), m0.precision, tuple(kept))
+        if key == self._key:
+            return
+        B, bands, Hh, Ww = shape
+        single = m0._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
+        self.desc = _lib.NetDesc(B, bands, Hh, Ww, m0._classes, m0._net_code, _lib.dtype_code(m0.precision), 0, 4,
+                                 H.BN_MOMENTUM, H.BN_EPS)
+        tables = self._tables([self.nets_mod[i] for i in kept])
+        if self.ensemble:
+            self.nets = (_lib.SubnetParams * len(kept))(*[t[0] for t in tables])
+            nbytes = L.dta_ensemble_workspace_bytes(C.byref(self.desc), len(kept))
+        else:
+            self.nets = tables[0]
+            nbytes = L.dta_net_workspace_bytes(C.byref(self.desc))
+        if nbytes == 0:
+            raise RuntimeError("workspace: " + L.dta_last_error().decode())
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.logits = torch.empty(B, m0._classes, dtype=torch.float32, device=self.device)
+        self.probs = torch.empty_like(self.logits)
+        self.top_idx = torch.empty(B, 2, dtype=torch.int64, device=self.device)
+        self.top_score = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+        self.single = single
+        self._key = key
+
+    def logits_of(self, images, present=None):
+        """Eval-mode scores (B, classes) of the batch; the returned tensor is reused by the next call."""
+        L = _lib.lib()
+        st = _lib.current_stream_ptr()
+        if self.ensemble:
+            if present is None:
+                present = (torch.stack([x.sum() for x in images]) != 0).tolist()
+            kept = [i for i, k in enumerate(present) if k]
+            if not kept:
+                raise RuntimeError("every year of the batch is all-zero: nothing to average (reference year.py:33)")
+            xs = [H._check_input(images[i]) for i in kept]
+            self._prepare(xs[0].shape, kept)
+            xptr = (C.c_void_p * len(kept))(*[x.data_ptr() for x in xs])
+            _lib.check(L.dta_ensemble_forward(C.byref(self.desc), len(kept), self.nets, xptr, _lib.ptr(self.ws),
+                                              _lib.ptr(self.logits), st), "dta_ensemble_forward")
+            return self.logits
+        x = H._check_input(images)
+        self._prepare(x.shape, [0])
+        m = self.nets_mod[0]
+        table = _lib.ScoreTable()
+        joint = _lib.ptr(self.logits)
+        if not self.single:
+            table[0][2] = self.logits.data_ptr()
+            joint = None
+        alpha = _lib.ptr(m.alpha) if m._net_code == _lib.NET_HANG2020 else None
+        _lib.check(L.dta_net_forward(C.byref(self.desc), self.nets, alpha, _lib.ptr(x), _lib.ptr(self.ws),
+                                     C.byref(table), joint, st), "dta_net_forward")
+        return self.logits
+
+    def __call__(self, images, return_probs=True, present=None):
+        """Returns (probs or None, top_idx [B,2] int64, top_score [B,2] float32); buffers are reused across calls."""
+        L = _lib.lib()
+        logits = self.logits_of(images, present)
+        Bn, classes = logits.shape
+        _lib.check(L.dta_softmax_top2(_lib.ptr(logits), Bn, classes, _lib.ptr(self.probs) if return_probs else None,
+                                      _lib.ptr(self.top_idx), _lib.ptr(self.top_score), _lib.current_stream_ptr()),
+                   "dta_softmax_top2")
+        return (self.probs if return_probs else None), self.top_idx, self.top_score
+
+
 def predict(model, images, return_probs=True):
-    """Inference step of the reference (`MultiStage.predict_step` / `TreeModel.predict_dataloader`): eval-mode forward,
-    softmax over classes and the top-2 labels/scores, all on the device.  Returns (probs or None, top_idx [B,2] int64,
-    top_score [B,2] float32)."""
-    L = _lib.lib()
-    was_training = model.training
-    model.eval()
-    try:
-        with torch.no_grad():
-            logits = model(images)
-    finally:
-        model.train(was_training)
-    if isinstance(logits, (list, tuple)):
-        logits = logits[-1]
-    logits = logits.contiguous().float()
-    Bn, classes = logits.shape
-    probs = torch.empty_like(logits) if return_probs else None
-    idx = torch.empty(Bn, 2, dtype=torch.int64, device=logits.device)
-    score = torch.empty(Bn, 2, dtype=torch.float32, device=logits.device)
-    _lib.check(L.dta_softmax_top2(_lib.ptr(logits), Bn, classes, _lib.ptr(probs), _lib.ptr(idx), _lib.ptr(score),
-                                  _lib.current_stream_ptr()), "dta_softmax_top2")
-    return probs, idx, score
+    """Inference step of the reference (`MultiStage.predict_step` / `TreeModel.predict_dataloader`): eval-mode forward
+    (whatever the module's current train/eval flag), softmax over classes and the top-2 labels/scores, all on the
+    device, through a Predictor cached on the module.  Returns (probs or None, top_idx [B,2] int64, top_score [B,2]
+    float32); the tensors are reused by the next call on the same module."""
+    pr = model.__dict__.get("_dta_predictor")
+    if pr is None:
+        pr = Predictor(model)
+        model.__dict__["_dta_predictor"] = pr
+    return pr(images, return_probs)

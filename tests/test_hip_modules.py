@@ -288,3 +288,36 @@ def test_grouped_ensemble_equals_independent_networks(years, hw, bands, prec):
         assert rel_l2(got[k].cpu().numpy(), p.grad.cpu().numpy()) < max(tol, 2e-5), k
     assert int(buf["year_models.1.conv1.bn1.num_batches_tracked"]) == 0      # the skipped year was not touched
     assert int(buf["year_models.0.conv1.bn1.num_batches_tracked"]) == 1
+
+
+def test_predictor_matches_module_eval_and_ensemble():
+    """Cached inference path vs the module-level eval forward + torch softmax/topk: Hang2020, a spectral network
+    (last head) and a year ensemble with a zero year."""
+    from deeptreeattention_amd.engine import Predictor
+    from deeptreeattention_amd.year import learned_ensemble
+    from deeptreeattention_amd import Hang2020 as H
+    torch.manual_seed(5)
+    B, bands, classes = 9, 16, 7
+    x = torch.rand(B, bands, 11, 11, device=dev())
+    for m in (H.Hang2020(bands, classes), H.spectral_network(bands, classes), H.vanilla_CNN(bands, classes)):
+        m = m.to(dev()).eval()
+        for bn in [q for q in m.modules() if isinstance(q, torch.nn.BatchNorm2d)]:
+            bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+        with torch.no_grad():
+            want = m(x)
+        want = want[-1] if isinstance(want, (list, tuple)) else want
+        pr = Predictor(m)
+        for _ in range(2):      # second call reuses every cached buffer
+            probs, idx, score = pr(x)
+            assert rel_l2(probs.cpu().numpy(), torch.softmax(want, 1).cpu().numpy()) < 1e-5
+            ts, ti = torch.softmax(want, 1).topk(2, dim=1)
+            assert torch.equal(idx, ti) and rel_l2(score.cpu().numpy(), ts.cpu().numpy()) < 1e-5
+        assert pr(x[:4])[1].shape == (4, 2)       # a new batch shape rebuilds the cache
+    ens = learned_ensemble(3, classes, {"pretrain_state_dict": None, "bands": bands}).to(dev()).eval()
+    imgs = [torch.rand(B, bands, 11, 11, device=dev()) for _ in range(3)]
+    imgs[0].zero_()
+    with torch.no_grad():
+        want = ens(imgs)
+    probs, idx, score = Predictor(ens)(imgs)
+    assert rel_l2(probs.cpu().numpy(), torch.softmax(want, 1).cpu().numpy()) < 1e-5
+    assert torch.equal(idx[:, 0], want.argmax(1))
