@@ -436,6 +436,60 @@ class MultiStageTrainer:
         return {"individual": individual, "yhat": torch.softmax(scores, dim=1), "label": y, "val_loss": loss}
 
 
+class MetadataTrainer:
+    """Fused train step of the site-metadata fusion model (reference src/models/metadata.py): the step
+    MetadataModel.training_step defines (:52-63: unweighted F.cross_entropy(model(images, site), y)) with Adam.
+    The HSI branch (Hang2020, >99.9 % of the work) runs through the fused C-ABI pieces on flat buffers; the 16-wide
+    site MLP and the 2*classes -> classes fusion layer (<0.2 MFLOP per sample) stay a small torch
+    autograd graph with their own torch Adam, joined to the HSI branch at its (B, classes) scores."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, process_group=None, overlap_comm=True,
+                 keep_grads=False):
+        from .metadata import metadata_sensor_fusion
+        if not isinstance(model, metadata_sensor_fusion):
+            raise TypeError("MetadataTrainer needs a deeptreeattention_amd.metadata.metadata_sensor_fusion")
+        self.model = model
+        self.sensor = FusedTrainer(model.sensor_model, lr, None, betas, eps, process_group, overlap_comm, keep_grads)
+        self.small = list(model.metadata_model.parameters()) + list(model.fc1.parameters())
+        self.opt = torch.optim.Adam(self.small, lr=lr, betas=betas, eps=eps)
+        self.world, self.pg = self.sensor.world, self.sensor.pg
+        if self.world > 1:
+            for t in self.small + list(model.metadata_model.buffers()):
+                torch.distributed.broadcast(t.data, 0, group=self.pg)
+
+    def _head(self, scores, site):
+        meta = self.model.metadata_model(site)
+        return torch.relu(self.model.fc1(torch.cat([meta, scores], dim=1)))
+
+    def train_step(self, images, site, y):
+        """images (B, bands, 11, 11) float32, site (B,) int64 site indices, y (B,) int64 labels -> loss (0-d tensor)."""
+        y = self.sensor._labels(y)
+        scores = self.sensor._forward_scores(images).detach().requires_grad_(True)
+        self.opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(self._head(scores, site), y)
+        loss.backward()                                   # the small graph: MLP / fusion grads and d(loss)/d(scores)
+        self.sensor._backward(scores.grad.contiguous())
+        self.sensor._adam()
+        if self.world > 1:
+            for p in self.small:
+                torch.distributed.all_reduce(p.grad, group=self.pg)
+                p.grad.mul_(1.0 / self.world)
+        self.opt.step()
+        return loss.detach()
+
+    def training_step(self, batch, batch_idx=0):
+        """metadata.py:52-63 unpacking: batch = (individual, {"HSI": images, "site": site}, y)."""
+        individual, inputs, y = batch
+        return self.train_step(inputs["HSI"], inputs["site"], y)
+
+    def validation_step(self, batch, batch_idx=0):
+        """metadata.py:65-83: forward + unweighted CE, no update."""
+        individual, inputs, y = batch
+        with torch.no_grad():
+            scores = self.sensor._forward_scores(inputs["HSI"])
+            return torch.nn.functional.cross_entropy(self._head(scores, inputs["site"]), self.sensor._labels(y))
+
+
 class Predictor:
     """Inference step of the reference (`MultiStage.predict_step` src/models/multi_stage.py:306-318,
     `TreeModel.predict_dataloader` src/main.py:165-205): eval-mode forward, softmax over the classes and the top-2

@@ -321,3 +321,35 @@ def test_predictor_matches_module_eval_and_ensemble():
     probs, idx, score = Predictor(ens)(imgs)
     assert rel_l2(probs.cpu().numpy(), torch.softmax(want, 1).cpu().numpy()) < 1e-5
     assert torch.equal(idx[:, 0], want.argmax(1))
+
+
+def test_metadata_trainer_matches_module_level_training():
+    """BASELINE configs[3]: the fused MetadataModel step (HSI branch through the C ABI, site MLP in torch) against
+    the same model trained through autograd + one torch Adam over all parameters (dropout disabled: it is the only
+    random op of the step)."""
+    import copy
+    from deeptreeattention_amd.metadata import metadata_sensor_fusion
+    from deeptreeattention_amd.engine import MetadataTrainer
+    bands, classes, sites, B, lr = 12, 5, 4, 8, 1e-3
+    torch.manual_seed(4)
+    a = metadata_sensor_fusion(bands=bands, sites=sites, classes=classes).to(dev()).train()
+    a.metadata_model.dropout.p = 0.0
+    b = copy.deepcopy(a)
+    opt = torch.optim.Adam(b.parameters(), lr=lr)
+    tr = MetadataTrainer(a, lr=lr)
+    for step in range(3):
+        x = torch.from_numpy(prng.uniform01(40 + step, 1, (B, bands, 11, 11))).to(dev())
+        site = torch.from_numpy(prng.randint(40 + step, 2, (B,), sites)).to(dev())
+        y = torch.from_numpy(prng.randint(40 + step, 3, (B,), classes)).to(dev())
+        la = tr.training_step((["id"] * B, {"HSI": x, "site": site}, y))
+        opt.zero_grad(set_to_none=True)
+        lb = torch.nn.functional.cross_entropy(b(x, site), y)
+        lb.backward()
+        opt.step()
+        assert abs(float(la) - float(lb.detach())) < 1e-4 * abs(float(lb.detach())), step
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sb:
+        if k.endswith("conv_layer.bias") or k.endswith("num_batches_tracked") or k.endswith("running_mean"):
+            continue
+        assert rel_l2(sa[k].cpu().numpy(), sb[k].cpu().numpy()) < 2e-3, k
+    assert float(tr.validation_step((["id"] * B, {"HSI": x, "site": site}, y))) > 0
