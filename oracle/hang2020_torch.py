@@ -119,3 +119,18 @@ class EnsembleTrainStep:
         loss.backward()
         self.opt.step()
         return scores.detach(), loss.detach()
+
+
+def metadata_sensor_fusion(p, images, site, training=True, dropout_p=0.7, pre=""):
+    """src/models/metadata.py:9-44 over a flat parameter dict: site branch = Embedding(sites, 16) -> BatchNorm1d ->
+    Dropout(0.7) -> Linear(16, classes) -> ReLU (:17-24); sensor branch = Hang2020 (:31, :39); fusion =
+    ReLU(Linear(cat([site, sensor], 1))) (:40-42)."""
+    e = F.embedding(site, p[pre + "metadata_model.embedding.weight"])
+    e = F.batch_norm(e, p[pre + "metadata_model.batch_norm.running_mean"], p[pre + "metadata_model.batch_norm.running_var"],
+                     p[pre + "metadata_model.batch_norm.weight"], p[pre + "metadata_model.batch_norm.bias"],
+                     training, 0.1, 1e-5)
+    e = F.dropout(e, dropout_p, training)
+    meta = F.relu(F.linear(e, p[pre + "metadata_model.mlp.weight"], p[pre + "metadata_model.mlp.bias"]))
+    sensor = hang2020({k[len(pre + "sensor_model."):]: v for k, v in p.items() if k.startswith(pre + "sensor_model.")},
+                      images, training)
+    return F.relu(F.linear(torch.cat([meta, sensor], dim=1), p[pre + "fc1.weight"], p[pre + "fc1.bias"]))

@@ -361,6 +361,108 @@ def case_preprocess():
     print("preprocess.npz", len(out), names)
 
 
+def _stub_missing_packages():
+    """src/models/metadata.py imports src.main, which imports the whole GIS / Lightning stack (absent here).  Every
+    missing top-level package becomes an empty stub module; pytorch_lightning.LightningModule becomes nn.Module.
+    Only the import succeeds this way -- nothing of those packages is ever called by the model classes."""
+    import importlib.abc
+    import importlib.machinery
+    roots = {"pytorch_lightning", "geopandas", "rasterio", "comet_ml", "deepforest", "dask", "distributed", "h5py",
+             "shapely", "rasterstats", "skimage", "torchvision", "descartes", "pyproj", "rtree", "cv2", "seaborn",
+             "albumentations", "imblearn"}
+
+    class Anything:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return Anything()
+
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return Anything()
+
+    class Stub(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            v = Anything()
+            setattr(self, k, v)
+            return v
+
+    class Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path, target=None):
+            if name.split(".")[0] in roots and name not in sys.modules:
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+        def create_module(self, spec):
+            return Stub(spec.name)
+
+        def exec_module(self, module):
+            pass
+
+    for k in [k for k in sys.modules if k.split(".")[0] in roots]:
+        del sys.modules[k]
+    sys.meta_path.insert(0, Finder())
+    import pytorch_lightning as pl
+
+    class LightningModule(torch.nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+    pl.LightningModule = LightningModule
+    pl.LightningDataModule = type("LightningDataModule", (), {})
+
+
+def case_metadata():
+    """metadata_sensor_fusion (src/models/metadata.py:9-44) and the step MetadataModel.training_step defines (:52-63,
+    unweighted CE): eval forward, and a train-mode forward/backward with the Dropout(p=0.7) of the site branch set to
+    p=0 (its mask is the only random quantity of the step)."""
+    _stub_missing_packages()
+    from src.models import metadata as RM
+    out = {}
+    bands, classes, sites, B = 12, 5, 4, 6
+    torch.manual_seed(17)
+    m = RM.metadata_sensor_fusion(bands=bands, sites=sites, classes=classes)
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=9)
+    load(m.sensor_model, p)
+    for k, v in m.state_dict().items():
+        if not k.startswith("sensor_model."):
+            out[f"init/{k}"] = v.numpy().copy()      # the small site branch / fusion layer: torch's own init, stored
+    x = torch.from_numpy(prng.uniform01(10, 1, (B, bands, 11, 11)))
+    site = torch.from_numpy(prng.randint(10, 2, (B,), sites))
+    y = torch.from_numpy(prng.randint(10, 3, (B,), classes))
+    m.eval()
+    with torch.no_grad():
+        out["eval/out"] = m(x, site).numpy()
+    m.train()
+    m.metadata_model.dropout.p = 0.0
+    yhat = m(x, site)
+    loss = F.cross_entropy(yhat, y)
+    loss.backward()
+    out["train/out"] = yhat.detach().numpy()
+    out["train/loss"] = np.float64(loss.item())
+    none = []
+    for k, prm in m.named_parameters():
+        if prm.grad is None:
+            none.append(k)
+        else:
+            out[f"train/gnorm/{k}"] = np.float64(prm.grad.double().norm().item())
+            if not k.startswith("sensor_model."):
+                out[f"train/g/{k}"] = prm.grad.numpy().copy()
+    out["train/none"] = np.array(none)
+    for k, b in m.named_buffers():
+        if not k.startswith("sensor_model."):
+            out[f"train/buf/{k}"] = b.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "metadata.npz"), **out)
+    print("metadata.npz", len(out))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:      # regenerate only the named cases, e.g. `make_golden.py case_ensemble_steps`
         for name in sys.argv[1:]:
@@ -372,3 +474,4 @@ if __name__ == "__main__":
     case_ensemble_steps()
     case_preprocess()
     case_hang_full()
+    case_metadata()          # last: it stubs packages process-wide

@@ -353,3 +353,44 @@ def test_metadata_trainer_matches_module_level_training():
             continue
         assert rel_l2(sa[k].cpu().numpy(), sb[k].cpu().numpy()) < 2e-3, k
     assert float(tr.validation_step((["id"] * B, {"HSI": x, "site": site}, y))) > 0
+
+
+def test_metadata_sensor_fusion_vs_reference_golden(golden):
+    """BASELINE configs[3] model against the reference's own outputs (tests/golden/metadata.npz): eval forward, and the
+    unweighted-CE train step's forward/backward with the site branch's dropout disabled."""
+    from deeptreeattention_amd.metadata import metadata_sensor_fusion
+    g = golden("metadata.npz")
+    bands, classes, sites, B = 12, 5, 4, 6
+    m = metadata_sensor_fusion(bands=bands, sites=sites, classes=classes)
+    sd = {"sensor_model." + k: torch.from_numpy(np.array(v)) for k, v in
+          O.init_params(O.hang2020_spec(bands, classes), seed=9).items()}
+    sd.update({k[len("init/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init/")})
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    x = torch.from_numpy(prng.uniform01(10, 1, (B, bands, 11, 11))).to(dev())
+    site = torch.from_numpy(prng.randint(10, 2, (B,), sites)).to(dev())
+    y = torch.from_numpy(prng.randint(10, 3, (B,), classes)).to(dev())
+    m.eval()
+    with torch.no_grad():
+        assert rel_l2(m(x, site).cpu().numpy(), g["eval/out"]) < TIGHT
+    m.train()
+    m.metadata_model.dropout.p = 0.0
+    out = m(x, site)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    assert rel_l2(out.detach().cpu().numpy(), g["train/out"]) < TIGHT
+    assert abs(float(loss.detach()) - float(g["train/loss"])) < TIGHT * abs(float(g["train/loss"]))
+    none = set(g["train/none"].tolist())
+    for k, prm in m.named_parameters():
+        if k in none:
+            assert prm.grad is None, k
+            continue
+        if k.endswith("conv_layer.bias"):
+            continue
+        ref = float(g[f"train/gnorm/{k}"])
+        assert abs(float(prm.grad.double().norm()) - ref) <= TOL * max(ref, 1e-9), k
+        if f"train/g/{k}" in g:
+            assert rel_l2(prm.grad.cpu().numpy(), g[f"train/g/{k}"]) < TOL, k
+    for k, b in m.named_buffers():
+        if f"train/buf/{k}" in g:
+            assert rel_l2(b.cpu().numpy(), g[f"train/buf/{k}"]) < TIGHT, k

@@ -261,3 +261,48 @@ def test_torch_oracle_ensemble_steps_match_reference_golden(golden):
             a = t.detach().numpy()
             assert abs(np.sqrt((a.astype(np.float64) ** 2).sum()) - float(g[f"step{step}/pnorm/{k}"])) \
                 <= 1e-5 * float(g[f"step{step}/pnorm/{k}"]), (step, k)
+
+
+def _metadata_params(g, bands, classes):
+    """Sensor weights from the portable PRNG, the small site branch / fusion layer from the stored torch init."""
+    import torch
+    from oracle import hang2020_torch as OT
+    p = OT.to_tensors({"sensor_model." + k: v for k, v in O.init_params(O.hang2020_spec(bands, classes), seed=9).items()})
+    for k in g.files:
+        if k.startswith("init/"):
+            t = torch.tensor(g[k])
+            if t.is_floating_point() and "running_" not in k:
+                t.requires_grad_(True)
+            p[k[len("init/"):]] = t
+    return p
+
+
+def test_torch_oracle_metadata_fusion_matches_reference_golden(golden):
+    """metadata_sensor_fusion of the reference (imported with the GIS / Lightning stack stubbed): eval output, and a
+    train-mode forward/backward of the unweighted-CE step with the site branch's dropout disabled."""
+    import torch
+    from oracle import hang2020_torch as OT
+    g = golden("metadata.npz")
+    bands, classes, sites, B = 12, 5, 4, 6
+    x = torch.from_numpy(prng.uniform01(10, 1, (B, bands, 11, 11)))
+    site = torch.from_numpy(prng.randint(10, 2, (B,), sites))
+    y = torch.from_numpy(prng.randint(10, 3, (B,), classes))
+    p = _metadata_params(g, bands, classes)
+    with torch.no_grad():
+        assert rel_l2(OT.metadata_sensor_fusion(p, x, site, False).numpy(), g["eval/out"]) < 1e-5
+    out = OT.metadata_sensor_fusion(p, x, site, True, dropout_p=0.0)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    assert rel_l2(out.detach().numpy(), g["train/out"]) < 1e-5
+    assert abs(float(loss.detach()) - float(g["train/loss"])) < 1e-5 * abs(float(g["train/loss"]))
+    none = set(g["train/none"].tolist())
+    for k, t in p.items():
+        if not t.requires_grad:
+            continue
+        if k in none:
+            assert t.grad is None or not t.grad.any(), k
+            continue
+        ref = float(g[f"train/gnorm/{k}"])
+        if k.endswith("conv_layer.bias"):
+            continue
+        assert abs(float(t.grad.double().norm()) - ref) <= 1e-4 * max(ref, 1e-9), k
