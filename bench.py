@@ -29,6 +29,7 @@ FLOP_PER_PATCH_STEP = 154_486_824       # torch FlopCounterMode 
 BYTES_PER_PATCH_STEP = 358_000          # compulsory HBM bytes per patch (fp32 input read twice)
 CONV1_FLOP_PER_PATCH = 2 * 25_717_824   # both branches' first conv, forward (== its weight-gradient FLOPs)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                           # HBM3E, MI355X_MICROARCH.md
 
 
 def parse():
@@ -179,6 +180,15 @@ def main():
                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes)",
                         "avg_launch_ms": round(avg_ms, 4), "launches": n,
                         "algorithmic_flop_per_launch": flops}
+                if a.site == "fwd0" and a.precision == "bf16":
+                    # the bf16 conv1 forward reads the fp32 NCHW input itself and leaves the bf16 tiles behind for the
+                    # weight gradient: per patch 369*121*4 B in, 384*121*2 B of tiles + 64*121*4 B of output out.
+                    # That makes it HBM-bound (its MFMA floor is ~21 us, its HBM floor ~39 us at 8 TB/s)
+                    nbytes = a.batch * (BANDS * HW * HW * 4 + 384 * HW * HW * 2 + 64 * HW * HW * 4)
+                    gbs = nbytes / (avg_ms * 1e-3) / 1e9
+                    roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
+                                 "mfma_tflops": round(ach, 2)})
         total = a.steps * a.batch * world
         value = total / el
         out = {

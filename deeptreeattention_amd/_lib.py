@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libdta_hip.so")
 
 DTA_F32, DTA_BF16 = 0, 1
 MAX_YEARS = 4   # DTA_MAX_YEARS
+FORWARD_ONLY = 8   # DTA_FORWARD_ONLY (heads_mask flag)
 NET_HANG2020, NET_SPECTRAL, NET_SPATIAL, NET_VANILLA = 0, 1, 2, 3
 SITE_CONV_FWD, SITE_CONV_WGRAD, SITE_CONV_DGRAD, SITE_STAGE_FWD, SITE_STAGE_BWD, SITE_GEMM = 0, 3, 6, 9, 12, 15
 _DTYPES = {"fp32": DTA_F32, "f32": DTA_F32, "float32": DTA_F32, "bf16": DTA_BF16, "bfloat16": DTA_BF16}

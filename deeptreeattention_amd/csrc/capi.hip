@@ -181,6 +181,9 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
   return 0;
 }
 
+// bf16 networks whose input tiles are halo-free: the first conv converts the fp32 input while staging it
+inline bool fused_input(const Plan& p) { return p.esz == 2 && p.x_compact && !getenv("DTA_NO_FUSED_INPUT"); }
+
 template <typename T> inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
 
 StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, void* ws, int L) {
@@ -253,7 +256,9 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
   }
   {
     PrepArgs pa = {};
-    pa.nx = p.shared_x ? 1 : G; pa.x_tl_gs = p.x_tl_gs;
+    // bf16, halo-free input tiles: the first conv reads the caller's fp32 tensor itself (and leaves the bf16 tiles
+    // behind for the weight gradient), so there is no input-pack job
+    pa.nx = fused_input(p) ? 0 : (p.shared_x ? 1 : G); pa.x_tl_gs = p.x_tl_gs;
     for (int g = 0; g < pa.nx; ++g) pa.x[g] = xs[g];
     pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
     pa.x_compact = p.x_compact;
@@ -269,8 +274,14 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     // conv
     ConvArgs ca;
     memset(&ca, 0, sizeof(ca));
-    if (L == 0) { ca.x_tl = at<char>(ws, p.x_tl); ca.x_gs = p.x_tl_gs / p.esz; ca.x_compact = p.x_compact; }
-    else { ca.x_tl = at<char>(ws, p.a_tl[L - 1]); ca.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
+    if (L == 0) {
+      ca.x_tl = at<char>(ws, p.x_tl); ca.x_gs = p.x_tl_gs / p.esz; ca.x_compact = p.x_compact;
+      if (fused_input(p)) {
+        for (int g = 0; g < G; ++g) ca.x_nchw[g] = xs[p.shared_x ? 0 : g];
+        ca.Cx = p.bands;
+        ca.x_tl_out = (d->heads_mask & DTA_FORWARD_ONLY) ? nullptr : at<char>(ws, p.x_tl);   // only the backward reads the tiles
+      }
+    } else { ca.x_tl = at<char>(ws, p.a_tl[L - 1]); ca.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
     ca.wp = at<char>(ws, p.wp[L]);
     for (int g = 0; g < G; ++g) ca.bias[g] = nets[g].conv_b[L];
     ca.bias_mode = pack_mode[L]; ca.bias_split = 32;
@@ -294,6 +305,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     if (launch_bn_finalize(bf, G, st)) return 1;
     // BN + ReLU + pool + attention
     StageArgs sa = stage_args(p, d, nets, ws, L);
+    if (d->heads_mask & DTA_FORWARD_ONLY) sa.attsave = nullptr;   // attention state is kept for the backward only
     prof_begin(DTA_SITE_STAGE_FWD + L, st);
     if (launch_stage_fwd<T>(sa, G, st)) return 1;
     prof_end(DTA_SITE_STAGE_FWD + L, st);
@@ -594,7 +606,7 @@ static int ensemble_desc(const dta_net_desc* d, int years, dta_net_desc* out, Pl
   if (!d || years < 1 || years > MAXG) { dta_set_error("%s: 1..%d years", who, MAXG); return 1; }
   if (d->kind != DTA_NET_SPECTRAL) { dta_set_error("%s: the descriptor's kind must be DTA_NET_SPECTRAL", who); return 1; }
   *out = *d;
-  out->heads_mask = 4;   // the ensemble keeps each year's last head only (reference year.py:30)
+  out->heads_mask = 4 | (d->heads_mask & DTA_FORWARD_ONLY);   // the ensemble keeps each year's last head only (reference year.py:30)
   return build_plan(out, p, years);
 }
 

@@ -10,6 +10,13 @@ namespace dta {
 constexpr int RB = 48;   // LDS bytes per 16-channel bf16 row: 32 data + 16 pad -> conflict-free b128 / tr_b16 reads
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
+// two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32)
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hw_bf16x2));
+}
+
 __device__ __forceinline__ bf16x8 lds_b128(const unsigned char* base, int off) {
   return *reinterpret_cast<const bf16x8*>(base + off);
 }
@@ -29,7 +36,7 @@ __device__ __forceinline__ bf16x8 lds_tr8w(const unsigned char* base, int off) {
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad conv
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT>
+template <int MT, int NT, bool XN>
 __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = 8, NTHR = 512;
@@ -100,6 +107,28 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     xsrc[u] = ((size_t)(b0 + pl) * a.NC) * xchunk + (size_t)o * 8;
     xdst[u] = (pl * Q + row) * RB + (o & 1) * 16;
   }
+  // ---- network input read directly as fp32 NCHW (no separate pack pass): thread t owns (patch, 4-channel group,
+  // pixel) quads t, t+512, ...; the 16 channel planes of a chunk are one contiguous run per patch, so consecutive lanes
+  // read consecutive floats.  Four channels of a pixel are converted and written to the LDS row as one 8-byte store.
+  constexpr int QV = 4;
+  constexpr bool xn = XN;
+  const float* xf = xn ? a.x_nchw[g] : nullptr;
+  const int nquad = xn ? npatch * 4 * HW : 0;
+  size_t qsrc[QV];
+  int qdst[QV], qch[QV];
+#pragma unroll
+  for (int u = 0; u < QV; ++u) {
+    int q = min(tid + u * NTHR, max(nquad, 1) - 1);
+    int pl = q / (4 * HW), rem = q - pl * 4 * HW;
+    int cq = rem / HW, px = rem - cq * HW;
+    const int hh = px / a.W;
+    const int row = (hh + 1) * W2 + (px - hh * a.W) + 1;
+    qsrc[u] = (size_t)(b0 + pl) * a.Cx * HW + px;    // channel 0 of the patch
+    qdst[u] = (pl * Q + row) * RB + cq * 8;
+    qch[u] = cq * 4;
+  }
+  float rf[QV][4];
+  bf16_t* xo = (XN && a.x_tl_out) ? (bf16_t*)a.x_tl_out + (size_t)g * a.x_gs : nullptr;
   if (xc) {   // the halo rows of both LDS stages
     u32x4* z = reinterpret_cast<u32x4*>(sbuf);
     const u32x4 zero = {0u, 0u, 0u, 0u};
@@ -114,15 +143,34 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   u32x4 rx[XV], rw[WV];
 #define DTA_FETCH(chunk_)                                                                             \
   {                                                                                                   \
-    _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                    \
-        rx[u] = *reinterpret_cast<const u32x4*>(xg + xsrc[u] + (size_t)(chunk_) * xchunk);            \
+    if (xn) {                                                                                         \
+      _Pragma("unroll") for (int u = 0; u < QV; ++u)                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+          const int ch_ = min((chunk_) * 16 + qch[u] + j, a.Cx - 1);   /* padded channels: clamped, zeroed at the store */ \
+          rf[u][j] = xf[qsrc[u] + (size_t)ch_ * HW];                                                  \
+        }                                                                                             \
+    } else {                                                                                          \
+      _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                  \
+          rx[u] = *reinterpret_cast<const u32x4*>(xg + xsrc[u] + (size_t)(chunk_) * xchunk);          \
+    }                                                                                                 \
     const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)(chunk_) * 9 * N * 16);           \
     _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[min(tid + u * NTHR, wvec - 1)];       \
   }
-#define DTA_STORE(sx_, sw_)                                                                           \
+#define DTA_STORE(sx_, sw_, chunk_)                                                                   \
   {                                                                                                   \
-    _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                    \
-        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((sx_) + xdst[u]) = rx[u];                 \
+    if (xn) {                                                                                         \
+      _Pragma("unroll") for (int u = 0; u < QV; ++u) {                                                \
+        /* channels past Cx (last chunk) hold a clamped copy of channel Cx-1: their packed weights are zero, and the */ \
+        /* weight-gradient reduction never reads their rows, so they need no masking */                \
+        u32x2 pk_;                                                                                    \
+        pk_.x = cvt_pk_bf16(rf[u][0], rf[u][1]);                                                      \
+        pk_.y = cvt_pk_bf16(rf[u][2], rf[u][3]);                                                      \
+        if (tid + u * NTHR < nquad) *reinterpret_cast<u32x2*>((sx_) + qdst[u]) = pk_;                 \
+      }                                                                                               \
+    } else {                                                                                          \
+      _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                  \
+          if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((sx_) + xdst[u]) = rx[u];               \
+    }                                                                                                 \
     _Pragma("unroll") for (int u = 0; u < WV; ++u)                                                    \
         if (tid + u * NTHR < wvec) *reinterpret_cast<u32x4*>((sw_) + wdst[u]) = rw[u];                \
   }
@@ -138,26 +186,104 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0); \
   }
 
+  if (XN && dbuf) {
+    // fp32 input, two LDS stages: the input of chunk k+2 AND k+3 is in flight (two register sets, alternating), because
+    // 16 dword loads per lane need more than one multiply phase to land; weights stay one chunk ahead
+    float rg[QV][4];
+#define DTA_FETCH_XF(dst_, chunk_)                                                                    \
+    _Pragma("unroll") for (int u = 0; u < QV; ++u)                                                    \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+        const int ch_ = min(min((chunk_), a.NC - 1) * 16 + qch[u] + j, a.Cx - 1);                     \
+        dst_[u][j] = xf[qsrc[u] + (size_t)ch_ * HW];                                                  \
+      }
+#define DTA_STORE_XF(src_, sx_)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < QV; ++u) {                                                  \
+      u32x2 pk_;                                                                                      \
+      pk_.x = cvt_pk_bf16(src_[u][0], src_[u][1]);                                                    \
+      pk_.y = cvt_pk_bf16(src_[u][2], src_[u][3]);                                                    \
+      if (tid + u * NTHR < nquad) *reinterpret_cast<u32x2*>((sx_) + qdst[u]) = pk_;                   \
+    }
+#define DTA_FETCH_W(chunk_)                                                                           \
+    {                                                                                                 \
+      const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)min((chunk_), a.NC - 1) * 9 * N * 16); \
+      _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[min(tid + u * NTHR, wvec - 1)];     \
+    }
+#define DTA_STORE_W(sw_)                                                                              \
+    _Pragma("unroll") for (int u = 0; u < WV; ++u)                                                    \
+        if (tid + u * NTHR < wvec) *reinterpret_cast<u32x4*>((sw_) + wdst[u]) = rw[u];
+#define DTA_TILE_OUT(cx_, chunk_)                                                                     \
+    if (xo) {   /* the chunk image just completed: its rows leave as the halo-free bf16 tile of (patch, chunk) */ \
+      _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                  \
+        if (tid + u * NTHR < nxv)                                                                     \
+          *reinterpret_cast<u32x4*>(xo + xsrc[u] + (size_t)(chunk_) * xchunk) =                       \
+              *reinterpret_cast<const u32x4*>((cx_) + xdst[u]);                                       \
+    }
+    DTA_FETCH_XF(rf, 0)
+    DTA_FETCH_W(0)
+    DTA_STORE_XF(rf, sbuf)
+    DTA_STORE_W(sbuf + xbytes)
+    DTA_FETCH_XF(rf, 1)
+    DTA_FETCH_W(1)
+    DTA_FETCH_XF(rg, 2)
+    __syncthreads();
+    unsigned char* s0 = sbuf;
+    unsigned char* s1 = sbuf + stage;
+    for (int chunk = 0; chunk < a.NC; chunk += 2) {
+      // even chunk in stage 0; chunk+1 (set rf) goes to stage 1, then rf refills with chunk+3
+      DTA_TILE_OUT(s0, chunk)
+      if (chunk + 1 < a.NC) {
+        DTA_STORE_XF(rf, s1)
+        DTA_STORE_W(s1 + xbytes)
+        DTA_FETCH_W(chunk + 2)
+        DTA_FETCH_XF(rf, chunk + 3)
+      }
+      DTA_COMPUTE(s0, s0 + xbytes)
+      __syncthreads();
+      if (chunk + 1 >= a.NC) break;
+      // odd chunk in stage 1; chunk+2 (set rg) goes to stage 0, then rg refills with chunk+4
+      DTA_TILE_OUT(s1, chunk + 1)
+      if (chunk + 2 < a.NC) {
+        DTA_STORE_XF(rg, s0)
+        DTA_STORE_W(s0 + xbytes)
+        DTA_FETCH_W(chunk + 3)
+        DTA_FETCH_XF(rg, chunk + 4)
+      }
+      DTA_COMPUTE(s1, s1 + xbytes)
+      __syncthreads();
+    }
+#undef DTA_TILE_OUT
+#undef DTA_STORE_W
+#undef DTA_FETCH_W
+#undef DTA_STORE_XF
+#undef DTA_FETCH_XF
+  } else {
   // chunk k+1 sits in registers while chunk k is multiplied; with two LDS stages its ds_writes also overlap
   DTA_FETCH(0)
-  DTA_STORE(sbuf, sbuf + xbytes)
+  DTA_STORE(sbuf, sbuf + xbytes, 0)
   if (a.NC > 1) DTA_FETCH(1)
   __syncthreads();
   for (int chunk = 0; chunk < a.NC; ++chunk) {
     unsigned char* cx = sbuf + ((dbuf && (chunk & 1)) ? stage : 0);
     unsigned char* nx = sbuf + ((dbuf && !(chunk & 1)) ? stage : 0);
     const bool more = chunk + 1 < a.NC;
+    if (xo) {   // the chunk image just completed: its rows leave as the halo-free bf16 tile of (patch, chunk)
+#pragma unroll
+      for (int u = 0; u < XV; ++u)
+        if (tid + u * NTHR < nxv)
+          *reinterpret_cast<u32x4*>(xo + xsrc[u] + (size_t)chunk * xchunk) = *reinterpret_cast<const u32x4*>(cx + xdst[u]);
+    }
     if (dbuf && more) {
-      DTA_STORE(nx, nx + xbytes)
+      DTA_STORE(nx, nx + xbytes, chunk + 1)
       if (chunk + 2 < a.NC) DTA_FETCH(chunk + 2)
     }
     DTA_COMPUTE(cx, cx + xbytes)
     __syncthreads();
     if (!dbuf && more) {
-      DTA_STORE(nx, nx + xbytes)
+      DTA_STORE(nx, nx + xbytes, chunk + 1)
       if (chunk + 2 < a.NC) DTA_FETCH(chunk + 2)
       __syncthreads();
     }
+  }
   }
 #undef DTA_COMPUTE
 #undef DTA_STORE
@@ -253,10 +379,12 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   if (a.ppw * a.Q * 2 > 4 * 512) { dta_set_error("conv3x3(bf16): %dx%d tile exceeds the staging plan", a.H, a.W); return 1; }
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT>), dim3(nwg, G), dim3(512), lds, st, a);
+  if (a.x_nchw[0]) hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, true>), dim3(nwg, G), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, false>), dim3(nwg, G), dim3(512), lds, st, a);
   DTA_CHECK_LAUNCH("k_conv3x3_bf16");
   return 0;
 }

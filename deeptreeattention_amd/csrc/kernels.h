@@ -21,6 +21,9 @@ struct ConvArgs {
   float* stats;                       // [G][nwg][N][2] (mean, M2) or null
   int B, H, W, NC, N, Q, HW, ppw, spp, dbuf;
   int x_compact;                      // bf16: input tiles are halo-free [patch][chunk][pixel][16] (network input only)
+  // bf16 first conv fed straight from the caller's tensor: x_nchw[g] = float32 [B][Cx][H][W]; the kernel converts while
+  // staging and (x_tl_out != null) writes the halo-free bf16 tiles it built as a by-product for the weight gradient
+  const float* x_nchw[MAXG]; int Cx; void* x_tl_out;
 };
 struct WgradArgs {
   const void* x_tl; size_t x_gs; int NCx;

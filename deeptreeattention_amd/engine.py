@@ -541,8 +541,8 @@ class Predictor:
             return
         B, bands, Hh, Ww = shape
         single = m0._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
-        self.desc = _lib.NetDesc(B, bands, Hh, Ww, m0._classes, m0._net_code, _lib.dtype_code(m0.precision), 0, 4,
-                                 H.BN_MOMENTUM, H.BN_EPS)
+        self.desc = _lib.NetDesc(B, bands, Hh, Ww, m0._classes, m0._net_code, _lib.dtype_code(m0.precision), 0,
+                                 4 | _lib.FORWARD_ONLY, H.BN_MOMENTUM, H.BN_EPS)
         tables = self._tables([self.nets_mod[i] for i in kept])
         if self.ensemble:
             self.nets = (_lib.SubnetParams * len(kept))(*[t[0] for t in tables])

@@ -30,7 +30,8 @@ typedef struct dta_net_desc {
   int kind;          /* DTA_NET_* */
   int dtype;         /* DTA_F32 (exact fp32 MFMA) or DTA_BF16 (bf16 MFMA inputs, fp32 accumulate) */
   int training;      /* 1: BatchNorm batch statistics + running-stat update; 0: running statistics */
-  int heads_mask;    /* bit L-1 set: compute classifier head L (Hang2020.forward only needs head 3 = 4) */
+  int heads_mask;    /* bit L-1 set: compute classifier head L (Hang2020.forward only needs head 3 = 4);
+                        | DTA_FORWARD_ONLY: no dta_net_backward will follow on this workspace (inference) */
   float bn_momentum, bn_eps;
 } dta_net_desc;
 
@@ -54,6 +55,9 @@ typedef struct dta_subnet_grads {
   float* att[3][6];
   float* fc_w[3]; float* fc_b[3];
 } dta_subnet_grads;
+
+/* heads_mask flag: the forward skips what only a backward would read (saved attention state, the bf16 input tiles) */
+#define DTA_FORWARD_ONLY 8
 
 int dta_abi_version(void);
 const char* dta_last_error(void);
