@@ -610,7 +610,8 @@ __device__ __forceinline__ void wgrad_reduce_blocks(const WgradReduceArgs& a, in
     for (; s + 12 < a.S; s += 16) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        float4 v = *reinterpret_cast<const float4*>(p + (size_t)(s + 4 * u) * sstride);
+        const f32x4 q_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)(s + 4 * u) * sstride));   // slabs: one reader
+        float4 v = make_float4(q_[0], q_[1], q_[2], q_[3]);
         acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
       }
     }

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     _Pragma("unroll") for (int u = 0; u < QV; ++u)                                                    \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
         const int ch_ = min(min((chunk_), a.NC - 1) * 16 + qch[u] + j, a.Cx - 1);                     \
-        dst_[u][j] = xf[qsrc[u] + (size_t)ch_ * HW];                                                  \
+        dst_[u][j] = __builtin_nontemporal_load(xf + qsrc[u] + (size_t)ch_ * HW);   /* read once per step */ \
       }
 #define DTA_STORE_XF(src_, sx_)                                                                       \
     _Pragma("unroll") for (int u = 0; u < QV; ++u) {                                                  \
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     if (xo) {   /* the chunk image just completed: its rows leave as the halo-free bf16 tile of (patch, chunk) */ \
       _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                  \
         if (tid + u * NTHR < nxv)                                                                     \
-          *reinterpret_cast<u32x4*>(xo + xsrc[u] + (size_t)(chunk_) * xchunk) =                       \
-              *reinterpret_cast<const u32x4*>((cx_) + xdst[u]);                                       \
+          __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>((cx_) + xdst[u]),               \
+                                      reinterpret_cast<u32x4*>(xo + xsrc[u] + (size_t)(chunk_) * xchunk)); \
     }
     DTA_FETCH_XF(rf, 0)
     DTA_FETCH_W(0)
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int c = cg * CT * 32 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (c < a.Cpad) out[((size_t)j * a.Cpad + c) * a.S * N + nt * 32 + (lane & 31)] = acc[j][r];
+      if (c < a.Cpad) __builtin_nontemporal_store(acc[j][r], &out[((size_t)j * a.Cpad + c) * a.S * N + nt * 32 + (lane & 31)]);
     }
   }
 }

@@ -994,16 +994,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
       const int i = i0 + u * 256;
       if (i < total) {
         const int pix = i >> c4sh, c4 = (i - (pix << c4sh)) * 4;
-        yv[u] = *(const f32x4*)(y + (size_t)pix * a.y_rs + c4);
+        yv[u] = __builtin_nontemporal_load((const f32x4*)(y + (size_t)pix * a.y_rs + c4));   // last reader of the conv output
         const int l = lut[pix];
         lq[u] = l;
-        if (!a.dv_compact) dvv[u] = *(const f32x4*)(dv + (size_t)pix * C + c4);
+        if (!a.dv_compact) dvv[u] = __builtin_nontemporal_load((const f32x4*)(dv + (size_t)pix * C + c4));
         else {
           // expand the pooled stage's compact gradient: the value lands on the window position the forward chose
           f32x4 dz = {0.f, 0.f, 0.f, 0.f};
           if (l >> 22) {
             const int pz = (l >> 10) & 1023, k = (l >> 20) & 3;
-            const f32x4 dc = *(const f32x4*)(dv + (size_t)pz * C + c4);
+            const f32x4 dc = __builtin_nontemporal_load((const f32x4*)(dv + (size_t)pz * C + c4));
             const unsigned fb = *(const unsigned*)(fpos + (size_t)pz * C + c4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) dz[j] = (int)((fb >> (8 * j)) & 0xFFu) == k ? dc[j] : 0.f;
