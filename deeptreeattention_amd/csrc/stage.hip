@@ -345,9 +345,9 @@ __device__ __forceinline__ void stage_fwd_patch(const StageArgs& a, const StageG
   if (a.attsave) {
     float* dst = a.attsave + ((size_t)g * a.B + b) * a.attsave_ld;
     if (kind == KIND_SPECTRAL) {
-      for (int i = t; i < 3 * C; i += 256) { const int k = i / C; dst[i] = v0[k * s.vslot + (i - k * C)]; }
+      for (int i = t; i < 3 * C; i += 256) { const int k = i / C; __builtin_nontemporal_store(v0[k * s.vslot + (i - k * C)], dst + i); }
     } else if (kind == KIND_SPATIAL) {
-      for (int i = t; i < 3 * s.vslot; i += 256) dst[i] = v0[i];
+      for (int i = t; i < 3 * s.vslot; i += 256) __builtin_nontemporal_store(v0[i], dst + i);   // read back by the backward only
     }
   }
 
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256, (CFG::fixed && CFG::P == 0) ? 4 : 1) void k_st
       const float* d_ = ba.da + (size_t)g * ba.da_gs + (size_t)(b_) * s.HWz * C;                     \
       _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                                               \
         const int i = t + u * 256;                                                                   \
-        if (i < NEL) { ry[u] = y_[(size_t)(i / CQ) * a.y_rs + (i % CQ)]; rq[u] = d_[i]; }            \
+        if (i < NEL) { ry[u] = y_[(size_t)(i / CQ) * a.y_rs + (i % CQ)]; rq[u] = __builtin_nontemporal_load(d_ + i); } \
       }                                                                                              \
     }
 #define DTA_STAGE_LAND(b_)                                                                           \
