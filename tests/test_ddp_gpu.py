@@ -2,6 +2,7 @@
 data-parallel train step: backward phases 1/2, side-stream all-reduce, 1/world scaling in the Adam kernel.
 Expected result: the oracle's Adam step on the MEAN of the two shards' gradients (per-rank BatchNorm statistics,
 per-rank loss normalisation = DDP semantics)."""
+import datetime
 import os
 import socket
 
@@ -27,7 +28,7 @@ def _worker(rank, world, port, overlap, out):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     from oracle import hang2020_np as O
     from oracle import prng
     from deeptreeattention_amd import Hang2020 as H

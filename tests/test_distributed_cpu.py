@@ -1,6 +1,7 @@
 """world_size-2 gloo tests (CPU) of the data-parallel host logic: gradient chunk all-reduce + averaging as the fused
 trainer does it, parameter broadcast at start-up, and per-rank data sharding.  The HIP kernels need a GPU; what
 is exercised here is deeptreeattention_amd.dist (the part of the N>1 path that is not a kernel)."""
+import datetime
 import os
 import socket
 
@@ -22,7 +23,7 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     from deeptreeattention_amd.dist import GradSync, shard_seed, flat_layout
     torch.manual_seed(100 + rank)
     n, split = 1000, 700
@@ -72,7 +73,7 @@ def test_flat_layout_puts_first_conv_last():
 def _ensemble_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     from deeptreeattention_amd.dist import GradSync, kept_anywhere
     # year 0 kept by both ranks, year 1 only by rank 1, year 2 by nobody
     local = [True, rank == 1, False]
