@@ -230,9 +230,9 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
   if (use_saved) {   // v0 | v1 | v2 as the forward kernel left them (padded maps include their zero borders)
     const float* src = a.attsave + ((size_t)g * a.B + b) * a.attsave_ld;
     if (kind == KIND_SPECTRAL) {   // three C-vectors, stored packed
-      for (int i = t; i < 3 * C; i += 256) { const int k = i / C; v0[k * s.vslot + (i - k * C)] = src[i]; }
+      for (int i = t; i < 3 * C; i += 256) { const int k = i / C; v0[k * s.vslot + (i - k * C)] = __builtin_nontemporal_load(src + i); }
     } else if (kind == KIND_SPATIAL) {
-      for (int i = t; i < 3 * s.vslot; i += 256) v0[i] = src[i];
+      for (int i = t; i < 3 * s.vslot; i += 256) v0[i] = __builtin_nontemporal_load(src + i);
     }
   } else if (kind == KIND_SPATIAL) {   // zero the padded maps' borders (interiors are overwritten below)
     for (int i = t; i < 2 * s.vslot; i += 256) v0[i] = 0.f;   // v0 and v1 are adjacent
@@ -244,7 +244,7 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
   float rd[ND];
   if (CFG::fixed && da) {
 #pragma unroll
-    for (int u = 0; u < ND; ++u) { const int i = t + u * 256; rd[u] = i < HZT * CT ? da[i] : 0.f; }
+    for (int u = 0; u < ND; ++u) { const int i = t + u * 256; rd[u] = i < HZT * CT ? __builtin_nontemporal_load(da + i) : 0.f; }
   }
   if (z_ready) {
     // the caller already built Z from prefetched registers
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
       const float* y_ = a.y + (size_t)g * a.y_gs + (size_t)(b_) * s.HWc * a.y_rs;                    \
       _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                                               \
         const int i = t + u * 256;                                                                   \
-        if (i < NEL) ry[u] = y_[(size_t)(i / CQ) * a.y_rs + (i % CQ)];                               \
+        if (i < NEL) ry[u] = __builtin_nontemporal_load(y_ + (size_t)(i / CQ) * a.y_rs + (i % CQ));  /* next reader: the backward */ \
       }                                                                                              \
     }
 #define DTA_STAGE_LAND()                                                                             \
@@ -767,9 +767,9 @@ __global__ __launch_bounds__(256, (CFG::fixed && CFG::P == 0) ? 4 : 1) void k_st
       }                                                                                              \
       const float* src = a.attsave + ((size_t)g * a.B + (b_)) * a.attsave_ld;                        \
       if (kind == KIND_SPECTRAL) {                                                                   \
-        for (int i = t; i < 3 * C; i += 256) { const int k = i / C; v0[k * s.vslot + (i - k * C)] = src[i]; } \
+        for (int i = t; i < 3 * C; i += 256) { const int k = i / C; v0[k * s.vslot + (i - k * C)] = __builtin_nontemporal_load(src + i); } \
       } else if (kind == KIND_SPATIAL) {                                                             \
-        for (int i = t; i < 3 * s.vslot; i += 256) v0[i] = src[i];                                   \
+        for (int i = t; i < 3 * s.vslot; i += 256) v0[i] = __builtin_nontemporal_load(src + i);      \
       }                                                                                              \
       __syncthreads();                                                                               \
     }
