@@ -28,6 +28,7 @@ def _worker(rank, world, port, overlap, out):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # single node: no hostname resolution in the rendezvous
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     from oracle import hang2020_np as O
     from oracle import prng

@@ -23,6 +23,7 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # single node: no hostname resolution in the rendezvous
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     from deeptreeattention_amd.dist import GradSync, shard_seed, flat_layout
     torch.manual_seed(100 + rank)
@@ -73,6 +74,7 @@ def test_flat_layout_puts_first_conv_last():
 def _ensemble_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # single node: no hostname resolution in the rendezvous
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     from deeptreeattention_amd.dist import GradSync, kept_anywhere
     # year 0 kept by both ranks, year 1 only by rank 1, year 2 by nobody
