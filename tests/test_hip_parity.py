@@ -344,3 +344,36 @@ def test_no_cpu_fallback():
     m = H.Hang2020(3, 10)
     with pytest.raises(RuntimeError):
         m(torch.zeros(2, 3, 11, 11))
+
+
+@pytest.mark.parametrize("B", [1, 3, 37, 130])
+def test_fused_input_conv_equals_separate_pack_pass(B, monkeypatch):
+    """bf16: the first conv that converts the fp32 NCHW input while staging it (and leaves the bf16 tiles behind for
+    the weight gradient) against the separate pack pass it replaced (developer switch DTA_NO_FUSED_INPUT): same tiles,
+    so logits and every gradient agree to reordering noise; ragged batches leave workgroups partly empty."""
+    from deeptreeattention_amd import Hang2020 as H
+    torch.manual_seed(B)
+    m = H.Hang2020(369, 11, precision="bf16").to(dev()).train()
+    x = torch.rand(B, 369, 11, 11, device=dev())
+    y = torch.randint(0, 11, (B,), device=dev())
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.reset_running_stats()
+        out = m(x)
+        torch.nn.functional.cross_entropy(out, y).backward()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    monkeypatch.delenv("DTA_NO_FUSED_INPUT", raising=False)
+    o1, g1 = run()
+    monkeypatch.setenv("DTA_NO_FUSED_INPUT", "1")
+    o2, g2 = run()
+    assert rel_l2(o1.cpu().numpy(), o2.cpu().numpy()) < 1e-5
+    for k in g2:
+        if k.endswith("conv_layer.bias") or float(g2[k].norm()) == 0:
+            continue
+        assert rel_l2(g1[k].cpu().numpy(), g2[k].cpu().numpy()) < 2e-3, k     # bf16 rounding flips downstream of 1e-7 noise
+    assert rel_l2(g1["spectral_network.conv1.conv_layer.weight"].cpu().numpy(),
+                  g2["spectral_network.conv1.conv_layer.weight"].cpu().numpy()) < 5e-4
