@@ -39,7 +39,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="patches per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--site", default="wgrad0", help="kernel site timed for the roofline object")
+    ap.add_argument("--site", default="fwd0",
+                    help="kernel site timed for the roofline object: fwd0 = the first conv's forward (the longest "
+                         "kernel of the step: it also converts the fp32 input and emits the bf16 tiles), wgrad0 = the "
+                         "first conv's weight gradient (the longest MFMA-bound kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
@@ -173,8 +176,8 @@ def main():
                     if tj.get("batch") == a.batch and tj.get("precision") == a.precision and a.site in tj:
                         traffic = tj[a.site]["hbm_bytes_per_launch"]
                 ach = flops / (avg_ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "kernel": {"fwd0": "k_conv3x3 (conv1, both branches)",
-                                                    "wgrad0": "k_conv_wgrad (conv1, both branches)"}[a.site],
+                roof = {"bound": "mfma", "kernel": {"fwd0": "k_conv3x3 (conv1 forward, both branches)",
+                                                    "wgrad0": "k_conv_wgrad (conv1 weight gradient, both branches)"}[a.site],
                         "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_TFLOPS[a.precision], 4), "traffic": traffic,
                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes)",
@@ -188,7 +191,9 @@ def main():
                     gbs = nbytes / (avg_ms * 1e-3) / 1e9
                     roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
-                                 "mfma_tflops": round(ach, 2)})
+                                 "mfma_tflops": round(ach, 2),
+                                 "kernel": "k_conv3x3_bf16<2,2,XN> (conv1 forward, both branches; converts the fp32 "
+                                           "input and emits the bf16 tiles)"})
         total = a.steps * a.batch * world
         value = total / el
         out = {
