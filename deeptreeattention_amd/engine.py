@@ -200,16 +200,6 @@ class FusedTrainer:
             self.sync.finish()
         self._grads_clear = False
 
-    def _reduce_zero_grads(self):
-        """Data-parallel step in which THIS rank skipped the network (all-zero year) while another rank did not:
-        take part in the same all-reduces with the (zero) gradient buffer."""
-        if self.world > 1:
-            self._zero_grads()
-            self.sync.reduce_early(self.flat_g[:self.split], self.alpha_g if self.hang else None)
-            self.sync.reduce_late(self.flat_g[self.split:])
-            self.sync.finish()
-            self._grads_clear = False
-
     def _zero_grads(self):
         if not self._grads_clear:
             self.flat_g.zero_()
@@ -372,12 +362,7 @@ class EnsembleTrainer:
                                            _lib.ptr(self.dscores), self._grads, _lib.current_stream_ptr()),
                    "dta_ensemble_backward")
         for i in kept:
-            t = self.years[i]
-            t._grads_clear = False
-            if t.world > 1:
-                t.sync.reduce_early(t.flat_g[:t.split])
-                t.sync.reduce_late(t.flat_g[t.split:])
-                t.sync.finish()
+            self.years[i]._grads_clear = False
 
     def _ce(self, y, want_grad):
         L = _lib.lib()
@@ -395,13 +380,18 @@ class EnsembleTrainer:
         self._ce(y, True)
         self.dscores.mul_(1.0 / len(kept))      # d(mean over kept years)/d(year score)
         self._backward(kept)
+        # gradient exchange in YEAR ORDER on every rank (the ranks may have kept different years, and collectives pair
+        # up by issue order): a year kept anywhere is reduced by all ranks, those that skipped it send zeros
         for i, t in enumerate(self.years):
-            if local[i]:
-                continue
-            if anywhere[i]:
-                t._reduce_zero_grads()
-            else:
+            if not anywhere[i]:
                 t._zero_grads()                 # skipped everywhere: grad None in the reference
+            elif self.world > 1:
+                if not local[i]:
+                    t._zero_grads()
+                t.sync.reduce_early(t.flat_g[:t.split])
+                t.sync.reduce_late(t.flat_g[t.split:])
+                t.sync.finish()
+                t._grads_clear = False
         for i, t in enumerate(self.years):
             if anywhere[i]:
                 t._adam()

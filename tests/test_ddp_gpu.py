@@ -88,3 +88,58 @@ def test_two_rank_train_step_matches_oracle(overlap):
     for rank in range(world):   # BatchNorm buffers stay per-rank (no sync_batchnorm in the reference)
         for k, v in upds[rank].items():
             assert rel_l2(out[rank][k], v) < 2e-4, (rank, k)
+
+
+def _ensemble_worker(rank, world, port, out):
+    import datetime
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    from oracle import prng
+    from deeptreeattention_amd.engine import EnsembleTrainer
+    from deeptreeattention_amd.year import learned_ensemble
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    torch.manual_seed(5 + rank)                       # different start per rank: the start-up broadcast must fix it
+    m = learned_ensemble(3, CLASSES, {"pretrain_state_dict": None, "bands": BANDS}).to(dev).train()
+    tr = EnsembleTrainer(m, lr=1e-3)
+    losses = []
+    for step in range(2):
+        imgs = [torch.from_numpy(prng.uniform01(200 + 10 * step + rank, yy, (B, BANDS, 11, 11))).to(dev) for yy in range(3)]
+        if rank == 0:
+            imgs[1].zero_()                           # year 1 is missing on rank 0 only: it still takes part in the reduce
+        if step == 1:
+            imgs[2].zero_()                           # year 2 is missing everywhere in the second step: untouched
+        y = torch.from_numpy(prng.randint(200 + rank, 2, (B,), CLASSES)).to(dev)
+        losses.append(float(tr.train_step(imgs, y)))
+    torch.cuda.synchronize()
+    out[rank] = ({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, losses,
+                 [t.step_count for t in tr.years])
+    dist.destroy_process_group()
+
+
+def test_two_rank_ensemble_step_keeps_replicas_identical():
+    """Year ensemble under data parallelism: a year missing on one rank only is still stepped everywhere (that rank
+    contributes zero gradients), a year missing everywhere is left alone, and the replicas stay identical."""
+    from conftest import rel_l2
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    for attempt in range(2):
+        try:
+            mp.spawn(_ensemble_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+            break
+        except Exception:
+            if attempt == 1:
+                raise
+    (sd0, l0, steps0), (sd1, l1, steps1) = out[0], out[1]
+    assert steps0 == steps1 == [2, 2, 1]
+    assert all(np.isfinite(l0)) and all(np.isfinite(l1))
+    for k in sd0:
+        if "running_" in k or "num_batches_tracked" in k:
+            continue                                   # BatchNorm buffers are per rank (no sync_batchnorm)
+        assert rel_l2(sd0[k], sd1[k]) < 1e-6, k
+    assert int(sd0["year_models.1.conv1.bn1.num_batches_tracked"]) == 0      # rank 0 never ran year 1
+    assert int(sd1["year_models.1.conv1.bn1.num_batches_tracked"]) == 2
