@@ -143,3 +143,49 @@ def test_two_rank_ensemble_step_keeps_replicas_identical():
         assert rel_l2(sd0[k], sd1[k]) < 1e-6, k
     assert int(sd0["year_models.1.conv1.bn1.num_batches_tracked"]) == 0      # rank 0 never ran year 1
     assert int(sd1["year_models.1.conv1.bn1.num_batches_tracked"]) == 2
+
+
+def _metadata_worker(rank, world, port, out):
+    import datetime
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    from oracle import prng
+    from deeptreeattention_amd.engine import MetadataTrainer
+    from deeptreeattention_amd.metadata import metadata_sensor_fusion
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    torch.manual_seed(9 + rank)
+    m = metadata_sensor_fusion(bands=BANDS, sites=4, classes=CLASSES).to(dev).train()
+    m.metadata_model.dropout.p = 0.0
+    tr = MetadataTrainer(m, lr=1e-3)
+    for step in range(2):
+        x = torch.from_numpy(prng.uniform01(300 + 10 * step + rank, 1, (B, BANDS, 11, 11))).to(dev)
+        site = torch.from_numpy(prng.randint(300 + rank, 2, (B,), 4)).to(dev)
+        y = torch.from_numpy(prng.randint(300 + rank, 3, (B,), CLASSES)).to(dev)
+        loss = tr.train_step(x, site, y)
+    torch.cuda.synchronize()
+    out[rank] = ({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, float(loss))
+    dist.destroy_process_group()
+
+
+def test_two_rank_metadata_step_keeps_replicas_identical():
+    from conftest import rel_l2
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    for attempt in range(2):
+        try:
+            mp.spawn(_metadata_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+            break
+        except Exception:
+            if attempt == 1:
+                raise
+    (sd0, l0), (sd1, l1) = out[0], out[1]
+    assert np.isfinite(l0) and np.isfinite(l1)
+    for k in sd0:
+        if "running_" in k or "num_batches_tracked" in k:
+            continue
+        assert rel_l2(sd0[k], sd1[k]) < 1e-6, k
