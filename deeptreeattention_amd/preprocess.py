@@ -40,13 +40,13 @@ def preprocess_batch(crops, image_size, train=False, pixel_interleaved=False, cl
         a = c.detach().cpu().numpy() if isinstance(c, torch.Tensor) else np.asarray(c)
         if a.ndim != 3:
             raise ValueError("each crop must be a 3-d array")
+        if a.dtype not in _DTYPES:
+            a = a.astype(np.float32)          # what the reference does with any dtype: np.asarray(image, dtype='float32')
         b, h, w = (a.shape if channel_is_first else (a.shape[2], a.shape[0], a.shape[1]))
         if bands is None:
             bands, dt = b, a.dtype
         if b != bands or a.dtype != dt:
             raise ValueError("all crops of a batch must share the band count and the dtype")
-        if a.dtype not in _DTYPES:
-            raise TypeError("raw crops must be float32, int16 or uint8 (got {})".format(a.dtype))
         hs.append(h); ws.append(w); offs.append(pos)
         arrs.append(np.ascontiguousarray(a).reshape(-1))
         pos += a.size

@@ -98,6 +98,17 @@ def test_hip_preprocess_ragged_batch_vs_oracle(dtype, size):
 
 
 @pytest.mark.gpu
+def test_hip_preprocess_other_raw_dtypes_go_through_float32():
+    """uint16 / float64 crops: the reference converts every dtype with np.asarray(image, dtype='float32')."""
+    from deeptreeattention_amd import preprocess as PP
+    rng = np.random.RandomState(4)
+    for dt in (np.uint16, np.float64, np.int32):
+        crops = [(rng.rand(40, 9, 7) * 60000).astype(dt), (rng.rand(40, 5, 12) * 60000).astype(dt)]
+        want = np.stack([P.load_crop(c.astype(np.float32), 11, True) for c in crops])
+        assert np.array_equal(PP.preprocess_batch(crops, 11, train=True).cpu().numpy(), want), dt
+
+
+@pytest.mark.gpu
 def test_hip_preprocess_feeds_the_network():
     """End to end: raw int16 crops -> device preprocessing -> Hang2020 forward, equal to feeding the oracle's batch."""
     from deeptreeattention_amd import preprocess as PP, Hang2020 as H
