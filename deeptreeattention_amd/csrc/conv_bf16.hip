@@ -151,7 +151,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
         }                                                                                             \
     } else {                                                                                          \
       _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                  \
-          rx[u] = *reinterpret_cast<const u32x4*>(xg + xsrc[u] + (size_t)(chunk_) * xchunk);          \
+          rx[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xg + xsrc[u] + (size_t)(chunk_) * xchunk)); /* next reader is far (weight gradient) or none */ \
     }                                                                                                 \
     const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)(chunk_) * 9 * N * 16);           \
     _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[min(tid + u * NTHR, wvec - 1)];       \

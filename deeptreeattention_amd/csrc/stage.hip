@@ -246,6 +246,8 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
 #pragma unroll
     for (int u = 0; u < ND; ++u) { const int i = t + u * 256; rd[u] = i < HZT * CT ? __builtin_nontemporal_load(da + i) : 0.f; }
   }
+  // the forward's next reader of the conv output is the backward, far away: load it nontemporally there
+  auto ldy = [&](const float* p_) { return use_saved ? *p_ : __builtin_nontemporal_load(p_); };
   if (z_ready) {
     // the caller already built Z from prefetched registers
   } else if (CT > 0) {
@@ -255,7 +257,7 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
     if (!pool) {
 #pragma unroll 8
       for (int p = p0; p < s.HWc; p += pstep) {      // unrolled: independent global loads in flight per thread
-        float v = y[(size_t)p * a.y_rs + c] * sc + sh;
+        float v = ldy(y + (size_t)p * a.y_rs + c) * sc + sh;
         if (a.relu) v = fmaxf(v, 0.f);
         Z[p * ld + c] = v;
       }
@@ -264,8 +266,8 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
       for (int pz = p0; pz < s.HWz; pz += pstep) {   // 2x2 max-pool straight from global memory (floor: last row/col dropped)
         int hz = pz / s.Wz, wz = pz - hz * s.Wz;
         const float* y0 = y + (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
-        float v0_ = y0[0] * sc + sh, v1_ = y0[a.y_rs] * sc + sh;
-        float v2_ = y0[(size_t)s.Wc * a.y_rs] * sc + sh, v3_ = y0[(size_t)(s.Wc + 1) * a.y_rs] * sc + sh;
+        float v0_ = ldy(y0) * sc + sh, v1_ = ldy(y0 + a.y_rs) * sc + sh;
+        float v2_ = ldy(y0 + (size_t)s.Wc * a.y_rs) * sc + sh, v3_ = ldy(y0 + (size_t)(s.Wc + 1) * a.y_rs) * sc + sh;
         float m = fmaxf(fmaxf(v0_, v1_), fmaxf(v2_, v3_));
         if (a.relu) m = fmaxf(m, 0.f);
         Z[pz * ld + c] = m;
