@@ -1,45 +1,42 @@
-"""Drop-in for the model classes of the reference's `src/models/metadata.py` (site-embedding late fusion).
+"""Site-metadata late fusion around the HIP-backed Hang2020 (drop-in for the model classes of the reference's
+`src/models/metadata.py`; parameter names and shapes are the reference's, so state_dicts interoperate).
 
-`metadata_sensor_fusion.sensor_model` is the HIP-backed Hang2020; the 16-wide site MLP and the 2*classes->classes
-fusion layer (<0.2 MFLOP per sample, SURVEY.md 8 a13: "fusion MLP is tiny, may stay torch") are stock torch modules
-with the reference's names, so state_dicts interoperate.  (The reference's MetadataModel LightningModule shell is
-out of scope; its training_step is `F.cross_entropy(model(images, metadata), y)`, metadata.py:52-63.)"""
+Only the sensor branch carries real work (>99.9 % of the FLOPs) and it is the HIP path.  The site branch - a 16-wide
+embedding, BatchNorm1d, Dropout(0.7) and one Linear - and the 2*classes -> classes fusion layer are <0.2 MFLOP per
+sample and stay stock torch modules.  The reference's MetadataModel LightningModule shell is out of
+scope; its step (metadata.py:52-63: unweighted cross-entropy of `model(images, site)`) is `engine.MetadataTrainer`."""
 import torch
 from torch import nn
-from torch.nn import functional as F
 
 from .Hang2020 import Hang2020
 
+_SITE_WIDTH = 16          # reference metadata.py:12
+_SITE_DROPOUT = 0.7       # reference metadata.py:15
+
 
 class metadata(nn.Module):
-    """reference metadata.py:9-24"""
+    """Site index -> (B, classes) scores: embedding -> BN -> dropout -> linear -> ReLU (reference metadata.py:9-24)."""
 
     def __init__(self, sites, classes):
         super().__init__()
-        self.embedding = nn.Embedding(sites, 16)
-        self.batch_norm = nn.BatchNorm1d(16)
-        self.mlp = nn.Linear(in_features=16, out_features=classes)
-        self.dropout = nn.Dropout(p=0.7)
+        self.embedding = nn.Embedding(sites, _SITE_WIDTH)
+        self.batch_norm = nn.BatchNorm1d(_SITE_WIDTH)
+        self.mlp = nn.Linear(_SITE_WIDTH, classes)
+        self.dropout = nn.Dropout(_SITE_DROPOUT)
 
     def forward(self, x):
-        x = self.embedding(x)
-        x = self.batch_norm(x)
-        x = self.dropout(x)
-        x = self.mlp(x)
-        return F.relu(x)
+        return torch.relu(self.mlp(self.dropout(self.batch_norm(self.embedding(x)))))
 
 
 class metadata_sensor_fusion(nn.Module):
-    """reference metadata.py:26-44"""
+    """ReLU(Linear(cat[site scores, Hang2020 scores])) (reference metadata.py:26-44)."""
 
     def __init__(self, bands, sites, classes, precision=None):
         super().__init__()
         self.metadata_model = metadata(sites, classes)
-        self.sensor_model = Hang2020(bands, classes, precision)
-        self.fc1 = nn.Linear(in_features=classes * 2, out_features=classes)
+        self.sensor_model = Hang2020(bands, classes, precision)      # the HIP path
+        self.fc1 = nn.Linear(2 * classes, classes)
 
     def forward(self, images, metadata):
-        metadata_softmax = self.metadata_model(metadata)
-        sensor_softmax = self.sensor_model(images)
-        concat_features = torch.cat([metadata_softmax, sensor_softmax], dim=1)
-        return F.relu(self.fc1(concat_features))
+        joined = torch.cat((self.metadata_model(metadata), self.sensor_model(images)), dim=1)
+        return torch.relu(self.fc1(joined))
