@@ -441,10 +441,11 @@ int launch_softmax_top2(const float* logits, int B, int classes, float* probs, l
 __global__ void k_adam(AdamArgs a) {
   const float ss = a.lr / a.bc1, rbc2 = rsqrtf(a.bc2);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+    // moments: touched once per step, by this kernel only -> nontemporal both ways (they would only evict useful lines)
     float g = a.g[i] * a.grad_scale;
-    float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
-    float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
-    a.m[i] = m; a.v[i] = v;
+    float m = a.beta1 * __builtin_nontemporal_load(a.m + i) + (1.f - a.beta1) * g;
+    float v = a.beta2 * __builtin_nontemporal_load(a.v + i) + (1.f - a.beta2) * g * g;
+    __builtin_nontemporal_store(m, a.m + i); __builtin_nontemporal_store(v, a.v + i);
     a.p[i] -= ss * (m / (sqrtf(v) * rbc2 + a.eps));
     if (a.gz) a.gz[i] = 0.f;
   }
