@@ -181,8 +181,13 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
   return 0;
 }
 
-// bf16 networks whose input tiles are halo-free: the first conv converts the fp32 input while staging it
-inline bool fused_input(const Plan& p) { return p.esz == 2 && p.x_compact && !getenv("DTA_NO_FUSED_INPUT"); }
+// bf16 networks whose input tiles are halo-free: the first conv converts the fp32 input while staging it.  With few
+// workgroups (small batches) the conversion's long per-chunk load chain is exposed and the wide, shallow pack job is
+// faster (measured crossover: ~100 first-conv workgroups, B ~ 450 for Hang2020)
+inline bool fused_input(const Plan& p) {
+  const int launchG = p.shared_x ? 1 : p.G;
+  return p.esz == 2 && p.x_compact && p.nwg[0] * launchG >= 100 && !getenv("DTA_NO_FUSED_INPUT");
+}
 
 template <typename T> inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
 
