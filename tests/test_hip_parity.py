@@ -346,7 +346,7 @@ def test_no_cpu_fallback():
         m(torch.zeros(2, 3, 11, 11))
 
 
-@pytest.mark.parametrize("B", [1, 3, 37, 130])
+@pytest.mark.parametrize("B", [421, 530])      # the fused path needs >= 100 first-conv workgroups (4 patches each)
 def test_fused_input_conv_equals_separate_pack_pass(B, monkeypatch):
     """bf16: the first conv that converts the fp32 NCHW input while staging it (and leaves the bf16 tiles behind for
     the weight gradient) against the separate pack pass it replaced (developer switch DTA_NO_FUSED_INPUT): same tiles,
@@ -374,6 +374,9 @@ def test_fused_input_conv_equals_separate_pack_pass(B, monkeypatch):
     for k in g2:
         if k.endswith("conv_layer.bias") or float(g2[k].norm()) == 0:
             continue
-        assert rel_l2(g1[k].cpu().numpy(), g2[k].cpu().numpy()) < 2e-3, k     # bf16 rounding flips downstream of 1e-7 noise
+        # bf16 rounding flips downstream of 1e-7 reordering noise; the gate biases of the spatial attention are nearly
+        # invariant directions under the next layer's batch-stat BN (cancelling sums: run-to-run noise up to 3e-3)
+        tol = 1e-2 if k.endswith("attention_conv2.bias") else 2e-3
+        assert rel_l2(g1[k].cpu().numpy(), g2[k].cpu().numpy()) < tol, k
     assert rel_l2(g1["spectral_network.conv1.conv_layer.weight"].cpu().numpy(),
                   g2["spectral_network.conv1.conv_layer.weight"].cpu().numpy()) < 5e-4
