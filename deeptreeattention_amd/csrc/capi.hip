@@ -527,10 +527,14 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     else { ap.dy_gs = (size_t)B * (C / 16) * p.Qin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
     if (launch_bn_bwd_apply<T>(ap, G, st)) return 1;
     // ---- conv weight gradient ----
-    if (L == 0) {   // end of phase 1: flush the deferred GEMMs
+    // end of phase 1: flush the deferred GEMMs -- unless the whole backward is this one call: then they ride in the
+    // launch of the split-K reductions at the very end (one dependent launch fewer)
+    const bool merge_tail = phases == 3 && !getenv("DTA_NO_TAIL_MERGE");
+    if (L == 0 && !merge_tail) {
       prof_begin(DTA_SITE_GEMM + 2, st);
       if (launch_gemm_group(deferred, st)) return 1;
       prof_end(DTA_SITE_GEMM + 2, st);
+      deferred.n = 0;
     }
     if (L > 0 || (phases & 2))
       if (conv_wgrad_layer<T>(p, d, grads, ws, L, reduces, st)) return 1;
@@ -552,6 +556,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       prof_end(DTA_SITE_CONV_DGRAD + L, st);
     }
   }
+  if (deferred.n > 0) return launch_gemm_group_with_reduce(deferred, reduces, st);
   return launch_wgrad_reduce_group(reduces, st);
 }
 

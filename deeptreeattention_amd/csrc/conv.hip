@@ -582,63 +582,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
     }
 }
 
-// out_g[n][c][tap] (torch layout) = sum_s partial[g][tap][c][s][n]
-__device__ __forceinline__ void wgrad_reduce_blocks(const WgradReduceArgs& a, int bx, int nblocks) {
-  // item = (group, tap, channel, 4 consecutive n); FOUR lanes share an item and each sums every fourth slab, then the
-  // four partial sums meet through two shuffles: this is a pure streaming read of S slabs, bound by the bytes in
-  // flight, and four times as many threads keep four times as many loads outstanding
-  const int N = a.N, N4 = N / 4;
-  const size_t total = (size_t)a.G * 9 * a.C * N4;
-  const size_t sstride = (size_t)N;              // the S partial rows of an item are adjacent
-  const int part = threadIdx.x & 3;
-  const size_t first = (bx * (size_t)blockDim.x + threadIdx.x) >> 2, step = ((size_t)nblocks * blockDim.x) >> 2;
-  const size_t iters = (total + step - 1) / step;   // all lanes of a quad iterate together (shuffles below)
-  for (size_t it = 0; it < iters; ++it) {
-    const size_t i = first + it * step;
-    const bool live = i < total;
-    const size_t ii = live ? i : 0;
-    int n4 = ii % N4;
-    size_t r = ii / N4;
-    int c = r % a.C; r /= a.C;
-    int tap = r % 9;
-    int g = r / 9;
-    const float* p = a.partial + (((size_t)g * 9 + tap) * a.Cpad + c) * a.S * N + n4 * 4;
-    float4 acc[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = part;
-    for (; s + 12 < a.S; s += 16) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const f32x4 q_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)(s + 4 * u) * sstride));   // slabs: one reader
-        float4 v = make_float4(q_[0], q_[1], q_[2], q_[3]);
-        acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
-      }
-    }
-    for (; s < a.S; s += 4) {
-      float4 v = *reinterpret_cast<const float4*>(p + (size_t)s * sstride);
-      acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
-    }
-    float out[4] = {(acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y),
-                    (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z), (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      out[k] += __shfl_xor(out[k], 1);
-      out[k] += __shfl_xor(out[k], 2);
-    }
-    if (live) {
-      // lane `part` of the quad writes output n4*4 + part
-      const int n = n4 * 4 + part;
-      int nn = n;
-      float* dst;
-      if (a.mode == 1) { dst = n < a.nsplit ? a.dst[0] : a.dst[1]; nn = n < a.nsplit ? n : n - a.nsplit; }
-      else dst = a.dst[g];
-      const float o = part == 0 ? out[0] : part == 1 ? out[1] : part == 2 ? out[2] : out[3];
-      if (dst) dst[((size_t)nn * a.C + c) * 9 + tap] = o;
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradReduceArgs a) { wgrad_reduce_blocks(a, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(256) void k_wgrad_reduce_group(WgradReduceGroup gr) {
   int j = 0;
@@ -692,7 +635,7 @@ int launch_conv_wgrad(const WgradArgs& a, int G, hipStream_t st) {
 }
 template int launch_conv_wgrad<float>(const WgradArgs&, int, hipStream_t);   // bf16: conv_bf16.hip
 
-static int wgrad_reduce_nblocks(const WgradReduceArgs& a) {
+int wgrad_reduce_nblocks(const WgradReduceArgs& a) {
   size_t total = (size_t)a.G * 9 * a.C * (a.N / 4) * 4;   // four lanes per item
   return (int)min((size_t)8192, (total + 255) / 256);
 }

@@ -202,6 +202,33 @@ int launch_gemm_group(GemmGroup& gg, hipStream_t st) {
   return 0;
 }
 
+__global__ __launch_bounds__(256) void k_gemm_group_reduce(GemmGroup gg, WgradReduceGroup gr, int ngemm) {
+  __shared__ __attribute__((aligned(16))) float As[64 * GP];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * GP];
+  if ((int)blockIdx.x < ngemm) { gemm_group_block(gg, As, Bs); return; }
+  const int bx = blockIdx.x - ngemm;
+  int j = 0;
+  while (j + 1 < gr.n && bx >= gr.start[j + 1]) ++j;
+  wgrad_reduce_blocks(gr.job[j], bx - gr.start[j], gr.start[j + 1] - gr.start[j]);
+}
+
+int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream_t st) {
+  if (gg.n == 0) return launch_wgrad_reduce_group(gr, st);
+  if (gr.n == 0) return launch_gemm_group(gg, st);
+  int ngemm = 0;
+  for (int i = 0; i < gg.n; ++i) {
+    gg.start[i] = ngemm;
+    ngemm += ((gg.g[i].M + 63) / 64) * ((gg.g[i].N + 63) / 64) * gg.g[i].ksplit;
+  }
+  gg.start[gg.n] = ngemm;
+  int total = 0;
+  for (int j = 0; j < gr.n; ++j) { gr.start[j] = total; total += wgrad_reduce_nblocks(gr.job[j]); }
+  gr.start[gr.n] = total;
+  hipLaunchKernelGGL(k_gemm_group_reduce, dim3(ngemm + total), dim3(256), 0, st, gg, gr, ngemm);
+  DTA_CHECK_LAUNCH("k_gemm_group_reduce");
+  return 0;
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   GemmGroup gg;
   gg.n = 1;
