@@ -380,3 +380,37 @@ def test_fused_input_conv_equals_separate_pack_pass(B, monkeypatch):
         assert rel_l2(g1[k].cpu().numpy(), g2[k].cpu().numpy()) < 2e-3, k
     assert rel_l2(g1["spectral_network.conv1.conv_layer.weight"].cpu().numpy(),
                   g2["spectral_network.conv1.conv_layer.weight"].cpu().numpy()) < 5e-4
+
+
+@pytest.mark.parametrize("kind,bands", [("vanilla", 5), ("vanilla", 37), ("spectral", 16), ("spatial", 33)])
+def test_fused_input_conv_other_networks_and_band_counts(kind, bands, monkeypatch):
+    """The fused fp32-input first conv for the single-branch networks and for band counts that leave the last
+    16-channel chunk mostly padding (5, 33, 37 bands: the clamped copies of the last real band meet zero weights)."""
+    from deeptreeattention_amd import Hang2020 as H
+    B, classes = 440, 6
+    torch.manual_seed(bands)
+    cls = {"vanilla": H.vanilla_CNN, "spectral": H.spectral_network, "spatial": H.spatial_network}[kind]
+    m = cls(bands, classes, precision="bf16").to(dev()).eval()      # eval: no batch-stat noise amplification
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 1.5)
+    x = torch.rand(B, bands, 11, 11, device=dev())
+    y = torch.randint(0, classes, (B,), device=dev())
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        out = m(x)
+        out = out[-1] if isinstance(out, (list, tuple)) else out
+        torch.nn.functional.cross_entropy(out, y).backward()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    monkeypatch.delenv("DTA_NO_FUSED_INPUT", raising=False)
+    o1, g1 = run()
+    monkeypatch.setenv("DTA_NO_FUSED_INPUT", "1")
+    o2, g2 = run()
+    assert torch.isfinite(o1).all()
+    assert rel_l2(o1.cpu().numpy(), o2.cpu().numpy()) < 1e-5
+    for k in g2:
+        if float(g2[k].norm()) == 0:
+            continue
+        assert rel_l2(g1[k].cpu().numpy(), g2[k].cpu().numpy()) < 1e-4, k
