@@ -1,0 +1,46 @@
+"""The bench.py output contract: ONE JSON line with the driver's keys plus the `roofline` and `cpu_baseline` objects.
+CPU: the committed artifact under profiles/ has the full schema.  GPU: a short live run prints a conforming line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+ROOF = {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def _check(line, want_cpu):
+    d = json.loads(line)
+    assert KEYS <= set(d), KEYS - set(d)
+    assert d["unit"] == "patches/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert "model" not in d["config"]
+    r = d["roofline"]
+    assert ROOF <= set(r), ROOF - set(r)
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(d["value"] - d["steps"] * d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-3 * d["value"]
+    if want_cpu:
+        c = d["cpu_baseline"]
+        assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] in ("port", "reference")
+    return d
+
+
+def test_committed_bench_artifact_has_the_contract_schema():
+    d = _check(open(os.path.join(REPO, "profiles", "r01_bench_bf16_default.json")).read(), True)
+    assert d["n_gpus"] == 1 and d["dtype"] == "bf16"
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_conforming_json_line():
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=240, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = _check(lines[0], False)
+    assert d["steps"] == 4 and d["warmup"] == 2 and d["n_gpus"] == 1
