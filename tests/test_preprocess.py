@@ -122,3 +122,22 @@ def test_hip_preprocess_feeds_the_network():
     assert torch.equal(x, want)
     with torch.no_grad():
         assert torch.isfinite(m(x)).all()
+
+
+def test_oracle_minmax_matches_sklearn_bit_exact_on_random_crops():
+    """The restated float32 MinMaxScaler arithmetic against scikit-learn itself (the routine the reference calls,
+    src/utils.py:47-49) on random crops, incl. constant and near-constant pixels and negative values."""
+    sk = pytest.importorskip("sklearn.preprocessing")
+    rng = np.random.RandomState(31)
+    for trial in range(20):
+        c, h, w = rng.randint(4, 60), rng.randint(1, 9), rng.randint(1, 9)
+        img = (rng.rand(c, h, w).astype(np.float32) - np.float32(0.3)) * np.float32(10 ** rng.randint(-3, 5))
+        if trial % 3 == 0:
+            img[:, 0, 0] = np.float32(2.5)
+        if trial % 4 == 0:
+            img[:, -1, -1] = np.float32(1.0) + np.arange(c, dtype=np.float32) * np.float32(1e-8)
+        data = img.reshape(c, h * w).T
+        want = sk.minmax_scale(data.copy(), axis=1).T.reshape(img.shape)
+        got = P.minmax_over_bands(img)
+        assert got.dtype == want.dtype == np.float32
+        assert np.array_equal(got, want), trial
