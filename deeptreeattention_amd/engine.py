@@ -425,6 +425,14 @@ class MultiStageTrainer:
         scores, loss = self.levels[dataloader_idx].forward_loss(inputs["HSI"], y, present)
         return {"individual": individual, "yhat": torch.softmax(scores, dim=1), "label": y, "val_loss": loss}
 
+    def predict_step(self, batch, batch_idx=0, present=None):
+        """multi_stage.py:306-318: every level's softmax scores for the same crops (eval-mode forward through a cached
+        Predictor per level; the year ensembles' zero years are skipped as in training)."""
+        individual, inputs = batch
+        if not hasattr(self, "_predictors"):
+            self._predictors = [Predictor(t.model) for t in self.levels]
+        return individual, [pr(inputs["HSI"], True, present)[0].clone() for pr in self._predictors]
+
 
 class MetadataTrainer:
     """Fused train step of the site-metadata fusion model (reference src/models/metadata.py): the step

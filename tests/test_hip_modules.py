@@ -248,6 +248,12 @@ def test_ensemble_trainer_steps_vs_reference_golden(golden, use_present):
     assert [t.step_count for t in tr.years] == [3, 4, 3]
     out = driver.validation_step(batch[0], 0, 0, present)
     assert out["yhat"].shape == (B, classes) and abs(float(out["yhat"].sum()) - B) < 1e-4
+    ids, yhats = driver.predict_step((batch[0][0], batch[0][1]))          # multi_stage.py:306-318
+    m.eval()
+    with torch.no_grad():
+        want = torch.softmax(m(batch[0][1]["HSI"]), dim=1)
+    m.train()
+    assert len(yhats) == 1 and rel_l2(yhats[0].cpu().numpy(), want.cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("years,hw,bands,prec,B", [(5, 11, 16, "fp32", 10), (3, 24, 20, "fp32", 10), (3, 11, 369, "bf16", 10),
