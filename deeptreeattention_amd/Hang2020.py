@@ -387,6 +387,13 @@ class vanilla_CNN(_Net):
         self._init_net(classes, precision)
 
     def forward(self, x):
+        # fc1 is Linear(512, classes) (reference Hang2020.py:43): only patches whose twice-pooled map flattens to 512
+        # features fit, and the reference raises a shape error otherwise -- the C side sizes the head GEMM from the
+        # patch, so a mismatch must never reach it
+        feats = 128 * (x.shape[-2] // 4) * (x.shape[-1] // 4)
+        if feats != self.fc1.in_features:
+            raise RuntimeError("vanilla_CNN: a {}x{} patch flattens to {} features but fc1 expects {} (the reference "
+                               "raises the same shape error)".format(x.shape[-2], x.shape[-1], feats, self.fc1.in_features))
         return self._run(x, 4)
 
 

@@ -1,5 +1,6 @@
 // C-ABI entry points (include/dta_hip.h) and the launch orchestration of the Hang2020 hot path.
 // Host code only decides buffer carving and launch order; all arithmetic is in conv.hip / stage.hip / heads.hip.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -92,6 +93,12 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
   p->Hc[1] = p->H; p->Wc[1] = p->W; p->Hz[1] = p->H / 2; p->Wz[1] = p->W / 2;
   p->Hc[2] = p->Hz[1]; p->Wc[2] = p->Wz[1]; p->Hz[2] = p->Hz[1] / 2; p->Wz[2] = p->Wz[1] / 2;
   if (p->Hz[2] < 1 || p->Wz[2] < 1) { dta_set_error("patch %dx%d too small for two 2x2 pools", p->H, p->W); return 1; }
+  if (d->kind == DTA_NET_VANILLA && CH[2] * p->Hz[2] * p->Wz[2] != 512) {
+    // vanilla_CNN's head is Linear(512, classes) (reference Hang2020.py:43): fc_w holds classes x 512 floats, so a patch
+    // that flattens to anything else would read / write past the caller's weight and gradient buffers
+    dta_set_error("vanilla_CNN: a %dx%d patch flattens to %d features, its head takes 512", p->H, p->W, CH[2] * p->Hz[2] * p->Wz[2]);
+    return 1;
+  }
   for (int L = 0; L < 3; ++L) {
     p->HWc[L] = p->Hc[L] * p->Wc[L]; p->HWz[L] = p->Hz[L] * p->Wz[L];
     p->Qin[L] = (p->Hc[L] + 2) * (p->Wc[L] + 2);
@@ -402,8 +409,12 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
   if (dscores)
     for (int g = 0; g < G; ++g)
       for (int L = 0; L < 3; ++L) dsc[g][L] = dscores[g][L];
-  if (d->kind == DTA_NET_HANG2020) {
-    if (!djoint || !alpha) { dta_set_error("Hang2020 backward needs djoint and alpha"); return 1; }
+  if (d->kind == DTA_NET_HANG2020 && !djoint) {
+    // all-heads mode (the Hang et al. multi-head training loss): gradients arrive per classifier head in `dscores`;
+    // the sigmoid(alpha) blend is not on the graph, so alpha gets no gradient (dalpha stays as the caller left it)
+    if (!dscores) { dta_set_error("Hang2020 backward needs djoint (blended scores) or dscores (per-head mode)"); return 1; }
+  } else if (d->kind == DTA_NET_HANG2020) {
+    if (!alpha) { dta_set_error("Hang2020 backward needs alpha"); return 1; }
     // the forward kept both branch scores in the workspace unless the caller supplied its own buffers; the
     // Python binding always lets the workspace hold them
     // d(joint)/d(branch score) = sigmoid(alpha) / 1 - sigmoid(alpha): folded into the head GEMMs as an output scale
@@ -695,9 +706,8 @@ static int adam_step_impl(float* p, const float* g, float* gz, float* m, float* 
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.gz = gz; a.alpha_gz = alpha_gz;
   a.alpha_p = alpha_p; a.alpha_g = alpha_g; a.alpha_m = alpha_m; a.alpha_v = alpha_v;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
-  double b1 = 1.0, b2 = 1.0;
-  for (int i = 0; i < step; ++i) { b1 *= (double)beta1; b2 *= (double)beta2; }
-  a.bc1 = (float)(1.0 - b1); a.bc2 = (float)(1.0 - b2);
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));   // O(1): a long run must not become host-bound
+  a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   return launch_adam(a, (hipStream_t)stream);
 }
 

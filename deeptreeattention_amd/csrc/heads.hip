@@ -359,7 +359,8 @@ int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hip
 }
 // ------------------------------------------------------------------------------------------------
 // F.cross_entropy(logits, y, weight=w): loss = sum_i w[y_i] * nll_i / sum_i w[y_i], plus dlogits.
-// Labels outside [0, classes) are ignored (torch's ignore_index behaviour).
+// Label -100 is ignored (torch's default ignore_index); any other label outside [0, classes) is a caller bug (torch
+// raises / device-asserts): it poisons the loss and that row's gradient with NaN so that it cannot train silently.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ce_rows(CeArgs a) {
   __shared__ float sc[4];
@@ -383,9 +384,10 @@ __global__ __launch_bounds__(256) void k_ce_rows(CeArgs a) {
   for (int n = lane; n < a.classes; n += 64) se += __expf(z[n] - mx);
   se = wave_sum(se);
   const float lse = __logf(se);
-  if (lane == 0) a.rowtmp[row] = ok ? wy * (lse + mx - z[y]) : 0.f;
+  const float poison = (ok || y == -100) ? 0.f : __builtin_nanf("");
+  if (lane == 0) a.rowtmp[row] = ok ? wy * (lse + mx - z[y]) : poison;
   if (a.dlogits) {
-    const float sc2 = den > 0.f ? wy / den : 0.f;
+    const float sc2 = (den > 0.f ? wy / den : 0.f) + poison;
     float* d = a.dlogits + (size_t)row * a.classes;
     for (int n = lane; n < a.classes; n += 64) {
       float p = __expf(z[n] - mx - lse);

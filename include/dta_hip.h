@@ -72,13 +72,17 @@ size_t dta_net_workspace_bytes(const dta_net_desc* d);
  *  alpha  : float64 scalar (Hang2020.alpha), HANG2020 only
  *  x      : float32 NCHW contiguous [batch][bands][height][width]
  *  scores : [net][L] -> float32 [batch][classes] outputs of the classifier heads selected by heads_mask
- *  joint  : HANG2020: sigmoid(alpha)-blended scores; VANILLA: fc1 output; else unused (may be null) */
+ *  joint  : HANG2020: sigmoid(alpha)-blended scores; VANILLA: fc1 output; else unused (may be null)
+ * DTA_NET_VANILLA: the head is Linear(512, classes) as in the reference (:43), so only patches whose twice-pooled map
+ * flattens to 128 * (H/4) * (W/4) = 512 features are accepted (the descriptor is rejected otherwise). */
 int dta_net_forward(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const float* x,
                     void* workspace, float* const scores[2][3], float* joint, void* stream);
 
 /* Replaces autograd's backward through the module above.  `workspace` is the blob the matching training (or eval)
  * forward filled.  dscores[net][L] / djoint: gradients wrt the forward outputs (null = that output unused; for
- * HANG2020 pass djoint, for the others dscores).  Every non-null gradient buffer in `grads`, and `dalpha`, must arrive
+ * HANG2020 pass djoint, for the others dscores; HANG2020 with djoint == NULL and dscores set is the all-heads mode of
+ * the Hang et al. multi-head loss: every listed head of both branches back-propagates, the blend and alpha do not).
+ * Every non-null gradient buffer in `grads`, and `dalpha`, must arrive
  * ZERO-FILLED (split-K partial sums are accumulated with atomics); on return it holds the gradient.
  * phases: bit 0 = everything except the first conv's weight gradient, bit 1 = the first conv's weight gradient
  * (the largest and last piece); 3 = all.  Two calls (1, then 2) let the caller start the gradient all-reduce of
@@ -126,7 +130,9 @@ int dta_preprocess_crops(const dta_crop_desc* d, const void* raw, const long lon
                          const int* widths, float* out, void* stream);
 
 /* Replaces F.cross_entropy(logits, y, weight=w) forward+backward (src/main.py:78, multi_stage.py:285).
- * weight may be null (= ones, metadata.py:61).  scratch: batch+1 floats.  dlogits may be null. */
+ * weight may be null (= ones, metadata.py:61).  scratch: batch+1 floats.  dlogits may be null.
+ * Labels: -100 is ignored as torch's default ignore_index; any other label outside [0, classes) is a caller bug
+ * (torch raises or device-asserts) and makes the loss and that row of dlogits NaN instead of being skipped silently. */
 int dta_weighted_ce(const float* logits, const long long* labels, const float* weight, int batch, int classes,
                     float* loss, float* dlogits, float* scratch, void* stream);
 

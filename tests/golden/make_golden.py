@@ -291,6 +291,50 @@ def case_ensemble_steps():
     print("ensemble_steps.npz", len(out))
 
 
+def case_three_head():
+    """The north-star's "three-head weighted cross-entropy" (the Hang et al. training recipe; the reference's own step
+    keeps only the last head): the reference's sub-networks return three heads each
+    (Hang2020.py:204, :240); the loss here is the SUM of F.cross_entropy(head, y, weight=w) over all heads of
+    spectral_network(x) + spatial_network(x) of a Hang2020 (six heads; `alpha` is not on the graph), and over the three
+    heads of a lone spectral_network.  Two torch-Adam steps each."""
+    out = {}
+    bands, classes, B, lr = 20, 7, 6, 1e-3
+    w = torch.from_numpy((0.1 + (np.arange(classes) % 7)).astype(np.float32))
+    xn, yn = inputs(92, B, bands, 11, 11, classes)
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    for tag, build, heads_of in (
+            ("hang/", lambda: R.Hang2020(bands, classes), lambda m: m.spectral_network(x) + m.spatial_network(x)),
+            ("spectral/", lambda: R.spectral_network(bands, classes), lambda m: m(x))):
+        spec = O.hang2020_spec(bands, classes) if tag == "hang/" else O.subnet_spec("spectral", bands, classes)
+        m = build()
+        load(m, O.init_params(spec, seed=91))
+        m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=lr)
+        for step in range(2):
+            opt.zero_grad(set_to_none=True)
+            heads = heads_of(m)
+            loss = sum(F.cross_entropy(h, y, weight=w) for h in heads)
+            loss.backward()
+            if step == 0:
+                for i, h in enumerate(heads):
+                    out[f"{tag}head{i}"] = h.detach().numpy()
+                out[f"{tag}loss"] = np.float64(loss.item())
+                pack_grads(list(m.named_parameters()), out, f"{tag}grad_")
+                for k, b in m.named_buffers():
+                    out[f"{tag}buf1/{k}"] = b.numpy().copy()
+            opt.step()
+            out[f"{tag}loss_step{step}"] = np.float64(loss.item())
+        for k, prm in m.named_parameters():
+            a = prm.detach().numpy()
+            out[f"{tag}p2_norm/{k}"] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+            if a.size <= 20000:
+                out[f"{tag}p2_full/{k}"] = a.copy()
+            else:
+                out[f"{tag}p2_samp/{k}"] = a.reshape(-1)[sample_idx(a.size)].copy()
+    np.savez_compressed(os.path.join(OUT, "three_head.npz"), **out)
+    print("three_head.npz", len(out))
+
+
 def _read_strip_tiff(path):
     """Minimal reader for the reference's test crops (uncompressed, strip-organised, pixel-interleaved TIFF): returns
     the band-first array rasterio's `.read()` gives.  rasterio itself is not installed here."""
@@ -472,6 +516,7 @@ if __name__ == "__main__":
     case_hang_small()
     case_subnets()
     case_ensemble_steps()
+    case_three_head()
     case_preprocess()
     case_hang_full()
     case_metadata()          # last: it stubs packages process-wide
