@@ -130,6 +130,7 @@ def lib():
         L.dta_profile_enable.argtypes = [C.c_int]
         L.dta_profile_collect.restype = C.c_int
         L.dta_profile_collect.argtypes = [C.POINTER(C.c_float), C.c_int]
+        L.dta_dev_reload_switches.restype = C.c_int
         if L.dta_abi_version() != 1:
             raise RuntimeError("libdta_hip.so ABI version mismatch")
         _lib = L

@@ -191,9 +191,16 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
 // bf16 networks whose input tiles are halo-free: the first conv converts the fp32 input while staging it.  With few
 // workgroups (small batches) the conversion's long per-chunk load chain is exposed and the wide, shallow pack job is
 // faster (measured crossover: ~100 first-conv workgroups, B ~ 450 for Hang2020)
+// Developer switches (same-box A/B runs): the environment is read once per process, not per call.
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel; };
+inline Switches read_switches() {
+  return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr};
+}
+Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
+inline const Switches& switches() { return g_switches; }
 inline bool fused_input(const Plan& p) {
   const int launchG = p.shared_x ? 1 : p.G;
-  return p.esz == 2 && p.x_compact && p.nwg[0] * launchG >= 100 && !getenv("DTA_NO_FUSED_INPUT");
+  return p.esz == 2 && p.x_compact && p.nwg[0] * launchG >= 100 && !switches().no_fused_input;
 }
 
 template <typename T> inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
@@ -314,9 +321,15 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     }
     bf.cat_mode = (cat && G == 2); bf.nsplit = 32;
     bf.coef = at<float>(ws, p.coef[L]); bf.training = d->training; bf.momentum = d->bn_momentum; bf.eps = d->bn_eps;
-    if (launch_bn_finalize(bf, G, st)) return 1;
     // BN + ReLU + pool + attention
     StageArgs sa = stage_args(p, d, nets, ws, L);
+    // eval mode: the coefficients are a function of the running statistics only, so every stage workgroup derives
+    // them itself and the finalize launch disappears (three dependent launches fewer per inference batch).  Training:
+    // combining the conv partials redundantly in every stage workgroup was measured SLOWER than the launch (each of
+    // 2048 workgroups pulls 64-128 KB through its XCD's L2: +5 / +14 / +13 us on the three layers against a 4-5 us
+    // launch), so it stays a separate wide-and-shallow launch; DTA_BN_INKERNEL=1 re-enables it for experiments
+    if ((!d->training || switches().bn_inkernel) && p.nwg[L] <= BN_INKERNEL_MAX_NWG) { sa.bn_inkernel = 1; sa.bnfin = bn_finalize_kargs(bf); }
+    else if (launch_bn_finalize(bf, G, st)) return 1;
     if (d->heads_mask & DTA_FORWARD_ONLY) sa.attsave = nullptr;   // attention state is kept for the backward only
     prof_begin(DTA_SITE_STAGE_FWD + L, st);
     if (launch_stage_fwd<T>(sa, G, st)) return 1;
@@ -540,7 +553,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     // ---- conv weight gradient ----
     // end of phase 1: flush the deferred GEMMs -- unless the whole backward is this one call: then they ride in the
     // launch of the split-K reductions at the very end (one dependent launch fewer)
-    const bool merge_tail = phases == 3 && !getenv("DTA_NO_TAIL_MERGE");
+    const bool merge_tail = phases == 3 && !switches().no_tail_merge;
     if (L == 0 && !merge_tail) {
       prof_begin(DTA_SITE_GEMM + 2, st);
       if (launch_gemm_group(deferred, st)) return 1;
@@ -576,6 +589,8 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
 extern "C" {
 
 int dta_abi_version(void) { return DTA_ABI_VERSION; }
+
+int dta_dev_reload_switches(void) { g_switches = read_switches(); return 0; }
 
 int dta_profile_enable(int site) {
   if (site >= 0 && !g_prof.created) {

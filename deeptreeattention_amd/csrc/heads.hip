@@ -240,12 +240,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
 // Column sums over the batch with a segment table: column j of A[rows][lda] lands in dst[seg][j - off].
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_colsum_scatter(ColsumArgs a) {
-  __shared__ float sc[32][33];
+  __shared__ float sc[16][16];
   colsum_scatter_block(a, blockIdx.x, sc);
 }
 
 int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_colsum_scatter, dim3((a.cols + 31) / 32), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(k_colsum_scatter, dim3(colsum_nblocks(a)), dim3(1024), 0, st, a);
   DTA_CHECK_LAUNCH("k_colsum_scatter");
   return 0;
 }

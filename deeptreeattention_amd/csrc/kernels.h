@@ -125,6 +125,19 @@ struct BnFinalizeArgs {
   int training; float momentum, eps;
 };
 int launch_bn_finalize(const BnFinalizeArgs& a, int G, hipStream_t st);
+// kernel-side form of the above (group offsets resolved)
+struct BnFinK {
+  const float* stats; size_t stats_goff; int stats_ld;
+  int nwg, C, HW, MWG, B;
+  const float* gamma[MAXG]; const float* beta[MAXG];
+  float* rmean[MAXG]; float* rvar[MAXG]; long long* nbt[MAXG];
+  float* coef; int training; float momentum, eps;
+};
+BnFinK bn_finalize_kargs(const BnFinalizeArgs& b);
+// the stage kernels can combine the conv partials themselves (every workgroup, redundantly and in the same order, so
+// all of them hold bit-identical coefficients) instead of waiting for a k_bn_finalize launch; worth it up to this many
+// conv workgroups (each stage workgroup reads nwg x C x 8 bytes of partials from L2)
+constexpr int BN_INKERNEL_MAX_NWG = 512;
 
 struct AttParams {          // forward-side attention parameters of one branch/stage (device pointers)
   // spectral: a1t/a2t = dense transposed centre taps [C][C] (in-major), c1/c2 biases
@@ -146,6 +159,10 @@ struct StageArgs {
   // attention intermediates of every patch ([G][B][attsave_ld] floats, >= 3 * vslot): written by the forward,
   // read back by the backward instead of recomputing the attention; null = backward recomputes
   float* attsave; int attsave_ld;
+  // bn_inkernel != 0: `coef` has not been computed yet -- every workgroup derives its group's scale/shift from `bnfin`
+  // (conv partials in training mode, running statistics otherwise) in its prologue; workgroup 0 of each group also
+  // writes them to `coef` for the backward and updates the running statistics
+  int bn_inkernel; BnFinK bnfin;
 };
 template <typename T> int launch_stage_fwd(const StageArgs& a, int G, hipStream_t st);
 
@@ -217,33 +234,52 @@ struct ColsumArgs {
   int nseg; int off[8], len[8]; float* dst[8]; long dst_stride[8];
 };
 #if defined(__HIPCC__)
-// one 1024-thread block: 32 columns x 32 row slices of A, partial sums through sc[32][33]
-__device__ __forceinline__ void colsum_scatter_block(const ColsumArgs& a, int bx, float (*sc)[33]) {
-  const int t = threadIdx.x, jl = t & 31, sl = t >> 5, j = bx * 32 + jl;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-  if (j < a.cols) {
-    int r = sl;
-    for (; r + 96 < a.rows; r += 128) {
-      acc0 += a.A[(size_t)r * a.lda + j];
-      acc1 += a.A[(size_t)(r + 32) * a.lda + j];
-      acc2 += a.A[(size_t)(r + 64) * a.lda + j];
-      acc3 += a.A[(size_t)(r + 96) * a.lda + j];
-    }
-    for (; r < a.rows; r += 32) acc0 += a.A[(size_t)r * a.lda + j];
-  }
-  sc[sl][jl] = (acc0 + acc1) + (acc2 + acc3);
-  __syncthreads();
-  if (t < 32 && j < a.cols) {
-    float v = 0.f;
+// Batch reductions over per-patch partials are latency problems (0.5-2 MB read by a handful of blocks): a 1024-thread
+// block owns 8 columns x 128 row slices, so a thread has at most rows/128 independent loads, all in flight at once,
+// then three shuffles fold the 8 slices of a wave and 16 wave partials meet in LDS.
+// colsum8<NV>: column j (< ncols <= 8) of A (row pitch lda floats, NV consecutive floats per item); on return threads
+// t < 8 * NV hold the sums in double (item t / NV, component t % NV).  sc: 16 x 16 floats.
+template <int NV>
+__device__ __forceinline__ double colsum8(const float* A, size_t lda, int rows, int ncols, float (*sc)[16]) {
+  const int t = threadIdx.x, cl = t & 7, sl = t >> 3, lane = t & 63, wave = t >> 6;
+  float acc[NV];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) v += sc[s][t];
+  for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+  if (cl < ncols) {
+#pragma unroll 8
+    for (int r = sl; r < rows; r += 128) {
+      const float* p = A + (size_t)r * lda + cl * NV;
+      if (NV == 2) { const float2 v = *reinterpret_cast<const float2*>(p); acc[0] += v.x; acc[NV - 1] += v.y; }
+      else acc[0] += p[0];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float v = acc[k];
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    if (lane < 8) sc[wave][lane * NV + k] = v;
+  }
+  __syncthreads();
+  double out = 0;
+  if (t < 8 * NV) {
+#pragma unroll
+    for (int w = 0; w < 16; ++w) out += (double)sc[w][t];
+  }
+  __syncthreads();
+  return out;
+}
+__device__ __forceinline__ void colsum_scatter_block(const ColsumArgs& a, int bx, float (*sc)[16]) {
+  const int j0 = bx * 8, t = threadIdx.x;
+  const double v = colsum8<1>(a.A + j0, (size_t)a.lda, a.rows, min(8, a.cols - j0), sc);
+  const int j = j0 + t;
+  if (t < 8 && j < a.cols)
     for (int s = 0; s < a.nseg; ++s)
       if (j >= a.off[s] && j < a.off[s] + a.len[s]) {
-        if (a.dst[s]) a.dst[s][(size_t)(j - a.off[s]) * a.dst_stride[s]] = v;
+        if (a.dst[s]) a.dst[s][(size_t)(j - a.off[s]) * a.dst_stride[s]] = (float)v;
         break;
       }
-  }
 }
+inline int colsum_nblocks(const ColsumArgs& a) { return (a.cols + 7) / 8; }
 #endif
 int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st);
 // BatchNorm-backward finalize and up to two batch column-sum jobs (spatial-attention parameter gradients) in one

@@ -11,14 +11,6 @@ namespace dta {
 // ------------------------------------------------------------------------------------------------
 // BatchNorm statistics: combine the conv workgroups' (mean, M2) partials (Chan et al.) in double.
 // ------------------------------------------------------------------------------------------------
-struct BnFinK {
-  const float* stats; size_t stats_goff; int stats_ld;
-  int nwg, C, HW, MWG, B;
-  const float* gamma[MAXG]; const float* beta[MAXG];
-  float* rmean[MAXG]; float* rvar[MAXG]; long long* nbt[MAXG];
-  float* coef; int training; float momentum, eps;
-};
-
 __device__ __forceinline__ int conv_wg_count(int wg, int HW, int MWG, int B) {
   if (HW <= MWG) { int ppw = MWG / HW; return min(ppw, B - wg * ppw) * HW; }
   int spp = (HW + MWG - 1) / MWG;
@@ -26,13 +18,16 @@ __device__ __forceinline__ int conv_wg_count(int wg, int HW, int MWG, int B) {
 }
 
 __global__ __launch_bounds__(1024) void k_bn_finalize(BnFinK a) {
-  // block = 32 channels x 32 slices of the conv workgroups' partials; grid = (C/32, G)
-  __shared__ double red[32][33];
+  // block = 8 channels x 128 slices of the conv workgroups' partials (grid = (C/8, G)): at most nwg/128 independent
+  // loads per thread, all in flight at once -- this launch is pure latency.  Single pass in double: with N = sum n_i,
+  //   mean = sum n_i m_i / N,   M2 = sum M2_i + sum n_i m_i^2 - N mean^2
+  // (m_i^2 is exact in double; the cancellation costs ~1e-13 of the variance)
+  __shared__ double red[16][24];
   const int g = blockIdx.y, t = threadIdx.x, C = a.C;
-  const int cl = t & 31, sl = t >> 5, c = blockIdx.x * 32 + cl;
+  const int cl = t & 7, sl = t >> 3, lane = t & 63, wave = t >> 6, c = blockIdx.x * 8 + cl;
   float* coef = a.coef + (size_t)g * C * 4;
   if (!a.training) {
-    if (t < 32 && c < C) {
+    if (t < 8 && c < C) {
       float rstd = rsqrtf(a.rvar[g][c] + a.eps);
       float sc = a.gamma[g][c] * rstd;
       coef[c * 4 + 0] = sc; coef[c * 4 + 1] = a.beta[g][c] - a.rmean[g][c] * sc;
@@ -41,35 +36,29 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(BnFinK a) {
     return;
   }
   const float* st = a.stats + (size_t)g * a.stats_goff;
-  // pass 1: grand mean = sum n_i mean_i / sum n_i
-  double sm = 0;
-  if (c < C)
-    for (int wg = sl; wg < a.nwg; wg += 32) {
-      double nb = conv_wg_count(wg, a.HW, a.MWG, a.B);
-      sm += nb * (double)st[((size_t)wg * a.stats_ld + c) * 2];
+  double s[3] = {0, 0, 0};
+  if (c < C) {
+#pragma unroll 4
+    for (int wg = sl; wg < a.nwg; wg += 128) {
+      const float2 v = *reinterpret_cast<const float2*>(st + ((size_t)wg * a.stats_ld + c) * 2);
+      const double nb = conv_wg_count(wg, a.HW, a.MWG, a.B), m = (double)v.x;
+      s[0] += nb * m; s[1] += nb * m * m; s[2] += (double)v.y;
     }
-  red[sl][cl] = sm;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double v = s[k];
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    if (lane < 8) red[wave][k * 8 + lane] = v;
+  }
   __syncthreads();
-  double tot = 0;
-#pragma unroll 8
-  for (int s = 0; s < 32; ++s) tot += red[s][cl];
-  const double n = (double)a.B * a.HW;
-  const double mean = tot / n;
-  __syncthreads();
-  // pass 2: M2 = sum M2_i + n_i (mean_i - mean)^2
-  double m2 = 0;
-  if (c < C)
-    for (int wg = sl; wg < a.nwg; wg += 32) {
-      double nb = conv_wg_count(wg, a.HW, a.MWG, a.B);
-      double d = (double)st[((size_t)wg * a.stats_ld + c) * 2] - mean;
-      m2 += (double)st[((size_t)wg * a.stats_ld + c) * 2 + 1] + nb * d * d;
-    }
-  red[sl][cl] = m2;
-  __syncthreads();
-  if (t < 32 && c < C) {
-    m2 = 0;
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) m2 += red[s][t];
+  if (t < 8 && c < C) {
+    double tot[3] = {0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { tot[0] += red[w][t]; tot[1] += red[w][8 + t]; tot[2] += red[w][16 + t]; }
+    const double n = (double)a.B * a.HW, mean = tot[0] / n;
+    double m2 = tot[2] + tot[1] - n * mean * mean;
+    m2 = m2 > 0 ? m2 : 0;
     double var = m2 / n;
     float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
     float sc = a.gamma[g][c] * rstd;
@@ -84,7 +73,7 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(BnFinK a) {
   }
 }
 
-int launch_bn_finalize(const BnFinalizeArgs& b, int G, hipStream_t st) {
+BnFinK bn_finalize_kargs(const BnFinalizeArgs& b) {
   BnFinK a;
   a.stats = b.stats; a.nwg = b.nwg; a.HW = b.HW; a.MWG = b.MWG; a.B = b.B;
   if (b.cat_mode) { a.C = b.nsplit; a.stats_goff = (size_t)b.nsplit * 2; a.stats_ld = b.N; }
@@ -93,9 +82,75 @@ int launch_bn_finalize(const BnFinalizeArgs& b, int G, hipStream_t st) {
     a.gamma[g] = b.gamma[g]; a.beta[g] = b.beta[g]; a.rmean[g] = b.rmean[g]; a.rvar[g] = b.rvar[g]; a.nbt[g] = b.nbt[g];
   }
   a.coef = b.coef; a.training = b.training; a.momentum = b.momentum; a.eps = b.eps;
-  hipLaunchKernelGGL(k_bn_finalize, dim3((a.C + 31) / 32, G), dim3(1024), 0, st, a);
+  return a;
+}
+
+int launch_bn_finalize(const BnFinalizeArgs& b, int G, hipStream_t st) {
+  BnFinK a = bn_finalize_kargs(b);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((a.C + 7) / 8, G), dim3(1024), 0, st, a);
   DTA_CHECK_LAUNCH("k_bn_finalize");
   return 0;
+}
+
+// The same statistics computed by a 256-thread stage workgroup for ALL C channels of its group, into LDS: lc[c][4] =
+// (scale, shift, mean, rstd).  Single pass over the partials in double: with N = sum n_i,
+//   mean = sum n_i m_i / N,   M2 = sum M2_i + sum n_i m_i^2 - N mean^2
+// (m_i^2 is exact in double and the sums have <= 512 terms, so the cancellation costs ~1e-13 of the variance).
+// Every workgroup runs the same instruction sequence on the same data: the coefficients are bit-identical everywhere.
+// `red` = 514 floats of scratch.  Workgroup `writer` also publishes the coefficients and the running statistics.
+__device__ __forceinline__ void bn_coef_block(const BnFinK& a, int g, float* lc, float* red, bool writer) {
+  const int t = threadIdx.x, C = a.C;
+  const int c = t % C, sl = t / C, T = 256 / C;     // C in {32, 64, 128}: T slices of the partials per channel
+  // 256 doubles, 8-byte aligned inside the 514-float scratch
+  double* dred = reinterpret_cast<double*>(red + ((reinterpret_cast<uintptr_t>(red) >> 2) & 1));
+  if (!a.training) {
+    if (t < C) {
+      const float rstd = rsqrtf(a.rvar[g][t] + a.eps), sc = a.gamma[g][t] * rstd;
+      lc[t * 4 + 0] = sc; lc[t * 4 + 1] = a.beta[g][t] - a.rmean[g][t] * sc;
+      lc[t * 4 + 2] = a.rmean[g][t]; lc[t * 4 + 3] = rstd;
+    }
+  } else {
+    const float* st = a.stats + (size_t)g * a.stats_goff;
+    double s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll 8
+    for (int wg = sl; wg < a.nwg; wg += T) {       // unrolled: independent L2 loads in flight
+      const float2 v = *reinterpret_cast<const float2*>(st + ((size_t)wg * a.stats_ld + c) * 2);
+      const double nb = conv_wg_count(wg, a.HW, a.MWG, a.B), m = (double)v.x;
+      s1 += nb * m; s2 += nb * m * m; s3 += (double)v.y;
+    }
+    double tot[3];
+    const double part[3] = {s1, s2, s3};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                  // three rounds through the 256-double scratch
+      __syncthreads();
+      dred[t] = part[k];
+      __syncthreads();
+      double acc = 0;
+      if (t < C)
+        for (int j = 0; j < T; ++j) acc += dred[j * C + t];
+      tot[k] = acc;
+    }
+    if (t < C) {
+      const double n = (double)a.B * a.HW, mean = tot[0] / n;
+      double m2 = tot[2] + tot[1] - n * mean * mean;
+      m2 = m2 > 0 ? m2 : 0;
+      const double var = m2 / n;
+      const float rstd = (float)(1.0 / sqrt(var + (double)a.eps)), sc = a.gamma[g][t] * rstd;
+      lc[t * 4 + 0] = sc; lc[t * 4 + 1] = a.beta[g][t] - (float)mean * sc;
+      lc[t * 4 + 2] = (float)mean; lc[t * 4 + 3] = rstd;
+      if (writer && a.rmean[g]) {
+        const double unb = n > 1 ? m2 / (n - 1) : var;
+        a.rmean[g][t] = (1.f - a.momentum) * a.rmean[g][t] + a.momentum * (float)mean;
+        a.rvar[g][t] = (1.f - a.momentum) * a.rvar[g][t] + a.momentum * (float)unb;
+        if (t == 0 && a.nbt[g]) a.nbt[g][0] += 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (writer && a.coef) {
+    float* coef = a.coef + (size_t)g * C * 4;
+    for (int i = t; i < C * 4; i += 256) coef[i] = lc[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -152,7 +207,7 @@ static size_t stage_lds_floats(const StageArgs& a, bool bwd) {
   size_t n = (size_t)HWz * ld;                 // Z
   if (bwd) n += (size_t)HWz * ld;               // D
   // vectors / padded maps + reduction scratch.  backward: v0..v4 full slots, v5 per-pixel-or-channel, v6 per-channel
-  n += bwd ? (size_t)5 * a.vslot + (HWz > a.C ? HWz : a.C) + a.C + 512 : (size_t)4 * a.vslot + 512;
+  n += bwd ? (size_t)5 * a.vslot + (HWz > a.C ? HWz : a.C) + a.C + 512 : (size_t)4 * a.vslot + 512 + 2 + 4 * a.C;
   return n;
 }
 
@@ -221,12 +276,12 @@ template <typename CFG>
 __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeom& s, int g, int b, int kind,
                                               float* Z, float* v0, float* v1, float* v2, float* scratch,
                                               bool use_saved = false, const float* da = nullptr, float* D = nullptr,
-                                              bool z_ready = false) {
+                                              bool z_ready = false, const float* lcoef = nullptr) {
   constexpr int CT = CFG::C;
   const bool pool = cfg_pool<CFG>(a);
   const int t = threadIdx.x, C = s.C, ld = s.ld;
   const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
-  const float* coef = a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr;
+  const float* coef = lcoef ? lcoef : (a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr);
   if (use_saved) {   // v0 | v1 | v2 as the forward kernel left them (padded maps include their zero borders)
     const float* src = a.attsave + ((size_t)g * a.B + b) * a.attsave_ld;
     if (kind == KIND_SPECTRAL) {   // three C-vectors, stored packed
@@ -340,10 +395,11 @@ __device__ __forceinline__ float gate_of(int kind, const float* v2, int p, int c
 // Forward of one patch (b, g).  z_ready: the caller already built Z (BN + ReLU of the conv output) in LDS.
 template <typename T, typename CFG>
 __device__ __forceinline__ void stage_fwd_patch(const StageArgs& a, const StageGeom& s, int b, int g, bool z_ready,
-                                                float* Z, float* v0, float* v1, float* v2, float* scratch) {
+                                                float* Z, float* v0, float* v1, float* v2, float* scratch,
+                                                const float* lcoef = nullptr) {
   const int t = threadIdx.x, C = s.C, ld = s.ld;
   const int kind = a.kind[g];
-  stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch, false, nullptr, nullptr, z_ready);
+  stage_forward<CFG>(a, s, g, b, kind, Z, v0, v1, v2, scratch, false, nullptr, nullptr, z_ready, lcoef);
   if (a.attsave) {
     float* dst = a.attsave + ((size_t)g * a.B + b) * a.attsave_ld;
     if (kind == KIND_SPECTRAL) {
@@ -411,6 +467,7 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
   float* v0 = Z + (size_t)s.HWz * ld;
   float* v1 = v0 + s.vslot; float* v2 = v1 + s.vslot; float* v3 = v2 + s.vslot;
   float* scratch = v3 + s.vslot;
+  float* lcoef = nullptr;
   // Un-pooled network stage launched with half a grid: two patches per workgroup, the second one's conv output is
   // fetched into registers while the first is processed (see k_stage_bwd).
   constexpr bool PIPE = CFG::fixed && CFG::P == 0;
@@ -418,8 +475,6 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
     constexpr int NQ = PIPE ? (CFG::H * CFG::W * CFG::C + 255) / 256 : 1;
     constexpr int CQ = PIPE ? CFG::C : 1, NEL = PIPE ? CFG::H * CFG::W * CFG::C : 0;
     float ry[NQ];
-    const float* coef = a.coef + (size_t)g * a.coef_gs;
-    const float psc = coef[(t % CQ) * 4 + 0], psh = coef[(t % CQ) * 4 + 1];
 #define DTA_STAGE_ISSUE(b_)                                                                          \
     {                                                                                                \
       const float* y_ = a.y + (size_t)g * a.y_gs + (size_t)(b_) * s.HWc * a.y_rs;                    \
@@ -434,20 +489,31 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
       if (i < NEL) Z[(i / CQ) * ld + (i % CQ)] = fmaxf(ry[u] * psc + psh, 0.f);                      \
     }
     const int b0 = blockIdx.x, b1 = blockIdx.x + gridDim.x;
-    DTA_STAGE_ISSUE(b0)
+    DTA_STAGE_ISSUE(b0)          // the first patch's conv output is in flight while the statistics are combined
+    const float* coef = a.coef + (size_t)g * a.coef_gs;
+    if (a.bn_inkernel) {
+      lcoef = scratch + 514;
+      bn_coef_block(a.bnfin, g, lcoef, scratch, blockIdx.x == 0);
+      coef = lcoef;
+    }
+    const float psc = coef[(t % CQ) * 4 + 0], psh = coef[(t % CQ) * 4 + 1];
     DTA_STAGE_LAND()
     if (b1 < a.B) DTA_STAGE_ISSUE(b1)
-    stage_fwd_patch<T, CFG>(a, s, b0, g, true, Z, v0, v1, v2, scratch);
+    stage_fwd_patch<T, CFG>(a, s, b0, g, true, Z, v0, v1, v2, scratch, lcoef);
     if (b1 < a.B) {
       __syncthreads();   // the second patch reuses the LDS tiles
       DTA_STAGE_LAND()
-      stage_fwd_patch<T, CFG>(a, s, b1, g, true, Z, v0, v1, v2, scratch);
+      stage_fwd_patch<T, CFG>(a, s, b1, g, true, Z, v0, v1, v2, scratch, lcoef);
     }
 #undef DTA_STAGE_LAND
 #undef DTA_STAGE_ISSUE
     return;
   }
-  stage_fwd_patch<T, CFG>(a, s, blockIdx.x, g, false, Z, v0, v1, v2, scratch);
+  if (a.bn_inkernel) {
+    lcoef = scratch + 514;
+    bn_coef_block(a.bnfin, g, lcoef, scratch, blockIdx.x == 0);
+  }
+  stage_fwd_patch<T, CFG>(a, s, blockIdx.x, g, false, Z, v0, v1, v2, scratch, lcoef);
 }
 
 template <typename T, typename CFG>
@@ -829,30 +895,16 @@ int launch_stage_bwd(const StageBwdArgs& a_in, int G, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // BatchNorm backward: reduce per-patch partials -> dgamma, dbeta and the apply coefficients.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdFinalizeArgs& a, int bx, int g, float (*s1)[33], float (*s2)[33]) {
-  // block = 32 channels x 32 batch slices
-  const int t = threadIdx.x, C = a.C;
-  const int cl = t & 31, sl = t >> 5, c = bx * 32 + cl;
-  const float* part = a.bnpart + (size_t)g * a.bnpart_gs;
-  float q1 = 0.f, q2 = 0.f, r1 = 0.f, r2 = 0.f;
-  if (c < C) {
-    int b = sl;
-    for (; b + 32 < a.B; b += 64) {
-      const float2 v0 = *reinterpret_cast<const float2*>(part + ((size_t)b * C + c) * 2);
-      const float2 v1 = *reinterpret_cast<const float2*>(part + ((size_t)(b + 32) * C + c) * 2);
-      q1 += v0.x; q2 += v0.y; r1 += v1.x; r2 += v1.y;
-    }
-    for (; b < a.B; b += 32) {
-      const float2 v0 = *reinterpret_cast<const float2*>(part + ((size_t)b * C + c) * 2);
-      q1 += v0.x; q2 += v0.y;
-    }
-  }
-  s1[sl][cl] = q1 + r1; s2[sl][cl] = q2 + r2;
-  __syncthreads();
-  if (t < 32 && c < C) {
-    double d1 = 0, d2 = 0;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) { d1 += s1[s][t]; d2 += s2[s][t]; }
+__device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdFinalizeArgs& a, int bx, int g, float (*sc)[16]) {
+  // block = 8 channels x 128 batch slices (see colsum8)
+  const int t = threadIdx.x, C = a.C, c0 = bx * 8;
+  const float* part = a.bnpart + (size_t)g * a.bnpart_gs + (size_t)c0 * 2;
+  const double v = colsum8<2>(part, (size_t)C * 2, a.B, min(8, C - c0), sc);
+  // thread 2j holds sum(dv) of channel c0 + j, thread 2j + 1 its sum(dv * xhat): the even thread finishes the channel
+  const double d2 = __shfl_down(v, 1);
+  const int c = c0 + (t >> 1);
+  if (t < 16 && !(t & 1) && c < C) {
+    const double d1 = v;
     const float* coef = a.coef + (size_t)g * a.coef_gs;
     float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
     float A = a.gamma[g][c] * coef[c * 4 + 3];
@@ -869,12 +921,12 @@ __device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdFinalizeArgs& a
 }
 
 __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(BnBwdFinalizeArgs a) {
-  __shared__ float s1[32][33], s2[32][33];
-  bn_bwd_finalize_block(a, blockIdx.x, blockIdx.y, s1, s2);   // grid = (C/32, G)
+  __shared__ float sc[16][16];
+  bn_bwd_finalize_block(a, blockIdx.x, blockIdx.y, sc);   // grid = (C/8, G)
 }
 
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, int G, hipStream_t st) {
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((a.C + 31) / 32, G), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((a.C + 7) / 8, G), dim3(1024), 0, st, a);
   DTA_CHECK_LAUNCH("k_bn_bwd_finalize");
   return 0;
 }
@@ -882,12 +934,12 @@ int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, int G, hipStream_t st) {
 // blocks [0, nbn): BatchNorm finalize (block -> (channel tile, group)); then the column-sum jobs
 struct ColsumPair { ColsumArgs cs[2]; int nblk[2]; };
 __global__ __launch_bounds__(1024) void k_bn_bwd_finalize_colsum(BnBwdFinalizeArgs a, int nbx, int nbn, ColsumPair cp) {
-  __shared__ float s1[32][33], s2[32][33];
+  __shared__ float sc[16][16];
   int bx = blockIdx.x;
-  if (bx < nbn) { bn_bwd_finalize_block(a, bx % nbx, bx / nbx, s1, s2); return; }
+  if (bx < nbn) { bn_bwd_finalize_block(a, bx % nbx, bx / nbx, sc); return; }
   bx -= nbn;
-  if (bx < cp.nblk[0]) { colsum_scatter_block(cp.cs[0], bx, s1); return; }
-  colsum_scatter_block(cp.cs[1], bx - cp.nblk[0], s1);
+  if (bx < cp.nblk[0]) { colsum_scatter_block(cp.cs[0], bx, sc); return; }
+  colsum_scatter_block(cp.cs[1], bx - cp.nblk[0], sc);
 }
 
 int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const ColsumArgs* cs, int ncs, hipStream_t st) {
@@ -895,8 +947,8 @@ int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const Colsu
   if (ncs > 2) { dta_set_error("bn_bwd_finalize_colsum: at most two column-sum jobs"); return 1; }
   ColsumPair cp = {};
   int extra = 0;
-  for (int i = 0; i < ncs; ++i) { cp.cs[i] = cs[i]; cp.nblk[i] = (cs[i].cols + 31) / 32; extra += cp.nblk[i]; }
-  const int nbx = (a.C + 31) / 32, nbn = nbx * G;
+  for (int i = 0; i < ncs; ++i) { cp.cs[i] = cs[i]; cp.nblk[i] = colsum_nblocks(cs[i]); extra += cp.nblk[i]; }
+  const int nbx = (a.C + 7) / 8, nbn = nbx * G;
   hipLaunchKernelGGL(k_bn_bwd_finalize_colsum, dim3(nbn + extra), dim3(1024), 0, st, a, nbx, nbn, cp);
   DTA_CHECK_LAUNCH("k_bn_bwd_finalize_colsum");
   return 0;

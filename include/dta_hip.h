@@ -205,6 +205,9 @@ enum { DTA_SITE_CONV_FWD = 0, DTA_SITE_CONV_WGRAD = 3, DTA_SITE_CONV_DGRAD = 6, 
        DTA_SITE_GEMM = 15 /* +0 classifier heads forward, +1 head input gradients, +2 parameter-gradient group */ };
 int dta_profile_enable(int site);
 int dta_profile_collect(float* ms, int max);
+/* Development aid: the library reads its developer environment switches (DTA_NO_FUSED_INPUT, DTA_NO_TAIL_MERGE,
+ * DTA_BN_INKERNEL: same-box A/B runs of alternative launch plans) once at load time; this re-reads them. */
+int dta_dev_reload_switches(void);
 
 #ifdef __cplusplus
 }

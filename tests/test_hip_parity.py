@@ -366,10 +366,17 @@ def test_fused_input_conv_equals_separate_pack_pass(B, monkeypatch):
         torch.nn.functional.cross_entropy(out, y).backward()
         return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
 
+    from deeptreeattention_amd import _lib
     monkeypatch.delenv("DTA_NO_FUSED_INPUT", raising=False)
+    _lib.lib().dta_dev_reload_switches()
     o1, g1 = run()
     monkeypatch.setenv("DTA_NO_FUSED_INPUT", "1")
-    o2, g2 = run()
+    _lib.lib().dta_dev_reload_switches()
+    try:
+        o2, g2 = run()
+    finally:
+        monkeypatch.delenv("DTA_NO_FUSED_INPUT", raising=False)
+        _lib.lib().dta_dev_reload_switches()
     assert rel_l2(o1.cpu().numpy(), o2.cpu().numpy()) < 1e-5
     for k in g2:
         # skipped: conv biases (zero under batch-stat BN) and the attention gates' output biases -- nearly invariant
@@ -404,10 +411,17 @@ def test_fused_input_conv_other_networks_and_band_counts(kind, bands, monkeypatc
         torch.nn.functional.cross_entropy(out, y).backward()
         return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
 
+    from deeptreeattention_amd import _lib
     monkeypatch.delenv("DTA_NO_FUSED_INPUT", raising=False)
+    _lib.lib().dta_dev_reload_switches()
     o1, g1 = run()
     monkeypatch.setenv("DTA_NO_FUSED_INPUT", "1")
-    o2, g2 = run()
+    _lib.lib().dta_dev_reload_switches()
+    try:
+        o2, g2 = run()
+    finally:
+        monkeypatch.delenv("DTA_NO_FUSED_INPUT", raising=False)
+        _lib.lib().dta_dev_reload_switches()
     assert torch.isfinite(o1).all()
     assert rel_l2(o1.cpu().numpy(), o2.cpu().numpy()) < 1e-5
     for k in g2:
