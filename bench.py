@@ -8,9 +8,13 @@ all-reduce when >1 GPU) at bands=369, 11x11, 200 classes (BASELINE.json metric /
 
 One process per GPU; per-GPU batch is fixed (weak scaling; 1024 per GPU = 8192 global on 8 GPUs).  Synthetic
 patches (U[0,1), like the reference's min-max-scaled crops) are resident in HBM before the timed region.  Rank 0
-prints ONE JSON line.  `roofline` times the dominant kernel with HIP events recorded on its own stream inside the
-timed loop; `cpu_baseline` times the torch-eager port of the reference step (oracle/hang2020_torch.py) on the
-host cores of the same box (rank 0, N=1 only, bounded sample).
+prints ONE JSON line.  Inside the timed loop the two first-conv kernels are timed with HIP events recorded on their own
+stream: `roofline` = the conv1 forward (the step's longest kernel; HBM-bound since it also converts the fp32 input and
+emits the bf16 tiles), `roofline_mfma` = the conv1 weight gradient (the longest MFMA-bound kernel); `step_roofline`
+prices the whole step's algorithmic FLOPs / bytes against the MI355X peaks.  `value` comes from the
+K timed steps exactly as the driver's contract says; because K steps of 0.6 ms are a short region, `steady_state`
+adds the median of >= 200 further steps timed one by one with HIP events.  `cpu_baseline` times the torch-eager port of
+the reference step (oracle/hang2020_torch.py) on the host cores of the same box (rank 0, N=1 only, bounded sample).
 """
 import argparse
 import ctypes as C
@@ -40,9 +44,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="patches per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--site", default="fwd0",
-                    help="kernel site timed for the roofline object: fwd0 = the first conv's forward (the longest "
+                    help="kernel site reported as `roofline` (the other first-conv kernel is reported as "
+                         "`roofline_mfma` / `roofline_hbm` beside it): fwd0 = the first conv's forward (the longest "
                          "kernel of the step: it also converts the fp32 input and emits the bf16 tiles), wgrad0 = the "
                          "first conv's weight gradient (the longest MFMA-bound kernel)")
+    ap.add_argument("--steady-steps", type=int, default=200,
+                    help="extra steps timed one by one after the contract's K steps (median reported); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
@@ -87,9 +94,10 @@ def cpu_baseline(batch, seconds):
         if best is None or rate > best[0]:
             best = (rate, thr, b, n, el)
     rate, thr, b, n, el = best
-    return {"value": round(rate, 1), "unit": "patches/s", "cores": thr, "kind": "port",
+    return {"value": round(rate, 1), "unit": "patches/s", "cores": ncpu, "threads": thr, "kind": "port",
             "sample": f"best of {len(settings)} settings ({', '.join(tried)} patches/s); reported: {n} train steps of "
-                      f"batch {b}, fp32, torch {torch.__version__} eager on host CPU, {thr} threads, {el:.1f} s"}
+                      f"batch {b}, fp32, torch {torch.__version__} eager on host CPU, {thr} of the box's {ncpu} "
+                      f"hardware threads (oneDNN does not scale this small model further), {el:.1f} s"}
 
 
 def main():
@@ -131,9 +139,7 @@ def main():
     ys = [torch.randint(0, CLASSES, (a.batch,), device=dev, generator=g) for _ in range(nb)]
 
     L = _lib.lib()
-    sites = {"fwd0": _lib.SITE_CONV_FWD, "wgrad0": _lib.SITE_CONV_WGRAD, "fwd1": _lib.SITE_CONV_FWD + 1,
-             "fwd2": _lib.SITE_CONV_FWD + 2, "wgrad1": _lib.SITE_CONV_WGRAD + 1, "wgrad2": _lib.SITE_CONV_WGRAD + 2,
-             "dgrad1": _lib.SITE_CONV_DGRAD + 1, "dgrad2": _lib.SITE_CONV_DGRAD + 2}
+    SITE = {"fwd0": _lib.SITE_CONV_FWD, "wgrad0": _lib.SITE_CONV_WGRAD}
 
     def barrier():
         if world > 1:
@@ -144,7 +150,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     if rank == 0:
-        L.dta_profile_enable(sites[a.site])
+        for site in SITE.values():           # both first-conv kernels are timed in the SAME run (two event sets)
+            L.dta_profile_enable(site)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -158,44 +165,79 @@ def main():
         el = float(t.item())
     final_loss = float(loss.item())
 
-    if rank == 0:
+    def collect(site):
         buf = (C.c_float * 512)()
-        n = L.dta_profile_collect(buf, 512)
+        n = L.dta_profile_collect_site(site, buf, 512)
+        return [buf[i] for i in range(max(n, 0))]
+    site_ms = {k: collect(v) for k, v in SITE.items()} if rank == 0 else {}
+    if rank == 0:
         L.dta_profile_enable(-1)
-        roof = None
-        if n > 0:
-            avg_ms = sum(buf[i] for i in range(n)) / n
-            flops = CONV1_FLOP_PER_PATCH * a.batch if a.site in ("fwd0", "wgrad0") else None
-            if flops:
-                # HBM bytes per launch of this kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-                # profiles/r01_traffic.json); only valid for the configuration it was measured on
-                traffic = None
-                tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
-                if os.path.exists(tpath):
-                    tj = json.load(open(tpath))
-                    if tj.get("batch") == a.batch and tj.get("precision") == a.precision and a.site in tj:
-                        traffic = tj[a.site]["hbm_bytes_per_launch"]
-                ach = flops / (avg_ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "kernel": {"fwd0": "k_conv3x3 (conv1 forward, both branches)",
-                                                    "wgrad0": "k_conv_wgrad (conv1 weight gradient, both branches)"}[a.site],
-                        "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_TFLOPS[a.precision], 4), "traffic": traffic,
-                        "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes)",
-                        "avg_launch_ms": round(avg_ms, 4), "launches": n,
-                        "algorithmic_flop_per_launch": flops}
-                if a.site == "fwd0" and a.precision == "bf16":
-                    # the bf16 conv1 forward reads the fp32 NCHW input itself and leaves the bf16 tiles behind for the
-                    # weight gradient: per patch 369*121*4 B in, 384*121*2 B of tiles + 64*121*4 B of output out.
-                    # That makes it HBM-bound (its MFMA floor is ~21 us, its HBM floor ~39 us at 8 TB/s)
-                    nbytes = a.batch * (BANDS * HW * HW * 4 + 384 * HW * HW * 2 + 64 * HW * HW * 4)
-                    gbs = nbytes / (avg_ms * 1e-3) / 1e9
-                    roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
-                                 "mfma_tflops": round(ach, 2),
-                                 "kernel": "k_conv3x3_bf16<2,2,XN> (conv1 forward, both branches; converts the fp32 "
-                                           "input and emits the bf16 tiles)"})
+
+    # steady state beyond the contract's K steps: each step bracketed by its own HIP events (no host sync in between)
+    steady = None
+    if a.steady_steps > 0:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steady_steps)]
+        for i, (e0, e1) in enumerate(evs):
+            e0.record()
+            trainer.train_step(xs[i % nb], ys[i % nb])
+            e1.record()
+        torch.cuda.synchronize()
+        barrier()
+        ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        steady = {"steps": a.steady_steps, "median_ms_per_step": round(ms[len(ms) // 2], 4), "min_ms_per_step": round(ms[0], 4),
+                  "p90_ms_per_step": round(ms[int(0.9 * (len(ms) - 1))], 4),
+                  "median_patches_per_s_per_gpu": round(a.batch / (ms[len(ms) // 2] * 1e-3), 1),
+                  "note": "per-step HIP events on this rank's stream after the contract's timed region"}
+
+    if rank == 0:
+        # HBM bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of this
+        # very command; tools/step_traffic.py): a constant of the configuration it was measured on, not a live counter
+        traffic = {}
+        tpath = os.path.join(REPO, "profiles", "r02_traffic_step.json")
+        if os.path.exists(tpath) and a.batch == 1024 and a.precision == "bf16":
+            tj = json.load(open(tpath))
+            for row in tj.get("kernels", []):
+                if row["kernel"].startswith("k_conv3x3_bf16<2, 2, true>"):
+                    traffic["fwd0"] = row["hbm_bytes_per_launch"]
+                if row["kernel"].startswith("k_conv_wgrad_bf16<2, 2"):
+                    traffic["wgrad0"] = row["hbm_bytes_per_launch"]
+            traffic["step_total"] = int(tj.get("hbm_mb_per_step", 0) * 1e6) or None
+        tsrc = "committed PMC passes (profiles/r02_traffic_step.json), valid for batch 1024 bf16 only"
+        flops = CONV1_FLOP_PER_PATCH * a.batch
+        roofs = {}
+        if site_ms.get("wgrad0"):
+            avg_ms = sum(site_ms["wgrad0"]) / len(site_ms["wgrad0"])
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            roofs["wgrad0"] = {"bound": "mfma", "kernel": "k_conv_wgrad (conv1 weight gradient, both branches)",
+                               "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_TFLOPS[a.precision], 4), "traffic": traffic.get("wgrad0"),
+                               "traffic_source": tsrc, "avg_launch_ms": round(avg_ms, 4), "launches": len(site_ms["wgrad0"]),
+                               "algorithmic_flop_per_launch": flops}
+        if site_ms.get("fwd0"):
+            avg_ms = sum(site_ms["fwd0"]) / len(site_ms["fwd0"])
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            r = {"bound": "mfma", "kernel": "k_conv3x3 (conv1 forward, both branches)", "achieved": round(ach, 2),
+                 "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[a.precision], 4),
+                 "traffic": traffic.get("fwd0"), "traffic_source": tsrc, "avg_launch_ms": round(avg_ms, 4),
+                 "launches": len(site_ms["fwd0"]), "algorithmic_flop_per_launch": flops}
+            if a.precision == "bf16":
+                # the bf16 conv1 forward reads the fp32 NCHW input itself and leaves the bf16 tiles behind for the
+                # weight gradient: per patch 369*121*4 B in, 384*121*2 B of tiles + 64*121*4 B of output out.
+                # That makes it HBM-bound (its MFMA floor is ~21 us, its HBM floor ~39 us at 8 TB/s).  Against the
+                # strictly compulsory bytes (input in + output out, the tiles being a by-product) the fraction is lower:
+                nbytes = a.batch * (BANDS * HW * HW * 4 + 384 * HW * HW * 2 + 64 * HW * HW * 4)
+                compulsory = a.batch * (BANDS * HW * HW * 4 + 64 * HW * HW * 4)
+                gbs = nbytes / (avg_ms * 1e-3) / 1e9
+                r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
+                          "frac_compulsory_bytes_only": round(compulsory / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                          "mfma_tflops": round(ach, 2),
+                          "kernel": "k_conv3x3_bf16<2,2,XN> (conv1 forward, both branches; converts the fp32 input and "
+                                    "emits the bf16 tiles)"})
+            roofs["fwd0"] = r
         total = a.steps * a.batch * world
         value = total / el
+        per_gpu = value / world
         out = {
             "metric": "patches/sec (train step) Hang2020 369-band 11x11",
             "value": round(value, 1), "unit": "patches/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -204,11 +246,22 @@ def main():
             "config": {"workload": "Hang2020 spectral+spatial attention train step (fwd + weighted CE + bwd + Adam"
                                    + (" + RCCL grad all-reduce" if world > 1 else "") + "), bands=369 11x11 classes=200",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "overlap_comm": bool(world > 1 and not a.no_overlap)},
+                       "parallelism": f"dp{world}", "overlap_comm": bool(world > 1 and not a.no_overlap),
+                       "collectives_per_step": (0 if world == 1 else (1 if a.no_overlap else 2))},
             "achieved_tflops_step": round(value * FLOP_PER_PATCH_STEP / 1e12, 2),
             "achieved_hbm_gbs_algorithmic": round(value * BYTES_PER_PATCH_STEP / 1e9, 1),
             "final_loss": round(final_loss, 5),
-            "roofline": roof,
+            "roofline": roofs.get(a.site),
+            ("roofline_mfma" if a.site == "fwd0" else "roofline_hbm"): roofs.get("wgrad0" if a.site == "fwd0" else "fwd0"),
+            "step_roofline": {
+                "bound": "mfma", "per_gpu": True,
+                "achieved": round(per_gpu * FLOP_PER_PATCH_STEP / 1e12, 2), "peak": PEAK_TFLOPS[a.precision],
+                "unit": "TFLOP/s", "frac": round(per_gpu * FLOP_PER_PATCH_STEP / 1e12 / PEAK_TFLOPS[a.precision], 4),
+                "algorithmic_flop_per_patch": FLOP_PER_PATCH_STEP,
+                "hbm_gbs_algorithmic": round(per_gpu * BYTES_PER_PATCH_STEP / 1e9, 1),
+                "hbm_frac_algorithmic": round(per_gpu * BYTES_PER_PATCH_STEP / 1e9 / PEAK_HBM_GBS, 4),
+                "traffic": traffic.get("step_total"), "traffic_source": tsrc},
+            "steady_state": steady,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_seconds)

@@ -177,6 +177,10 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, x, heads_mask, *params):
         L = _lib.lib()
+        if x.requires_grad:
+            raise RuntimeError("deeptreeattention_amd networks do not produce a gradient for their input patches "
+                               "(the reference's step never asks for one): pass x.detach()")
+        ctx.set_materialize_grads(False)               # unused heads arrive as None, not as zero-filled tensors
         subnets = owner._subnets()                     # [(kind, module, [relative names])]
         B, bands, H, W = x.shape
         desc = _lib.NetDesc(B, bands, H, W, owner._classes, owner._net_code, _lib.dtype_code(owner.precision),
@@ -235,6 +239,8 @@ class _NetFn(torch.autograd.Function):
         djoint = None
         used_heads = 0
         if owner._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA):
+            if gouts[0] is None:
+                return (None, None, None) + (None,) * len(params)
             djoint = gouts[0].contiguous().float()
             used_heads = 4
         else:
@@ -281,6 +287,10 @@ class _NetFn(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+def _bump_epoch(module, incompatible_keys):
+    module.__dict__["_dta_epoch"] = module.__dict__.get("_dta_epoch", 0) + 1
+
+
 class _Net(nn.Module):
     """Shared plumbing of the four network classes."""
     _net_code = None
@@ -290,6 +300,10 @@ class _Net(nn.Module):
         self._classes = int(classes)
         self.precision = precision or _DEFAULT_PRECISION
         _lib.dtype_code(self.precision)
+        # load_state_dict may replace Parameter objects (assign=True): cached raw-pointer tables (engine.Predictor) watch
+        # this counter
+        self.__dict__["_dta_epoch"] = 0
+        self.register_load_state_dict_post_hook(_bump_epoch)
 
     def _subnets(self):
         return [(self._kind, self, _subnet_param_names(self._kind))]

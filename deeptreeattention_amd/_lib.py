@@ -106,6 +106,12 @@ def lib():
                                     C.c_float, C.c_float, C.c_void_p]
         L.dta_adam_step_zero_grad.restype = C.c_int
         L.dta_adam_step_zero_grad.argtypes = L.dta_adam_step.argtypes
+        L.dta_adam_step_gated.restype = C.c_int
+        L.dta_adam_step_gated.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.dta_ensemble_backward_phased.restype = C.c_int
+        L.dta_ensemble_backward_phased.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams), C.c_void_p,
+                                                   C.c_void_p, C.POINTER(SubnetGrads), C.c_int, C.c_void_p]
         vp = C.c_void_p
         L.dta_conv_module_workspace_bytes.restype = C.c_size_t
         L.dta_conv_module_workspace_bytes.argtypes = [C.POINTER(ConvModuleDesc)]
@@ -130,6 +136,8 @@ def lib():
         L.dta_profile_enable.argtypes = [C.c_int]
         L.dta_profile_collect.restype = C.c_int
         L.dta_profile_collect.argtypes = [C.POINTER(C.c_float), C.c_int]
+        L.dta_profile_collect_site.restype = C.c_int
+        L.dta_profile_collect_site.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int]
         L.dta_dev_reload_switches.restype = C.c_int
         if L.dta_abi_version() != 1:
             raise RuntimeError("libdta_hip.so ABI version mismatch")

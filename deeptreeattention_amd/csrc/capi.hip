@@ -23,15 +23,25 @@ namespace {
 // Optional HIP-event timing of one launch site (bench.py's roofline leg): events are recorded on the same
 // stream as the kernel, immediately before and after its launch.  Host-side state only; off by default.
 struct Prof {
-  int site = -1, n = 0;
+  static constexpr int SLOTS = 4, CAP = 512;
+  int site[SLOTS] = {-1, -1, -1, -1}, n[SLOTS] = {0, 0, 0, 0}, nslots = 0;
   bool created = false;
-  hipEvent_t ev[512][2];
+  hipEvent_t ev[SLOTS][CAP][2];
 } g_prof;
+inline int prof_slot(int site) {
+  for (int s = 0; s < g_prof.nslots; ++s)
+    if (g_prof.site[s] == site) return s;
+  return -1;
+}
 inline void prof_begin(int site, hipStream_t st) {
-  if (site == g_prof.site && g_prof.n < 512) hipEventRecord(g_prof.ev[g_prof.n][0], st);
+  if (g_prof.nslots == 0) return;
+  const int s = prof_slot(site);
+  if (s >= 0 && g_prof.n[s] < Prof::CAP) hipEventRecord(g_prof.ev[s][g_prof.n[s]][0], st);
 }
 inline void prof_end(int site, hipStream_t st) {
-  if (site == g_prof.site && g_prof.n < 512) { hipEventRecord(g_prof.ev[g_prof.n][1], st); ++g_prof.n; }
+  if (g_prof.nslots == 0) return;
+  const int s = prof_slot(site);
+  if (s >= 0 && g_prof.n[s] < Prof::CAP) { hipEventRecord(g_prof.ev[s][g_prof.n[s]][1], st); ++g_prof.n[s]; }
 }
 
 constexpr int CH[3] = {32, 64, 128};
@@ -551,10 +561,10 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     else { ap.dy_gs = (size_t)B * (C / 16) * p.Qin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
     if (launch_bn_bwd_apply<T>(ap, G, st)) return 1;
     // ---- conv weight gradient ----
-    // end of phase 1: flush the deferred GEMMs -- unless the whole backward is this one call: then they ride in the
-    // launch of the split-K reductions at the very end (one dependent launch fewer)
-    const bool merge_tail = phases == 3 && !switches().no_tail_merge;
-    if (L == 0 && !merge_tail) {
+    // the deferred parameter-gradient GEMMs always ride in the launch of the split-K reductions that ends this call
+    // (phase 1 of a data-parallel step: the reductions of layers 3 and 2, so the first gradient bucket is complete
+    // when the call returns; the whole backward: all three layers); DTA_NO_TAIL_MERGE=1 flushes them separately
+    if (L == 0 && switches().no_tail_merge) {
       prof_begin(DTA_SITE_GEMM + 2, st);
       if (launch_gemm_group(deferred, st)) return 1;
       prof_end(DTA_SITE_GEMM + 2, st);
@@ -593,28 +603,46 @@ int dta_abi_version(void) { return DTA_ABI_VERSION; }
 int dta_dev_reload_switches(void) { g_switches = read_switches(); return 0; }
 
 int dta_profile_enable(int site) {
-  if (site >= 0 && !g_prof.created) {
-    for (int i = 0; i < 512; ++i)
-      for (int j = 0; j < 2; ++j)
-        if (hipEventCreate(&g_prof.ev[i][j]) != hipSuccess) { dta_set_error("hipEventCreate failed"); return 1; }
+  if (site < 0) {   // stop timing, forget every site
+    g_prof.nslots = 0;
+    for (int s = 0; s < Prof::SLOTS; ++s) { g_prof.site[s] = -1; g_prof.n[s] = 0; }
+    return 0;
+  }
+  if (!g_prof.created) {
+    for (int s = 0; s < Prof::SLOTS; ++s)
+      for (int i = 0; i < Prof::CAP; ++i)
+        for (int j = 0; j < 2; ++j)
+          if (hipEventCreate(&g_prof.ev[s][i][j]) != hipSuccess) { dta_set_error("hipEventCreate failed"); return 1; }
     g_prof.created = true;
   }
-  g_prof.site = site;
-  g_prof.n = 0;
+  int s = prof_slot(site);
+  if (s < 0) {
+    if (g_prof.nslots >= Prof::SLOTS) { dta_set_error("dta_profile_enable: at most %d sites at once", Prof::SLOTS); return 1; }
+    s = g_prof.nslots++;
+    g_prof.site[s] = site;
+  }
+  g_prof.n[s] = 0;
   return 0;
 }
 
-int dta_profile_collect(float* ms, int max) {
-  int n = g_prof.n < max ? g_prof.n : max;
+int dta_profile_collect_site(int site, float* ms, int max) {
+  const int s = prof_slot(site);
+  if (s < 0) { dta_set_error("dta_profile_collect_site: site %d is not being timed", site); return -1; }
+  int n = g_prof.n[s] < max ? g_prof.n[s] : max;
   for (int i = 0; i < n; ++i) {
-    if (hipEventSynchronize(g_prof.ev[i][1]) != hipSuccess ||
-        hipEventElapsedTime(&ms[i], g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) {
+    if (hipEventSynchronize(g_prof.ev[s][i][1]) != hipSuccess ||
+        hipEventElapsedTime(&ms[i], g_prof.ev[s][i][0], g_prof.ev[s][i][1]) != hipSuccess) {
       dta_set_error("profile event readback failed");
       return -1;
     }
   }
-  g_prof.n = 0;
+  g_prof.n[s] = 0;
   return n;
+}
+
+int dta_profile_collect(float* ms, int max) {
+  if (g_prof.nslots == 0) return 0;
+  return dta_profile_collect_site(g_prof.site[0], ms, max);
 }
 const char* dta_last_error(void) { return g_err; }
 
@@ -673,14 +701,19 @@ int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_para
 
 int dta_ensemble_backward(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
                           const float* dscore, const dta_subnet_grads* grads, void* stream) {
+  return dta_ensemble_backward_phased(d, years, nets, workspace, dscore, grads, 3, stream);
+}
+
+int dta_ensemble_backward_phased(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
+                                 const float* dscore, const dta_subnet_grads* grads, int phases, void* stream) {
   Plan p; dta_net_desc dd;
-  if (!nets || !workspace || !dscore || !grads) { dta_set_error("dta_ensemble_backward: null argument"); return 1; }
+  if (!nets || !workspace || !dscore || !grads || !(phases & 3)) { dta_set_error("dta_ensemble_backward: null argument"); return 1; }
   if (ensemble_desc(d, years, &dd, &p, "dta_ensemble_backward")) return 1;
   const float* dsc[MAXG][3] = {};
   for (int g = 0; g < years; ++g) dsc[g][2] = dscore;   // d(mean)/d(year score) is the same 1/years for every year
   hipStream_t st = (hipStream_t)stream;
-  if (dd.dtype == DTA_BF16) return backward_t<bf16_t>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, 3, st);
-  if (dd.dtype == DTA_F32) return backward_t<float>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, 3, st);
+  if (dd.dtype == DTA_BF16) return backward_t<bf16_t>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, phases, st);
+  if (dd.dtype == DTA_F32) return backward_t<float>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, phases, st);
   dta_set_error("unknown dtype %d", dd.dtype);
   return 1;
 }
@@ -715,9 +748,13 @@ int dta_softmax_top2(const float* logits, int batch, int classes, float* probs, 
 
 static int adam_step_impl(float* p, const float* g, float* gz, float* m, float* v, size_t n, double* alpha_p,
                           const double* alpha_g, double* alpha_gz, double* alpha_m, double* alpha_v, int step, float lr,
-                          float beta1, float beta2, float eps, float grad_scale, void* stream) {
-  if (step < 1 || (n && (!p || !g || !m || !v))) { dta_set_error("dta_adam_step: bad argument"); return 1; }
+                          float beta1, float beta2, float eps, float grad_scale, void* stream,
+                          const float* active = nullptr, const int* dev_step = nullptr) {
+  if ((step < 1 && !active) || (n && (!p || !g || !m || !v))) { dta_set_error("dta_adam_step: bad argument"); return 1; }
   AdamArgs a;
+  a.active = active; a.dev_step = dev_step;
+  if (active && !dev_step) { dta_set_error("dta_adam_step_gated: needs a device step counter"); return 1; }
+  if (step < 1) step = 1;
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.gz = gz; a.alpha_gz = alpha_gz;
   a.alpha_p = alpha_p; a.alpha_g = alpha_g; a.alpha_m = alpha_m; a.alpha_v = alpha_v;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
@@ -731,6 +768,13 @@ int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double
                   float grad_scale, void* stream) {
   return adam_step_impl(p, g, nullptr, m, v, n, alpha_p, alpha_g, nullptr, alpha_m, alpha_v, step, lr, beta1, beta2, eps,
                         grad_scale, stream);
+}
+
+int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const float* active, const int* dev_step,
+                        float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  if (!active) { dta_set_error("dta_adam_step_gated: null gate"); return 1; }
+  return adam_step_impl(p, g, g, m, v, n, nullptr, nullptr, nullptr, nullptr, nullptr, 0, lr, beta1, beta2, eps,
+                        grad_scale, stream, active, dev_step);
 }
 
 int dta_adam_step_zero_grad(float* p, float* g, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,

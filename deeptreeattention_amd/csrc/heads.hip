@@ -468,7 +468,17 @@ int launch_softmax_top2(const float* logits, int B, int classes, float* probs, l
 // torch.optim.Adam (defaults: no weight decay, no amsgrad) over one flat fp32 buffer + the fp64 alpha.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_adam(AdamArgs a) {
-  const float ss = a.lr / a.bc1, rbc2 = rsqrtf(a.bc2);
+  float bc1 = a.bc1, bc2 = a.bc2;
+  if (a.active) {
+    if (!(a.active[0] > 0.f)) {      // skipped everywhere: only optimizer.zero_grad()'s part of the pass
+      if (a.gz)
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) a.gz[i] = 0.f;
+      return;
+    }
+    const double st = (double)a.dev_step[0];
+    bc1 = (float)(1.0 - pow((double)a.beta1, st)); bc2 = (float)(1.0 - pow((double)a.beta2, st));
+  }
+  const float ss = a.lr / bc1, rbc2 = rsqrtf(bc2);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
     // moments: touched once per step, by this kernel only -> nontemporal both ways (they would only evict useful lines)
     float g = a.g[i] * a.grad_scale;
@@ -483,7 +493,7 @@ __global__ void k_adam(AdamArgs a) {
     double m = (double)a.beta1 * a.alpha_m[0] + (1.0 - (double)a.beta1) * g;
     double v = (double)a.beta2 * a.alpha_v[0] + (1.0 - (double)a.beta2) * g * g;
     a.alpha_m[0] = m; a.alpha_v[0] = v;
-    a.alpha_p[0] -= ((double)a.lr / (double)a.bc1) * (m / (sqrt(v) / sqrt((double)a.bc2) + (double)a.eps));
+    a.alpha_p[0] -= ((double)a.lr / (double)bc1) * (m / (sqrt(v) / sqrt((double)bc2) + (double)a.eps));
     if (a.alpha_gz) a.alpha_gz[0] = 0.0;
   }
 }

@@ -336,6 +336,11 @@ struct AdamArgs {
   double* alpha_p; const double* alpha_g; double* alpha_m; double* alpha_v;
   float lr, beta1, beta2, eps, bc1, bc2; float grad_scale;
   float* gz; double* alpha_gz;         // non-null: gradients are cleared after use (step + zero_grad in one pass)
+  // device-side gating (year ensembles under data parallelism): when `active` is non-null the step is applied only if
+  // active[0] > 0 (otherwise the moments do not decay and the parameters stay, exactly as torch's Adam passes over a
+  // parameter whose grad is None; the gradient buffer is still cleared), and the bias corrections come from the
+  // DEVICE step counter dev_step[0] (already advanced by the caller for this step) instead of bc1 / bc2
+  const float* active; const int* dev_step;
 };
 int launch_adam(const AdamArgs& a, hipStream_t st);
 int launch_softmax_top2(const float* logits, int B, int classes, float* probs, long long* top_idx, float* top_score,

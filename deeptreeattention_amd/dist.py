@@ -1,10 +1,11 @@
 """Host-side data-parallel plumbing of the fused trainer (one process per GPU, torch.distributed; backend "nccl" is
 RCCL on ROCm, "gloo" in the CPU tests).  No kernels here.
 
-The Hang2020 train step has exactly one exchange: the sum of the flat gradient (3.6 MB fp32 + the float64 alpha)
-over ranks; BatchNorm statistics stay per rank (reference train.py:89-98 does not enable sync_batchnorm).  The
-flat buffer is laid out [everything else | first-conv weights] so that the first all-reduce (issued after backward
-phase 1, on a side HIP stream) overlaps with the first conv's weight-gradient kernel, the last and largest piece."""
+The Hang2020 train step has exactly one exchange: the sum of the flat gradient (3.6 MB fp32, the float64 alpha's
+gradient riding in one fp32 slot of it) over ranks; BatchNorm statistics stay per rank (reference train.py:89-98 does
+not enable sync_batchnorm).  The flat buffer is laid out [everything else | alpha slot | first-conv weights] so that the
+first all-reduce (issued after backward phase 1, on a side HIP stream) overlaps with the first conv's weight-gradient
+kernel, the last and largest piece; without overlap the whole buffer is ONE collective."""
 import torch
 import torch.distributed as dist
 
@@ -24,31 +25,48 @@ def flat_layout(named_sizes, late):
 
 
 class GradSync:
-    """Two-phase gradient all-reduce (sum); averaging is folded into the optimizer kernel (grad_scale)."""
+    """Gradient all-reduce (sum) of the flat fp32 buffer; averaging is folded into the optimizer kernel (grad_scale).
+
+    Two buckets when overlapping ([everything else | first-conv weights]: the first is reduced on a side stream while
+    the first conv's weight gradient is still being computed), ONE collective over the whole buffer otherwise.  The
+    float64 alpha gradient travels inside the fp32 buffer ("fold into the fp32 buffer, keep the fp64
+    master"): its slot is filled right before the collective and read back right after, on the collective's stream, so
+    no step issues more than two collectives and none of them is 8 bytes long."""
 
     def __init__(self, world, group=None, side_stream=None):
         self.world, self.group, self.side = int(world), group, side_stream
         self.grad_scale = 1.0 / self.world
+        self.collectives = 0          # all-reduces issued so far (tests: <= 2 per step)
 
     def _ar(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.collectives += 1
 
-    def _on_side(self, tensors):
+    def _run(self, fn):
         if self.side is None:
-            for t in tensors:
-                self._ar(t)
+            fn()
             return
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
-            for t in tensors:
-                self._ar(t)
+            fn()
 
-    def reduce_early(self, flat_head, alpha_grad=None):
-        """Everything except the first conv's weight gradient (ready when backward phase 1 has been enqueued)."""
-        self._on_side([flat_head] + ([alpha_grad] if alpha_grad is not None else []))
+    def reduce_early(self, flat_head, alpha_grad=None, alpha_slot=None):
+        """Everything except the first conv's weight gradient (ready when backward phase 1 has been enqueued).
+        alpha_grad: 0-d float64 gradient whose exchange rides in `alpha_slot`, a 1-element view of flat_head."""
+        def fn():
+            if alpha_grad is not None:
+                alpha_slot.copy_(alpha_grad.reshape(1))
+            self._ar(flat_head)
+            if alpha_grad is not None:
+                alpha_grad.copy_(alpha_slot.reshape(alpha_grad.shape))
+        self._run(fn)
 
     def reduce_late(self, flat_tail):
-        self._on_side([flat_tail])
+        self._run(lambda: self._ar(flat_tail))
+
+    def reduce_all(self, flat, alpha_grad=None, alpha_slot=None):
+        """Single-bucket mode (no overlap): one collective over the whole flat gradient."""
+        self.reduce_early(flat, alpha_grad, alpha_slot)
 
     def finish(self):
         """Make the compute stream wait for the reductions before the optimizer kernel."""

@@ -16,6 +16,20 @@ from . import Hang2020 as H
 from .dist import GradSync, kept_anywhere
 
 
+def _round4(n):
+    return (int(n) + 3) & ~3
+
+
+def _aligned_offsets(params):
+    """Element offsets of `params` laid out back to back with every start on a multiple of 4 elements (16 bytes);
+    returns (offsets, total rounded up to 4)."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off = _round4(off + p.numel())
+    return offs, off
+
+
 class FusedTrainer:
     """Owns flat fp32 parameter / gradient / Adam-moment buffers; the model's Parameters become views of the
     flat parameter buffer (state_dict keys and shapes are unchanged).
@@ -26,7 +40,16 @@ class FusedTrainer:
     """
 
     def __init__(self, model, lr, loss_weight=None, betas=(0.9, 0.999), eps=1e-8, process_group=None,
-                 overlap_comm=True, keep_grads=False, last_head_only=False):
+                 overlap_comm=True, keep_grads=False, last_head_only=False, three_head_loss=False,
+                 extra_grad_slots=0, storage=None):
+        """three_head_loss: train on the SUM of the class-weighted cross-entropies of every classifier head (the Hang
+        et al. recipe BASELINE.json's north_star words as "three-head weighted cross-entropy"): three heads for a
+        spectral / spatial network, all six for Hang2020 (whose sigmoid(alpha) blend is then not on the graph, so
+        alpha is left alone, as torch leaves a parameter whose grad is None).  Default False = the reference's own
+        step, which keeps the last head only (Hang2020.py:256-257, src/main.py:78).
+        extra_grad_slots: fp32 slots appended to the first gradient bucket for a caller's own small gradients
+        (MetadataTrainer: the site MLP / fusion layer travel in the same collective).
+        storage: (p, g, m, v) flat fp32 tensors to carve the buffers from (EnsembleTrainer: one buffer for all years)."""
         if not isinstance(model, H._Net):
             raise TypeError("FusedTrainer needs a deeptreeattention_amd network module")
         self.model = model
@@ -40,41 +63,66 @@ class FusedTrainer:
         self.overlap = overlap_comm and self.world > 1
         self.hang = model._net_code == _lib.NET_HANG2020
         self.single_score = model._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
+        self.three_head = bool(three_head_loss)
+        if self.three_head and model._net_code == _lib.NET_VANILLA:
+            raise ValueError("vanilla_CNN has a single head")
         # a spectral/spatial network whose caller keeps only the last head's scores (year ensemble, year.py:30)
-        self.last_head_only = bool(last_head_only) and not self.single_score
+        self.last_head_only = bool(last_head_only) and not self.single_score and not self.three_head
+        self.alpha_on_graph = self.hang and not self.three_head
         plist = model._param_list()
         dev = plist[-1].device
         if dev.type != "cuda":
             raise RuntimeError("FusedTrainer needs the model on a ROCm device (model.cuda()); there is no CPU path")
         self.device = dev
         fp32 = [p for p in plist if p.dtype == torch.float32]
-        # flat layout: [everything except the first conv's weights | first conv's weights] so that the gradient
-        # all-reduce of the first part overlaps with the first conv's weight-gradient kernel (the last to finish)
+        # flat layout: [everything except the first conv's weights | caller's extra slots | alpha's exchange slot |
+        # first conv's weights]: the gradient all-reduce of the first part overlaps with the first conv's
+        # weight-gradient kernel (the last to finish); alpha's float64 gradient crosses the ranks in its fp32 slot
         first = [p for kind, mod, names in model._subnets() for p in [H._get(mod, "conv1.conv_layer.weight")]]
         first_ids = {id(p) for p in first}
-        order = [p for p in fp32 if id(p) not in first_ids] + first
-        n = sum(p.numel() for p in order)
-        self.n = n
-        self.split = n - sum(p.numel() for p in first)
-        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
-        self._grads_clear = True       # flat_g / alpha_g hold zeros (kept so by dta_adam_step_zero_grad)
-        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        rest = [p for p in fp32 if id(p) not in first_ids]
+        # every tensor starts on a 16-byte boundary of the flat buffers (the small GEMMs and the Adam pass use 16-byte
+        # accesses when they can: a classifier weight that starts 4, 8 or 12 bytes off falls back to scalar loads)
+        rest_off, n_rest = _aligned_offsets(rest)
+        first_off, n_first = _aligned_offsets(first)
+        self.extra_off, self.extra_n = n_rest, int(extra_grad_slots)
+        self.split = _round4(n_rest + self.extra_n + (1 if self.hang else 0))
+        self.alpha_slot_off = n_rest + self.extra_n
+        n = self.split + n_first
+        self.n, self.n_first = n, n_first
+        if storage is None:
+            self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+            head = tuple(t[:self.split] for t in (self.flat_p, self.flat_g, self.flat_m, self.flat_v))
+            tail = tuple(t[self.split:] for t in (self.flat_p, self.flat_g, self.flat_m, self.flat_v))
+        else:
+            # two separately placed segments (EnsembleTrainer: all years' first buckets are adjacent, so are their
+            # second buckets): (p, g, m, v) of the head [rest | extra | alpha slot] and of the tail [first-conv weights]
+            head, tail = storage
+            assert all(t.numel() == self.split and t.dtype == torch.float32 and t.is_contiguous() for t in head)
+            assert all(t.numel() == n_first and t.dtype == torch.float32 and t.is_contiguous() for t in tail)
+            self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
+        self.p_head, self.g_head, self.m_head, self.v_head = head
+        self.p_tail, self.g_tail, self.m_tail, self.v_tail = tail
+        self._grads_clear = True       # gradient buffers / alpha_g hold zeros (kept so by dta_adam_step_zero_grad)
         self._gview = {}
-        off = 0
         with torch.no_grad():
-            for p in order:
-                k = p.numel()
-                self.flat_p[off:off + k].copy_(p.reshape(-1))
-                p.data = self.flat_p[off:off + k].view(p.shape)
-                self._gview[id(p)] = self.flat_g[off:off + k].view(p.shape)
-                off += k
+            for group, offs, pbuf, gbuf in ((rest, rest_off, self.p_head, self.g_head),
+                                            (first, first_off, self.p_tail, self.g_tail)):
+                for p, off in zip(group, offs):
+                    k = p.numel()
+                    pbuf[off:off + k].copy_(p.reshape(-1))
+                    p.data = pbuf[off:off + k].view(p.shape)
+                    self._gview[id(p)] = gbuf[off:off + k].view(p.shape)
+        self.extra_g = self.g_head[self.extra_off:self.extra_off + self.extra_n]
         if self.hang:
             self.alpha = model.alpha
             self.alpha_g = torch.zeros((), dtype=torch.float64, device=dev)
             self.alpha_m = torch.zeros((), dtype=torch.float64, device=dev)
             self.alpha_v = torch.zeros((), dtype=torch.float64, device=dev)
+            self.alpha_slot = self.g_head[self.alpha_slot_off:self.alpha_slot_off + 1]
         self.loss_weight = None if loss_weight is None else loss_weight.to(dev, torch.float32).contiguous()
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self._ws = None
@@ -82,13 +130,22 @@ class FusedTrainer:
         self._desc_key = None
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self.sync = GradSync(self.world, self.pg, self._side)
-        if self.world > 1:
+        if self.world > 1 and storage is None:
             self.broadcast_parameters()
+
+    @staticmethod
+    def bucket_sizes(model, extra_grad_slots=0):
+        """(head, tail) element counts of the two gradient buckets a FusedTrainer for `model` uses (see `storage`)."""
+        first = [H._get(mod, "conv1.conv_layer.weight") for kind, mod, names in model._subnets()]
+        ids = {id(p) for p in first}
+        rest = [p for p in model._param_list() if p.dtype == torch.float32 and id(p) not in ids]
+        n_rest, n_first = _aligned_offsets(rest)[1], _aligned_offsets(first)[1]
+        return _round4(n_rest + int(extra_grad_slots) + (1 if model._net_code == _lib.NET_HANG2020 else 0)), n_first
 
     # ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src=0):
         """DDP start-up semantics: every rank starts from rank `src`'s parameters and buffers."""
-        self.sync.broadcast([self.flat_p] + ([self.alpha.data] if self.hang else []) + list(self.model.buffers()), src)
+        self.sync.broadcast([self.p_head, self.p_tail] + ([self.alpha.data] if self.hang else []) + list(self.model.buffers()), src)
 
     def grad_of(self, param):
         """Gradient view (inside the flat gradient buffer) of one of the model's fp32 parameters.  After train_step
@@ -105,7 +162,7 @@ class FusedTrainer:
             tensors = {n: H._get(mod, n) for n in names}
             gt = {}
             for n in names:
-                if (self.hang or self.last_head_only) and ("classifier1" in n or "classifier2" in n):
+                if ((self.hang and not self.three_head) or self.last_head_only) and ("classifier1" in n or "classifier2" in n):
                     continue   # only the last heads reach the loss (reference Hang2020.py:256-257, year.py:30)
                 gt[n] = self._gview[id(tensors[n])]
             for Lv in (1, 2, 3):
@@ -123,9 +180,9 @@ class FusedTrainer:
         m = self.model
         key = (B, bands, Hh, Ww, m.precision, m.training)
         if key != self._desc_key:
+            all_heads = self.three_head or not (self.single_score or self.last_head_only)
             self.desc = _lib.NetDesc(B, bands, Hh, Ww, m._classes, m._net_code, _lib.dtype_code(m.precision),
-                                     1 if m.training else 0, 4 if (self.single_score or self.last_head_only) else 7,
-                                     H.BN_MOMENTUM, H.BN_EPS)
+                                     1 if m.training else 0, 7 if all_heads else 4, H.BN_MOMENTUM, H.BN_EPS)
             self.nets, self.grads = self._structs()
             self._desc_key = key
         return key
@@ -143,25 +200,56 @@ class FusedTrainer:
             self.logits = torch.empty(B, m._classes, dtype=torch.float32, device=self.device)
             self.dlogits = torch.empty_like(self.logits)
             self.ce_scratch = torch.empty(B + 1, dtype=torch.float32, device=self.device)
+            if self.three_head:      # per-head scores / score gradients / losses: [net][head]
+                nn_ = 2 if self.hang else 1
+                self.head_scores = torch.empty(nn_, 3, B, m._classes, dtype=torch.float32, device=self.device)
+                self.head_dscores = torch.empty_like(self.head_scores)
+                self.head_losses = torch.zeros(nn_ * 3, dtype=torch.float32, device=self.device)
             self._ws_key = key
 
     def _forward_scores(self, x):
-        """Enqueue the network forward; the (B, classes) scores the loss consumes land in self.logits."""
+        """Enqueue the network forward; the (B, classes) scores the loss consumes land in self.logits (three-head
+        mode: every head's scores in self.head_scores[net][head]; self.logits holds Hang2020's blended scores or the
+        last head)."""
         L = _lib.lib()
         x = H._check_input(x)
         self._prepare(x)
         table = _lib.ScoreTable()
         joint = _lib.ptr(self.logits)
-        if not self.single_score:
+        if self.three_head:
+            for g in range(self.head_scores.shape[0]):
+                for hd in range(3):
+                    table[g][hd] = self.head_scores[g, hd].data_ptr()
+            if not self.hang:
+                joint = None
+        elif not self.single_score:
             if not self.last_head_only:
-                raise RuntimeError("the fused step needs a single-score model (Hang2020, vanilla_CNN) or a "
-                                   "spectral/spatial network built with last_head_only=True")
+                raise RuntimeError("the fused step needs a single-score model (Hang2020, vanilla_CNN), a spectral/"
+                                   "spatial network built with last_head_only=True, or three_head_loss=True")
             table[0][2] = self.logits.data_ptr()
             joint = None
         _lib.check(L.dta_net_forward(C.byref(self.desc), self.nets, _lib.ptr(self.alpha) if self.hang else None,
                                      _lib.ptr(x), _lib.ptr(self._ws), C.byref(table), joint,
                                      _lib.current_stream_ptr()), "dta_net_forward")
+        if self.three_head and not self.hang:
+            self.logits = self.head_scores[0, 2]
         return self.logits
+
+    def _loss_heads(self, y, want_grad):
+        """Sum over all heads of the class-weighted cross-entropy; d(loss)/d(head scores) in self.head_dscores."""
+        L = _lib.lib()
+        st = _lib.current_stream_ptr()
+        hs = self.head_scores
+        k = 0
+        for g in range(hs.shape[0]):
+            for hd in range(3):
+                _lib.check(L.dta_weighted_ce(_lib.ptr(hs[g, hd]), _lib.ptr(y), _lib.ptr(self.loss_weight), hs.shape[2],
+                                             hs.shape[3], C.c_void_p(self.head_losses.data_ptr() + 4 * k),
+                                             _lib.ptr(self.head_dscores[g, hd]) if want_grad else None,
+                                             _lib.ptr(self.ce_scratch), st), "dta_weighted_ce")
+                k += 1
+        torch.sum(self.head_losses, dim=0, out=self.loss)
+        return self.loss
 
     def _loss(self, logits, y, want_grad):
         L = _lib.lib()
@@ -173,36 +261,56 @@ class FusedTrainer:
 
     def _backward(self, dlogits):
         """Enqueue the backward of the last forward from d(loss)/d(scores); gradients land in the flat buffer
-        (summed over ranks when data-parallel)."""
+        (summed over ranks when data-parallel).  Three-head mode: dlogits is ignored, self.head_dscores is used."""
         L = _lib.lib()
         st = _lib.current_stream_ptr()
         d = C.byref(self.desc)
         alpha = _lib.ptr(self.alpha) if self.hang else None
-        dalpha = _lib.ptr(self.alpha_g) if self.hang else None
+        dalpha = _lib.ptr(self.alpha_g) if self.alpha_on_graph else None
         table = _lib.ScoreTable()
         djoint = _lib.ptr(dlogits)
-        if not self.single_score:
+        if self.three_head:
+            for g in range(self.head_dscores.shape[0]):
+                for hd in range(3):
+                    table[g][hd] = self.head_dscores[g, hd].data_ptr()
+            djoint = None
+        elif not self.single_score:
             table[0][2] = dlogits.data_ptr()
             djoint = None
         self._zero_grads()             # C-ABI contract: gradient buffers (and dalpha) arrive zero-filled
+
+        def run(phases):
+            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table), djoint, self.grads,
+                                          dalpha, phases, st), "dta_net_backward")
+        ag, slot = (self.alpha_g, self.alpha_slot) if self.alpha_on_graph else (None, None)
         if self.world == 1:
-            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table), djoint, self.grads,
-                                          dalpha, 3, st), "dta_net_backward")
+            run(3)
+        elif self.overlap:
+            # phase 1: everything but the first conv's weight gradient; its all-reduce (side stream) runs while
+            # phase 2, the first conv's weight gradient, is computed: two collectives per step
+            run(1)
+            self.sync.reduce_early(self.g_head, ag, slot)
+            run(2)
+            self.sync.reduce_late(self.g_tail)
+            self.sync.finish()
+        elif self.flat_g is not None:
+            run(3)                     # no overlap: ONE collective over the whole flat gradient
+            self.sync.reduce_all(self.flat_g, ag, slot)
+            self.sync.finish()
         else:
-            # phase 1: everything but the first conv's weight gradient; its all-reduce (side stream when overlap is
-            # on) runs while phase 2, the first conv's weight gradient, is computed
-            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table), djoint, self.grads,
-                                          dalpha, 1, st), "dta_net_backward")
-            self.sync.reduce_early(self.flat_g[:self.split], self.alpha_g if self.hang else None)
-            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table), djoint, self.grads,
-                                          dalpha, 2, st), "dta_net_backward")
-            self.sync.reduce_late(self.flat_g[self.split:])
+            run(3)
+            self.sync.reduce_early(self.g_head, ag, slot)
+            self.sync.reduce_late(self.g_tail)
             self.sync.finish()
         self._grads_clear = False
 
     def _zero_grads(self):
         if not self._grads_clear:
-            self.flat_g.zero_()
+            if self.flat_g is not None:
+                self.flat_g.zero_()
+            else:
+                self.g_head.zero_()
+                self.g_tail.zero_()
             if self.hang:
                 self.alpha_g.zero_()
             self._grads_clear = True
@@ -212,14 +320,23 @@ class FusedTrainer:
         self.step_count += 1
         # default: step + zero_grad in one pass, so the next backward finds its gradient buffers already cleared
         adam = L.dta_adam_step if self.keep_grads else L.dta_adam_step_zero_grad
-        _lib.check(adam(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v),
-                        self.n,
-                        _lib.ptr(self.alpha) if self.hang else None,
-                        _lib.ptr(self.alpha_g) if self.hang else None,
-                        _lib.ptr(self.alpha_m) if self.hang else None,
-                        _lib.ptr(self.alpha_v) if self.hang else None,
-                        self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
-                        self.sync.grad_scale, _lib.current_stream_ptr()), "dta_adam_step")
+        al = self.alpha_on_graph
+        if self.flat_p is not None:
+            segs = [(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.n)]
+        elif all(h.data_ptr() + 4 * self.split == t.data_ptr() for h, t in
+                 ((self.p_head, self.p_tail), (self.g_head, self.g_tail), (self.m_head, self.m_tail),
+                  (self.v_head, self.v_tail))):
+            segs = [(self.p_head, self.g_head, self.m_head, self.v_head, self.n)]   # adjacent segments: one pass
+        else:
+            segs = [(self.p_head, self.g_head, self.m_head, self.v_head, self.split),
+                    (self.p_tail, self.g_tail, self.m_tail, self.v_tail, self.n_first)]
+        for i, (p, g, m, v, n) in enumerate(segs):
+            a = al and i == 0
+            _lib.check(adam(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n,
+                            _lib.ptr(self.alpha) if a else None, _lib.ptr(self.alpha_g) if a else None,
+                            _lib.ptr(self.alpha_m) if a else None, _lib.ptr(self.alpha_v) if a else None,
+                            self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                            self.sync.grad_scale, _lib.current_stream_ptr()), "dta_adam_step")
         self._grads_clear = not self.keep_grads
 
     def _labels(self, y):
@@ -229,16 +346,21 @@ class FusedTrainer:
 
     def train_step(self, x, y):
         """One optimisation step on the batch (x: float32 NCHW on the device, y: int64 labels).  Returns the loss
-        as a 0-d device tensor (no host sync)."""
-        if not self.single_score:
-            raise RuntimeError("train_step supports Hang2020 and vanilla_CNN (single-score models); a year ensemble "
-                               "of spectral networks trains through EnsembleTrainer")
+        as a fresh 0-d device tensor (no host sync; safe to collect across steps, as Lightning does)."""
+        if not (self.single_score or self.three_head or self.last_head_only):
+            raise RuntimeError("train_step supports Hang2020 / vanilla_CNN (single score), any network with "
+                               "three_head_loss=True, or a spectral/spatial network with last_head_only=True; a year "
+                               "ensemble of spectral networks trains through EnsembleTrainer")
         y = self._labels(y)
         logits = self._forward_scores(x)
-        self._loss(logits, y, True)
-        self._backward(self.dlogits)
+        if self.three_head:
+            self._loss_heads(y, True)
+            self._backward(None)
+        else:
+            self._loss(logits, y, True)
+            self._backward(self.dlogits)
         self._adam()
-        return self.loss
+        return self.loss.clone()
 
     def training_step(self, batch, batch_idx=0):
         """The reference's TreeModel.training_step unpacking (src/main.py:71-80): batch = (individual, inputs, y),
@@ -252,9 +374,10 @@ class FusedTrainer:
         return self.forward_loss(inputs["HSI"], y)[1]
 
     def forward_loss(self, x, y):
-        """Forward + loss only (validation_step, reference src/main.py:82-94); returns (logits, loss)."""
+        """Forward + loss only (validation_step, reference src/main.py:82-94); returns fresh (logits, loss) tensors."""
         logits = self._forward_scores(x)
-        return logits, self._loss(logits, self._labels(y), False)
+        loss = self._loss_heads(self._labels(y), False) if self.three_head else self._loss(logits, self._labels(y), False)
+        return logits.clone(), loss.clone()
 
 
 class EnsembleTrainer:
@@ -262,16 +385,21 @@ class EnsembleTrainer:
     drives one level of it (src/models/multi_stage.py:277-288 training_step, :258-275 one Adam per level):
     scores = mean over the kept years of each year's last-head scores, loss = weighted CE, backward, Adam.
 
-    Every year's spectral_network owns flat parameter / gradient / moment buffers (a FusedTrainer restricted to the
-    last head).  A year whose whole batch tensor sums to zero is skipped exactly as the reference skips it: no
-    forward (BatchNorm running statistics and num_batches_tracked untouched), no gradient, and -- since torch's Adam
-    passes over parameters whose grad is None -- no moment decay and no step-count advance for that year.  The
-    zero-year test costs ONE host transfer per step (the reference: one blocking comparison per year); callers that
-    know which years are present (the reference's dataset zero-fills missing years, src/data.py) pass `present`
-    and the step enqueues without any host synchronisation.
+    All years share ONE set of flat parameter / gradient / moment buffers laid out
+    [year 0..Y-1 first buckets | Y year flags | year 0..Y-1 first-conv weights]; each year's spectral_network is a
+    FusedTrainer (restricted to the last head) on its two segments.  A year whose whole batch tensor sums to zero is
+    skipped exactly as the reference skips it: no forward (BatchNorm running statistics and num_batches_tracked
+    untouched), no gradient, and -- since torch's Adam passes over parameters whose grad is None -- no moment decay
+    and no step-count advance for that year.  The zero-year test costs ONE host transfer per step (the reference: one
+    blocking comparison per year); callers that know which years are present (the reference's dataset zero-fills
+    missing years, src/data.py) pass `present` and the step enqueues without any host synchronisation.
 
-    Data-parallel: a year is stepped when any rank kept it; ranks that skipped it contribute zero gradients to the
-    same all-reduces (what DDP does for unused parameters)."""
+    Data-parallel: a year is stepped when ANY rank kept it; ranks that skipped it contribute the zeros their gradient
+    segment holds.  Which years were kept anywhere is decided ON THE DEVICE: every rank writes its 0/1 year flags into
+    the flag slots of the gradient buffer, the SUM all-reduce of the first bucket carries them along, and the
+    optimizer launches are gated by the reduced flags and a device-side step counter (`dta_adam_step_gated`) -- no
+    extra collective and no host round trip.  Two collectives per step when overlapping (the first runs beside the
+    years' first-conv weight gradients), one otherwise."""
 
     def __init__(self, model, lr, loss_weight=None, betas=(0.9, 0.999), eps=1e-8, process_group=None,
                  overlap_comm=True, keep_grads=False):
@@ -279,15 +407,54 @@ class EnsembleTrainer:
         if not isinstance(model, learned_ensemble):
             raise TypeError("EnsembleTrainer needs a deeptreeattention_amd.year.learned_ensemble")
         self.model = model
-        self.years = [FusedTrainer(m, lr, loss_weight, betas, eps, process_group, overlap_comm, keep_grads,
-                                   last_head_only=True) for m in model.year_models]
+        mods = list(model.year_models)
+        Y = len(mods)
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("EnsembleTrainer needs the model on a ROCm device (model.cuda()); there is no CPU path")
+        sizes = [FusedTrainer.bucket_sizes(m) for m in mods]
+        n_head, n_tail = sum(h for h, _ in sizes), sum(t for _, t in sizes)
+        world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            world = torch.distributed.get_world_size(process_group)
+        self.flat = [torch.zeros(_round4(n_head + Y) + n_tail, dtype=torch.float32, device=dev) for _ in range(4)]   # p g m v
+        self.years = []
+        if world == 1:
+            # no exchange: each year's two segments adjacent, so its optimizer pass is one launch; flags unused
+            off = 0
+            for m, (h, t) in zip(mods, sizes):
+                storage = (tuple(b[off:off + h] for b in self.flat), tuple(b[off + h:off + h + t] for b in self.flat))
+                self.years.append(FusedTrainer(m, lr, loss_weight, betas, eps, None, overlap_comm, keep_grads,
+                                               last_head_only=True, storage=storage))
+                off += h + t
+            self.g_head = self.g_tail = self.flags = None
+        else:
+            self.n_head = _round4(n_head + Y)          # first bucket: all years' first segments + the year flags
+            self.g_head, self.g_tail = self.flat[1][:self.n_head], self.flat[1][self.n_head:]
+            self.flags = self.g_head[n_head:n_head + Y]  # this rank's 0/1 flags -> after the reduce: ranks that kept it
+            ho, to = 0, self.n_head
+            for m, (h, t) in zip(mods, sizes):
+                storage = (tuple(b[ho:ho + h] for b in self.flat), tuple(b[to:to + t] for b in self.flat))
+                self.years.append(FusedTrainer(m, lr, loss_weight, betas, eps, process_group, overlap_comm, keep_grads,
+                                               last_head_only=True, storage=storage))
+                ho += h
+                to += t
         first = self.years[0]
         self.device, self.world, self.pg = first.device, first.world, first.pg
+        self.overlap, self.keep_grads = first.overlap, bool(keep_grads)
+        self.betas, self.eps = betas, float(eps)
+        self.sync = first.sync
         self.loss_weight = first.loss_weight
         self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self._shape = None
         self._ws = None
         self._ws_key = None
+        if self.world > 1:
+            self.sync.broadcast([self.flat[0]] + list(model.buffers()), 0)
+            self.dev_steps = torch.zeros(Y, dtype=torch.int32, device=dev)     # per-year optimizer step counts
+            # the 2^Y possible flag vectors, resident on the device: setting the flags is a device-to-device copy
+            self._flag_table = torch.tensor([[(mask >> i) & 1 for i in range(Y)] for mask in range(1 << Y)],
+                                            dtype=torch.float32, device=dev)
 
     @property
     def lr(self):
@@ -297,6 +464,12 @@ class EnsembleTrainer:
     def lr(self, value):       # ReduceLROnPlateau-style schedulers set one rate per level
         for t in self.years:
             t.lr = float(value)
+
+    def step_counts(self):
+        """Optimizer steps taken per year (data-parallel: read back from the device counters, one host sync)."""
+        if self.world > 1:
+            return [int(v) for v in self.dev_steps.tolist()]
+        return [t.step_count for t in self.years]
 
     def grad_of(self, param):
         for t in self.years:
@@ -311,12 +484,9 @@ class EnsembleTrainer:
             # reference year.py:27 (`x.sum() == 0`), all years in one host transfer
             present = (torch.stack([x.sum() for x in images]) != 0).tolist()
         local = [bool(k) for k in present]
-        if not any(local):
+        if not any(local) and self.world == 1:
             raise RuntimeError("every year of the batch is all-zero: the reference has nothing to average (year.py:33)")
-        anywhere = local
-        if self.world > 1:
-            anywhere = kept_anywhere(local, self.pg, self.device)
-        return local, anywhere
+        return local
 
     def _buffers(self, B, classes):
         if self._shape != (B, classes):
@@ -329,6 +499,8 @@ class EnsembleTrainer:
         """All kept years as the groups of one set of launches (dta_ensemble_forward); self.scores = their mean."""
         L = _lib.lib()
         kept = [i for i, k in enumerate(local) if k]
+        if not kept:
+            raise RuntimeError("every year of this rank's batch is all-zero: nothing to average (reference year.py:33)")
         if len(kept) > _lib.MAX_YEARS:
             raise RuntimeError("at most {} years per grouped launch".format(_lib.MAX_YEARS))
         xs = [H._check_input(images[i]) for i in kept]
@@ -354,13 +526,14 @@ class EnsembleTrainer:
         self._live = xs     # inputs stay referenced until the step's launches are enqueued
         return kept
 
-    def _backward(self, kept):
+    def _backward(self, kept, phases=3):
         L = _lib.lib()
-        for i in kept:
-            self.years[i]._zero_grads()          # C-ABI contract: gradient buffers arrive zero-filled
-        _lib.check(L.dta_ensemble_backward(C.byref(self._desc), len(kept), self._nets, _lib.ptr(self._ws),
-                                           _lib.ptr(self.dscores), self._grads, _lib.current_stream_ptr()),
-                   "dta_ensemble_backward")
+        if phases & 1:
+            for i in kept:
+                self.years[i]._zero_grads()      # C-ABI contract: gradient buffers arrive zero-filled
+        _lib.check(L.dta_ensemble_backward_phased(C.byref(self._desc), len(kept), self._nets, _lib.ptr(self._ws),
+                                                  _lib.ptr(self.dscores), self._grads, phases,
+                                                  _lib.current_stream_ptr()), "dta_ensemble_backward")
         for i in kept:
             self.years[i]._grads_clear = False
 
@@ -371,38 +544,57 @@ class EnsembleTrainer:
                                      _lib.ptr(self.dscores) if want_grad else None, _lib.ptr(self.ce_scratch),
                                      _lib.current_stream_ptr()), "dta_weighted_ce")
 
+    def _adam_gated(self):
+        """One gated optimizer pass per year and bucket, driven by the reduced flags / device step counters."""
+        L = _lib.lib()
+        st = _lib.current_stream_ptr()
+        for i, t in enumerate(self.years):
+            active = C.c_void_p(self.flags.data_ptr() + 4 * i)
+            step = C.c_void_p(self.dev_steps.data_ptr() + 4 * i)
+            for p, g, m, v, n in ((t.p_head, t.g_head, t.m_head, t.v_head, t.split),
+                                  (t.p_tail, t.g_tail, t.m_tail, t.v_tail, t.n_first)):
+                _lib.check(L.dta_adam_step_gated(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, active, step,
+                                                 t.lr, self.betas[0], self.betas[1], self.eps, self.sync.grad_scale,
+                                                 st), "dta_adam_step_gated")
+            t._grads_clear = True
+
     def train_step(self, images, y, present=None):
         """images: list of (B, bands, H, W) float32 device tensors, one per year; y: int64 labels.  Returns the loss
-        as a 0-d device tensor."""
-        local, anywhere = self._kept(images, present)
+        as a fresh 0-d device tensor."""
+        local = self._kept(images, present)
         y = self.years[0]._labels(y)
         kept = self._forward(images, local)
         self._ce(y, True)
         self.dscores.mul_(1.0 / len(kept))      # d(mean over kept years)/d(year score)
-        self._backward(kept)
-        # gradient exchange in YEAR ORDER on every rank (the ranks may have kept different years, and collectives pair
-        # up by issue order): a year kept anywhere is reduced by all ranks, those that skipped it send zeros
-        for i, t in enumerate(self.years):
-            if not anywhere[i]:
-                t._zero_grads()                 # skipped everywhere: grad None in the reference
-            elif self.world > 1:
-                if not local[i]:
-                    t._zero_grads()
-                t.sync.reduce_early(t.flat_g[:t.split])
-                t.sync.reduce_late(t.flat_g[t.split:])
-                t.sync.finish()
-                t._grads_clear = False
-        for i, t in enumerate(self.years):
-            if anywhere[i]:
-                t._adam()
-        return self.loss
+        if self.world == 1:
+            self._backward(kept)
+            for i, t in enumerate(self.years):
+                if local[i]:
+                    t._adam()
+            return self.loss.clone()
+        # data-parallel: every rank issues the same collectives whatever it kept; skipped years send their zeros
+        mask = sum(1 << i for i, k in enumerate(local) if k)
+        if self.overlap:
+            self._backward(kept, 1)
+            self.flags.copy_(self._flag_table[mask])
+            self.sync.reduce_early(self.g_head)
+            self._backward(kept, 2)
+            self.sync.reduce_late(self.g_tail)
+        else:
+            self._backward(kept, 3)
+            self.flags.copy_(self._flag_table[mask])
+            self.sync.reduce_all(self.flat[1])
+        self.sync.finish()
+        self.dev_steps.add_((self.flags > 0).to(torch.int32))
+        self._adam_gated()
+        return self.loss.clone()
 
     def forward_loss(self, images, y, present=None):
         """validation_step of the level (multi_stage.py:290-304): ensemble scores + weighted CE, no update."""
-        local, _ = self._kept(images, present)
+        local = self._kept(images, present)
         self._forward(images, local)
         self._ce(self.years[0]._labels(y), False)
-        return self.scores, self.loss
+        return self.scores.clone(), self.loss.clone()
 
 
 class MultiStageTrainer:
@@ -439,7 +631,9 @@ class MetadataTrainer:
     MetadataModel.training_step defines (:52-63: unweighted F.cross_entropy(model(images, site), y)) with Adam.
     The HSI branch (Hang2020, >99.9 % of the work) runs through the fused C-ABI pieces on flat buffers; the 16-wide
     site MLP and the 2*classes -> classes fusion layer (<0.2 MFLOP per sample) stay a small torch
-    autograd graph with their own torch Adam, joined to the HSI branch at its (B, classes) scores."""
+    autograd graph with their own torch Adam, joined to the HSI branch at its (B, classes) scores.  Data-parallel: the
+    small parameters' gradients travel in spare slots of the HSI branch's first gradient bucket, so the whole model
+    still exchanges gradients in at most two collectives per step."""
 
     def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, process_group=None, overlap_comm=True,
                  keep_grads=False):
@@ -447,13 +641,25 @@ class MetadataTrainer:
         if not isinstance(model, metadata_sensor_fusion):
             raise TypeError("MetadataTrainer needs a deeptreeattention_amd.metadata.metadata_sensor_fusion")
         self.model = model
-        self.sensor = FusedTrainer(model.sensor_model, lr, None, betas, eps, process_group, overlap_comm, keep_grads)
         self.small = list(model.metadata_model.parameters()) + list(model.fc1.parameters())
+        self.small_sizes = [p.numel() for p in self.small]
+        self.sensor = FusedTrainer(model.sensor_model, lr, None, betas, eps, process_group, overlap_comm, keep_grads,
+                                   extra_grad_slots=sum(self.small_sizes))
         self.opt = torch.optim.Adam(self.small, lr=lr, betas=betas, eps=eps)
         self.world, self.pg = self.sensor.world, self.sensor.pg
         if self.world > 1:
             for t in self.small + list(model.metadata_model.buffers()):
                 torch.distributed.broadcast(t.data, 0, group=self.pg)
+
+    @property
+    def lr(self):
+        return self.sensor.lr
+
+    @lr.setter
+    def lr(self, value):
+        self.sensor.lr = float(value)
+        for gr in self.opt.param_groups:
+            gr["lr"] = float(value)
 
     def _head(self, scores, site):
         meta = self.model.metadata_model(site)
@@ -466,12 +672,17 @@ class MetadataTrainer:
         self.opt.zero_grad(set_to_none=True)
         loss = torch.nn.functional.cross_entropy(self._head(scores, site), y)
         loss.backward()                                   # the small graph: MLP / fusion grads and d(loss)/d(scores)
-        self.sensor._backward(scores.grad.contiguous())
-        self.sensor._adam()
         if self.world > 1:
-            for p in self.small:
-                torch.distributed.all_reduce(p.grad, group=self.pg)
-                p.grad.mul_(1.0 / self.world)
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.small]
+            self.sensor._zero_grads()
+            torch.cat([g.reshape(-1) for g in grads], out=self.sensor.extra_g)     # ride in the first bucket
+        self.sensor._backward(scores.grad.contiguous())
+        if self.world > 1:
+            chunks = self.sensor.extra_g.split(self.small_sizes)
+            for p, g, c in zip(self.small, grads, chunks):
+                p.grad = g
+                g.copy_(c.view_as(g)).mul_(1.0 / self.world)
+        self.sensor._adam()                               # also clears the spare slots
         self.opt.step()
         return loss.detach()
 
@@ -500,20 +711,46 @@ class Predictor:
     (in-place updates, e.g. by FusedTrainer or load_state_dict, need nothing)."""
 
     def __init__(self, model):
+        import weakref
         from .year import learned_ensemble
-        self.model = model
+        self._model_ref = weakref.ref(model)        # no strong reference: the cache must not keep the model alive
         self.ensemble = isinstance(model, learned_ensemble)
         nets = list(model.year_models) if self.ensemble else [model]
         if not all(isinstance(n, H._Net) for n in nets):
             raise TypeError("Predictor needs a deeptreeattention_amd network or learned_ensemble")
-        self.nets_mod = nets
         self.device = next(model.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("Predictor needs the model on a ROCm device (model.cuda()); there is no CPU path")
         self._key = None
+        self._tensors = None
+
+    @property
+    def model(self):
+        return self._model_ref()
+
+    @property
+    def nets_mod(self):
+        m = self.model
+        return list(m.year_models) if self.ensemble else [m]
 
     def refresh(self):
         self._key = None
+        self._tensors = None
+
+    def _fingerprint(self):
+        """Storage addresses of every parameter and BatchNorm buffer the pointer tables were built from.  The tables
+        hold raw device pointers, so anything that re-homes a tensor (FusedTrainer moving the parameters into its flat
+        buffer, model.to(), load_state_dict(assign=True)) must rebuild them: ~8 us of data_ptr() calls per batch buy
+        that.  The tensor objects themselves are re-collected when a load_state_dict ran (it may replace Parameter
+        objects; see _Net._dta_epoch)."""
+        nets = self.nets_mod
+        epoch = tuple(n.__dict__.get("_dta_epoch", 0) for n in nets)
+        if self._tensors is None or self._tensors[0] != epoch:
+            ts = []
+            for n in nets:
+                ts += list(n.parameters()) + list(n.buffers())
+            self._tensors = (epoch, ts)
+        return (epoch,) + tuple(t.data_ptr() for t in self._tensors[1])
 
     def _tables(self, mods):
         out = []
@@ -533,15 +770,16 @@ class Predictor:
 
     def _prepare(self, shape, kept):
         L = _lib.lib()
-        m0 = self.nets_mod[0]
-        key = (tuple(shape), m0.precision, tuple(kept))
+        nets_mod = self.nets_mod
+        m0 = nets_mod[0]
+        key = (tuple(shape), m0.precision, tuple(kept), self._fingerprint())
         if key == self._key:
             return
         B, bands, Hh, Ww = shape
         single = m0._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
         self.desc = _lib.NetDesc(B, bands, Hh, Ww, m0._classes, m0._net_code, _lib.dtype_code(m0.precision), 0,
                                  4 | _lib.FORWARD_ONLY, H.BN_MOMENTUM, H.BN_EPS)
-        tables = self._tables([self.nets_mod[i] for i in kept])
+        tables = self._tables([nets_mod[i] for i in kept])
         if self.ensemble:
             self.nets = (_lib.SubnetParams * len(kept))(*[t[0] for t in tables])
             nbytes = L.dta_ensemble_workspace_bytes(C.byref(self.desc), len(kept))
@@ -598,13 +836,21 @@ class Predictor:
         return (self.probs if return_probs else None), self.top_idx, self.top_score
 
 
+_PREDICTORS = None      # model -> Predictor, weakly keyed: nothing is stored on the module (deepcopy / torch.save stay clean)
+
+
 def predict(model, images, return_probs=True):
     """Inference step of the reference (`MultiStage.predict_step` / `TreeModel.predict_dataloader`): eval-mode forward
     (whatever the module's current train/eval flag), softmax over classes and the top-2 labels/scores, all on the
-    device, through a Predictor cached on the module.  Returns (probs or None, top_idx [B,2] int64, top_score [B,2]
-    float32); the tensors are reused by the next call on the same module."""
-    pr = model.__dict__.get("_dta_predictor")
+    device, through a Predictor cached per module (weakly; its pointer tables follow the parameters wherever a trainer
+    or `.to()` moves them).  Returns (probs or None, top_idx [B,2] int64, top_score [B,2] float32); the tensors are
+    reused by the next call on the same module."""
+    global _PREDICTORS
+    if _PREDICTORS is None:
+        import weakref
+        _PREDICTORS = weakref.WeakKeyDictionary()
+    pr = _PREDICTORS.get(model)
     if pr is None:
         pr = Predictor(model)
-        model.__dict__["_dta_predictor"] = pr
+        _PREDICTORS[model] = pr
     return pr(images, return_probs)

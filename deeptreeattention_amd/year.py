@@ -21,6 +21,9 @@ class _EnsembleFn(torch.autograd.Function):
         L = _lib.lib()
         n = len(kept)
         xs, params = args[:n], args[n:]
+        if any(x.requires_grad for x in xs):
+            raise RuntimeError("the year ensemble does not produce a gradient for its input crops: pass detached tensors")
+        ctx.set_materialize_grads(False)
         nets_mod = [owner.year_models[i] for i in kept]
         names = Hang2020._subnet_param_names("spectral")
         B, bands, H, W = xs[0].shape
@@ -53,6 +56,8 @@ class _EnsembleFn(torch.autograd.Function):
         L = _lib.lib()
         ws, *params = ctx.saved_tensors
         n, names = ctx.n, ctx.names
+        if gout is None:
+            return (None, None) + (None,) * n + (None,) * len(params)
         dscore = (gout.contiguous().float() / n).contiguous()      # d(mean over years)/d(one year's scores)
         wanted = [i for i in range(len(params)) if "classifier1" not in names[i % len(names)]
                   and "classifier2" not in names[i % len(names)]]  # heads 1-2 never reach the loss: grad None

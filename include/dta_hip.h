@@ -108,6 +108,10 @@ int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_para
  * classifier1/2 gradients are not produced (those heads never reach the loss). */
 int dta_ensemble_backward(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
                           const float* dscore, const dta_subnet_grads* grads, void* stream);
+/* Same with the `phases` split of dta_net_backward (bit 0: everything but the years' first-conv weight gradients,
+ * bit 1: those), so that a data-parallel caller can overlap the first gradient exchange with them. */
+int dta_ensemble_backward_phased(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
+                                 const float* dscore, const dta_subnet_grads* grads, int phases, void* stream);
 
 /* ---- Crop preprocessing on the device: replaces load_image / preprocess_image (src/utils.py:36-79: drop the first and
  * last `clip` bands when there are more than 3, float32, per-pixel min-max over the bands as
@@ -154,6 +158,14 @@ int dta_adam_step_zero_grad(float* p, float* g, float* m, float* v, size_t n, do
                             double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
                             float grad_scale, void* stream);
 
+/* optimizer.step() + zero_grad() gated ON THE DEVICE (year ensembles under data parallelism, where whether a year is
+ * stepped -- "some rank kept it", src/models/year.py:27 -- is only known on the device after the gradient exchange):
+ * active[0] > 0: Adam step with bias corrections taken from the device counter dev_step[0] (1-based, already advanced
+ * by the caller for this step); otherwise nothing but the gradient clear happens (no moment decay, as torch's Adam
+ * passes over parameters whose grad is None).  No float64 alpha here (spectral networks have none). */
+int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const float* active, const int* dev_step,
+                        float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
 /* ---- stand-alone building blocks (same kernels as the network-level path) ------------------------------------ */
 
 typedef struct dta_conv_module_desc {
@@ -197,14 +209,16 @@ int dta_linear_forward(const float* x, const float* w, const float* b, int batch
 int dta_linear_backward(const float* x, const float* w, const float* dout, int batch, int in_features, int out_features,
                         float* dx, float* gw, float* gb, void* stream);
 
-/* Measurement aid (host-side state only): record a HIP-event pair around every launch of one kernel site, on the
- * stream the kernel is launched on.  site = DTA_SITE_* + layer (0..2); -1 disables.  dta_profile_collect waits
- * for the recorded events, writes up to `max` durations in milliseconds (HOST pointer) and returns the count. */
+/* Measurement aid (host-side state only): record a HIP-event pair around every launch of a kernel site, on the
+ * stream the kernel is launched on.  site = DTA_SITE_* + layer (0..2); each call adds a site (up to four are timed at
+ * once), -1 stops and forgets them all.  dta_profile_collect_site waits for the recorded events of one site, writes up
+ * to `max` durations in milliseconds (HOST pointer) and returns the count; dta_profile_collect = the first site. */
 enum { DTA_SITE_CONV_FWD = 0, DTA_SITE_CONV_WGRAD = 3, DTA_SITE_CONV_DGRAD = 6, DTA_SITE_STAGE_FWD = 9,
        DTA_SITE_STAGE_BWD = 12,
        DTA_SITE_GEMM = 15 /* +0 classifier heads forward, +1 head input gradients, +2 parameter-gradient group */ };
 int dta_profile_enable(int site);
 int dta_profile_collect(float* ms, int max);
+int dta_profile_collect_site(int site, float* ms, int max);
 /* Development aid: the library reads its developer environment switches (DTA_NO_FUSED_INPUT, DTA_NO_TAIL_MERGE,
  * DTA_BN_INKERNEL: same-box A/B runs of alternative launch plans) once at load time; this re-reads them. */
 int dta_dev_reload_switches(void);

@@ -44,3 +44,32 @@ def test_bench_prints_one_conforming_json_line():
     assert len(lines) == 1
     d = _check(lines[0], False)
     assert d["steps"] == 4 and d["warmup"] == 2 and d["n_gpus"] == 1
+    # both first-conv kernels timed in the same run, the whole step priced, a >= 200-step median beside the K steps
+    m = d["roofline_mfma"]
+    assert ROOF <= set(m) and m["bound"] == "mfma" and m["launches"] == 4 and d["roofline"]["launches"] == 4
+    sr = d["step_roofline"]
+    assert abs(sr["frac"] - sr["achieved"] / sr["peak"]) < 1e-3 and sr["algorithmic_flop_per_patch"] == 154486824
+    ss = d["steady_state"]
+    assert ss["steps"] >= 200 and 0.5 * d["ms_per_step"] < ss["median_ms_per_step"] < 2 * d["ms_per_step"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_print_one_json_line():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with both ranks on
+    the one GPU of the test box and gloo standing in for RCCL (DTA_BENCH_BACKEND=gloo, development only): exercises
+    the rendezvous, the barriers, the two-bucket overlapped exchange, the max-over-ranks timing and rank 0's single
+    JSON line.  Nothing about its speed is meaningful."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, DTA_BENCH_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo", MASTER_ADDR="127.0.0.1")
+    for flags, ncoll in (([], 2), (["--no-overlap"], 1)):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                              "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--steady-steps", "0"]
+                             + flags, capture_output=True, text=True, timeout=420, cwd=REPO, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+        assert d["config"]["collectives_per_step"] == ncoll and "cpu_baseline" not in d

@@ -29,18 +29,27 @@ def _worker(rank, world, port, out):
     torch.manual_seed(100 + rank)
     n, split = 1000, 700
     g = torch.randn(n, dtype=torch.float32)
+    g[split - 1] = 0.0                     # the float64 alpha gradient's exchange slot inside the first bucket
     alpha_g = torch.tensor(float(rank + 1), dtype=torch.float64)
     mine = g.clone()
     sync = GradSync(world=world, group=None, side_stream=None)
-    # two-phase reduction exactly as FusedTrainer.train_step issues it
-    sync.reduce_early(g[:split], alpha_g)
+    # two-phase reduction exactly as FusedTrainer.train_step issues it: two collectives, alpha rides in its slot
+    sync.reduce_early(g[:split], alpha_g, g[split - 1:split])
     sync.reduce_late(g[split:])
     sync.finish()
+    assert sync.collectives == 2
     gathered = [torch.zeros(n) for _ in range(world)]
     dist.all_gather(gathered, mine)
     want = torch.stack(gathered).sum(0)
+    want[split - 1] = sum(range(1, world + 1))
     ok_sum = torch.allclose(g, want, atol=1e-6)
     ok_alpha = abs(alpha_g.item() - sum(range(1, world + 1))) < 1e-12
+    # single-bucket mode: ONE collective over the whole buffer
+    g2 = mine.clone()
+    a2 = torch.tensor(float(rank + 1), dtype=torch.float64)
+    sync.reduce_all(g2, a2, g2[split - 1:split])
+    sync.finish()
+    assert sync.collectives == 3 and torch.allclose(g2, want, atol=1e-6) and abs(a2.item() - want[split - 1].item()) < 1e-12
     # averaging is applied by the optimizer kernel through grad_scale = 1/world
     ok_scale = abs(sync.grad_scale - 1.0 / world) < 1e-12
     # parameter broadcast

@@ -306,3 +306,64 @@ def test_torch_oracle_metadata_fusion_matches_reference_golden(golden):
         if k.endswith("conv_layer.bias"):
             continue
         assert abs(float(t.grad.double().norm()) - ref) <= 1e-4 * max(ref, 1e-9), k
+
+
+def _three_head_oracle(p, kind, x, y, w, dt=np.float64):
+    """Sum over all classifier heads of the class-weighted cross-entropy (the Hang et al. multi-head loss) through the
+    oracle's sub-network forward/backward: loss, per-head scores, gradients, BatchNorm updates."""
+    nets = [("spectral_network.", "spectral"), ("spatial_network.", "spatial")] if kind == "hang" else [("", kind)]
+    heads, grads, upd, loss = [], {}, {}, 0.0
+    for pre, k in nets:
+        s, cache, u = O.subnet_fwd(p, pre, k, x, True, dt)
+        ds = []
+        for h in s:
+            l, d = O.weighted_cross_entropy(h, y, w)
+            loss += l
+            ds.append(d.astype(dt))
+        grads.update(O.subnet_bwd(p, pre, cache, ds, dt))
+        upd.update(u)
+        heads += list(s)
+    return loss, heads, grads, upd
+
+
+def test_three_head_loss_oracle_vs_reference_golden(golden):
+    """tests/golden/three_head.npz: the reference's sub-networks' three heads each (Hang2020.py:204, :240) summed into
+    one class-weighted loss, gradients and two torch-Adam steps (make_golden.case_three_head)."""
+    g = golden("three_head.npz")
+    bands, classes, B = 20, 7, 6
+    x = prng.uniform01(92, 1, (B, bands, 11, 11))
+    y = prng.randint(92, 2, (B,), classes)
+    w = (0.1 + (np.arange(classes) % 7)).astype(np.float32)
+    for tag, kind, spec in (("hang/", "hang", O.hang2020_spec(bands, classes)),
+                            ("spectral/", "spectral", O.subnet_spec("spectral", bands, classes))):
+        p = O.init_params(spec, seed=91)
+        state = {}
+        for step in range(2):
+            loss, heads, grads, upd = _three_head_oracle(p, kind, x, y, w)
+            assert abs(loss - float(g[f"{tag}loss_step{step}"])) / float(g[f"{tag}loss_step{step}"]) < 2e-5, (tag, step)
+            if step == 0:
+                for i, h in enumerate(heads):
+                    assert rel_l2(h, g[f"{tag}head{i}"]) < 2e-5, (tag, i)
+                none = set(g[f"{tag}grad_none"].tolist())
+                assert none == ({"alpha"} if kind == "hang" else set())      # the blend is not on this loss' graph
+                for k, v in grads.items():
+                    if k.endswith("conv_layer.bias") or k in none:
+                        continue
+                    assert abs(np.sqrt((np.asarray(v, np.float64) ** 2).sum()) - float(g[f"{tag}grad_norm/{k}"])) \
+                        <= 2e-4 * float(g[f"{tag}grad_norm/{k}"]), (tag, k)
+                    if f"{tag}grad_full/{k}" in g and np.any(g[f"{tag}grad_full/{k}"]):
+                        assert rel_l2(v, g[f"{tag}grad_full/{k}"]) < 2e-4, (tag, k)
+                for k, v in upd.items():
+                    assert rel_l2(v, g[f"{tag}buf1/{k}"]) < 2e-5, (tag, k)
+            grads.pop("alpha", None)
+            gg = {k: v for k, v in grads.items()}
+            if kind == "hang":
+                gg["alpha"] = None               # torch's Adam passes over a parameter without gradient
+            p = O.adam_step(p, {k: v for k, v in gg.items() if v is not None}, state, lr=1e-3)
+            p.update(upd)
+        for k in spec:
+            name = k[0]
+            if O.is_buffer(name) or name.endswith("conv_layer.bias"):
+                continue
+            ref = float(g[f"{tag}p2_norm/{name}"])
+            assert abs(np.sqrt((np.asarray(p[name], np.float64) ** 2).sum()) - ref) <= 2e-4 * max(ref, 1e-12), (tag, name)

@@ -1,0 +1,188 @@
+"""GPU tests of the round-2 additions around the hot path: the three-head loss option against the reference's own golden
+(tests/golden/three_head.npz), the Trainer-shaped loop (BASELINE configs[0]: vanilla_CNN(5, 3) through
+training_step / validation_step), and the robustness fixes (stale Predictor tables, aliased loss tensors, out-of-range
+labels, vanilla_CNN patch-size guard)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import hang2020_np as O
+from oracle import prng
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _load(m, p):
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in p.items()})
+    return m.to(dev()).train()
+
+
+@pytest.mark.parametrize("tag", ["hang/", "spectral/"])
+def test_three_head_loss_vs_reference_golden(golden, tag):
+    """FusedTrainer(three_head_loss=True): loss = sum over every classifier head of the class-weighted CE (six heads for
+    Hang2020, three for a lone sub-network), as the reference's modules produce it when their three heads are all used
+    (Hang2020.py:204, :240): heads, loss, every gradient, BatchNorm buffers and two Adam steps vs the reference."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    g = golden("three_head.npz")
+    bands, classes, B = 20, 7, 6
+    x = torch.from_numpy(prng.uniform01(92, 1, (B, bands, 11, 11))).to(dev())
+    y = torch.from_numpy(prng.randint(92, 2, (B,), classes)).to(dev())
+    w = torch.from_numpy((0.1 + (np.arange(classes) % 7)).astype(np.float32))
+    if tag == "hang/":
+        m = _load(H.Hang2020(bands, classes), O.init_params(O.hang2020_spec(bands, classes), seed=91))
+    else:
+        m = _load(H.spectral_network(bands, classes), O.init_params(O.subnet_spec("spectral", bands, classes), seed=91))
+    alpha0 = float(m.alpha) if tag == "hang/" else None
+    tr = FusedTrainer(m, lr=1e-3, loss_weight=w, three_head_loss=True, keep_grads=True)
+    for step in range(2):
+        loss = tr.train_step(x, y)
+        ref = float(g[f"{tag}loss_step{step}"])
+        assert abs(float(loss) - ref) / ref < 2e-4, (step, float(loss), ref)
+        if step == 0:
+            hs = tr.head_scores
+            k = 0
+            for net in range(hs.shape[0]):
+                for hd in range(3):
+                    assert rel_l2(hs[net, hd].cpu().numpy(), g[f"{tag}head{k}"]) < 2e-4, k
+                    k += 1
+            none = set(g[f"{tag}grad_none"].tolist())
+            for name, prm in m.named_parameters():
+                if name in none or name.endswith("conv_layer.bias") or prm.dtype != torch.float32:
+                    continue
+                got = tr.grad_of(prm).cpu().numpy()
+                ref_n = float(g[f"{tag}grad_norm/{name}"])
+                assert abs(np.linalg.norm(got.astype(np.float64)) - ref_n) <= 1e-3 * ref_n, name
+                if f"{tag}grad_full/{name}" in g and np.any(g[f"{tag}grad_full/{name}"]):
+                    assert rel_l2(got, g[f"{tag}grad_full/{name}"]) < 1e-3, name
+            sd = m.state_dict()
+            for name in sd:
+                if O.is_buffer(name):
+                    assert rel_l2(sd[name].cpu().numpy(), g[f"{tag}buf1/{name}"]) < 2e-4, name
+    sd = m.state_dict()
+    for name, prm in m.named_parameters():
+        if name.endswith("conv_layer.bias"):
+            continue
+        ref_n = float(g[f"{tag}p2_norm/{name}"])
+        assert abs(float(prm.double().norm()) - ref_n) <= 1e-3 * max(ref_n, 1e-12), name
+    if alpha0 is not None:
+        assert float(m.alpha) == alpha0          # the blend is not on this loss' graph: alpha untouched, as in torch
+
+
+def test_fit_loop_vanilla_cnn_config1():
+    """BASELINE configs[0]: vanilla_CNN(bands=5, classes=3) driven through training_step / validation_step by the
+    Trainer-shaped loop with the reference's plateau scheduler; the reference's own living test of this plumbing is
+    tests/test_multi_stage.py:12-19 (fit one epoch, losses finite)."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    from deeptreeattention_amd.loop import PlateauScheduler, SyntheticTreeDataset, fit
+    torch.manual_seed(0)
+    m = H.vanilla_CNN(bands=5, classes=3).to(dev()).train()
+    tr = FusedTrainer(m, lr=5e-3)
+    train = SyntheticTreeDataset(96, bands=5, classes=3, seed=1)
+    val = SyntheticTreeDataset(32, bands=5, classes=3, seed=2)
+    # learnable synthetic labels: the class is the brightest of the first three bands' means
+    for ds in (train, val):
+        ds.labels = ds.hsi[:, :3].mean(dim=(2, 3)).argmax(1)
+    sched = PlateauScheduler(tr, patience=1)
+    hist = fit(tr, train, val, epochs=6, batch_size=16, scheduler=sched)
+    assert len(hist) == 6 and all(np.isfinite(h["train_loss"]) and np.isfinite(h["val_loss"]) for h in hist)
+    assert hist[-1]["train_loss"] < hist[0]["train_loss"] - 0.05
+    assert tr.step_count == 6 * 6
+    assert int(m.conv1.bn1.num_batches_tracked) == 6 * 6          # validation ran in eval mode, as under Lightning
+    assert m.training
+
+
+def test_fit_loop_hang2020_and_losses_are_fresh_tensors():
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    from deeptreeattention_amd.loop import SyntheticTreeDataset
+    torch.manual_seed(1)
+    m = H.Hang2020(bands=12, classes=4).to(dev()).train()
+    tr = FusedTrainer(m, lr=1e-3)
+    ds = SyntheticTreeDataset(48, bands=12, classes=4, seed=3)
+    losses = [tr.training_step(b, i) for i, b in enumerate(ds.loader(16))]
+    vals = [float(v) for v in losses]
+    assert len({v.data_ptr() for v in losses}) == 3 and len(set(vals)) == 3     # collected losses are not aliases
+    m.eval()
+    v = tr.validation_step(next(ds.loader(16)))
+    assert np.isfinite(float(v))
+    logits, loss = tr.forward_loss(ds.hsi[:16], ds.labels[:16])
+    l2, _ = tr.forward_loss(ds.hsi[16:32], ds.labels[16:32])
+    assert logits.data_ptr() != l2.data_ptr()
+
+
+def test_predictor_follows_rehomed_parameters():
+    """predict() before and after a FusedTrainer moves the parameters into its flat buffer (and trains): the cached
+    pointer tables must follow (the old storages are freed)."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd import engine
+    torch.manual_seed(2)
+    m = H.Hang2020(bands=9, classes=5).to(dev()).eval()
+    x = torch.rand(8, 9, 11, 11, device=dev())
+    y = torch.randint(0, 5, (8,), device=dev())
+    p0, idx0, _ = engine.predict(m, x)
+    p0 = p0.clone()
+    with torch.no_grad():
+        assert rel_l2(p0.cpu().numpy(), torch.softmax(m(x), 1).cpu().numpy()) < 1e-5
+    m.train()
+    tr = engine.FusedTrainer(m, lr=1e-2)
+    junk = [torch.full((1 << 20,), float("nan"), device=dev()) for _ in range(4)]   # recycle the freed parameter blocks
+    for _ in range(3):
+        tr.train_step(x, y)
+    m.eval()
+    p1, _, _ = engine.predict(m, x)
+    with torch.no_grad():
+        want = torch.softmax(m(x), 1)
+    assert torch.isfinite(p1).all()
+    assert rel_l2(p1.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    assert rel_l2(p1.cpu().numpy(), p0.cpu().numpy()) > 1e-3       # the three steps did change the model
+    del junk
+    import copy
+    copy.deepcopy(m)                                               # nothing un-copyable was hung on the module
+
+
+def test_cross_entropy_flags_out_of_range_labels():
+    from deeptreeattention_amd import _lib
+    L = _lib.lib()
+    B, classes = 6, 5
+    z = torch.randn(B, classes, device=dev())
+    loss = torch.zeros((), device=dev())
+    dl = torch.empty_like(z)
+    scratch = torch.empty(B + 1, device=dev())
+
+    def run(y):
+        _lib.check(L.dta_weighted_ce(_lib.ptr(z), _lib.ptr(y), None, B, classes, _lib.ptr(loss), _lib.ptr(dl),
+                                     _lib.ptr(scratch), _lib.current_stream_ptr()), "ce")
+        return float(loss), dl.clone()
+    y = torch.tensor([0, 1, 2, 3, 4, 1], device=dev())
+    ref = torch.nn.functional.cross_entropy(z, y)
+    l, d = run(y)
+    assert abs(l - float(ref)) < 1e-5
+    y_ign = y.clone(); y_ign[2] = -100                           # torch's ignore_index: dropped from the mean
+    l, d = run(y_ign)
+    assert abs(l - float(torch.nn.functional.cross_entropy(z, y_ign))) < 1e-5
+    assert float(d[2].abs().max()) == 0.0
+    y_bad = y.clone(); y_bad[4] = classes                        # a label-mapping bug must not train silently
+    l, d = run(y_bad)
+    assert np.isnan(l) and torch.isnan(d[4]).all() and torch.isfinite(d[0]).all()
+
+
+def test_vanilla_cnn_rejects_patches_its_head_cannot_take():
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd import _lib
+    m = H.vanilla_CNN(bands=5, classes=3).to(dev())
+    with pytest.raises(RuntimeError, match="512"):
+        m(torch.rand(2, 5, 24, 24, device=dev()))
+    L = _lib.lib()
+    desc = _lib.NetDesc(2, 5, 24, 24, 3, _lib.NET_VANILLA, _lib.DTA_F32, 1, 4, 0.1, 1e-5)
+    assert L.dta_net_workspace_bytes(C.byref(desc)) == 0
+    assert b"512" in L.dta_last_error()

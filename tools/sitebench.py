@@ -9,7 +9,7 @@ tr = FusedTrainer(m, lr=1e-4)
 x = torch.rand(1024, 369, 11, 11, device="cuda"); y = torch.randint(0, 200, (1024,), device="cuda")
 for _ in range(5): tr.train_step(x, y)
 torch.cuda.synchronize()
-L = _lib.lib(); L.dta_profile_enable(site)
+L = _lib.lib(); L.dta_profile_enable(-1); L.dta_profile_enable(site)
 for _ in range(30): tr.train_step(x, y)
 torch.cuda.synchronize()
 buf = (C.c_float * 512)(); n = L.dta_profile_collect(buf, 512)

@@ -11,7 +11,7 @@ for _ in range(5): tr.train_step(x, y)
 torch.cuda.synchronize()
 L = _lib.lib()
 for site in sites:
-    L.dta_profile_enable(site)
+    L.dta_profile_enable(-1); L.dta_profile_enable(site)
     for _ in range(20): tr.train_step(x, y)
     torch.cuda.synchronize()
     buf = (C.c_float * 512)(); n = L.dta_profile_collect(buf, 512)
