@@ -44,6 +44,14 @@ inline void prof_end(int site, hipStream_t st) {
   if (s >= 0 && g_prof.n[s] < Prof::CAP) { hipEventRecord(g_prof.ev[s][g_prof.n[s]][1], st); ++g_prof.n[s]; }
 }
 
+// Developer switches (same-box A/B runs): the environment is read once per process, not per call.
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act; };
+inline Switches read_switches() {
+  return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr,
+          getenv("DTA_FP32_ACT") != nullptr};
+}
+Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
+inline const Switches& switches() { return g_switches; }
 constexpr int CH[3] = {32, 64, 128};
 constexpr int SPEC_K[3] = {3, 5, 7};   // reference Hang2020.py:136-141
 constexpr int SPAT_K[3] = {7, 5, 3};   // :77-85
@@ -70,6 +78,7 @@ struct Plan {
   size_t dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart[3];
   size_t attsave[3]; int attsave_ld[3];
   int x_compact;   // bf16, 11x11-class patches: the network-input tiles are stored without their halo rows
+  int y_fmt;       // storage of the conv outputs between kernels: fp32, or IEEE half in bf16 mode (common.h)
   size_t scores_all, scores_bytes, dfeat_all, dfeat_bytes;
   size_t total;
 };
@@ -85,6 +94,7 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
   p->shared_x = d->kind == DTA_NET_HANG2020;
   p->B = d->batch; p->bands = d->bands; p->H = d->height; p->W = d->width; p->classes = d->classes;
   p->esz = d->dtype == DTA_BF16 ? 2 : 4;
+  p->y_fmt = (d->dtype == DTA_BF16 && !switches().fp32_act) ? FMT_F16 : FMT_F32;
   switch (d->kind) {
     case DTA_NET_HANG2020: p->kinds[0] = KIND_SPECTRAL; p->kinds[1] = KIND_SPATIAL; break;
     case DTA_NET_SPECTRAL: p->kinds[0] = KIND_SPECTRAL; break;
@@ -125,7 +135,7 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
       } else if (L == 2) f = CH[2] * p->HWz[2];
       p->F[g][L] = f;
       if (f > p->Fmax[L]) p->Fmax[L] = f;
-      if (vl > p->vec_ld[L]) p->vec_ld[L] = vl;
+      if (vl > p->vec_ld[L]) p->vec_ld[L] = (vl + 3) & ~3;   // rows 16-byte aligned: the batch GEMMs over them use vector loads
     }
     int Nconv = (L == 0 && p->shared_x) ? 32 * G : CH[L];
     p->MWG[L] = conv_mwg(Nconv);
@@ -201,13 +211,6 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
 // bf16 networks whose input tiles are halo-free: the first conv converts the fp32 input while staging it.  With few
 // workgroups (small batches) the conversion's long per-chunk load chain is exposed and the wide, shallow pack job is
 // faster (measured crossover: ~100 first-conv workgroups, B ~ 450 for Hang2020)
-// Developer switches (same-box A/B runs): the environment is read once per process, not per call.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel; };
-inline Switches read_switches() {
-  return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr};
-}
-Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
-inline const Switches& switches() { return g_switches; }
 inline bool fused_input(const Plan& p) {
   const int launchG = p.shared_x ? 1 : p.G;
   return p.esz == 2 && p.x_compact && p.nwg[0] * launchG >= 100 && !switches().no_fused_input;
@@ -233,6 +236,7 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
     }
   }
   s.y = at<float>(ws, p.y[L]);
+  s.y_fmt = p.y_fmt;
   if (L == 0 && p.shared_x) { s.y_gs = 32; s.y_rs = 32 * G; }
   else { s.y_gs = (size_t)B * p.HWc[L] * C; s.y_rs = C; }
   s.coef = at<float>(ws, p.coef[L]); s.coef_gs = C * 4;
@@ -314,7 +318,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     ca.wp = at<char>(ws, p.wp[L]);
     for (int g = 0; g < G; ++g) ca.bias[g] = nets[g].conv_b[L];
     ca.bias_mode = pack_mode[L]; ca.bias_split = 32;
-    ca.y = at<float>(ws, p.y[L]);
+    ca.y = at<float>(ws, p.y[L]); ca.y_fmt = p.y_fmt;
     if (cat) { ca.y_gs = 0; ca.y_rs = Nconv; } else { ca.y_gs = (size_t)B * p.HWc[L] * C; ca.y_rs = C; }
     ca.stats = d->training ? at<float>(ws, p.stats[L]) : nullptr;
     ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
@@ -552,7 +556,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     if (launch_bn_bwd_finalize_colsum(bf, G, cs_jobs, ncs_jobs, st)) return 1;
     BnBwdApplyArgs ap;
     memset(&ap, 0, sizeof(ap));
-    ap.dv = sb.dv; ap.dv_gs = sb.dv_gs; ap.y = sa.y; ap.y_gs = sa.y_gs; ap.y_rs = sa.y_rs;
+    ap.dv = sb.dv; ap.dv_gs = sb.dv_gs; ap.y = sa.y; ap.y_gs = sa.y_gs; ap.y_rs = sa.y_rs; ap.y_fmt = sa.y_fmt;
     ap.coef = sa.coef; ap.coef_gs = sa.coef_gs; ap.bcoef = bf.bcoef; ap.bcoef_gs = bf.bcoef_gs;
     ap.B = B; ap.C = C; ap.H = p.Hc[L]; ap.W = p.Wc[L];
     ap.dv_compact = sb.dv_compact; ap.Hz = p.Hz[L]; ap.Wz = p.Wz[L];

@@ -23,6 +23,63 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
+// Storage formats of the activations / gradients that travel between kernels through HBM.  fp32 everywhere in fp32
+// mode; in bf16 mode the conv outputs (pre-BatchNorm) are kept in IEEE half (their next use normalises them, so the
+// three extra mantissa bits over bf16 matter and their range is small) and the gradient maps in bf16 (range first).
+enum { FMT_F32 = 0, FMT_F16 = 1, FMT_BF16 = 2 };
+__host__ __device__ __forceinline__ int fmt_bytes(int fmt) { return fmt == FMT_F32 ? 4 : 2; }
+typedef _Float16 hw_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hw_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pack2_fmt(float lo, float hi, int fmt) {
+  if (fmt == FMT_F16) {   // saturating: a value beyond the half range must not become inf (and NaN after BatchNorm)
+    hw_f16x2 h = {(_Float16)__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+    return __builtin_bit_cast(unsigned, h);
+  }
+  unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);     // bf16, round to nearest even
+  a += 0x7FFFu + ((a >> 16) & 1u); b += 0x7FFFu + ((b >> 16) & 1u);
+  return (a >> 16) | (b & 0xFFFF0000u);
+}
+__device__ __forceinline__ float unpack_lo(unsigned u, int fmt) {
+  if (fmt == FMT_F16) { hw_f16x2 h = __builtin_bit_cast(hw_f16x2, u); return (float)h[0]; }
+  return __uint_as_float(u << 16);
+}
+__device__ __forceinline__ float unpack_hi(unsigned u, int fmt) {
+  if (fmt == FMT_F16) { hw_f16x2 h = __builtin_bit_cast(hw_f16x2, u); return (float)h[1]; }
+  return __uint_as_float(u & 0xFFFF0000u);
+}
+// element i of a tensor stored in `fmt` (pass a compile-time constant inside loops: a run-time format puts every load
+// behind a branch and the loads of an unrolled loop no longer overlap)
+template <bool NT = false>
+__device__ __forceinline__ float ld_fmt(const void* base, size_t i, int fmt) {
+  if (fmt == FMT_F32) { const float* p = (const float*)base + i; return NT ? __builtin_nontemporal_load(p) : *p; }
+  const unsigned short* p = (const unsigned short*)base + i;
+  const unsigned short u = NT ? __builtin_nontemporal_load(p) : *p;
+  if (fmt == FMT_F16) return (float)__builtin_bit_cast(_Float16, u);
+  return __uint_as_float(((unsigned)u) << 16);
+}
+// four consecutive elements starting at i (i % 4 == 0, base 16-byte aligned)
+template <bool NT = false>
+__device__ __forceinline__ void ld4_fmt(float (&v)[4], const void* base, size_t i, int fmt) {
+  if (fmt == FMT_F32) {
+    const f32x4* p = (const f32x4*)((const float*)base + i);
+    const f32x4 q = NT ? __builtin_nontemporal_load(p) : *p;
+    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+  } else {
+    const u32x2* p = (const u32x2*)((const unsigned short*)base + i);
+    const u32x2 q = NT ? __builtin_nontemporal_load(p) : *p;
+    v[0] = unpack_lo(q.x, fmt); v[1] = unpack_hi(q.x, fmt); v[2] = unpack_lo(q.y, fmt); v[3] = unpack_hi(q.y, fmt);
+  }
+}
+__device__ __forceinline__ void st_fmt(void* base, size_t i, float v, int fmt) {
+  if (fmt == FMT_F32) ((float*)base)[i] = v;
+  else if (fmt == FMT_F16) ((_Float16*)base)[i] = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  else ((unsigned short*)base)[i] = (unsigned short)(pack2_fmt(v, 0.f, FMT_BF16) & 0xFFFFu);
+}
+// exchange with the neighbouring lane (lane ^ 1) without touching LDS
+__device__ __forceinline__ float lane_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
+}
+
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
   __device__ static __forceinline__ float to(float v) { return v; }

@@ -305,19 +305,47 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) csum[nt] = 0.f;
   float* yg = a.y + (size_t)g * a.y_gs;
+  if (a.y_fmt == FMT_F32) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int lr = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      int orow = rowtab[lr];
+      for (int r = 0; r < 16; ++r) {
+        int lr = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int orow = rowtab[lr];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        float v = acc[mt][nt][r] + bias[nt];
-        acc[mt][nt][r] = v;
-        if (orow >= 0) {
-          yg[(size_t)orow * a.y_rs + nt * 32 + (lane & 31)] = v;
-          csum[nt] += v;
+        for (int nt = 0; nt < NT; ++nt) {
+          float v = acc[mt][nt][r] + bias[nt];
+          acc[mt][nt][r] = v;
+          if (orow >= 0) {
+            yg[(size_t)orow * a.y_rs + nt * 32 + (lane & 31)] = v;
+            csum[nt] += v;
+          }
+        }
+      }
+    }
+  } else {
+    // 16-bit output rows: a lane holds ONE column of 16 rows, so neighbouring lanes trade values (rows r and r + 1 are
+    // consecutive pixels): the even lane packs columns (n, n + 1) of row r, the odd lane the same pair of row r + 1 ->
+    // 4-byte stores, 64 contiguous bytes per row and half-wave, instead of 2-byte ones.  Statistics stay on the fp32 values
+    unsigned short* y16 = reinterpret_cast<unsigned short*>(a.y) + (size_t)g * a.y_gs;
+    const bool odd = lane & 1;
+    const int ncol = (lane & 31) & ~1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int lr0 = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int orow0 = rowtab[lr0], orow1 = rowtab[lr0 + 1];
+        const int orow = odd ? orow1 : orow0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float v0 = acc[mt][nt][r] + bias[nt], v1 = acc[mt][nt][r + 1] + bias[nt];
+          acc[mt][nt][r] = v0; acc[mt][nt][r + 1] = v1;
+          if (orow0 >= 0) csum[nt] += v0;
+          if (orow1 >= 0) csum[nt] += v1;
+          const float got = lane_xor1(odd ? v0 : v1);      // even lane <- neighbour's row r, odd lane <- neighbour's row r + 1
+          const unsigned pk = odd ? pack2_fmt(got, v1, a.y_fmt) : pack2_fmt(v0, got, a.y_fmt);
+          if (orow >= 0) *reinterpret_cast<unsigned*>(y16 + (size_t)orow * a.y_rs + nt * 32 + ncol) = pk;
         }
       }
     }

@@ -16,7 +16,7 @@ constexpr int GP = 36;   // LDS row pitch (floats): 16-byte aligned rows, confli
 // 16 k values one lane feeds to the 16 MFMAs of a chunk (k = 2j + lane/32) are contiguous -> four ds_read_b128.
 enum { LD_SCALAR = 0, LD_VEC_K = 1, LD_VEC_ROW = 2, LD_RUNTIME = 3 };
 
-__device__ __forceinline__ int gemm_load_mode(const float* p, int rows, int K, long s_row, long s_k) {
+__host__ __device__ __forceinline__ int gemm_load_mode(const float* p, int rows, int K, long s_row, long s_k) {
   const bool al = (((size_t)p) & 15) == 0;
   if (s_k == 1 && al && (s_row & 3) == 0 && (K & 3) == 0) return LD_VEC_K;
   if (s_row == 1 && al && (s_k & 3) == 0 && (rows & 3) == 0) return LD_VEC_ROW;
@@ -156,26 +156,167 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, in
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-tile form (both operands 16-byte loadable): a workgroup owns ONE 32x32 output tile and its four waves split the
+// K range; every wave stages its own 32 x 32 operand chunks through a private LDS region (no workgroup barrier in the
+// K loop), and the four partial tiles meet in LDS at the end -> plain coalesced stores, no atomics and no pre-zeroed
+// output unless the caller also splits K across workgroups (ksplit > 1).  These GEMMs are latency problems (0.3 GFLOP
+// over 200-500 workgroups): 4x as many, 4x shorter dependent chains than the 64x64 form below.
+// ------------------------------------------------------------------------------------------------
+constexpr int WT_REGION = 2 * 32 * GP;     // floats per wave: A chunk + B chunk ([32][GP] k-fast or [32][32] row-fast)
+__host__ __device__ __forceinline__ bool gemm_wave_tiles(const GemmArgs& a) {
+  const int am = gemm_load_mode(a.A, a.M, a.K, a.sa_m, a.sa_k), bm = gemm_load_mode(a.Bm, a.N, a.K, a.sb_n, a.sb_k);
+  return am != LD_SCALAR && bm != LD_SCALAR;
+}
+__host__ __device__ __forceinline__ int gemm_nblocks(const GemmArgs& a) {
+  const int ks = a.ksplit < 1 ? 1 : a.ksplit;
+  if (gemm_wave_tiles(a)) return ((a.M + 31) / 32) * ((a.N + 31) / 32) * ks;
+  return ((a.M + 63) / 64) * ((a.N + 63) / 64) * ks;
+}
+// one 32 x GK operand chunk -> 16 floats per lane (four 16-byte loads)
+template <int MODE>
+__device__ __forceinline__ void wt_load(f32x4 (&r)[4], const float* p, int rows, int r0, long s_row, long s_k, int k0, int kend, int lane) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = lane + u * 64;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == LD_VEC_K) {
+      const int row = i >> 3, k = (i & 7) * 4;
+      if (r0 + row < rows && k0 + k < kend) v = *(const f32x4*)(p + (size_t)(r0 + row) * s_row + (k0 + k));
+    } else {
+      const int k = i >> 3, row = (i & 7) * 4;
+      if (r0 + row < rows && k0 + k < kend) v = *(const f32x4*)(p + (size_t)(k0 + k) * s_k + (r0 + row));
+    }
+    r[u] = v;
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void wt_store(float* S, const f32x4 (&r)[4], int lane) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = lane + u * 64;
+    if (MODE == LD_VEC_K) {
+      const int row = i >> 3, k = (i & 7) * 4;        // k, k+2 -> even half; k+1, k+3 -> odd half (kperm)
+      *(f32x2*)&S[row * GP + (k >> 1)] = f32x2{r[u][0], r[u][2]};
+      *(f32x2*)&S[row * GP + 16 + (k >> 1)] = f32x2{r[u][1], r[u][3]};
+    } else {
+      const int k = i >> 3, row = (i & 7) * 4;
+      *(f32x4*)&S[k * 32 + row] = r[u];
+    }
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void wt_fetch(float (&v)[16], const float* S, int row, int h) {
+  if (MODE == LD_VEC_ROW) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = S[(2 * j + h) * 32 + row];
+  } else {
+    const f32x4* p = (const f32x4*)&S[row * GP + h * 16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f32x4 q = p[j]; v[4 * j] = q[0]; v[4 * j + 1] = q[1]; v[4 * j + 2] = q[2]; v[4 * j + 3] = q[3]; }
+  }
+}
+template <int AM, int BM>
+__device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by, int bz, float* smem) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m0 = bx * 32, n0 = by * 32;
+  const int ks = a.ksplit < 1 ? 1 : a.ksplit;
+  const int kblk = ((a.K + ks - 1) / ks + GK - 1) / GK * GK;            // this workgroup's K range
+  const int kb0 = bz * kblk, kb1 = min(a.K, kb0 + kblk);
+  const int kper = (((kb1 - kb0) + 3) / 4 + GK - 1) / GK * GK;          // this wave's share of it
+  const int kbeg = kb0 + wave * kper, kend = min(kb1, kbeg + kper);
+  float* As = smem + wave * WT_REGION;
+  float* Bs = As + 32 * GP;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float rsum = 0.f;
+  f32x4 ra[4], rb[4];
+  if (kbeg < kend) {
+    wt_load<AM>(ra, a.A, a.M, m0, a.sa_m, a.sa_k, kbeg, kend, lane);
+    wt_load<BM>(rb, a.Bm, a.N, n0, a.sb_n, a.sb_k, kbeg, kend, lane);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    // the region is private to this wave: program order (plus the compiler's lgkmcnt waits) is all the ordering needed
+    wt_store<AM>(As, ra, lane);
+    wt_store<BM>(Bs, rb, lane);
+    if (k0 + GK < kend) {
+      wt_load<AM>(ra, a.A, a.M, m0, a.sa_m, a.sa_k, k0 + GK, kend, lane);
+      wt_load<BM>(rb, a.Bm, a.N, n0, a.sb_n, a.sb_k, k0 + GK, kend, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (a.rowsum_out && by == 0 && lane < 32) {
+#pragma unroll
+      for (int k = 0; k < GK; ++k) rsum += AM == LD_VEC_ROW ? As[k * 32 + lane] : As[lane * GP + k];
+    }
+    float av[16], bv[16];
+    wt_fetch<AM>(av, As, lane & 31, lane >> 5);
+    wt_fetch<BM>(bv, Bs, lane & 31, lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+  }
+  float osc = 1.f;
+  if (a.sig_mode) {
+    const double wd = 1.0 / (1.0 + exp(-a.sig_alpha[0]));
+    osc = a.sig_mode == 1 ? (float)wd : (float)(1.0 - wd);
+  }
+  // partial tiles -> LDS ([wave][32][33]), then all 256 threads sum the four and store rows of 32 consecutive columns
+  float* P = smem + wave * WT_REGION;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) P[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[r];
+  if (a.rowsum_out && by == 0 && lane < 32) P[32 * 33 + lane] = rsum;
+  __syncthreads();
+  if (a.rowsum_out && by == 0 && t < 32 && m0 + t < a.M) {
+    float rs = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) rs += smem[w * WT_REGION + 32 * 33 + t];
+    atomicAdd(a.rowsum_out + m0 + t, rs * osc);
+  }
+  const int n = n0 + (t & 31);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ml = (t >> 5) + 8 * j, m = m0 + ml;
+    if (m >= a.M || n >= a.N) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += smem[w * WT_REGION + ml * 33 + (t & 31)];
+    v = v * osc + ((a.bias && bz == 0) ? a.bias[n] : 0.f);
+    float* c = a.C + (size_t)m * a.sc_m + (size_t)n * a.sc_n;
+    if (ks > 1) atomicAdd(c, v);
+    else if (a.accumulate) *c += v;
+    else *c = v;
+  }
+}
+
 // Several independent small GEMMs in one launch: block -> (problem, m-tile, n-tile, k-slice).
-__device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, float* As, float* Bs) {
+__device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, float* smem) {
   int pi = 0;
   while (pi + 1 < gg.n && (int)blockIdx.x >= gg.start[pi + 1]) ++pi;
   const GemmArgs& a = gg.g[pi];
   int local = blockIdx.x - gg.start[pi];
+  const int am = gemm_load_mode(a.A, a.M, a.K, a.sa_m, a.sa_k), bm = gemm_load_mode(a.Bm, a.N, a.K, a.sb_n, a.sb_k);
+  if (am != LD_SCALAR && bm != LD_SCALAR) {
+    const int tm = (a.M + 31) / 32, tn = (a.N + 31) / 32;
+    const int bx = local % tm; local /= tm;
+    const int by = local % tn;
+    const int bz = local / tn;
+    if (am == LD_VEC_K && bm == LD_VEC_K) gemm_block_wt<LD_VEC_K, LD_VEC_K>(a, bx, by, bz, smem);              // x W^T
+    else if (am == LD_VEC_K && bm == LD_VEC_ROW) gemm_block_wt<LD_VEC_K, LD_VEC_ROW>(a, bx, by, bz, smem);     // dy W
+    else if (am == LD_VEC_ROW && bm == LD_VEC_ROW) gemm_block_wt<LD_VEC_ROW, LD_VEC_ROW>(a, bx, by, bz, smem); // dy^T x
+    else gemm_block_wt<LD_VEC_ROW, LD_VEC_K>(a, bx, by, bz, smem);
+    return;
+  }
   const int tm = (a.M + 63) / 64, tn = (a.N + 63) / 64;
   const int bx = local % tm; local /= tm;
   const int by = local % tn;
   const int bz = local / tn;
-  const int am = gemm_load_mode(a.A, a.M, a.K, a.sa_m, a.sa_k), bm = gemm_load_mode(a.Bm, a.N, a.K, a.sb_n, a.sb_k);
-  if (am == LD_VEC_K && bm == LD_VEC_K) gemm_block<LD_VEC_K, LD_VEC_K>(a, bx, by, bz, As, Bs);              // x W^T
-  else if (am == LD_VEC_K && bm == LD_VEC_ROW) gemm_block<LD_VEC_K, LD_VEC_ROW>(a, bx, by, bz, As, Bs);     // dy W
-  else if (am == LD_VEC_ROW && bm == LD_VEC_ROW) gemm_block<LD_VEC_ROW, LD_VEC_ROW>(a, bx, by, bz, As, Bs); // dy^T x
-  else gemm_block<LD_RUNTIME, LD_RUNTIME>(a, bx, by, bz, As, Bs);
+  gemm_block<LD_RUNTIME, LD_RUNTIME>(a, bx, by, bz, smem, smem + 64 * GP);   // any strides, any alignment
 }
+constexpr int GEMM_SMEM_FLOATS = 4 * WT_REGION;     // 36 KiB (the 64x64 form needs 2 * 64 * GP of it)
 __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup gg) {
-  __shared__ __attribute__((aligned(16))) float As[64 * GP];
-  __shared__ __attribute__((aligned(16))) float Bs[64 * GP];
-  gemm_group_block(gg, As, Bs);
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_SMEM_FLOATS];
+  gemm_group_block(gg, smem);
 }
 
 int gemm_auto_ksplit(int M, int N, int K) {
@@ -189,12 +330,20 @@ int gemm_auto_ksplit(int M, int N, int K) {
   return ks < 1 ? 1 : ks;
 }
 
+// wave-tile GEMMs split K inside the workgroup: no cross-workgroup split (and so no atomics, no pre-zeroed output,
+// run-to-run identical sums) unless K is huge
+static void gemm_group_plan(GemmGroup& gg) {
+  for (int i = 0; i < gg.n; ++i)
+    if (gemm_wave_tiles(gg.g[i]) && gg.g[i].K <= 8192) gg.g[i].ksplit = 1;
+}
+
 int launch_gemm_group(GemmGroup& gg, hipStream_t st) {
   if (gg.n == 0) return 0;
+  gemm_group_plan(gg);
   int total = 0;
   for (int i = 0; i < gg.n; ++i) {
     gg.start[i] = total;
-    total += ((gg.g[i].M + 63) / 64) * ((gg.g[i].N + 63) / 64) * gg.g[i].ksplit;
+    total += gemm_nblocks(gg.g[i]);
   }
   gg.start[gg.n] = total;
   hipLaunchKernelGGL(k_gemm_group, dim3(total), dim3(256), 0, st, gg);
@@ -203,9 +352,8 @@ int launch_gemm_group(GemmGroup& gg, hipStream_t st) {
 }
 
 __global__ __launch_bounds__(256) void k_gemm_group_reduce(GemmGroup gg, WgradReduceGroup gr, int ngemm) {
-  __shared__ __attribute__((aligned(16))) float As[64 * GP];
-  __shared__ __attribute__((aligned(16))) float Bs[64 * GP];
-  if ((int)blockIdx.x < ngemm) { gemm_group_block(gg, As, Bs); return; }
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_SMEM_FLOATS];
+  if ((int)blockIdx.x < ngemm) { gemm_group_block(gg, smem); return; }
   const int bx = blockIdx.x - ngemm;
   int j = 0;
   while (j + 1 < gr.n && bx >= gr.start[j + 1]) ++j;
@@ -215,10 +363,11 @@ __global__ __launch_bounds__(256) void k_gemm_group_reduce(GemmGroup gg, WgradRe
 int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream_t st) {
   if (gg.n == 0) return launch_wgrad_reduce_group(gr, st);
   if (gr.n == 0) return launch_gemm_group(gg, st);
+  gemm_group_plan(gg);
   int ngemm = 0;
   for (int i = 0; i < gg.n; ++i) {
     gg.start[i] = ngemm;
-    ngemm += ((gg.g[i].M + 63) / 64) * ((gg.g[i].N + 63) / 64) * gg.g[i].ksplit;
+    ngemm += gemm_nblocks(gg.g[i]);
   }
   gg.start[gg.n] = ngemm;
   int total = 0;
@@ -335,10 +484,9 @@ __global__ __launch_bounds__(256) void k_blend_bwd_fin(BlendBwdArgs a) {
 }
 // grouped GEMMs + trailing blocks that reduce the blend's d(alpha) (independent of the GEMMs)
 __global__ __launch_bounds__(256) void k_gemm_group_fin(GemmGroup gg, BlendBwdArgs fin, int ngemm) {
-  __shared__ __attribute__((aligned(16))) float As[64 * GP];
-  __shared__ __attribute__((aligned(16))) float Bs[64 * GP];
-  if ((int)blockIdx.x >= ngemm) { blend_bwd_fin_block(fin, reinterpret_cast<double*>(As), blockIdx.x - ngemm, gridDim.x - ngemm); return; }
-  gemm_group_block(gg, As, Bs);
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_SMEM_FLOATS];
+  if ((int)blockIdx.x >= ngemm) { blend_bwd_fin_block(fin, reinterpret_cast<double*>(smem), blockIdx.x - ngemm, gridDim.x - ngemm); return; }
+  gemm_group_block(gg, smem);
 }
 int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hipStream_t st) {
   const int nfin = BLEND_FIN_BLOCKS;
@@ -347,10 +495,11 @@ int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hip
     DTA_CHECK_LAUNCH("k_blend_bwd_fin");
     return 0;
   }
+  gemm_group_plan(gg);
   int total = 0;
   for (int i = 0; i < gg.n; ++i) {
     gg.start[i] = total;
-    total += ((gg.g[i].M + 63) / 64) * ((gg.g[i].N + 63) / 64) * gg.g[i].ksplit;
+    total += gemm_nblocks(gg.g[i]);
   }
   gg.start[gg.n] = total;
   hipLaunchKernelGGL(k_gemm_group_fin, dim3(total + nfin), dim3(256), 0, st, gg, fin, total);

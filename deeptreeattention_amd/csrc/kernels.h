@@ -17,7 +17,8 @@ struct ConvArgs {
   const void* x_tl; size_t x_gs;      // input tiles, group stride in elements (0 = shared by groups)
   const void* wp;                     // [G][NC][9][N][16]
   const float* bias[MAXG]; int bias_mode, bias_split;
-  float* y; size_t y_gs; int y_rs;    // fp32 output rows [row][y_rs], group offset y_gs
+  float* y; size_t y_gs; int y_rs;    // output rows [row][y_rs], group offset y_gs (elements); storage format y_fmt
+  int y_fmt;                          // FMT_F32 (default) / FMT_F16 / FMT_BF16: bf16 kernels only
   float* stats;                       // [G][nwg][N][2] (mean, M2) or null
   int B, H, W, NC, N, Q, HW, ppw, spp, dbuf;
   int x_compact;                      // bf16: input tiles are halo-free [patch][chunk][pixel][16] (network input only)
@@ -146,7 +147,8 @@ struct AttParams {          // forward-side attention parameters of one branch/s
 };
 struct StageArgs {
   int kind[MAXG];                      // per group
-  const float* y; size_t y_gs; int y_rs;        // conv output (or raw activations when !apply_bn)
+  const float* y; size_t y_gs; int y_rs;        // conv output (or raw activations when !apply_bn); strides in elements
+  int y_fmt;                           // its storage format (FMT_*): the pointer is only a base address
   const float* coef; int coef_gs;      // [..][C][4]
   int apply_bn, relu, pool;            // pool: 2x2 floor max-pool after ReLU
   int B, C, Hc, Wc;                    // conv-resolution dims
@@ -193,7 +195,7 @@ struct BnBwdFinalizeArgs {
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, int G, hipStream_t st);
 
 struct BnBwdApplyArgs {
-  const float* dv; size_t dv_gs; const float* y; size_t y_gs; int y_rs;
+  const float* dv; size_t dv_gs; const float* y; size_t y_gs; int y_rs; int y_fmt;
   const float* coef; int coef_gs; const float* bcoef; int bcoef_gs;
   int B, C, H, W;
   void* dy_tl; size_t dy_gs; int dy_nc, dy_ch0;

@@ -168,9 +168,11 @@ __host__ __device__ inline int stage_vslot(int C, int Hz, int Wz) {
 }
 // Compile-time specialisation of a stage: CT channels, HT x WT conv-resolution map, PT = 2x2 pool after ReLU.
 // HT == 0 keeps the geometry (and the stencil sizes) as run-time values.
-template <int CT, int HT, int WT, int PT>
+// YT = storage format of the conv output the stage reads (FMT_F32, or FMT_F16 in bf16 mode): compile-time, so that the
+// loads of the unrolled fetch loops stay free of branches.
+template <int CT, int HT, int WT, int PT, int YT = FMT_F32>
 struct StageCfg {
-  static constexpr int C = CT, H = HT, W = WT, P = PT;
+  static constexpr int C = CT, H = HT, W = WT, P = PT, YF = YT;
   static constexpr bool fixed = HT > 0;
 };
 template <typename CFG>
@@ -280,7 +282,8 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
   constexpr int CT = CFG::C;
   const bool pool = cfg_pool<CFG>(a);
   const int t = threadIdx.x, C = s.C, ld = s.ld;
-  const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
+  const size_t ybase = (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;   // element index: the conv output may be 16-bit
+  constexpr int yf = CFG::YF;
   const float* coef = lcoef ? lcoef : (a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr);
   if (use_saved) {   // v0 | v1 | v2 as the forward kernel left them (padded maps include their zero borders)
     const float* src = a.attsave + ((size_t)g * a.B + b) * a.attsave_ld;
@@ -302,7 +305,7 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
     for (int u = 0; u < ND; ++u) { const int i = t + u * 256; rd[u] = i < HZT * CT ? __builtin_nontemporal_load(da + i) : 0.f; }
   }
   // the forward's next reader of the conv output is the backward, far away: load it nontemporally there
-  auto ldy = [&](const float* p_) { return use_saved ? *p_ : __builtin_nontemporal_load(p_); };
+  auto ldy = [&](size_t i_) { return use_saved ? ld_fmt<false>(a.y, ybase + i_, yf) : ld_fmt<true>(a.y, ybase + i_, yf); };
   if (z_ready) {
     // the caller already built Z from prefetched registers
   } else if (CT > 0) {
@@ -312,7 +315,7 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
     if (!pool) {
 #pragma unroll 8
       for (int p = p0; p < s.HWc; p += pstep) {      // unrolled: independent global loads in flight per thread
-        float v = ldy(y + (size_t)p * a.y_rs + c) * sc + sh;
+        float v = ldy((size_t)p * a.y_rs + c) * sc + sh;
         if (a.relu) v = fmaxf(v, 0.f);
         Z[p * ld + c] = v;
       }
@@ -320,7 +323,7 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
 #pragma unroll 2
       for (int pz = p0; pz < s.HWz; pz += pstep) {   // 2x2 max-pool straight from global memory (floor: last row/col dropped)
         int hz = pz / s.Wz, wz = pz - hz * s.Wz;
-        const float* y0 = y + (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
+        const size_t y0 = (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
         float v0_ = ldy(y0) * sc + sh, v1_ = ldy(y0 + a.y_rs) * sc + sh;
         float v2_ = ldy(y0 + (size_t)s.Wc * a.y_rs) * sc + sh, v3_ = ldy(y0 + (size_t)(s.Wc + 1) * a.y_rs) * sc + sh;
         float m = fmaxf(fmaxf(v0_, v1_), fmaxf(v2_, v3_));
@@ -334,12 +337,12 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
       int p = i / C, c = i - p * C;
       const float sc = a.apply_bn ? coef[c * 4 + 0] : 1.f, sh = a.apply_bn ? coef[c * 4 + 1] : 0.f;
       float v;
-      if (!pool) v = y[(size_t)p * a.y_rs + c] * sc + sh;
+      if (!pool) v = ldy((size_t)p * a.y_rs + c) * sc + sh;
       else {
         int hz = p / s.Wz, wz = p - hz * s.Wz;
-        const float* y0 = y + (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
-        v = fmaxf(fmaxf(y0[0] * sc + sh, y0[a.y_rs] * sc + sh),
-                  fmaxf(y0[(size_t)s.Wc * a.y_rs] * sc + sh, y0[(size_t)(s.Wc + 1) * a.y_rs] * sc + sh));
+        const size_t y0 = (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
+        v = fmaxf(fmaxf(ldy(y0) * sc + sh, ldy(y0 + a.y_rs) * sc + sh),
+                  fmaxf(ldy(y0 + (size_t)s.Wc * a.y_rs) * sc + sh, ldy(y0 + (size_t)(s.Wc + 1) * a.y_rs) * sc + sh));
       }
       if (a.relu) v = fmaxf(v, 0.f);
       Z[p * ld + c] = v;
@@ -477,10 +480,10 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
     float ry[NQ];
 #define DTA_STAGE_ISSUE(b_)                                                                          \
     {                                                                                                \
-      const float* y_ = a.y + (size_t)g * a.y_gs + (size_t)(b_) * s.HWc * a.y_rs;                    \
+      const size_t y_ = (size_t)g * a.y_gs + (size_t)(b_) * s.HWc * a.y_rs;                          \
       _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                                               \
         const int i = t + u * 256;                                                                   \
-        if (i < NEL) ry[u] = __builtin_nontemporal_load(y_ + (size_t)(i / CQ) * a.y_rs + (i % CQ));  /* next reader: the backward */ \
+        if (i < NEL) ry[u] = ld_fmt<true>(a.y, y_ + (size_t)(i / CQ) * a.y_rs + (i % CQ), CFG::YF);  /* next reader: the backward */ \
       }                                                                                              \
     }
 #define DTA_STAGE_LAND()                                                                             \
@@ -548,6 +551,18 @@ int launch_stage_fwd(const StageArgs& a_in, int G, hipStream_t st) {
   if (lds > 160 * 1024) { dta_set_error("stage_fwd: %dx%dx%d patch needs %zu B of LDS", a.Hc, a.Wc, a.C, lds); return 1; }
   // the three stages of the 11x11 network are fully specialised (stencils unroll, no index divisions)
   const bool net = a.apply_bn && a.relu && stage_net_cfg(a);
+  if (a.y_fmt == FMT_F16) {     // bf16 mode: conv outputs stored as IEEE half
+    if (a.C != 32 && a.C != 64 && a.C != 128) { dta_set_error("stage_fwd: 16-bit conv outputs need 32/64/128 channels"); return 1; }
+    if (net && a.C == 32) return launch_stage_fwd_c<T, StageCfg<32, 11, 11, 0, FMT_F16>>(a, G, lds, st);
+    if (net && a.C == 64) return launch_stage_fwd_c<T, StageCfg<64, 11, 11, 1, FMT_F16>>(a, G, lds, st);
+    if (net && a.C == 128) return launch_stage_fwd_c<T, StageCfg<128, 5, 5, 1, FMT_F16>>(a, G, lds, st);
+    switch (a.C) {
+      case 32: return launch_stage_fwd_c<T, StageCfg<32, 0, 0, 0, FMT_F16>>(a, G, lds, st);
+      case 64: return launch_stage_fwd_c<T, StageCfg<64, 0, 0, 0, FMT_F16>>(a, G, lds, st);
+      default: return launch_stage_fwd_c<T, StageCfg<128, 0, 0, 0, FMT_F16>>(a, G, lds, st);
+    }
+  }
+  if (a.y_fmt != FMT_F32) { dta_set_error("stage_fwd: unsupported conv-output format %d", a.y_fmt); return 1; }
   if (net && a.C == 32) return launch_stage_fwd_c<T, StageCfg<32, 11, 11, 0>>(a, G, lds, st);
   if (net && a.C == 64) return launch_stage_fwd_c<T, StageCfg<64, 11, 11, 1>>(a, G, lds, st);
   if (net && a.C == 128) return launch_stage_fwd_c<T, StageCfg<128, 5, 5, 1>>(a, G, lds, st);
@@ -720,7 +735,7 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
   TICK(3);
   // pool + ReLU backward, write dv and the per-patch BatchNorm-backward partial sums
   float* dv = ba.dv + (size_t)g * ba.dv_gs + (size_t)b * s.HWc * C;
-  const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
+  const size_t ybase = (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
   const float* coef = a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr;
   const int c = t % C, sl = t / C, nsl = 256 / C;
   float s1 = 0.f, s2 = 0.f;
@@ -738,7 +753,7 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
         if (a.relu && r <= 0.f) d = 0.f;
         dv[(size_t)p * C + c] = d;
         if (a.apply_bn) {
-          float xh = recover ? (r - bet) * inv_gam : (y[(size_t)p * a.y_rs + c] - mean) * rstd;
+          float xh = recover ? (r - bet) * inv_gam : (ld_fmt(a.y, ybase + (size_t)p * a.y_rs + c, CFG::YF) - mean) * rstd;
           s1 += d; s2 += d * xh;
         }
       }
@@ -753,7 +768,7 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
         int first = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          yv[k] = y[(size_t)po[k] * a.y_rs + c];
+          yv[k] = ld_fmt(a.y, ybase + (size_t)po[k] * a.y_rs + c, CFG::YF);
           float v = yv[k] * scale + shift;
           if (v > m) { m = v; first = k; }
         }
@@ -814,11 +829,11 @@ __global__ __launch_bounds__(256, (CFG::fixed && CFG::P == 0) ? 4 : 1) void k_st
     const float psc = coef[(t % CQ) * 4 + 0], psh = coef[(t % CQ) * 4 + 1];
 #define DTA_STAGE_ISSUE(b_)                                                                          \
     {                                                                                                \
-      const float* y_ = a.y + (size_t)g * a.y_gs + (size_t)(b_) * s.HWc * a.y_rs;                    \
+      const size_t y_ = (size_t)g * a.y_gs + (size_t)(b_) * s.HWc * a.y_rs;                          \
       const float* d_ = ba.da + (size_t)g * ba.da_gs + (size_t)(b_) * s.HWz * C;                     \
       _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                                               \
         const int i = t + u * 256;                                                                   \
-        if (i < NEL) { ry[u] = y_[(size_t)(i / CQ) * a.y_rs + (i % CQ)]; rq[u] = __builtin_nontemporal_load(d_ + i); } \
+        if (i < NEL) { ry[u] = ld_fmt<false>(a.y, y_ + (size_t)(i / CQ) * a.y_rs + (i % CQ), CFG::YF); rq[u] = __builtin_nontemporal_load(d_ + i); } \
       }                                                                                              \
     }
 #define DTA_STAGE_LAND(b_)                                                                           \
@@ -881,6 +896,18 @@ int launch_stage_bwd(const StageBwdArgs& a_in, int G, hipStream_t st) {
   size_t lds = stage_lds_floats(a.f, true) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_bwd: %dx%dx%d patch needs %zu B of LDS", a.f.Hc, a.f.Wc, a.f.C, lds); return 1; }
   const bool net = a.f.apply_bn && a.f.relu && stage_net_cfg(a.f);
+  if (a.f.y_fmt == FMT_F16) {
+    if (a.f.C != 32 && a.f.C != 64 && a.f.C != 128) { dta_set_error("stage_bwd: 16-bit conv outputs need 32/64/128 channels"); return 1; }
+    if (net && a.f.C == 32) return launch_stage_bwd_c<StageCfg<32, 11, 11, 0, FMT_F16>>(a, G, lds, st);
+    if (net && a.f.C == 64) return launch_stage_bwd_c<StageCfg<64, 11, 11, 1, FMT_F16>>(a, G, lds, st);
+    if (net && a.f.C == 128) return launch_stage_bwd_c<StageCfg<128, 5, 5, 1, FMT_F16>>(a, G, lds, st);
+    switch (a.f.C) {
+      case 32: return launch_stage_bwd_c<StageCfg<32, 0, 0, 0, FMT_F16>>(a, G, lds, st);
+      case 64: return launch_stage_bwd_c<StageCfg<64, 0, 0, 0, FMT_F16>>(a, G, lds, st);
+      default: return launch_stage_bwd_c<StageCfg<128, 0, 0, 0, FMT_F16>>(a, G, lds, st);
+    }
+  }
+  if (a.f.y_fmt != FMT_F32) { dta_set_error("stage_bwd: unsupported conv-output format %d", a.f.y_fmt); return 1; }
   if (net && a.f.C == 32) return launch_stage_bwd_c<StageCfg<32, 11, 11, 0>>(a, G, lds, st);
   if (net && a.f.C == 64) return launch_stage_bwd_c<StageCfg<64, 11, 11, 1>>(a, G, lds, st);
   if (net && a.f.C == 128) return launch_stage_bwd_c<StageCfg<128, 5, 5, 1>>(a, G, lds, st);
@@ -954,14 +981,14 @@ int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const Colsu
   return 0;
 }
 
-template <typename T>
+template <typename T, int YF>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
   // per channel: dy = k0 * dv + k1 * y + k2  (folded from A*(dv - Bc - ((y-mean)*rstd)*Cc)), coefficients in LDS
   __shared__ float sk[3][128];
   const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = a.C;
   const int W2 = a.W + 2, Q = (a.H + 2) * W2, HW = a.H * a.W, nch = C / 16;
   const float* dv = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
-  const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs;
+  const size_t ybase = (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs;   // element index (the conv output may be 16-bit)
   const float* coef = a.coef + (size_t)g * a.coef_gs;
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
   for (int c = t; c < C; c += 256) {
@@ -985,8 +1012,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
       float yv[VW], dvv[VW];
 #pragma unroll
       for (int k = 0; k < VW; k += 4) {
-        float4 t4 = *reinterpret_cast<const float4*>(y + (size_t)p * a.y_rs + cb + k);
-        yv[k] = t4.x; yv[k + 1] = t4.y; yv[k + 2] = t4.z; yv[k + 3] = t4.w;
+        float t4[4];
+        ld4_fmt(t4, a.y, ybase + (size_t)p * a.y_rs + cb + k, YF);
+        yv[k] = t4[0]; yv[k + 1] = t4[1]; yv[k + 2] = t4[2]; yv[k + 3] = t4[3];
         float4 d4 = *reinterpret_cast<const float4*>(dv + (size_t)p * C + cb + k);
         dvv[k] = d4.x; dvv[k + 1] = d4.y; dvv[k + 2] = d4.z; dvv[k + 3] = d4.w;
       }
@@ -1006,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
 
 // Same transform, patch image assembled in LDS: pixel-major float4 reads of dv / y (fully coalesced), the tile-layout
 // image of the patch (halo included) built in LDS, then one linear 16-byte-per-lane copy to HBM.
-template <typename T>
+template <typename T, int YF>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_apply[];
   // a workgroup = one patch x one slice of CS channels (blockIdx.z): small LDS images keep 8 workgroups on a CU
@@ -1018,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   T* img = (T*)(smem_apply + ((3 * CS * 4 + HW * 4 + 15) & ~15)); // [nch][Q][16]
   const float* dvp = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
   const float* dv = dvp + c0;
-  const float* y = a.y + (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs + c0;
+  const size_t ybase = (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs + c0;   // element index (the conv output may be 16-bit)
   const unsigned char* fpos = reinterpret_cast<const unsigned char*>(dvp + (size_t)a.Hz * a.Wz * C) + c0;   // compact form only
   const float* coef = a.coef + (size_t)g * a.coef_gs;
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
@@ -1041,14 +1069,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   const int total = HW * C4;
   constexpr int UB = 4;
   for (int i0 = t; i0 < total; i0 += 256 * UB) {
-    f32x4 yv[UB], dvv[UB];
+    float yv[UB][4];
+    f32x4 dvv[UB];
     int lq[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int i = i0 + u * 256;
       if (i < total) {
         const int pix = i >> c4sh, c4 = (i - (pix << c4sh)) * 4;
-        yv[u] = __builtin_nontemporal_load((const f32x4*)(y + (size_t)pix * a.y_rs + c4));   // last reader of the conv output
+        ld4_fmt<true>(yv[u], a.y, ybase + (size_t)pix * a.y_rs + c4, YF);   // last reader of the conv output
         const int l = lut[pix];
         lq[u] = l;
         if (!a.dv_compact) dvv[u] = __builtin_nontemporal_load((const f32x4*)(dv + (size_t)pix * C + c4));
@@ -1112,12 +1141,16 @@ int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st) {
   a.cslice = bn_bwd_apply_cslice(a.C, a.H, a.W, sizeof(T));
   const size_t lds = bn_bwd_apply_lds_bytes(a.cslice, a.H, a.W, sizeof(T));
   if (a.dv_compact && lds > 48 * 1024) { dta_set_error("bn_bwd_apply: compact dv needs the LDS-image kernel"); return 1; }
+  if (a.y_fmt != FMT_F32 && a.y_fmt != FMT_F16) { dta_set_error("bn_bwd_apply: unsupported conv-output format %d", a.y_fmt); return 1; }
+  const bool h = a.y_fmt == FMT_F16;
   if (lds <= 48 * 1024) {
-    hipLaunchKernelGGL(k_bn_bwd_apply_lds<T>, dim3(a.B, G, a.C / a.cslice), dim3(256), lds, st, a);
+    if (h) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16>), dim3(a.B, G, a.C / a.cslice), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F32>), dim3(a.B, G, a.C / a.cslice), dim3(256), lds, st, a);
     DTA_CHECK_LAUNCH("k_bn_bwd_apply_lds");
     return 0;
   }
-  hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(a.B, G), dim3(256), 0, st, a);
+  if (h) hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F16>), dim3(a.B, G), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F32>), dim3(a.B, G), dim3(256), 0, st, a);
   DTA_CHECK_LAUNCH("k_bn_bwd_apply");
   return 0;
 }

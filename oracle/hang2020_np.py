@@ -220,6 +220,38 @@ def _q(a):
     return a if _QUANT is None else _QUANT(a)
 
 
+def f16_round(a):
+    """Round to IEEE half (saturating at +-65504) and return in the input's dtype: how the bf16 mode of the HIP path
+    stores the conv outputs between kernels."""
+    return np.clip(a, -65504.0, 65504.0).astype(np.float16).astype(a.dtype)
+
+
+_QUANT_Y = None
+_QUANT_G = None
+
+
+def set_storage_quantizers(conv_output=None, grad_map=None):
+    """Emulate the 16-bit inter-kernel storage of the HIP path's bf16 mode: `conv_output` rounds the pre-BatchNorm conv
+    outputs AFTER their batch statistics were taken from the exact values (f16_round), `grad_map` rounds the gradient
+    maps handed from one backward kernel to the next (bf16_round).  None = keep wide (default)."""
+    global _QUANT_Y, _QUANT_G
+    _QUANT_Y, _QUANT_G = conv_output, grad_map
+
+
+def bf16_mode(on=True):
+    """All roundings of the HIP path's bf16 mode at once (operands bf16, conv outputs half, gradient maps bf16)."""
+    set_conv_operand_quantizer(bf16_round if on else None)
+    set_storage_quantizers(f16_round if on else None, bf16_round if on else None)
+
+
+def _qy(a):
+    return a if _QUANT_Y is None else _QUANT_Y(a)
+
+
+def _qg(a):
+    return a if _QUANT_G is None else _QUANT_G(a)
+
+
 # ----------------------------------------------------------------------------------------
 # conv_module  (src/models/Hang2020.py:14-31)
 # ----------------------------------------------------------------------------------------
@@ -244,6 +276,7 @@ def conv_module_fwd(p, pre, x, pool, training, dt=np.float32):
         mu = p[pre + "bn1.running_mean"].astype(dt)
         var = p[pre + "bn1.running_var"].astype(dt)
     rstd = 1.0 / np.sqrt(var + BN_EPS)
+    y = _qy(y)        # (statistics above come from the unrounded values, as in the conv kernel's epilogue)
     xhat = (y - mu[None, :, None, None]) * rstd[None, :, None, None]
     v = xhat * g[None, :, None, None] + be[None, :, None, None]
     r = np.maximum(v, 0)

@@ -53,13 +53,13 @@ def _whole(got, want, skip=("conv_layer.bias",)):
 
 def _oracle(p, x, y, w, quantized):
     if quantized:
-        O.set_conv_operand_quantizer(O.bf16_round)
+        O.bf16_mode(True)
     try:
         logits, cache, upd = O.hang2020_fwd(p, x, True, np.float64)
         loss, dl = O.weighted_cross_entropy(logits, y, w)
         g = O.hang2020_bwd(p, cache, dl, np.float64)
     finally:
-        O.set_conv_operand_quantizer(None)
+        O.bf16_mode(False)
     return logits, loss, g, upd
 
 
@@ -91,13 +91,13 @@ def test_fused_input_bf16_step_vs_oracle(bands, classes, B):
         # oracle above in fp64; values that land on different sides of a bf16 rounding boundary of the NEXT operand
         # (gated maps, output gradients) differ by a whole bf16 ulp.  The oracle itself, run in float32, is equally far
         # from its float64 run -- that distance, not the 1e-2 budget, is the resolution of this comparison
-        O.set_conv_operand_quantizer(O.bf16_round)
+        O.bf16_mode(True)
         try:
             l32, c32, _ = O.hang2020_fwd(p, x, True, np.float32)
             _, dl32 = O.weighted_cross_entropy(l32, y, w)
             g32 = O.hang2020_bwd(p, c32, dl32, np.float32)
         finally:
-            O.set_conv_operand_quantizer(None)
+            O.bf16_mode(False)
         self_noise, _ = _whole(g32, q_g)
         print(f"B={B}: float32 oracle vs float64 oracle (same rounded operands): whole-gradient rel-L2 {self_noise:.2e}")
         bound = max(bound, 1.5 * self_noise)

@@ -162,12 +162,12 @@ def test_spectral_network_24x24_crops(golden, precision):
             if not k.endswith("conv_layer.bias"):
                 assert rel_l2(prm.grad.cpu().numpy(), g[f"spectral24/g/{k}"]) < TOL, k
         return
-    O.set_conv_operand_quantizer(O.bf16_round)
+    O.bf16_mode(True)
     try:
         rs, cache, _ = O.subnet_fwd(p, "", "spectral", xn, True, np.float64)
         rg = O.subnet_bwd(p, "", cache, [d.astype(np.float64) for d in dsn], np.float64)
     finally:
-        O.set_conv_operand_quantizer(None)
+        O.bf16_mode(False)
     for i in range(3):
         assert rel_l2(s[i].detach().cpu().numpy(), rs[i]) < 1e-3
         assert rel_l2(s[i].detach().cpu().numpy(), g[f"spectral24/head{i + 1}"]) < 1e-2     # vs the exact reference

@@ -308,13 +308,13 @@ def test_bf16_path_within_tolerance(bands, classes, B, seed):
     print("bf16 total grad norm rel err vs exact", abs(tot - tot_ref) / tot_ref)
     assert abs(tot - tot_ref) / tot_ref < BF16_TOL
     # same operand rounding in the oracle -> tensor-by-tensor agreement
-    O.set_conv_operand_quantizer(O.bf16_round)
+    O.bf16_mode(True)
     try:
         q_logits, qc, _ = O.hang2020_fwd(p, x, True, np.float64)
         _, qdl = O.weighted_cross_entropy(q_logits, y, w)
         q_g = O.hang2020_bwd(p, qc, qdl, np.float64)
     finally:
-        O.set_conv_operand_quantizer(None)
+        O.bf16_mode(False)
     assert rel_l2(logits.detach().cpu().numpy(), q_logits) < 1e-3
     got = grads_of(m)
     worst = (0.0, None)
