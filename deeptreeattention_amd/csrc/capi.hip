@@ -45,10 +45,10 @@ inline void prof_end(int site, hipStream_t st) {
 }
 
 // Developer switches (same-box A/B runs): the environment is read once per process, not per call.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act; };
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; };
 inline Switches read_switches() {
   return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr,
-          getenv("DTA_FP32_ACT") != nullptr};
+          getenv("DTA_FP32_ACT") != nullptr, getenv("DTA_NO_LEAN") != nullptr};
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -237,6 +237,7 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
   }
   s.y = at<float>(ws, p.y[L]);
   s.y_fmt = p.y_fmt;
+  s.lean = !switches().no_lean;
   if (L == 0 && p.shared_x) { s.y_gs = 32; s.y_rs = 32 * G; }
   else { s.y_gs = (size_t)B * p.HWc[L] * C; s.y_rs = C; }
   s.coef = at<float>(ws, p.coef[L]); s.coef_gs = C * 4;

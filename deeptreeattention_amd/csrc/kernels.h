@@ -165,6 +165,7 @@ struct StageArgs {
   // (conv partials in training mode, running statistics otherwise) in its prologue; workgroup 0 of each group also
   // writes them to `coef` for the backward and updates the running statistics
   int bn_inkernel; BnFinK bnfin;
+  int lean;                            // allow the lean register-resident kernels for the 11x11 network stages
 };
 template <typename T> int launch_stage_fwd(const StageArgs& a, int G, hipStream_t st);
 

@@ -543,10 +543,15 @@ static bool stage_net_cfg(const StageArgs& a) {
   return true;
 }
 
+template <typename T> int launch_stage_fwd_lean(const StageArgs& a, int G, hipStream_t st);
+
 template <typename T>
 int launch_stage_fwd(const StageArgs& a_in, int G, hipStream_t st) {
   StageArgs a = a_in;
   a.vslot = stage_vslot_for(a, G);
+  // the three stages of the 11x11 networks have lean register-resident forms (end of this file)
+  if (a.lean && a.apply_bn && a.relu && stage_net_cfg(a) && !a.a_nchw && (a.y_fmt == FMT_F32 || a.y_fmt == FMT_F16))
+    return launch_stage_fwd_lean<T>(a, G, st);
   size_t lds = stage_lds_floats(a, false) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_fwd: %dx%dx%d patch needs %zu B of LDS", a.Hc, a.Wc, a.C, lds); return 1; }
   // the three stages of the 11x11 network are fully specialised (stencils unroll, no index divisions)
@@ -1156,5 +1161,353 @@ int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st) {
 }
 template int launch_bn_bwd_apply<float>(const BnBwdApplyArgs&, int, hipStream_t);
 template int launch_bn_bwd_apply<bf16_t>(const BnBwdApplyArgs&, int, hipStream_t);
+
+// ================================================================================================
+// Lean forms of the three 11x11-network stages.
+//
+// The kernels above keep a patch as [pixel][channel] floats in LDS and run every step as a loop of scalar LDS / global
+// accesses with per-element index arithmetic; on the bench size they are instruction-issue bound (SQ counters: the
+// SIMDs issue 50-75 % of the time, >80 % of it address arithmetic).  Here a thread owns ITEMS (pixel, 8-channel octet):
+// the conv output arrives as one 16-byte load per item (8 halves, or two for fp32), the gated map leaves as one
+// 16-byte tile-row store per item, BatchNorm / ReLU / pooling / gating happen in registers, and LDS only carries what
+// crosses threads: the patch for the per-channel sums, the attention vectors / single-channel maps, the reductions.
+// Restates the same reference lines as above (Hang2020.py:24-31, :105-124, :149-168).
+// ================================================================================================
+template <int C_, int HC_, int WC_, int POOL_, int YF_>
+struct LeanCfg {
+  static constexpr int C = C_, HC = HC_, WC = WC_, POOL = POOL_, YF = YF_;
+  static constexpr int HZ = POOL ? HC / 2 : HC, WZ = POOL ? WC / 2 : WC, NP = HZ * WZ, HWC = HC * WC;
+  static constexpr int NO = C / 8;                        // octets per pixel
+  static constexpr int ITEMS = NP * NO;                   // (pixel, octet) items per patch
+  static constexpr int PPW = ITEMS <= 64 ? 4 : 1;         // patches per 256-thread workgroup
+  static constexpr int TPP = 256 / PPW;                   // threads per patch
+  static constexpr int IPT = (ITEMS + TPP - 1) / TPP;     // items per thread
+  static constexpr int K = C == 32 ? 7 : (C == 64 ? 5 : 3);     // spatial stencil size (Hang2020.py:77-85)
+  static constexpr int PS = C == 32 ? 4 : (C == 64 ? 2 : 1);    // spatial class-pool size (:91-99)
+  static constexpr int R = K / 2, WP = WZ + 2 * R, HPAD = HZ + 2 * R, NPAD = HPAD * WP;
+  static constexpr int W2 = WZ + 2, QZ = (HZ + 2) * W2;   // haloed grid of the gated map's conv tiles
+  static constexpr int NPART = 256 / C;                   // matvec: input slices per output
+  // LDS floats per patch slot: the patch [NP][C], then vectors: spectral pooled|h|gate, spatial m|t1 (padded) | s
+  static constexpr int VEC = 3 * C > 2 * NPAD + NP ? 3 * C : 2 * NPAD + NP;
+  static constexpr int SLOT = NP * C + VEC;
+  static constexpr int RED = 1032;                        // reduction scratch shared by the workgroup (>= 4 C + 516)
+  static constexpr int LDS_FWD = 2 * C + PPW * SLOT + RED;
+};
+
+// eight consecutive channels of one conv-output pixel -> floats
+template <int YF, bool NT>
+__device__ __forceinline__ void lean_ld8(float (&v)[8], const void* base, size_t i) {
+  if (YF == FMT_F32) {
+    const f32x4* p = (const f32x4*)((const float*)base + i);
+    const f32x4 a = NT ? __builtin_nontemporal_load(p) : p[0], b = NT ? __builtin_nontemporal_load(p + 1) : p[1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+  } else {
+    const u32x4* p = (const u32x4*)((const unsigned short*)base + i);
+    const u32x4 q = NT ? __builtin_nontemporal_load(p) : *p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = unpack_lo(q[e], YF); v[2 * e + 1] = unpack_hi(q[e], YF); }
+  }
+}
+// one octet of a tile row: channels 8 * (o & 1) .. + 8 of chunk o / 2 at haloed-grid row q
+__device__ __forceinline__ void lean_tl_store8(bf16_t* tile, int NCQ, int q, int o, const float (&v)[8]) {
+  (void)NCQ;
+  u32x4 u;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) u[e] = pack2_fmt(v[2 * e], v[2 * e + 1], FMT_BF16);
+  *reinterpret_cast<u32x4*>(tile + ((size_t)(o >> 1) * NCQ + q) * 16 + (o & 1) * 8) = u;
+}
+__device__ __forceinline__ void lean_tl_store8(float* tile, int NCQ, int q, int o, const float (&v)[8]) {
+  // fp32 rows are XOR-swizzled (tl_pos<float>): channel c16 sits at c16 ^ (q & 15); an aligned octet stays one
+  const int s = q & 15, half = (o & 1) ^ (s >> 3), sw = s & 7;
+  float w[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) w[e] = v[e ^ sw];       // out[e ^ sw] = v[e]  <=>  out[e] = v[e ^ sw]
+  float* row = tile + ((size_t)(o >> 1) * NCQ + q) * 16 + half * 8;
+  *reinterpret_cast<f32x4*>(row) = f32x4{w[0], w[1], w[2], w[3]};
+  *reinterpret_cast<f32x4*>(row + 4) = f32x4{w[4], w[5], w[6], w[7]};
+}
+// zero the halo rows of one patch's tiles (the workspace is borrowed: nothing in it can be assumed)
+template <typename T, typename CFG>
+__device__ __forceinline__ void lean_tl_halo(T* tile, int lt) {
+  constexpr int NH = 2 * CFG::W2 + 2 * CFG::HZ, NCH = CFG::C / 16, VPR = 16 * (int)sizeof(T) / 16;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  for (int i = lt; i < NH * NCH * VPR; i += CFG::TPP) {
+    const int v = i % VPR, r = (i / VPR) % NH, ch = i / (VPR * NH);
+    int q;
+    if (r < CFG::W2) q = r;
+    else if (r < 2 * CFG::W2) q = (CFG::HZ + 1) * CFG::W2 + (r - CFG::W2);
+    else { const int k = r - 2 * CFG::W2; q = ((k >> 1) + 1) * CFG::W2 + (k & 1) * (CFG::W2 - 1); }
+    reinterpret_cast<u32x4*>(tile + ((size_t)ch * CFG::QZ + q) * 16)[v] = zero;
+  }
+}
+// per-channel sum over the pixels of f(p, c) with the patch in LDS ([NP][C]); all 256 threads call it.
+// red: RED floats; out[slot][c] for every patch slot.
+template <typename CFG, typename F>
+__device__ __forceinline__ void lean_colsum(float* red, float* out, int out_stride, float scale, F f) {
+  constexpr int C = CFG::C, TPP = CFG::TPP, NP = CFG::NP;
+  const int t = threadIdx.x, slot = t / TPP, lt = t % TPP;
+  if (TPP >= C) {
+    constexpr int RS = TPP / C > 0 ? TPP / C : 1;
+    const int c = lt % C, sl = lt / C;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int p = sl; p < NP; p += RS) acc += f(slot, p, c);
+    red[t] = acc;
+    __syncthreads();
+    if (lt < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < RS; ++k) s += red[slot * TPP + k * C + lt];
+      out[slot * out_stride + lt] = s * scale;
+    }
+  } else {
+    for (int c = lt; c < C; c += TPP) {
+      float acc = 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) acc += f(slot, p, c);
+      out[slot * out_stride + c] = acc * scale;
+    }
+  }
+  __syncthreads();
+}
+// y[slot][o] = sum_i W[i * C + o] * x[slot][i] for every patch slot of the workgroup (W input-major, so lanes read
+// consecutive o): thread (o, part) covers C / NPART inputs for all slots, the parts meet in LDS.  `fin(slot, o, sum)`.
+template <typename CFG, typename F>
+__device__ __forceinline__ void lean_matvec(const float* W, const float* x, int x_stride, float* red, F fin) {
+  constexpr int C = CFG::C, NPART = CFG::NPART, PPW = CFG::PPW, PER = C / NPART;
+  const int t = threadIdx.x, o = t % C, part = t / C;
+  float acc[PPW];
+#pragma unroll
+  for (int s = 0; s < PPW; ++s) acc[s] = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < PER; ++k) {
+    const int i = part * PER + k;
+    const float w = W[(size_t)i * C + o];
+#pragma unroll
+    for (int s = 0; s < PPW; ++s) acc[s] += w * x[s * x_stride + i];
+  }
+#pragma unroll
+  for (int s = 0; s < PPW; ++s) red[(s * NPART + part) * C + o] = acc[s];
+  __syncthreads();
+  for (int i = t; i < PPW * C; i += 256) {
+    const int s = i / C, oo = i % C;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) v += red[(s * NPART + k) * C + oo];
+    fin(s, oo, v);
+  }
+  __syncthreads();
+}
+// sum over the NO lanes that share a pixel (consecutive lanes: o = item % NO); every lane ends with the total
+template <int NO>
+__device__ __forceinline__ float lean_octet_sum(float v) {
+  v += lane_xor1(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
+  if (NO >= 8) v += __shfl_xor(v, 4);
+  if (NO >= 16) v += __shfl_xor(v, 8);
+  return v;
+}
+
+template <typename T, typename CFG>
+__global__ __launch_bounds__(256) void k_stage_fwd_lean(StageArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int C = CFG::C, NO = CFG::NO, NP = CFG::NP, TPP = CFG::TPP, IPT = CFG::IPT, PPW = CFG::PPW, WZ = CFG::WZ;
+  constexpr int K = CFG::K, R = CFG::R, WP = CFG::WP, NPAD = CFG::NPAD;
+  const int g = blockIdx.y, t = threadIdx.x, slot = t / TPP, lt = t % TPP;
+  const int b = blockIdx.x * PPW + slot;
+  const bool live = b < a.B;
+  const int kind = a.kind[g];
+  float* coefL = sm;                                   // [C][2] scale, shift
+  float* Zs = sm + 2 * C + slot * CFG::SLOT;           // [NP][C]
+  float* vec = Zs + NP * C;                            // spectral: pooled | h | gate ; spatial: m | t1 (padded maps) | s
+  float* red = sm + 2 * C + PPW * CFG::SLOT;           // [RED]
+  float* vec0 = sm + 2 * C + NP * C;                   // slot 0's vectors (matvec operands are addressed with a slot stride)
+
+  // ---- conv output of this thread's items in flight first ----
+  float z[IPT][8];
+  const size_t ypatch = (size_t)g * a.y_gs + (size_t)(live ? b : 0) * CFG::HWC * a.y_rs;
+  float yraw[IPT][CFG::POOL ? 4 : 1][8];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0;
+    const int p = itc / NO, o = itc % NO;
+    if (CFG::POOL) {
+      const int hz = p / WZ, wz = p % WZ, p00 = (2 * hz) * CFG::WC + 2 * wz;
+      const int po[4] = {p00, p00 + 1, p00 + CFG::WC, p00 + CFG::WC + 1};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lean_ld8<CFG::YF, true>(yraw[j][k], a.y, ypatch + (size_t)po[k] * a.y_rs + o * 8);
+    } else {
+      lean_ld8<CFG::YF, true>(yraw[j][0], a.y, ypatch + (size_t)p * a.y_rs + o * 8);
+    }
+  }
+  // ---- BatchNorm coefficients (from the finalize launch, or derived here in eval mode) ----
+  if (a.bn_inkernel) {
+    float* lc = red;                                    // [C][4], C <= 128 -> 512 floats, then 514 of scratch
+    bn_coef_block(a.bnfin, g, lc, red + 4 * C, blockIdx.x == 0);
+    for (int i = t; i < 2 * C; i += 256) coefL[i] = lc[(i >> 1) * 4 + (i & 1)];
+  } else {
+    const float* coef = a.coef + (size_t)g * a.coef_gs;
+    for (int i = t; i < 2 * C; i += 256) coefL[i] = coef[(i >> 1) * 4 + (i & 1)];
+  }
+  if (kind == KIND_SPATIAL)
+    for (int i = lt; i < 2 * NPAD; i += TPP) vec[i] = 0.f;      // borders of the padded maps
+  __syncthreads();
+  // ---- BN -> ReLU -> (2x2 max-pool), patch into LDS ----
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int it = lt + j * TPP;
+    const int itc = it < CFG::ITEMS ? it : 0, p = itc / NO, o = itc % NO;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(coefL + (o * 8 + e) * 2);
+      sc[e] = q[0]; sh[e] = q[1]; sc[e + 1] = q[2]; sh[e + 1] = q[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float m = yraw[j][0][e] * sc[e] + sh[e];
+      if (CFG::POOL) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) m = fmaxf(m, yraw[j][k][e] * sc[e] + sh[e]);
+      }
+      z[j][e] = (live && it < CFG::ITEMS) ? fmaxf(m, 0.f) : 0.f;
+    }
+    if (it < CFG::ITEMS) {
+      *reinterpret_cast<f32x4*>(Zs + p * C + o * 8) = f32x4{z[j][0], z[j][1], z[j][2], z[j][3]};
+      *reinterpret_cast<f32x4*>(Zs + p * C + o * 8 + 4) = f32x4{z[j][4], z[j][5], z[j][6], z[j][7]};
+    }
+  }
+  __syncthreads();
+  T* tile = a.a_tl ? (T*)a.a_tl + (size_t)g * a.a_gs + ((size_t)(live ? b : 0) * a.a_nc + a.a_ch0) * CFG::QZ * 16 : nullptr;
+  float* feat = (a.feat && live) ? a.feat + (size_t)g * a.feat_gs + (size_t)b * a.F[g] : nullptr;
+  float* save = (a.attsave && live) ? a.attsave + ((size_t)g * a.B + b) * a.attsave_ld : nullptr;
+  float* sm0 = sm + 2 * C;
+  if (kind == KIND_SPECTRAL) {
+    float* pooled = vec; float* hL = vec + C; float* gL = vec + 2 * C;
+    lean_colsum<CFG>(red, vec0, CFG::SLOT, 1.f / (float)NP, [&](int s, int p, int c) { return sm0[s * CFG::SLOT + p * C + c]; });
+    const float* c1 = a.att[g].p[1]; const float* c2 = a.att[g].p[3];
+    lean_matvec<CFG>(a.att[g].p[0], vec0, CFG::SLOT, red,
+                     [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + C + o] = fmaxf(v + c1[o], 0.f); });
+    lean_matvec<CFG>(a.att[g].p[2], vec0 + C, CFG::SLOT, red,
+                     [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + 2 * C + o] = sigmoidf_(v + c2[o]); });
+    if (save) for (int i = lt; i < 3 * C; i += TPP) __builtin_nontemporal_store(vec[i], save + i);
+    if (feat) for (int c = lt; c < C; c += TPP) feat[c] = gL[c] * pooled[c];      // mean_p(z * gate) = gate * mean_p(z)
+    if (tile && live) {
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = lt + j * TPP;
+        if (it >= CFG::ITEMS) continue;
+        const int p = it / NO, o = it % NO, h = p / WZ, w = p % WZ;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = z[j][e] * gL[o * 8 + e];
+        lean_tl_store8(tile, CFG::QZ, (h + 1) * CFG::W2 + w + 1, o, v);
+      }
+    }
+  } else if (kind == KIND_SPATIAL) {
+    float* mL = vec; float* t1L = vec + NPAD; float* sL = vec + 2 * NPAD;
+    const float* wc = a.att[g].p[0]; const float bc = a.att[g].p[1][0];
+    const float* k1 = a.att[g].p[2]; const float b1 = a.att[g].p[3][0];
+    const float* k2 = a.att[g].p[4]; const float b2 = a.att[g].p[5][0];
+    // m = relu(channel_pool(z)): 8 channels per lane, the NO lanes of a pixel meet through DPP / shuffles
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, p = itc / NO, o = itc % NO;
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += wc[o * 8 + e] * z[j][e];
+      acc = lean_octet_sum<NO>(acc);
+      if (it < CFG::ITEMS && o == 0) mL[(p / WZ + R) * WP + p % WZ + R] = fmaxf(acc + bc, 0.f);
+    }
+    __syncthreads();
+    // the two k x k stencils: the NO lanes of a pixel split the kernel rows
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const float* src = pass ? t1L : mL; const float* kw = pass ? k2 : k1;
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, p = itc / NO, o = itc % NO, h = p / WZ, w = p % WZ;
+        float acc = 0.f;
+        for (int ky = o; ky < K; ky += NO) {
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) acc += kw[ky * K + kx] * src[(h + ky) * WP + w + kx];
+        }
+        acc = lean_octet_sum<NO>(acc);
+        if (it < CFG::ITEMS && o == 0) {
+          if (pass == 0) t1L[(h + R) * WP + w + R] = fmaxf(acc + b1, 0.f);
+          else sL[p] = sigmoidf_(acc + b2);
+        }
+      }
+      __syncthreads();
+    }
+    if (save) {     // m | t1 (padded maps, zero borders included) | s, one slot of a.vslot floats each
+      for (int i = lt; i < NPAD; i += TPP) {
+        __builtin_nontemporal_store(mL[i], save + i);
+        __builtin_nontemporal_store(t1L[i], save + a.vslot + i);
+      }
+      for (int p = lt; p < NP; p += TPP) __builtin_nontemporal_store(sL[p], save + 2 * a.vslot + p);
+    }
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int it = lt + j * TPP;
+      if (it >= CFG::ITEMS) continue;
+      const int p = it / NO, o = it % NO, h = p / WZ, w = p % WZ;
+      const float sp = sL[p];
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = z[j][e] * sp;
+      if (tile && live) lean_tl_store8(tile, CFG::QZ, (h + 1) * CFG::W2 + w + 1, o, v);
+      if (feat) {   // the gated map replaces the patch in LDS for the class pool below
+        *reinterpret_cast<f32x4*>(Zs + p * C + o * 8) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(Zs + p * C + o * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      }
+    }
+    if (a.feat) {
+      __syncthreads();
+      if (feat) {
+        constexpr int PS = CFG::PS, HPc = CFG::HZ / PS, WPc = CFG::WZ / PS;
+        for (int i = lt; i < C * HPc * WPc; i += TPP) {       // flatten order of the reference: (c, ph, pw)
+          const int c = i / (HPc * WPc), rem = i % (HPc * WPc), ph = rem / WPc, pw = rem % WPc;
+          float m = -3.4e38f;
+#pragma unroll
+          for (int dy = 0; dy < PS; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < PS; ++dx) m = fmaxf(m, Zs[((ph * PS + dy) * WZ + pw * PS + dx) * C + c]);
+          feat[i] = m;
+        }
+      }
+    }
+  } else if (feat) {   // plain network (vanilla_CNN): the last stage's map is the classifier input, NCHW flatten
+    for (int i = lt; i < C * NP; i += TPP) feat[i] = Zs[(i % NP) * C + i / NP];
+  }
+  if (kind != KIND_SPECTRAL && kind != KIND_SPATIAL && tile && live) {
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int it = lt + j * TPP;
+      if (it >= CFG::ITEMS) continue;
+      const int p = it / NO, o = it % NO;
+      lean_tl_store8(tile, CFG::QZ, (p / WZ + 1) * CFG::W2 + p % WZ + 1, o, z[j]);
+    }
+  }
+  if (tile && live) lean_tl_halo<T, CFG>(tile, lt);
+}
+
+template <typename T, typename CFG>
+static int launch_stage_fwd_lean_c(const StageArgs& a, int G, hipStream_t st) {
+  const size_t lds = (size_t)CFG::LDS_FWD * 4;     // < 24 KiB: no attribute needed
+  hipLaunchKernelGGL((k_stage_fwd_lean<T, CFG>), dim3((a.B + CFG::PPW - 1) / CFG::PPW, G), dim3(256), lds, st, a);
+  DTA_CHECK_LAUNCH("k_stage_fwd_lean");
+  return 0;
+}
+template <typename T>
+int launch_stage_fwd_lean(const StageArgs& a, int G, hipStream_t st) {
+  const bool h = a.y_fmt == FMT_F16;
+  if (a.C == 32) return h ? launch_stage_fwd_lean_c<T, LeanCfg<32, 11, 11, 0, FMT_F16>>(a, G, st) : launch_stage_fwd_lean_c<T, LeanCfg<32, 11, 11, 0, FMT_F32>>(a, G, st);
+  if (a.C == 64) return h ? launch_stage_fwd_lean_c<T, LeanCfg<64, 11, 11, 1, FMT_F16>>(a, G, st) : launch_stage_fwd_lean_c<T, LeanCfg<64, 11, 11, 1, FMT_F32>>(a, G, st);
+  return h ? launch_stage_fwd_lean_c<T, LeanCfg<128, 5, 5, 1, FMT_F16>>(a, G, st) : launch_stage_fwd_lean_c<T, LeanCfg<128, 5, 5, 1, FMT_F32>>(a, G, st);
+}
+template int launch_stage_fwd_lean<float>(const StageArgs&, int, hipStream_t);
+template int launch_stage_fwd_lean<bf16_t>(const StageArgs&, int, hipStream_t);
 
 }  // namespace dta
