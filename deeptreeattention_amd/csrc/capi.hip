@@ -1,6 +1,7 @@
 // C-ABI entry points (include/dta_hip.h) and the launch orchestration of the Hang2020 hot path.
 // Host code only decides buffer carving and launch order; all arithmetic is in conv.hip / stage.hip / heads.hip.
 #include <math.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -19,6 +20,9 @@ void dta_set_error(const char* fmt, ...) {
 }
 
 namespace {
+
+// lean stage kernels in use: bit 0 = forward stages, bits 1..3 = backward of the 32 / 64 / 128-channel stage
+constexpr int DTA_LEAN_DEFAULT = 15;
 
 // Optional HIP-event timing of one launch site (bench.py's roofline leg): events are recorded on the same
 // stream as the kernel, immediately before and after its launch.  Host-side state only; off by default.
@@ -45,10 +49,11 @@ inline void prof_end(int site, hipStream_t st) {
 }
 
 // Developer switches (same-box A/B runs): the environment is read once per process, not per call.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; };
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; };
 inline Switches read_switches() {
   return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr,
-          getenv("DTA_FP32_ACT") != nullptr, getenv("DTA_NO_LEAN") != nullptr};
+          getenv("DTA_FP32_ACT") != nullptr, getenv("DTA_NO_LEAN") != nullptr,
+          getenv("DTA_LEAN_MASK") ? atoi(getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT};
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -237,7 +242,7 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
   }
   s.y = at<float>(ws, p.y[L]);
   s.y_fmt = p.y_fmt;
-  s.lean = !switches().no_lean;
+  s.lean = switches().no_lean ? 0 : switches().lean_mask;
   if (L == 0 && p.shared_x) { s.y_gs = 32; s.y_rs = 32 * G; }
   else { s.y_gs = (size_t)B * p.HWc[L] * C; s.y_rs = C; }
   s.coef = at<float>(ws, p.coef[L]); s.coef_gs = C * 4;

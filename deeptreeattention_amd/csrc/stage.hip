@@ -97,10 +97,11 @@ int launch_bn_finalize(const BnFinalizeArgs& b, int G, hipStream_t st) {
 //   mean = sum n_i m_i / N,   M2 = sum M2_i + sum n_i m_i^2 - N mean^2
 // (m_i^2 is exact in double and the sums have <= 512 terms, so the cancellation costs ~1e-13 of the variance).
 // Every workgroup runs the same instruction sequence on the same data: the coefficients are bit-identical everywhere.
-// `red` = 514 floats of scratch.  Workgroup `writer` also publishes the coefficients and the running statistics.
+// `red` = 2 NTHR + 2 floats of scratch.  Workgroup `writer` also publishes the coefficients and the running statistics.
+template <int NTHR = 256>
 __device__ __forceinline__ void bn_coef_block(const BnFinK& a, int g, float* lc, float* red, bool writer) {
   const int t = threadIdx.x, C = a.C;
-  const int c = t % C, sl = t / C, T = 256 / C;     // C in {32, 64, 128}: T slices of the partials per channel
+  const int c = t % C, sl = t / C, T = NTHR / C;    // C in {32, 64, 128}: T slices of the partials per channel
   // 256 doubles, 8-byte aligned inside the 514-float scratch
   double* dred = reinterpret_cast<double*>(red + ((reinterpret_cast<uintptr_t>(red) >> 2) & 1));
   if (!a.training) {
@@ -149,7 +150,7 @@ __device__ __forceinline__ void bn_coef_block(const BnFinK& a, int g, float* lc,
   __syncthreads();
   if (writer && a.coef) {
     float* coef = a.coef + (size_t)g * C * 4;
-    for (int i = t; i < C * 4; i += 256) coef[i] = lc[i];
+    for (int i = t; i < C * 4; i += NTHR) coef[i] = lc[i];
   }
 }
 
@@ -550,7 +551,7 @@ int launch_stage_fwd(const StageArgs& a_in, int G, hipStream_t st) {
   StageArgs a = a_in;
   a.vslot = stage_vslot_for(a, G);
   // the three stages of the 11x11 networks have lean register-resident forms (end of this file)
-  if (a.lean && a.apply_bn && a.relu && stage_net_cfg(a) && !a.a_nchw && (a.y_fmt == FMT_F32 || a.y_fmt == FMT_F16))
+  if ((a.lean & 1) && a.apply_bn && a.relu && stage_net_cfg(a) && !a.a_nchw && (a.y_fmt == FMT_F32 || a.y_fmt == FMT_F16))
     return launch_stage_fwd_lean<T>(a, G, st);
   size_t lds = stage_lds_floats(a, false) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_fwd: %dx%dx%d patch needs %zu B of LDS", a.Hc, a.Wc, a.C, lds); return 1; }
@@ -895,9 +896,21 @@ static int launch_stage_bwd_c(const StageBwdArgs& a, int G, size_t lds, hipStrea
   return 0;
 }
 
+int launch_stage_bwd_lean(const StageBwdArgs& a, int G, hipStream_t st);
+
 int launch_stage_bwd(const StageBwdArgs& a_in, int G, hipStream_t st) {
   StageBwdArgs a = a_in;
   a.f.vslot = stage_vslot_for(a.f, G);
+  {
+    // lean form (end of this file): needs the forward's saved attention state, the [B][HWz][C] gradient layout and, for
+    // spatial groups with a classifier gradient, the un-pooled class pool of the last stage
+    const int lbit = a.f.C == 32 ? 2 : (a.f.C == 64 ? 4 : 8);
+    bool ok = (a.f.lean & lbit) && a.f.apply_bn && a.f.relu && stage_net_cfg(a.f) && a.f.attsave && !a.da_nchw && a.dv &&
+              (a.f.y_fmt == FMT_F32 || a.f.y_fmt == FMT_F16);
+    for (int g = 0; g < G; ++g)
+      if (a.f.kind[g] == KIND_SPATIAL && a.dfeat && a.f.C != 128) ok = false;
+    if (ok) return launch_stage_bwd_lean(a, G, st);
+  }
   size_t lds = stage_lds_floats(a.f, true) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_bwd: %dx%dx%d patch needs %zu B of LDS", a.f.Hc, a.f.Wc, a.f.C, lds); return 1; }
   const bool net = a.f.apply_bn && a.f.relu && stage_net_cfg(a.f);
@@ -1179,18 +1192,19 @@ struct LeanCfg {
   static constexpr int HZ = POOL ? HC / 2 : HC, WZ = POOL ? WC / 2 : WC, NP = HZ * WZ, HWC = HC * WC;
   static constexpr int NO = C / 8;                        // octets per pixel
   static constexpr int ITEMS = NP * NO;                   // (pixel, octet) items per patch
-  static constexpr int PPW = ITEMS <= 64 ? 4 : 1;         // patches per 256-thread workgroup
-  static constexpr int TPP = 256 / PPW;                   // threads per patch
+  static constexpr int NT = ITEMS > 256 ? 512 : 256;      // threads per workgroup (one item per thread when they fit)
+  static constexpr int PPW = ITEMS <= 64 ? 4 : 1;         // patches per workgroup
+  static constexpr int TPP = NT / PPW;                    // threads per patch
   static constexpr int IPT = (ITEMS + TPP - 1) / TPP;     // items per thread
   static constexpr int K = C == 32 ? 7 : (C == 64 ? 5 : 3);     // spatial stencil size (Hang2020.py:77-85)
   static constexpr int PS = C == 32 ? 4 : (C == 64 ? 2 : 1);    // spatial class-pool size (:91-99)
   static constexpr int R = K / 2, WP = WZ + 2 * R, HPAD = HZ + 2 * R, NPAD = HPAD * WP;
   static constexpr int W2 = WZ + 2, QZ = (HZ + 2) * W2;   // haloed grid of the gated map's conv tiles
-  static constexpr int NPART = 256 / C;                   // matvec: input slices per output
+  static constexpr int NPART = NT / C;                    // matvec: input slices per output
   // LDS floats per patch slot: the patch [NP][C], then vectors: spectral pooled|h|gate, spatial m|t1 (padded) | s
   static constexpr int VEC = 3 * C > 2 * NPAD + NP ? 3 * C : 2 * NPAD + NP;
   static constexpr int SLOT = NP * C + VEC;
-  static constexpr int RED = 1032;                        // reduction scratch shared by the workgroup (>= 4 C + 516)
+  static constexpr int RED = C >= 128 ? 4608 : (1536 > PPW * NT + 2 * C * PPW ? 1536 : PPW * NT + 2 * C * PPW);                        // reduction scratch shared by the workgroup (>= 4 C + 516, >= 256 + 2 C PPW)
   static constexpr int LDS_FWD = 2 * C + PPW * SLOT + RED;
 };
 
@@ -1276,6 +1290,44 @@ __device__ __forceinline__ void lean_colsum(float* red, float* out, int out_stri
 template <typename CFG, typename F>
 __device__ __forceinline__ void lean_matvec(const float* W, const float* x, int x_stride, float* red, F fin) {
   constexpr int C = CFG::C, NPART = CFG::NPART, PPW = CFG::PPW, PER = C / NPART;
+  if constexpr (C >= 128) {
+    // wide layers: a thread owns FOUR consecutive outputs (16-byte weight loads) and 1/NP4 of the inputs, so the whole
+    // weight slice of a thread is a handful of loads in flight at once instead of 64 scalar ones in eight round trips
+    constexpr int OT = C / 4, NP4 = CFG::NT / OT, PER4 = C / NP4;
+    const int t = threadIdx.x, o4 = (t % OT) * 4, part = t / OT;
+    float acc[PPW][4];
+#pragma unroll
+    for (int s = 0; s < PPW; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[s][e] = 0.f;
+    f32x4 w[PER4];
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) w[k] = *reinterpret_cast<const f32x4*>(W + (size_t)(part * PER4 + k) * C + o4);
+#pragma unroll
+    for (int k = 0; k < PER4; ++k) {
+#pragma unroll
+      for (int s = 0; s < PPW; ++s) {
+        const float xv = x[s * x_stride + part * PER4 + k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[s][e] += w[k][e] * xv;
+      }
+    }
+    // partials [slot][part][C] -> the same meeting point as the scalar form below (NP4 parts)
+    static_assert(PPW * NP4 * C <= CFG::RED, "matvec scratch");
+#pragma unroll
+    for (int s = 0; s < PPW; ++s)
+      *reinterpret_cast<f32x4*>(red + (s * NP4 + part) * C + o4) = f32x4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]};
+    __syncthreads();
+    for (int i = t; i < PPW * C; i += CFG::NT) {
+      const int s = i / C, oo = i % C;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < NP4; ++k) v += red[(s * NP4 + k) * C + oo];
+      fin(s, oo, v);
+    }
+    __syncthreads();
+    return;
+  }
   const int t = threadIdx.x, o = t % C, part = t / C;
   float acc[PPW];
 #pragma unroll
@@ -1290,7 +1342,7 @@ __device__ __forceinline__ void lean_matvec(const float* W, const float* x, int 
 #pragma unroll
   for (int s = 0; s < PPW; ++s) red[(s * NPART + part) * C + o] = acc[s];
   __syncthreads();
-  for (int i = t; i < PPW * C; i += 256) {
+  for (int i = t; i < PPW * C; i += CFG::NT) {
     const int s = i / C, oo = i % C;
     float v = 0.f;
 #pragma unroll
@@ -1310,7 +1362,7 @@ __device__ __forceinline__ float lean_octet_sum(float v) {
 }
 
 template <typename T, typename CFG>
-__global__ __launch_bounds__(256) void k_stage_fwd_lean(StageArgs a) {
+__global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int C = CFG::C, NO = CFG::NO, NP = CFG::NP, TPP = CFG::TPP, IPT = CFG::IPT, PPW = CFG::PPW, WZ = CFG::WZ;
   constexpr int K = CFG::K, R = CFG::R, WP = CFG::WP, NPAD = CFG::NPAD;
@@ -1344,11 +1396,11 @@ __global__ __launch_bounds__(256) void k_stage_fwd_lean(StageArgs a) {
   // ---- BatchNorm coefficients (from the finalize launch, or derived here in eval mode) ----
   if (a.bn_inkernel) {
     float* lc = red;                                    // [C][4], C <= 128 -> 512 floats, then 514 of scratch
-    bn_coef_block(a.bnfin, g, lc, red + 4 * C, blockIdx.x == 0);
-    for (int i = t; i < 2 * C; i += 256) coefL[i] = lc[(i >> 1) * 4 + (i & 1)];
+    bn_coef_block<CFG::NT>(a.bnfin, g, lc, red + 4 * C, blockIdx.x == 0);
+    for (int i = t; i < 2 * C; i += CFG::NT) coefL[i] = lc[(i >> 1) * 4 + (i & 1)];
   } else {
     const float* coef = a.coef + (size_t)g * a.coef_gs;
-    for (int i = t; i < 2 * C; i += 256) coefL[i] = coef[(i >> 1) * 4 + (i & 1)];
+    for (int i = t; i < 2 * C; i += CFG::NT) coefL[i] = coef[(i >> 1) * 4 + (i & 1)];
   }
   if (kind == KIND_SPATIAL)
     for (int i = lt; i < 2 * NPAD; i += TPP) vec[i] = 0.f;      // borders of the padded maps
@@ -1493,10 +1545,331 @@ __global__ __launch_bounds__(256) void k_stage_fwd_lean(StageArgs a) {
   if (tile && live) lean_tl_halo<T, CFG>(tile, lt);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lean backward of a stage: same item ownership.  Per patch and group it needs
+//   spectral: T_c = sum_p D z, two C x C mat-vecs, then dZ = D g + dp ;  spatial: per-pixel sums of D z, two transposed
+//   k x k stencils, dZ = D s + dm wc ; then the ReLU / pool mask, the BatchNorm partial sums (sum dv, sum dv xhat) and
+//   the attention parameter-gradient vectors.  D = incoming gradient of the gated map (+ the classifier-feature path).
+// ------------------------------------------------------------------------------------------------
+template <typename CFG>
+struct LeanBwd {
+  static constexpr int C = CFG::C, NP = CFG::NP, NPAD = CFG::NPAD;
+  static constexpr int VEC = 8 * C > 4 * NPAD + 2 * NP + 3 * C ? 8 * C : 4 * NPAD + 2 * NP + 3 * C;
+  static constexpr int SLOT = 2 * NP * C + VEC;
+  static constexpr int LDS = 4 * C + CFG::PPW * SLOT + CFG::RED;
+};
+
+template <typename CFG>
+__global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const StageArgs& a = ba.f;
+  constexpr int C = CFG::C, NO = CFG::NO, NP = CFG::NP, TPP = CFG::TPP, IPT = CFG::IPT, PPW = CFG::PPW, WZ = CFG::WZ;
+  constexpr int K = CFG::K, KK = K * K, R = CFG::R, WP = CFG::WP, NPAD = CFG::NPAD;
+  constexpr int SLOT = LeanBwd<CFG>::SLOT;
+  const int g = blockIdx.y, t = threadIdx.x, slot = t / TPP, lt = t % TPP;
+  const int b = blockIdx.x * PPW + slot;
+  const bool live = b < a.B;
+  const int bb = live ? b : 0;
+  const int kind = a.kind[g];
+  float* coefL = sm;                                   // [C][4] scale, shift, mean, rstd
+  float* sm0 = sm + 4 * C;
+  float* Z1 = sm0 + slot * SLOT;                       // [NP][C]
+  float* Z2 = Z1 + NP * C;                             // [NP][C]
+  float* vec = Z2 + NP * C;
+  float* red = sm0 + PPW * SLOT;
+  constexpr int VOFF = 2 * NP * C;                     // vectors of slot s start at sm0 + s * SLOT + VOFF
+
+  // ---- loads in flight: conv output, incoming gradient ----
+  const size_t ypatch = (size_t)g * a.y_gs + (size_t)bb * CFG::HWC * a.y_rs;
+  float yraw[IPT][CFG::POOL ? 4 : 1][8];
+  float D[IPT][8];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0;
+    const int p = itc / NO, o = itc % NO;
+    if (CFG::POOL) {
+      const int hz = p / WZ, wz = p % WZ, p00 = (2 * hz) * CFG::WC + 2 * wz;
+      const int po[4] = {p00, p00 + 1, p00 + CFG::WC, p00 + CFG::WC + 1};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lean_ld8<CFG::YF, false>(yraw[j][k], a.y, ypatch + (size_t)po[k] * a.y_rs + o * 8);
+    } else {
+      lean_ld8<CFG::YF, false>(yraw[j][0], a.y, ypatch + (size_t)p * a.y_rs + o * 8);
+    }
+    if (ba.da) lean_ld8<FMT_F32, true>(D[j], ba.da, (size_t)g * ba.da_gs + ((size_t)bb * NP + p) * C + o * 8);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) D[j][e] = 0.f;
+    }
+  }
+  {
+    const float* coef = a.coef + (size_t)g * a.coef_gs;
+    for (int i = t; i < 4 * C; i += CFG::NT) coefL[i] = coef[i];
+  }
+  // saved attention state -> LDS
+  const float* save = a.attsave + ((size_t)g * a.B + bb) * a.attsave_ld;
+  if (kind == KIND_SPECTRAL) {
+    for (int i = lt; i < 3 * C; i += TPP) vec[i] = __builtin_nontemporal_load(save + i);        // pooled | h | gate
+  } else if (kind == KIND_SPATIAL) {
+    for (int i = lt; i < NPAD; i += TPP) {
+      vec[i] = __builtin_nontemporal_load(save + i);                                              // m (padded)
+      vec[NPAD + i] = __builtin_nontemporal_load(save + a.vslot + i);                             // t1 (padded)
+      vec[2 * NPAD + NP + i] = 0.f; vec[3 * NPAD + NP + i] = 0.f;                                 // d2, d1 (padded): borders
+    }
+    for (int p = lt; p < NP; p += TPP) vec[2 * NPAD + p] = __builtin_nontemporal_load(save + 2 * a.vslot + p);   // s
+  }
+  const float* df = (ba.dfeat && live) ? ba.dfeat + (size_t)g * ba.dfeat_gs + (size_t)b * a.F[g] : nullptr;
+  __syncthreads();
+
+  // ---- recompute BN -> ReLU -> pool; keep z, the window position of the maximum and xhat there ----
+  float z[IPT][8], xh[IPT][8];
+  unsigned first[IPT];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, o = itc % NO;
+    first[j] = 0u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(coefL + (o * 8 + e) * 4);
+      float m = yraw[j][0][e] * q[0] + q[1], ys = yraw[j][0][e];
+      if (CFG::POOL) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const float v = yraw[j][k][e] * q[0] + q[1];
+          if (v > m) { m = v; ys = yraw[j][k][e]; first[j] = (first[j] & ~(3u << (2 * e))) | ((unsigned)k << (2 * e)); }
+        }
+      }
+      z[j][e] = (live && it < CFG::ITEMS) ? fmaxf(m, 0.f) : 0.f;
+      xh[j][e] = (ys - q[2]) * q[3];
+    }
+  }
+  float* bnp = (ba.bnpart && live) ? ba.bnpart + (size_t)g * ba.bnpart_gs + (size_t)b * C * 2 : nullptr;
+  float* vout = (ba.vec && live) ? ba.vec + (size_t)g * ba.vec_gs + (size_t)b * ba.vec_ld : nullptr;
+
+  auto put8 = [&](float* Zx, int p, int o, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(Zx + p * C + o * 8) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(Zx + p * C + o * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  };
+  float dv[IPT][8];
+  if (kind == KIND_SPECTRAL) {
+    float* pooled = vec; float* hL = vec + C; float* gL = vec + 2 * C;
+    float* d2L = vec + 3 * C; float* d1L = vec + 4 * C; float* dpL = vec + 5 * C;
+    const float inv = 1.f / (float)NP;
+    // D += df / NP (the features are the pixel mean of the gated map), T_c = sum_p D z
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int it = lt + j * TPP;
+      if (it >= CFG::ITEMS) continue;
+      const int p = it / NO, o = it % NO;
+      float pr[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (df) D[j][e] += df[o * 8 + e] * inv;
+        pr[e] = D[j][e] * z[j][e];
+      }
+      put8(Z1, p, o, pr);
+    }
+    __syncthreads();
+    lean_colsum<CFG>(red, sm0 + VOFF + 3 * C, SLOT, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + p * C + c]; });
+    for (int c = lt; c < C; c += TPP) d2L[c] = d2L[c] * gL[c] * (1.f - gL[c]);
+    __syncthreads();
+    lean_matvec<CFG>(a.att[g].p[5], sm0 + VOFF + 3 * C, SLOT, red, [&](int s, int i, float v) {
+      float* vs = sm0 + s * SLOT + VOFF;
+      vs[4 * C + i] = vs[C + i] > 0.f ? v : 0.f;
+    });
+    lean_matvec<CFG>(a.att[g].p[4], sm0 + VOFF + 4 * C, SLOT, red, [&](int s, int i, float v) {
+      sm0[s * SLOT + VOFF + 5 * C + i] = v * inv;
+    });
+    if (vout)
+      for (int c = lt; c < C; c += TPP) { vout[c] = d2L[c]; vout[C + c] = hL[c]; vout[2 * C + c] = d1L[c]; vout[3 * C + c] = pooled[c]; }
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, o = itc % NO;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dz = D[j][e] * gL[o * 8 + e] + dpL[o * 8 + e];
+        dv[j][e] = z[j][e] > 0.f ? dz : 0.f;
+      }
+    }
+  } else if (kind == KIND_SPATIAL) {
+    float* mL = vec; float* t1L = vec + NPAD; float* sL = vec + 2 * NPAD;
+    float* d2L = sL + NP; float* d1L = d2L + NPAD; float* dmL = d1L + NPAD;
+    const float* wc = a.att[g].p[0]; const float* k1 = a.att[g].p[2]; const float* k2 = a.att[g].p[4];
+    // classifier-feature path: only the un-pooled class pool (PS == 1) is handled here; the launcher keeps the older
+    // kernel for stages whose features come from a real max-pool
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, p = itc / NO, o = itc % NO;
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (CFG::PS == 1 && df) D[j][e] += df[(o * 8 + e) * NP + p];
+        acc += D[j][e] * z[j][e];
+      }
+      acc = lean_octet_sum<NO>(acc);
+      if (it < CFG::ITEMS && o == 0) { const float sp = sL[p]; d2L[(p / WZ + R) * WP + p % WZ + R] = acc * sp * (1.f - sp); }
+    }
+    __syncthreads();
+    // d1 = (transposed k2 stencil of d2) masked by t1 > 0 ;  dm = (transposed k1 stencil of d1) masked by m > 0
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const float* src = pass ? d1L : d2L; const float* kw = pass ? k1 : k2; const float* gate = pass ? mL : t1L;
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, p = itc / NO, o = itc % NO, h = p / WZ, w = p % WZ;
+        float acc = 0.f;
+        for (int ky = o; ky < K; ky += NO) {
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) acc += kw[(K - 1 - ky) * K + (K - 1 - kx)] * src[(h + ky) * WP + w + kx];
+        }
+        acc = lean_octet_sum<NO>(acc);
+        if (it < CFG::ITEMS && o == 0) {
+          const int pi = (h + R) * WP + w + R;
+          const float v = gate[pi] > 0.f ? acc : 0.f;
+          if (pass == 0) d1L[pi] = v; else dmL[p] = v;
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, p = itc / NO, o = itc % NO;
+      const float sp = sL[p], dm = dmL[p];
+      float w8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dz = D[j][e] * sp + dm * wc[o * 8 + e];
+        dv[j][e] = z[j][e] > 0.f ? dz : 0.f;
+        w8[e] = dm * z[j][e];
+      }
+      if (it < CFG::ITEMS && vout != nullptr) put8(Z1, p, o, w8);
+    }
+    if (ba.vec) {
+      // [dwc (C) | dbc | dK1 (kk) | db1 | dK2 (kk) | db2]
+      __syncthreads();
+      float* dwcL = dmL + NP;
+      lean_colsum<CFG>(red, sm0 + VOFF + (int)(dmL + NP - vec), SLOT, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + p * C + c]; });
+      if (vout) {
+        for (int c = lt; c < C; c += TPP) vout[c] = dwcL[c];
+        // stencil-weight gradients: task = (kernel, tap), NP products each
+        for (int task = lt >> 1; task < 2 * KK; task += TPP / 2) {      // a lane pair per (kernel, tap): rows split
+          const bool fst = task < KK;
+          const int jj = fst ? task : task - KK, ky = jj / K, kx = jj % K;
+          const float* src = fst ? mL : t1L; const float* dd = fst ? d1L : d2L;
+          float acc = 0.f;
+          for (int h = lt & 1; h < CFG::HZ; h += 2)
+#pragma unroll
+            for (int w = 0; w < WZ; ++w) acc += src[(h + ky) * WP + w + kx] * dd[(h + R) * WP + w + R];
+          acc += lane_xor1(acc);
+          if (!(lt & 1)) vout[fst ? C + 1 + jj : C + 2 + KK + jj] = acc;
+        }
+      }
+      // bias gradients: sums of dm, d1, d2 (borders of the padded maps are zero): three waves, one map each
+      {
+        const int wv = lt >> 6, ln = lt & 63;
+        if (wv < 3 && TPP >= 192) {
+          const float* mp = wv == 0 ? dmL : (wv == 1 ? d1L : d2L);
+          const int n = wv == 0 ? NP : NPAD;
+          float acc = 0.f;
+          for (int q = ln; q < n; q += 64) acc += mp[q];
+          acc = wave_sum(acc);
+          if (ln == 0 && vout) vout[wv == 0 ? C : (wv == 1 ? C + 1 + KK : C + 2 + 2 * KK)] = acc;
+        } else if (TPP < 192 && lt < 3 && vout) {     // four patches per workgroup (2x2 maps): a handful of terms
+          float acc = 0.f;
+          if (lt == 0) { for (int p = 0; p < NP; ++p) acc += dmL[p]; }
+          else { const float* mp = lt == 1 ? d1L : d2L; for (int q = 0; q < NPAD; ++q) acc += mp[q]; }
+          vout[lt == 0 ? C : (lt == 1 ? C + 1 + KK : C + 2 + 2 * KK)] = acc;
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // plain stage (vanilla_CNN): the gradient of the map is the incoming gradient (+ the classifier's, NCHW flatten)
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, p = itc / NO, o = itc % NO;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float dz = D[j][e];
+        if (df) dz += df[(o * 8 + e) * NP + p];
+        dv[j][e] = z[j][e] > 0.f ? dz : 0.f;
+      }
+    }
+  }
+  // ---- outputs: dv (dense, or compact value + window position for pooled stages), BatchNorm partial sums ----
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int it = lt + j * TPP;
+    if (it >= CFG::ITEMS) continue;
+    const int p = it / NO, o = it % NO;
+    float w8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w8[e] = dv[j][e] * xh[j][e];
+    put8(Z1, p, o, dv[j]);
+    put8(Z2, p, o, w8);
+    if (live) {
+      float* dvp = ba.dv + (size_t)g * ba.dv_gs + (size_t)b * CFG::HWC * C;
+      if (!CFG::POOL || ba.dv_compact) {
+        *reinterpret_cast<f32x4*>(dvp + (size_t)p * C + o * 8) = f32x4{dv[j][0], dv[j][1], dv[j][2], dv[j][3]};
+        *reinterpret_cast<f32x4*>(dvp + (size_t)p * C + o * 8 + 4) = f32x4{dv[j][4], dv[j][5], dv[j][6], dv[j][7]};
+        if (CFG::POOL) {
+          unsigned lo = 0u, hi = 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { lo |= ((first[j] >> (2 * e)) & 3u) << (8 * e); hi |= ((first[j] >> (2 * (e + 4))) & 3u) << (8 * e); }
+          unsigned char* fpos = reinterpret_cast<unsigned char*>(dvp + (size_t)NP * C);
+          *reinterpret_cast<u32x2*>(fpos + (size_t)p * C + o * 8) = u32x2{lo, hi};
+        }
+      } else {
+        // dense map of a pooled stage: the gradient lands on the window position of the maximum, zeros elsewhere
+        const int hz = p / WZ, wz = p % WZ, p00 = (2 * hz) * CFG::WC + 2 * wz;
+        const int po[4] = {p00, p00 + 1, p00 + CFG::WC, p00 + CFG::WC + 1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float q8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) q8[e] = ((first[j] >> (2 * e)) & 3u) == (unsigned)k ? dv[j][e] : 0.f;
+          *reinterpret_cast<f32x4*>(dvp + (size_t)po[k] * C + o * 8) = f32x4{q8[0], q8[1], q8[2], q8[3]};
+          *reinterpret_cast<f32x4*>(dvp + (size_t)po[k] * C + o * 8 + 4) = f32x4{q8[4], q8[5], q8[6], q8[7]};
+        }
+      }
+    }
+  }
+  if (CFG::POOL && !ba.dv_compact && live) {
+    // conv-resolution positions the floor pooling dropped (last row / column of an odd map) get no gradient
+    float* dvp = ba.dv + (size_t)g * ba.dv_gs + (size_t)b * CFG::HWC * C;
+    for (int i = lt; i < CFG::HWC * (C / 4); i += TPP) {
+      const int pix = i / (C / 4), c4 = (i % (C / 4)) * 4, h = pix / CFG::WC, w = pix % CFG::WC;
+      if ((h >> 1) >= CFG::HZ || (w >> 1) >= WZ) *reinterpret_cast<f32x4*>(dvp + (size_t)pix * C + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  if (ba.bnpart) {
+    float* s1L = red + PPW * CFG::NT + slot * 2 * C;     // (the head of red is the column-sum scratch)
+    lean_colsum<CFG>(red, red + PPW * CFG::NT, 2 * C, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + p * C + c]; });
+    lean_colsum<CFG>(red, red + PPW * CFG::NT + C, 2 * C, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + NP * C + p * C + c]; });
+    if (bnp)
+      for (int c = lt; c < C; c += TPP) *reinterpret_cast<f32x2*>(bnp + c * 2) = f32x2{s1L[c], s1L[C + c]};
+  }
+}
+
+template <typename CFG>
+static int launch_stage_bwd_lean_c(const StageBwdArgs& a, int G, hipStream_t st) {
+  const size_t lds = (size_t)LeanBwd<CFG>::LDS * 4;
+  static_assert(LeanBwd<CFG>::LDS * 4 <= 64 * 1024, "lean stage backward: LDS plan exceeds the default 64 KiB limit");
+  hipLaunchKernelGGL((k_stage_bwd_lean<CFG>), dim3((a.f.B + CFG::PPW - 1) / CFG::PPW, G), dim3(CFG::NT), lds, st, a);
+  DTA_CHECK_LAUNCH("k_stage_bwd_lean");
+  return 0;
+}
+int launch_stage_bwd_lean(const StageBwdArgs& a, int G, hipStream_t st) {
+  const bool h = a.f.y_fmt == FMT_F16;
+  if (a.f.C == 32) return h ? launch_stage_bwd_lean_c<LeanCfg<32, 11, 11, 0, FMT_F16>>(a, G, st) : launch_stage_bwd_lean_c<LeanCfg<32, 11, 11, 0, FMT_F32>>(a, G, st);
+  if (a.f.C == 64) return h ? launch_stage_bwd_lean_c<LeanCfg<64, 11, 11, 1, FMT_F16>>(a, G, st) : launch_stage_bwd_lean_c<LeanCfg<64, 11, 11, 1, FMT_F32>>(a, G, st);
+  return h ? launch_stage_bwd_lean_c<LeanCfg<128, 5, 5, 1, FMT_F16>>(a, G, st) : launch_stage_bwd_lean_c<LeanCfg<128, 5, 5, 1, FMT_F32>>(a, G, st);
+}
+
 template <typename T, typename CFG>
 static int launch_stage_fwd_lean_c(const StageArgs& a, int G, hipStream_t st) {
   const size_t lds = (size_t)CFG::LDS_FWD * 4;     // < 24 KiB: no attribute needed
-  hipLaunchKernelGGL((k_stage_fwd_lean<T, CFG>), dim3((a.B + CFG::PPW - 1) / CFG::PPW, G), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_stage_fwd_lean<T, CFG>), dim3((a.B + CFG::PPW - 1) / CFG::PPW, G), dim3(CFG::NT), lds, st, a);
   DTA_CHECK_LAUNCH("k_stage_fwd_lean");
   return 0;
 }
