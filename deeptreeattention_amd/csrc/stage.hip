@@ -1205,7 +1205,7 @@ struct LeanCfg {
   static constexpr int VEC = 3 * C > 2 * NPAD + NP ? 3 * C : 2 * NPAD + NP;
   static constexpr int SLOT = NP * C + VEC;
   static constexpr int RED = C >= 128 ? 4608 : (1536 > PPW * NT + 2 * C * PPW ? 1536 : PPW * NT + 2 * C * PPW);                        // reduction scratch shared by the workgroup (>= 4 C + 516, >= 256 + 2 C PPW)
-  static constexpr int LDS_FWD = 2 * C + PPW * SLOT + RED;
+  static constexpr int LDS_FWD = 2 * C + PPW * SLOT + RED + C + 2 * K * K;
 };
 
 // eight consecutive channels of one conv-output pixel -> floats
@@ -1285,6 +1285,39 @@ __device__ __forceinline__ void lean_colsum(float* red, float* out, int out_stri
   }
   __syncthreads();
 }
+// The scalar mat-vec in two halves, so that callers can fetch a thread's weight slice (C / NPART values) at kernel entry,
+// long before the vector it multiplies exists: the weights then cost no latency on the dependent chain.
+template <typename CFG>
+__device__ __forceinline__ void lean_matvec_load(const float* W, float (&w)[CFG::C / CFG::NPART]) {
+  constexpr int C = CFG::C, PER = C / CFG::NPART;
+  const int t = threadIdx.x, o = t % C, part = t / C;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) w[k] = W[(size_t)(part * PER + k) * C + o];
+}
+template <typename CFG, typename F>
+__device__ __forceinline__ void lean_matvec_run(const float (&w)[CFG::C / CFG::NPART], const float* x, int x_stride, float* red, F fin) {
+  constexpr int C = CFG::C, NPART = CFG::NPART, PPW = CFG::PPW, PER = C / NPART;
+  const int t = threadIdx.x, o = t % C, part = t / C;
+  float acc[PPW];
+#pragma unroll
+  for (int s = 0; s < PPW; ++s) acc[s] = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+#pragma unroll
+    for (int s = 0; s < PPW; ++s) acc[s] += w[k] * x[s * x_stride + part * PER + k];
+  }
+#pragma unroll
+  for (int s = 0; s < PPW; ++s) red[(s * NPART + part) * C + o] = acc[s];
+  __syncthreads();
+  for (int i = t; i < PPW * C; i += CFG::NT) {
+    const int s = i / C, oo = i % C;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) v += red[(s * NPART + k) * C + oo];
+    fin(s, oo, v);
+  }
+  __syncthreads();
+}
 // y[slot][o] = sum_i W[i * C + o] * x[slot][i] for every patch slot of the workgroup (W input-major, so lanes read
 // consecutive o): thread (o, part) covers C / NPART inputs for all slots, the parts meet in LDS.  `fin(slot, o, sum)`.
 template <typename CFG, typename F>
@@ -1328,28 +1361,9 @@ __device__ __forceinline__ void lean_matvec(const float* W, const float* x, int 
     __syncthreads();
     return;
   }
-  const int t = threadIdx.x, o = t % C, part = t / C;
-  float acc[PPW];
-#pragma unroll
-  for (int s = 0; s < PPW; ++s) acc[s] = 0.f;
-#pragma unroll 8
-  for (int k = 0; k < PER; ++k) {
-    const int i = part * PER + k;
-    const float w = W[(size_t)i * C + o];
-#pragma unroll
-    for (int s = 0; s < PPW; ++s) acc[s] += w * x[s * x_stride + i];
-  }
-#pragma unroll
-  for (int s = 0; s < PPW; ++s) red[(s * NPART + part) * C + o] = acc[s];
-  __syncthreads();
-  for (int i = t; i < PPW * C; i += CFG::NT) {
-    const int s = i / C, oo = i % C;
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < NPART; ++k) v += red[(s * NPART + k) * C + oo];
-    fin(s, oo, v);
-  }
-  __syncthreads();
+  float w[PER];
+  lean_matvec_load<CFG>(W, w);
+  lean_matvec_run<CFG>(w, x, x_stride, red, fin);
 }
 // sum over the NO lanes that share a pixel (consecutive lanes: o = item % NO); every lane ends with the total
 template <int NO>
@@ -1393,6 +1407,14 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
       lean_ld8<CFG::YF, true>(yraw[j][0], a.y, ypatch + (size_t)p * a.y_rs + o * 8);
     }
   }
+  // ---- attention weights in flight as well: the spectral mat-vec slices go to registers, the spatial stencils to LDS ----
+  constexpr bool PRE = C < 128;                          // (the 128-wide mat-vecs load 16-byte slices at their call)
+  float w1[C / CFG::NPART], w2[C / CFG::NPART];
+  if (PRE && kind == KIND_SPECTRAL) { lean_matvec_load<CFG>(a.att[g].p[0], w1); lean_matvec_load<CFG>(a.att[g].p[2], w2); }
+  float* wL = sm + 2 * C + PPW * CFG::SLOT + CFG::RED;   // [C + 2 K K] wc | k1 | k2
+  if (kind == KIND_SPATIAL)
+    for (int i = t; i < C + 2 * K * K; i += CFG::NT)
+      wL[i] = i < C ? a.att[g].p[0][i] : (i < C + K * K ? a.att[g].p[2][i - C] : a.att[g].p[4][i - C - K * K]);
   // ---- BatchNorm coefficients (from the finalize launch, or derived here in eval mode) ----
   if (a.bn_inkernel) {
     float* lc = red;                                    // [C][4], C <= 128 -> 512 floats, then 514 of scratch
@@ -1439,10 +1461,15 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
     float* pooled = vec; float* hL = vec + C; float* gL = vec + 2 * C;
     lean_colsum<CFG>(red, vec0, CFG::SLOT, 1.f / (float)NP, [&](int s, int p, int c) { return sm0[s * CFG::SLOT + p * C + c]; });
     const float* c1 = a.att[g].p[1]; const float* c2 = a.att[g].p[3];
-    lean_matvec<CFG>(a.att[g].p[0], vec0, CFG::SLOT, red,
-                     [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + C + o] = fmaxf(v + c1[o], 0.f); });
-    lean_matvec<CFG>(a.att[g].p[2], vec0 + C, CFG::SLOT, red,
-                     [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + 2 * C + o] = sigmoidf_(v + c2[o]); });
+    auto fin1 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + C + o] = fmaxf(v + c1[o], 0.f); };
+    auto fin2 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + 2 * C + o] = sigmoidf_(v + c2[o]); };
+    if constexpr (PRE) {
+      lean_matvec_run<CFG>(w1, vec0, CFG::SLOT, red, fin1);
+      lean_matvec_run<CFG>(w2, vec0 + C, CFG::SLOT, red, fin2);
+    } else {
+      lean_matvec<CFG>(a.att[g].p[0], vec0, CFG::SLOT, red, fin1);
+      lean_matvec<CFG>(a.att[g].p[2], vec0 + C, CFG::SLOT, red, fin2);
+    }
     if (save) for (int i = lt; i < 3 * C; i += TPP) __builtin_nontemporal_store(vec[i], save + i);
     if (feat) for (int c = lt; c < C; c += TPP) feat[c] = gL[c] * pooled[c];      // mean_p(z * gate) = gate * mean_p(z)
     if (tile && live) {
@@ -1459,9 +1486,9 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
     }
   } else if (kind == KIND_SPATIAL) {
     float* mL = vec; float* t1L = vec + NPAD; float* sL = vec + 2 * NPAD;
-    const float* wc = a.att[g].p[0]; const float bc = a.att[g].p[1][0];
-    const float* k1 = a.att[g].p[2]; const float b1 = a.att[g].p[3][0];
-    const float* k2 = a.att[g].p[4]; const float b2 = a.att[g].p[5][0];
+    const float* wc = wL; const float bc = a.att[g].p[1][0];
+    const float* k1 = wL + C; const float b1 = a.att[g].p[3][0];
+    const float* k2 = wL + C + K * K; const float b2 = a.att[g].p[5][0];
     // m = relu(channel_pool(z)): 8 channels per lane, the NO lanes of a pixel meet through DPP / shuffles
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
@@ -1556,7 +1583,7 @@ struct LeanBwd {
   static constexpr int C = CFG::C, NP = CFG::NP, NPAD = CFG::NPAD;
   static constexpr int VEC = 8 * C > 4 * NPAD + 2 * NP + 3 * C ? 8 * C : 4 * NPAD + 2 * NP + 3 * C;
   static constexpr int SLOT = 2 * NP * C + VEC;
-  static constexpr int LDS = 4 * C + CFG::PPW * SLOT + CFG::RED;
+  static constexpr int LDS = 4 * C + CFG::PPW * SLOT + CFG::RED + C + 2 * CFG::K * CFG::K;
 };
 
 template <typename CFG>
@@ -1605,6 +1632,14 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     const float* coef = a.coef + (size_t)g * a.coef_gs;
     for (int i = t; i < 4 * C; i += CFG::NT) coefL[i] = coef[i];
   }
+  // attention weights in flight too: spectral mat-vec slices -> registers, spatial stencils -> LDS
+  constexpr bool PRE = C < 128;
+  float w1[C / CFG::NPART], w2[C / CFG::NPART];
+  if (PRE && kind == KIND_SPECTRAL) { lean_matvec_load<CFG>(a.att[g].p[5], w2); lean_matvec_load<CFG>(a.att[g].p[4], w1); }
+  float* wL = sm0 + PPW * SLOT + CFG::RED;               // [C + 2 K K] wc | k1 | k2
+  if (kind == KIND_SPATIAL)
+    for (int i = t; i < C + 2 * KK; i += CFG::NT)
+      wL[i] = i < C ? a.att[g].p[0][i] : (i < C + KK ? a.att[g].p[2][i - C] : a.att[g].p[4][i - C - KK]);
   // saved attention state -> LDS
   const float* save = a.attsave + ((size_t)g * a.B + bb) * a.attsave_ld;
   if (kind == KIND_SPECTRAL) {
@@ -1672,13 +1707,18 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     lean_colsum<CFG>(red, sm0 + VOFF + 3 * C, SLOT, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + p * C + c]; });
     for (int c = lt; c < C; c += TPP) d2L[c] = d2L[c] * gL[c] * (1.f - gL[c]);
     __syncthreads();
-    lean_matvec<CFG>(a.att[g].p[5], sm0 + VOFF + 3 * C, SLOT, red, [&](int s, int i, float v) {
+    auto fin2 = [&](int s, int i, float v) {
       float* vs = sm0 + s * SLOT + VOFF;
       vs[4 * C + i] = vs[C + i] > 0.f ? v : 0.f;
-    });
-    lean_matvec<CFG>(a.att[g].p[4], sm0 + VOFF + 4 * C, SLOT, red, [&](int s, int i, float v) {
-      sm0[s * SLOT + VOFF + 5 * C + i] = v * inv;
-    });
+    };
+    auto fin1 = [&](int s, int i, float v) { sm0[s * SLOT + VOFF + 5 * C + i] = v * inv; };
+    if constexpr (PRE) {
+      lean_matvec_run<CFG>(w2, sm0 + VOFF + 3 * C, SLOT, red, fin2);
+      lean_matvec_run<CFG>(w1, sm0 + VOFF + 4 * C, SLOT, red, fin1);
+    } else {
+      lean_matvec<CFG>(a.att[g].p[5], sm0 + VOFF + 3 * C, SLOT, red, fin2);
+      lean_matvec<CFG>(a.att[g].p[4], sm0 + VOFF + 4 * C, SLOT, red, fin1);
+    }
     if (vout)
       for (int c = lt; c < C; c += TPP) { vout[c] = d2L[c]; vout[C + c] = hL[c]; vout[2 * C + c] = d1L[c]; vout[3 * C + c] = pooled[c]; }
 #pragma unroll
@@ -1693,7 +1733,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
   } else if (kind == KIND_SPATIAL) {
     float* mL = vec; float* t1L = vec + NPAD; float* sL = vec + 2 * NPAD;
     float* d2L = sL + NP; float* d1L = d2L + NPAD; float* dmL = d1L + NPAD;
-    const float* wc = a.att[g].p[0]; const float* k1 = a.att[g].p[2]; const float* k2 = a.att[g].p[4];
+    const float* wc = wL; const float* k1 = wL + C; const float* k2 = wL + C + KK;
     // classifier-feature path: only the un-pooled class pool (PS == 1) is handled here; the launcher keeps the older
     // kernel for stages whose features come from a real max-pool
 #pragma unroll
