@@ -463,6 +463,19 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     dsc[0][2] = djoint ? djoint : dsc[0][2];
   }
 
+  // which levels run the lean stage-backward kernel (they can take / leave 16-bit gradient maps)
+  const bool g16 = p.esz == 2 && p.y_fmt == FMT_F16;
+  bool lean_lvl[3];
+  for (int L = 0; L < 3; ++L) {
+    StageBwdArgs probe;
+    memset(&probe, 0, sizeof(probe));
+    probe.f = stage_args(p, d, nets, ws, L);
+    bool any_head = false;
+    for (int g = 0; g < G; ++g) any_head |= dsc[g][L] != nullptr && p.F[g][L] > 0;
+    probe.dfeat = any_head ? at<float>(ws, p.dfeat[L]) : nullptr;
+    probe.dv = at<float>(ws, p.dv[L]);
+    lean_lvl[L] = stage_bwd_is_lean(probe, G);
+  }
   GemmGroup deferred;   // parameter-gradient GEMMs nothing downstream waits for: one grouped launch at the end
   WgradReduceGroup reduces;   // likewise the split-K reductions of the conv weight gradients
   for (int L = 2; L >= 0; --L) {
@@ -513,6 +526,11 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     sb.dfeat = any_head ? at<float>(ws, p.dfeat[L]) : nullptr; sb.dfeat_gs = fgs;
     sb.dv = at<float>(ws, p.dv[L]); sb.dv_gs = (size_t)B * p.HWc[L] * C;
     sb.dv_compact = L > 0 && bn_bwd_apply_uses_lds(C, p.Hc[L], p.Wc[L], p.esz);   // pooled stages: 3/4 of dv is zeros
+    // bf16 mode + lean stage kernels: the gradient maps between the backward kernels are stored in bf16 (the conv
+    // operand they become is bf16 anyway); `da` was written by the NEXT layer's input-gradient conv in the format that
+    // layer chose from lean_lvl[L] (same predicate, evaluated before the loop)
+    sb.da_fmt = (L < 2 && lean_lvl[L] && g16) ? FMT_BF16 : FMT_F32;
+    sb.dv_fmt = (lean_lvl[L] && g16) ? FMT_BF16 : FMT_F32;
     sb.bnpart = at<float>(ws, p.bnpart[L]); sb.bnpart_gs = (size_t)B * C * 2;
     sb.vec = at<float>(ws, p.vec[L]); sb.vec_gs = (size_t)B * p.vec_ld[L]; sb.vec_ld = p.vec_ld[L];
     prof_begin(DTA_SITE_STAGE_BWD + L, st);
@@ -565,7 +583,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     ap.dv = sb.dv; ap.dv_gs = sb.dv_gs; ap.y = sa.y; ap.y_gs = sa.y_gs; ap.y_rs = sa.y_rs; ap.y_fmt = sa.y_fmt;
     ap.coef = sa.coef; ap.coef_gs = sa.coef_gs; ap.bcoef = bf.bcoef; ap.bcoef_gs = bf.bcoef_gs;
     ap.B = B; ap.C = C; ap.H = p.Hc[L]; ap.W = p.Wc[L];
-    ap.dv_compact = sb.dv_compact; ap.Hz = p.Hz[L]; ap.Wz = p.Wz[L];
+    ap.dv_compact = sb.dv_compact; ap.Hz = p.Hz[L]; ap.Wz = p.Wz[L]; ap.dv_fmt = sb.dv_fmt;
     ap.dy_tl = at<char>(ws, p.dy_tl[L]);
     if (L == 0 && p.shared_x) { ap.dy_gs = (size_t)2 * p.Qin[0] * 16; ap.dy_nc = 2 * G; ap.dy_ch0 = 0; }   // group g -> chunks [2g, 2g+2)
     else { ap.dy_gs = (size_t)B * (C / 16) * p.Qin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
@@ -594,6 +612,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       memset(&ca, 0, sizeof(ca));
       ca.x_tl = ap.dy_tl; ca.x_gs = ap.dy_gs; ca.wp = at<char>(ws, p.wd[L]);
       ca.y = at<float>(ws, p.da[L]); ca.y_gs = (size_t)B * p.HWc[L] * CH[L - 1]; ca.y_rs = CH[L - 1];
+      ca.y_fmt = (lean_lvl[L - 1] && g16) ? FMT_BF16 : FMT_F32;      // read by stage L-1's backward
       ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = C / 16; ca.N = CH[L - 1]; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
       prof_begin(DTA_SITE_CONV_DGRAD + L, st);
       if (launch_conv3x3<T>(ca, G, st)) return 1;

@@ -181,8 +181,12 @@ struct StageBwdArgs {
   // [HWz][C] gradient values followed by [HWz][C] window positions (1 byte) instead of the dense [HWc][C] map;
   // k_bn_bwd_apply_lds expands it on the fly (same per-patch stride)
   int dv_compact;
+  // storage formats (FMT_F32 / FMT_BF16) of the incoming gradient map `da` and of `dv`; 16-bit only with the lean kernels
+  // (stage_bwd_is_lean): per-patch strides stay the same element counts, the compact position bytes follow the values
+  int da_fmt, dv_fmt;
 };
 int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st);
+bool stage_bwd_is_lean(const StageBwdArgs& a, int G);
 
 struct BnBwdFinalizeArgs {
   const float* bnpart; size_t bnpart_gs; int B, C, HW;
@@ -196,7 +200,7 @@ struct BnBwdFinalizeArgs {
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, int G, hipStream_t st);
 
 struct BnBwdApplyArgs {
-  const float* dv; size_t dv_gs; const float* y; size_t y_gs; int y_rs; int y_fmt;
+  const float* dv; size_t dv_gs; const float* y; size_t y_gs; int y_rs; int y_fmt; int dv_fmt;
   const float* coef; int coef_gs; const float* bcoef; int bcoef_gs;
   int B, C, H, W;
   void* dy_tl; size_t dy_gs; int dy_nc, dy_ch0;

@@ -897,20 +897,22 @@ static int launch_stage_bwd_c(const StageBwdArgs& a, int G, size_t lds, hipStrea
 }
 
 int launch_stage_bwd_lean(const StageBwdArgs& a, int G, hipStream_t st);
+// lean form (end of this file): needs the forward's saved attention state, the [B][HWz][C] gradient layout and, for
+// spatial groups with a classifier gradient, the un-pooled class pool of the last stage
+bool stage_bwd_is_lean(const StageBwdArgs& a, int G) {
+  const int lbit = a.f.C == 32 ? 2 : (a.f.C == 64 ? 4 : 8);
+  bool ok = (a.f.lean & lbit) && a.f.apply_bn && a.f.relu && stage_net_cfg(a.f) && a.f.attsave && !a.da_nchw && a.dv &&
+            (a.f.y_fmt == FMT_F32 || a.f.y_fmt == FMT_F16);
+  for (int g = 0; g < G; ++g)
+    if (a.f.kind[g] == KIND_SPATIAL && a.dfeat && a.f.C != 128) ok = false;
+  return ok;
+}
 
 int launch_stage_bwd(const StageBwdArgs& a_in, int G, hipStream_t st) {
   StageBwdArgs a = a_in;
   a.f.vslot = stage_vslot_for(a.f, G);
-  {
-    // lean form (end of this file): needs the forward's saved attention state, the [B][HWz][C] gradient layout and, for
-    // spatial groups with a classifier gradient, the un-pooled class pool of the last stage
-    const int lbit = a.f.C == 32 ? 2 : (a.f.C == 64 ? 4 : 8);
-    bool ok = (a.f.lean & lbit) && a.f.apply_bn && a.f.relu && stage_net_cfg(a.f) && a.f.attsave && !a.da_nchw && a.dv &&
-              (a.f.y_fmt == FMT_F32 || a.f.y_fmt == FMT_F16);
-    for (int g = 0; g < G; ++g)
-      if (a.f.kind[g] == KIND_SPATIAL && a.dfeat && a.f.C != 128) ok = false;
-    if (ok) return launch_stage_bwd_lean(a, G, st);
-  }
+  if (stage_bwd_is_lean(a, G)) return launch_stage_bwd_lean(a, G, st);
+  if (a.da_fmt != FMT_F32 || a.dv_fmt != FMT_F32) { dta_set_error("stage_bwd: 16-bit gradient maps need the lean kernels"); return 1; }
   size_t lds = stage_lds_floats(a.f, true) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_bwd: %dx%dx%d patch needs %zu B of LDS", a.f.Hc, a.f.Wc, a.f.C, lds); return 1; }
   const bool net = a.f.apply_bn && a.f.relu && stage_net_cfg(a.f);
@@ -999,13 +1001,13 @@ int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const Colsu
   return 0;
 }
 
-template <typename T, int YF>
+template <typename T, int YF, int DVF>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
   // per channel: dy = k0 * dv + k1 * y + k2  (folded from A*(dv - Bc - ((y-mean)*rstd)*Cc)), coefficients in LDS
   __shared__ float sk[3][128];
   const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = a.C;
   const int W2 = a.W + 2, Q = (a.H + 2) * W2, HW = a.H * a.W, nch = C / 16;
-  const float* dv = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
+  const size_t dvbase = (size_t)g * a.dv_gs + (size_t)b * HW * C;      // element index (dv may be bf16)
   const size_t ybase = (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs;   // element index (the conv output may be 16-bit)
   const float* coef = a.coef + (size_t)g * a.coef_gs;
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
@@ -1033,8 +1035,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
         float t4[4];
         ld4_fmt(t4, a.y, ybase + (size_t)p * a.y_rs + cb + k, YF);
         yv[k] = t4[0]; yv[k + 1] = t4[1]; yv[k + 2] = t4[2]; yv[k + 3] = t4[3];
-        float4 d4 = *reinterpret_cast<const float4*>(dv + (size_t)p * C + cb + k);
-        dvv[k] = d4.x; dvv[k + 1] = d4.y; dvv[k + 2] = d4.z; dvv[k + 3] = d4.w;
+        float d4[4];
+        ld4_fmt(d4, a.dv, dvbase + (size_t)p * C + cb + k, DVF);
+        dvv[k] = d4[0]; dvv[k + 1] = d4[1]; dvv[k + 2] = d4[2]; dvv[k + 3] = d4[3];
       }
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
@@ -1052,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
 
 // Same transform, patch image assembled in LDS: pixel-major float4 reads of dv / y (fully coalesced), the tile-layout
 // image of the patch (halo included) built in LDS, then one linear 16-byte-per-lane copy to HBM.
-template <typename T, int YF>
+template <typename T, int YF, int DVF>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_apply[];
   // a workgroup = one patch x one slice of CS channels (blockIdx.z): small LDS images keep 8 workgroups on a CU
@@ -1062,10 +1065,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   float* sk = (float*)smem_apply;                       // [3][CS]
   int* lut = (int*)(smem_apply + 3 * CS * 4);            // [HW] pixel -> haloed row q | pooled element << 10 | window position << 20 | in-window << 22
   T* img = (T*)(smem_apply + ((3 * CS * 4 + HW * 4 + 15) & ~15)); // [nch][Q][16]
-  const float* dvp = a.dv + (size_t)g * a.dv_gs + (size_t)b * HW * C;
-  const float* dv = dvp + c0;
+  const size_t dvbase = (size_t)g * a.dv_gs + (size_t)b * HW * C;      // element index of the patch (dv may be bf16)
   const size_t ybase = (size_t)g * a.y_gs + (size_t)b * HW * a.y_rs + c0;   // element index (the conv output may be 16-bit)
-  const unsigned char* fpos = reinterpret_cast<const unsigned char*>(dvp + (size_t)a.Hz * a.Wz * C) + c0;   // compact form only
+  const unsigned char* fpos = reinterpret_cast<const unsigned char*>(a.dv) +
+                              (dvbase + (size_t)a.Hz * a.Wz * C) * (DVF == FMT_F32 ? 4 : 2) + c0;   // compact form only
   const float* coef = a.coef + (size_t)g * a.coef_gs;
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
   for (int c = t; c < CS; c += 256) {
@@ -1088,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   constexpr int UB = 4;
   for (int i0 = t; i0 < total; i0 += 256 * UB) {
     float yv[UB][4];
-    f32x4 dvv[UB];
+    float dvv[UB][4];
     int lq[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
@@ -1098,18 +1101,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
         ld4_fmt<true>(yv[u], a.y, ybase + (size_t)pix * a.y_rs + c4, YF);   // last reader of the conv output
         const int l = lut[pix];
         lq[u] = l;
-        if (!a.dv_compact) dvv[u] = __builtin_nontemporal_load((const f32x4*)(dv + (size_t)pix * C + c4));
+        if (!a.dv_compact) ld4_fmt<true>(dvv[u], a.dv, dvbase + (size_t)pix * C + c0 + c4, DVF);
         else {
           // expand the pooled stage's compact gradient: the value lands on the window position the forward chose
-          f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dvv[u][j] = 0.f;
           if (l >> 22) {
             const int pz = (l >> 10) & 1023, k = (l >> 20) & 3;
-            const f32x4 dc = __builtin_nontemporal_load((const f32x4*)(dv + (size_t)pz * C + c4));
+            float dc[4];
+            ld4_fmt<true>(dc, a.dv, dvbase + (size_t)pz * C + c0 + c4, DVF);
             const unsigned fb = *(const unsigned*)(fpos + (size_t)pz * C + c4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dz[j] = (int)((fb >> (8 * j)) & 0xFFu) == k ? dc[j] : 0.f;
+            for (int j = 0; j < 4; ++j) dvv[u][j] = (int)((fb >> (8 * j)) & 0xFFu) == k ? dc[j] : 0.f;
           }
-          dvv[u] = dz;
         }
       }
     }
@@ -1160,15 +1164,20 @@ int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st) {
   const size_t lds = bn_bwd_apply_lds_bytes(a.cslice, a.H, a.W, sizeof(T));
   if (a.dv_compact && lds > 48 * 1024) { dta_set_error("bn_bwd_apply: compact dv needs the LDS-image kernel"); return 1; }
   if (a.y_fmt != FMT_F32 && a.y_fmt != FMT_F16) { dta_set_error("bn_bwd_apply: unsupported conv-output format %d", a.y_fmt); return 1; }
-  const bool h = a.y_fmt == FMT_F16;
+  if (a.dv_fmt != FMT_F32 && a.dv_fmt != FMT_BF16) { dta_set_error("bn_bwd_apply: unsupported gradient-map format %d", a.dv_fmt); return 1; }
+  const bool h = a.y_fmt == FMT_F16, d16 = a.dv_fmt == FMT_BF16;
+  if (d16 && !h) { dta_set_error("bn_bwd_apply: bf16 gradient maps come with half conv outputs (bf16 mode)"); return 1; }
   if (lds <= 48 * 1024) {
-    if (h) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16>), dim3(a.B, G, a.C / a.cslice), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F32>), dim3(a.B, G, a.C / a.cslice), dim3(256), lds, st, a);
+    const dim3 grid(a.B, G, a.C / a.cslice);
+    if (d16) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16, FMT_BF16>), grid, dim3(256), lds, st, a);
+    else if (h) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16, FMT_F32>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F32, FMT_F32>), grid, dim3(256), lds, st, a);
     DTA_CHECK_LAUNCH("k_bn_bwd_apply_lds");
     return 0;
   }
-  if (h) hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F16>), dim3(a.B, G), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F32>), dim3(a.B, G), dim3(256), 0, st, a);
+  if (d16) hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F16, FMT_BF16>), dim3(a.B, G), dim3(256), 0, st, a);
+  else if (h) hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F16, FMT_F32>), dim3(a.B, G), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F32, FMT_F32>), dim3(a.B, G), dim3(256), 0, st, a);
   DTA_CHECK_LAUNCH("k_bn_bwd_apply");
   return 0;
 }
@@ -1622,7 +1631,10 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     } else {
       lean_ld8<CFG::YF, false>(yraw[j][0], a.y, ypatch + (size_t)p * a.y_rs + o * 8);
     }
-    if (ba.da) lean_ld8<FMT_F32, true>(D[j], ba.da, (size_t)g * ba.da_gs + ((size_t)bb * NP + p) * C + o * 8);
+    if (ba.da) {
+      const size_t di = (size_t)g * ba.da_gs + ((size_t)bb * NP + p) * C + o * 8;
+      if (ba.da_fmt == FMT_BF16) lean_ld8<FMT_BF16, true>(D[j], ba.da, di); else lean_ld8<FMT_F32, true>(D[j], ba.da, di);
+    }
     else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) D[j][e] = 0.f;
@@ -1847,15 +1859,26 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     put8(Z1, p, o, dv[j]);
     put8(Z2, p, o, w8);
     if (live) {
-      float* dvp = ba.dv + (size_t)g * ba.dv_gs + (size_t)b * CFG::HWC * C;
+      const size_t dvi = (size_t)g * ba.dv_gs + (size_t)b * CFG::HWC * C;          // element index of the patch
+      const bool h16 = ba.dv_fmt == FMT_BF16;
+      auto st8 = [&](size_t i, const float (&q)[8]) {
+        if (h16) {
+          u32x4 u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[e] = pack2_fmt(q[2 * e], q[2 * e + 1], FMT_BF16);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(ba.dv) + dvi + i) = u;
+        } else {
+          *reinterpret_cast<f32x4*>(ba.dv + dvi + i) = f32x4{q[0], q[1], q[2], q[3]};
+          *reinterpret_cast<f32x4*>(ba.dv + dvi + i + 4) = f32x4{q[4], q[5], q[6], q[7]};
+        }
+      };
       if (!CFG::POOL || ba.dv_compact) {
-        *reinterpret_cast<f32x4*>(dvp + (size_t)p * C + o * 8) = f32x4{dv[j][0], dv[j][1], dv[j][2], dv[j][3]};
-        *reinterpret_cast<f32x4*>(dvp + (size_t)p * C + o * 8 + 4) = f32x4{dv[j][4], dv[j][5], dv[j][6], dv[j][7]};
+        st8((size_t)p * C + o * 8, dv[j]);
         if (CFG::POOL) {
           unsigned lo = 0u, hi = 0u;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { lo |= ((first[j] >> (2 * e)) & 3u) << (8 * e); hi |= ((first[j] >> (2 * (e + 4))) & 3u) << (8 * e); }
-          unsigned char* fpos = reinterpret_cast<unsigned char*>(dvp + (size_t)NP * C);
+          unsigned char* fpos = reinterpret_cast<unsigned char*>(ba.dv) + (dvi + (size_t)NP * C) * (h16 ? 2 : 4);
           *reinterpret_cast<u32x2*>(fpos + (size_t)p * C + o * 8) = u32x2{lo, hi};
         }
       } else {
@@ -1867,18 +1890,20 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
           float q8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) q8[e] = ((first[j] >> (2 * e)) & 3u) == (unsigned)k ? dv[j][e] : 0.f;
-          *reinterpret_cast<f32x4*>(dvp + (size_t)po[k] * C + o * 8) = f32x4{q8[0], q8[1], q8[2], q8[3]};
-          *reinterpret_cast<f32x4*>(dvp + (size_t)po[k] * C + o * 8 + 4) = f32x4{q8[4], q8[5], q8[6], q8[7]};
+          st8((size_t)po[k] * C + o * 8, q8);
         }
       }
     }
   }
   if (CFG::POOL && !ba.dv_compact && live) {
     // conv-resolution positions the floor pooling dropped (last row / column of an odd map) get no gradient
-    float* dvp = ba.dv + (size_t)g * ba.dv_gs + (size_t)b * CFG::HWC * C;
+    const size_t dvi = (size_t)g * ba.dv_gs + (size_t)b * CFG::HWC * C;
     for (int i = lt; i < CFG::HWC * (C / 4); i += TPP) {
       const int pix = i / (C / 4), c4 = (i % (C / 4)) * 4, h = pix / CFG::WC, w = pix % CFG::WC;
-      if ((h >> 1) >= CFG::HZ || (w >> 1) >= WZ) *reinterpret_cast<f32x4*>(dvp + (size_t)pix * C + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((h >> 1) >= CFG::HZ || (w >> 1) >= WZ) {
+        if (ba.dv_fmt == FMT_BF16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(ba.dv) + dvi + (size_t)pix * C + c4) = u32x2{0u, 0u};
+        else *reinterpret_cast<f32x4*>(ba.dv + dvi + (size_t)pix * C + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
   __syncthreads();

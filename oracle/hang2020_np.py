@@ -295,7 +295,7 @@ def conv_module_bwd(cache, pre, dz, need_dx=True):
         dr = maxpool_floor_bwd(dz, c["arg"], 2, *c["hw"])
     else:
         dr = dz
-    dv = dr * (c["v"] > 0)
+    dv = _qg(dr * (c["v"] > 0))     # (bf16 mode of the HIP path: this map crosses HBM in bf16)
     n = dv.shape[0] * dv.shape[2] * dv.shape[3]
     dbeta = dv.sum(axis=(0, 2, 3))
     dgamma = (dv * c["xhat"]).sum(axis=(0, 2, 3))
@@ -305,6 +305,8 @@ def conv_module_bwd(cache, pre, dz, need_dx=True):
     else:
         dy = (c["g"] * c["rstd"])[None, :, None, None] * dv
     dx, dw, db = conv2d_same_bwd(c["x"], c["w"], _q(dy), need_dx)
+    if dx is not None:
+        dx = _qg(dx)                # (likewise the input-gradient map handed to the previous stage)
     grads = {pre + "conv_layer.weight": dw, pre + "conv_layer.bias": db,
              pre + "bn1.weight": dgamma, pre + "bn1.bias": dbeta}
     return dx, grads
