@@ -49,11 +49,11 @@ inline void prof_end(int site, hipStream_t st) {
 }
 
 // Developer switches (same-box A/B runs): the environment is read once per process, not per call.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; };
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles; };
 inline Switches read_switches() {
   return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr,
           getenv("DTA_FP32_ACT") != nullptr, getenv("DTA_NO_LEAN") != nullptr,
-          getenv("DTA_LEAN_MASK") ? atoi(getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT};
+          getenv("DTA_LEAN_MASK") ? atoi(getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, getenv("DTA_HALO_TILES") != nullptr};
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -84,6 +84,8 @@ struct Plan {
   size_t attsave[3]; int attsave_ld[3];
   int x_compact;   // bf16, 11x11-class patches: the network-input tiles are stored without their halo rows
   int y_fmt;       // storage of the conv outputs between kernels: fp32, or IEEE half in bf16 mode (common.h)
+  int tl_compact;  // bf16 11x11 networks on the lean stage kernels: gated-map and output-gradient tiles are halo-free too
+  int Rin[3];      // tile rows per chunk of layer L's conv INPUT tiles and of its output-gradient tiles (Qin or HWc)
   size_t scores_all, scores_bytes, dfeat_all, dfeat_bytes;
   size_t total;
 };
@@ -161,6 +163,10 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
     int bl, wr, nb;
     wgrad_band_plan(p->Qin[0], p->Wc[0], 252, &bl, &wr, &nb);
     p->x_compact = d->dtype == DTA_BF16 && nb == 1 && bl >= 16 && wr <= 256;
+    // every layer of the 11x11 networks is a single-band plan; the lean forward kernels write the halo-free gated maps
+    const bool net11 = p->H == 11 && p->W == 11;
+    p->tl_compact = p->x_compact && net11 && !switches().no_lean && (switches().lean_mask & 1) && !switches().halo_tiles;
+    for (int L = 0; L < 3; ++L) p->Rin[L] = p->tl_compact ? p->HWc[L] : p->Qin[L];
   }
   Carver c;
   const size_t e = p->esz;
@@ -251,7 +257,8 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
   if (L < 2) {
     s.a_tl = at<char>(ws, p.a_tl[L]);
     s.a_nc = C / 16; s.a_ch0 = 0;
-    s.a_gs = (size_t)B * (C / 16) * p.Qin[L + 1] * 16;
+    s.a_gs = (size_t)B * (C / 16) * p.Rin[L + 1] * 16;
+    s.a_compact = p.tl_compact;
   }
   s.attsave = at<float>(ws, p.attsave[L]); s.attsave_ld = p.attsave_ld[L];
   s.feat = at<float>(ws, p.feat[L]);
@@ -320,7 +327,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
         ca.Cx = p.bands;
         ca.x_tl_out = (d->heads_mask & DTA_FORWARD_ONLY) ? nullptr : at<char>(ws, p.x_tl);   // only the backward reads the tiles
       }
-    } else { ca.x_tl = at<char>(ws, p.a_tl[L - 1]); ca.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
+    } else { ca.x_tl = at<char>(ws, p.a_tl[L - 1]); ca.x_gs = (size_t)B * p.NCin[L] * p.Rin[L] * 16; ca.x_compact = p.tl_compact; }
     ca.wp = at<char>(ws, p.wp[L]);
     for (int g = 0; g < G; ++g) ca.bias[g] = nets[g].conv_b[L];
     ca.bias_mode = pack_mode[L]; ca.bias_split = 32;
@@ -406,10 +413,11 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
   WgradArgs wa;
   memset(&wa, 0, sizeof(wa));
   if (L == 0) { wa.x_tl = at<char>(ws, p.x_tl); wa.x_gs = p.x_tl_gs / p.esz; wa.x_compact = p.x_compact; }
-  else { wa.x_tl = at<char>(ws, p.a_tl[L - 1]); wa.x_gs = (size_t)B * p.NCin[L] * p.Qin[L] * 16; }
+  else { wa.x_tl = at<char>(ws, p.a_tl[L - 1]); wa.x_gs = (size_t)B * p.NCin[L] * p.Rin[L] * 16; wa.x_compact = p.tl_compact; }
   wa.NCx = p.NCin[L];
   wa.dy_tl = at<char>(ws, p.dy_tl[L]);
-  wa.dy_gs = cat ? 0 : (size_t)B * (C / 16) * p.Qin[L] * 16;
+  wa.dy_gs = cat ? 0 : (size_t)B * (C / 16) * p.Rin[L] * 16;
+  wa.y_compact = p.tl_compact;
   wa.NCy = Nconv / 16; wa.ych0 = 0;
   wa.partial = at<float>(ws, p.wpart[L]);
   wa.B = B; wa.H = p.Hc[L]; wa.W = p.Wc[L]; wa.Q = p.Qin[L]; wa.N = Nconv; wa.Cpad = p.CpadW[L]; wa.S = p.S[L];
@@ -585,8 +593,9 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     ap.B = B; ap.C = C; ap.H = p.Hc[L]; ap.W = p.Wc[L];
     ap.dv_compact = sb.dv_compact; ap.Hz = p.Hz[L]; ap.Wz = p.Wz[L]; ap.dv_fmt = sb.dv_fmt;
     ap.dy_tl = at<char>(ws, p.dy_tl[L]);
-    if (L == 0 && p.shared_x) { ap.dy_gs = (size_t)2 * p.Qin[0] * 16; ap.dy_nc = 2 * G; ap.dy_ch0 = 0; }   // group g -> chunks [2g, 2g+2)
-    else { ap.dy_gs = (size_t)B * (C / 16) * p.Qin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
+    if (L == 0 && p.shared_x) { ap.dy_gs = (size_t)2 * p.Rin[0] * 16; ap.dy_nc = 2 * G; ap.dy_ch0 = 0; }   // group g -> chunks [2g, 2g+2)
+    else { ap.dy_gs = (size_t)B * (C / 16) * p.Rin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
+    ap.dy_compact = p.tl_compact;
     if (launch_bn_bwd_apply<T>(ap, G, st)) return 1;
     // ---- conv weight gradient ----
     // the deferred parameter-gradient GEMMs always ride in the launch of the split-K reductions that ends this call
@@ -610,7 +619,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
         if (launch_pack_conv_w<T>(pw, at<char>(ws, p.wd[L]), st)) return 1;
       ConvArgs ca;
       memset(&ca, 0, sizeof(ca));
-      ca.x_tl = ap.dy_tl; ca.x_gs = ap.dy_gs; ca.wp = at<char>(ws, p.wd[L]);
+      ca.x_tl = ap.dy_tl; ca.x_gs = ap.dy_gs; ca.wp = at<char>(ws, p.wd[L]); ca.x_compact = p.tl_compact;
       ca.y = at<float>(ws, p.da[L]); ca.y_gs = (size_t)B * p.HWc[L] * CH[L - 1]; ca.y_rs = CH[L - 1];
       ca.y_fmt = (lean_lvl[L - 1] && g16) ? FMT_BF16 : FMT_F32;      // read by stage L-1's backward
       ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = C / 16; ca.N = CH[L - 1]; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];

@@ -547,13 +547,15 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   const bool xc = a.x_compact != 0;
   const int HWp = a.H * a.W;
   const int vpcx = xc ? HWp * 2 : vpc, xtrows = xc ? HWp : Q;
-  const int nxv = nxch * vpcx, nyv = YCH * vpc;
+  const bool yc = a.y_compact != 0;            // likewise the dY tiles
+  const int vpcy = yc ? HWp * 2 : vpc, ytrows = yc ? HWp : Q;
+  const int nxv = nxch * vpcx, nyv = YCH * vpcy;
   const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs;
   const bf16_t* yg = (const bf16_t*)a.dy_tl + (size_t)g * a.dy_gs;
-  const size_t xpatch = (size_t)a.NCx * xtrows * 16, ypatch = (size_t)a.NCy * Q * 16;
+  const size_t xpatch = (size_t)a.NCx * xtrows * 16, ypatch = (size_t)a.NCy * ytrows * 16;
   // per vector: element offset inside the patch's tile and window row.  (The LDS image is linear: vector v of a part
   // lives at byte 16*v.)  Vectors past the end of the part are not stored; their loads are pointed at a valid row.
-  int xsrc[XV], ysrc[YV], xrow[XV], yrow[YV], xdst[XV];
+  int xsrc[XV], ysrc[YV], xrow[XV], yrow[YV], xdst[XV], ydst[YV];
 #pragma unroll
   for (int u = 0; u < XV; ++u) {
     int v = min(tid + u * NTHR, max(nxv, 1) - 1);
@@ -567,9 +569,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
 #pragma unroll
   for (int u = 0; u < YV; ++u) {
     int v = min(tid + u * NTHR, nyv - 1);
-    int ch = v / vpc, o = v - ch * vpc;
-    yrow[u] = o >> 1;
-    ysrc[u] = (a.ych0 + ch) * Q * 16 + o * 8;
+    int ch = v / vpcy, o = v - ch * vpcy;
+    int row = o >> 1;
+    ysrc[u] = (a.ych0 + ch) * ytrows * 16 + o * 8;
+    if (yc) { const int hh = row / a.W; row = (hh + 1) * W2 + (row - hh * a.W) + 1; }   // pixel -> haloed-grid row
+    yrow[u] = yc ? 0 : row;
+    ydst[u] = (ch * WR + row) * RW + (o & 1) * 16;
   }
   u32x4 rx[XV], ry[YV];
   // Branch-free fetch: wave-uniform base (patch, band) + per-lane 32-bit offset.  A window row that falls beyond the
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                                \
         if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((base_) + xdst[u]) = rx[u];                           \
     _Pragma("unroll") for (int u = 0; u < YV; ++u)                                                                \
-        if (tid + u * NTHR < nyv) *reinterpret_cast<u32x4*>((base_) + xbytes + (tid + u * NTHR) * 16) = ry[u];    \
+        if (tid + u * NTHR < nyv) *reinterpret_cast<u32x4*>((base_) + xbytes + ydst[u]) = ry[u];                  \
   }
   // flattened (patch, band) iteration space of this workgroup
   const int npb = (a.B - s + a.S - 1) / a.S;

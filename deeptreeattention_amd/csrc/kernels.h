@@ -33,6 +33,7 @@ struct WgradArgs {
   int B, H, W, Q, N, Cpad, S, dbuf, cgroups, G;
   int bl, wr, nbands;                 // K-band plan (rows per band, LDS window rows, bands per patch)
   int x_compact;                      // bf16, single band: X tiles are halo-free [patch][chunk][pixel][16]
+  int y_compact;                      // likewise the dY tiles
 };
 // bl = rows per band (multiple of 16), wr = bl + 2*(W+3) rounded up to 4 (mod 8), wr <= wr_max
 void wgrad_band_plan(int Q, int W, int wr_max, int* bl, int* wr, int* nbands);
@@ -156,6 +157,7 @@ struct StageArgs {
   int att_k[MAXG], att_pool[MAXG];           // spatial stencil size / class-pool size
   int vslot;                           // LDS vector slot (floats); filled by the launcher
   void* a_tl; size_t a_gs; int a_nc, a_ch0;      // gated map as tiles for the next conv (or null)
+  int a_compact;                       // bf16 + lean kernels: halo-free tiles [patch][chunk][pixel][16]
   float* a_nchw; size_t a_nchw_gs;     // gated map as fp32 NCHW (standalone modules) or null
   float* feat; size_t feat_gs; int F[MAXG];      // [B][F]
   // attention intermediates of every patch ([G][B][attsave_ld] floats, >= 3 * vslot): written by the forward,
@@ -187,6 +189,7 @@ struct StageBwdArgs {
 };
 int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st);
 bool stage_bwd_is_lean(const StageBwdArgs& a, int G);
+bool stage_fwd_is_lean(const StageArgs& a);
 
 struct BnBwdFinalizeArgs {
   const float* bnpart; size_t bnpart_gs; int B, C, HW;
@@ -204,6 +207,7 @@ struct BnBwdApplyArgs {
   const float* coef; int coef_gs; const float* bcoef; int bcoef_gs;
   int B, C, H, W;
   void* dy_tl; size_t dy_gs; int dy_nc, dy_ch0;
+  int dy_compact;                      // halo-free output tiles [patch][chunk][pixel][16] (LDS-image kernel, bf16)
   int dv_compact, Hz, Wz;              // see StageBwdArgs::dv_compact
   int cslice;                          // channels per workgroup (filled by the launcher)
 };

@@ -545,14 +545,17 @@ static bool stage_net_cfg(const StageArgs& a) {
 }
 
 template <typename T> int launch_stage_fwd_lean(const StageArgs& a, int G, hipStream_t st);
+bool stage_fwd_is_lean(const StageArgs& a) {
+  return (a.lean & 1) && a.apply_bn && a.relu && stage_net_cfg(a) && !a.a_nchw && (a.y_fmt == FMT_F32 || a.y_fmt == FMT_F16);
+}
 
 template <typename T>
 int launch_stage_fwd(const StageArgs& a_in, int G, hipStream_t st) {
   StageArgs a = a_in;
   a.vslot = stage_vslot_for(a, G);
   // the three stages of the 11x11 networks have lean register-resident forms (end of this file)
-  if ((a.lean & 1) && a.apply_bn && a.relu && stage_net_cfg(a) && !a.a_nchw && (a.y_fmt == FMT_F32 || a.y_fmt == FMT_F16))
-    return launch_stage_fwd_lean<T>(a, G, st);
+  if (stage_fwd_is_lean(a)) return launch_stage_fwd_lean<T>(a, G, st);
+  if (a.a_compact) { dta_set_error("stage_fwd: halo-free tiles need the lean kernels"); return 1; }
   size_t lds = stage_lds_floats(a, false) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_fwd: %dx%dx%d patch needs %zu B of LDS", a.Hc, a.Wc, a.C, lds); return 1; }
   // the three stages of the 11x11 network are fully specialised (stencils unroll, no index divisions)
@@ -1083,9 +1086,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
     const int inw = (a.dv_compact && hz < a.Hz && wz < a.Wz) ? 1 : 0;
     lut[pix] = ((hh + 1) * W2 + ww + 1) | ((inw ? hz * a.Wz + wz : 0) << 10) | ((((hh & 1) << 1) | (ww & 1)) << 20) | (inw << 22);
   }
-  const int nvec = nch * Q * 16 * (int)sizeof(T) / 16;
+  // dy_compact: the image holds the HW pixels only (no halo rows to zero, 28 % fewer bytes out for an 11x11 patch)
+  const int QI = a.dy_compact ? HW : Q;
+  const int nvec = nch * QI * 16 * (int)sizeof(T) / 16;
   u32x4* img4 = (u32x4*)img;
-  for (int i = t; i < nvec; i += 256) img4[i] = u32x4{0u, 0u, 0u, 0u};
+  if (!a.dy_compact)
+    for (int i = t; i < nvec; i += 256) img4[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   const int total = HW * C4;
   constexpr int UB = 4;
@@ -1122,11 +1128,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
       const int i = i0 + u * 256;
       if (i < total) {
         const int pix = i >> c4sh, c4 = (i - (pix << c4sh)) * 4;
-        const int q = lq[u] & 1023;
+        const int q = a.dy_compact ? pix : (lq[u] & 1023);
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = sk[c4 + j] * dvv[u][j] + sk[CS + c4 + j] * yv[u][j] + sk[2 * CS + c4 + j];
-        T* row = img + ((size_t)(c4 >> 4) * Q + q) * 16;
+        T* row = img + ((size_t)(c4 >> 4) * QI + q) * 16;
         if constexpr (sizeof(T) == 2) {
           u32x2 pk = {(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
           *(u32x2*)(row + (c4 & 15)) = pk;
@@ -1142,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
     }
   }
   __syncthreads();
-  u32x4* dst = (u32x4*)((T*)a.dy_tl + (size_t)g * a.dy_gs + ((size_t)b * a.dy_nc + a.dy_ch0 + c0 / 16) * Q * 16);
+  u32x4* dst = (u32x4*)((T*)a.dy_tl + (size_t)g * a.dy_gs + ((size_t)b * a.dy_nc + a.dy_ch0 + c0 / 16) * QI * 16);
   for (int i = t; i < nvec; i += 256) dst[i] = img4[i];
 }
 
@@ -1162,7 +1168,8 @@ int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st) {
   BnBwdApplyArgs a = a_in;
   a.cslice = bn_bwd_apply_cslice(a.C, a.H, a.W, sizeof(T));
   const size_t lds = bn_bwd_apply_lds_bytes(a.cslice, a.H, a.W, sizeof(T));
-  if (a.dv_compact && lds > 48 * 1024) { dta_set_error("bn_bwd_apply: compact dv needs the LDS-image kernel"); return 1; }
+  if ((a.dv_compact || a.dy_compact) && lds > 48 * 1024) { dta_set_error("bn_bwd_apply: compact dv / dy need the LDS-image kernel"); return 1; }
+  if (a.dy_compact && sizeof(T) != 2) { dta_set_error("bn_bwd_apply: halo-free output tiles are a bf16 layout"); return 1; }
   if (a.y_fmt != FMT_F32 && a.y_fmt != FMT_F16) { dta_set_error("bn_bwd_apply: unsupported conv-output format %d", a.y_fmt); return 1; }
   if (a.dv_fmt != FMT_F32 && a.dv_fmt != FMT_BF16) { dta_set_error("bn_bwd_apply: unsupported gradient-map format %d", a.dv_fmt); return 1; }
   const bool h = a.y_fmt == FMT_F16, d16 = a.dv_fmt == FMT_BF16;
@@ -1462,7 +1469,10 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
     }
   }
   __syncthreads();
-  T* tile = a.a_tl ? (T*)a.a_tl + (size_t)g * a.a_gs + ((size_t)(live ? b : 0) * a.a_nc + a.a_ch0) * CFG::QZ * 16 : nullptr;
+  // tile rows per chunk: the haloed grid, or (a_compact) the pixels only -- the readers keep the halo in LDS
+  const int trows = a.a_compact ? NP : CFG::QZ;
+  T* tile = a.a_tl ? (T*)a.a_tl + (size_t)g * a.a_gs + ((size_t)(live ? b : 0) * a.a_nc + a.a_ch0) * trows * 16 : nullptr;
+  auto trow = [&](int p) { return a.a_compact ? p : (p / WZ + 1) * CFG::W2 + p % WZ + 1; };
   float* feat = (a.feat && live) ? a.feat + (size_t)g * a.feat_gs + (size_t)b * a.F[g] : nullptr;
   float* save = (a.attsave && live) ? a.attsave + ((size_t)g * a.B + b) * a.attsave_ld : nullptr;
   float* sm0 = sm + 2 * C;
@@ -1490,7 +1500,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = z[j][e] * gL[o * 8 + e];
-        lean_tl_store8(tile, CFG::QZ, (h + 1) * CFG::W2 + w + 1, o, v);
+        lean_tl_store8(tile, trows, trow(p), o, v);
       }
     }
   } else if (kind == KIND_SPATIAL) {
@@ -1545,7 +1555,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = z[j][e] * sp;
-      if (tile && live) lean_tl_store8(tile, CFG::QZ, (h + 1) * CFG::W2 + w + 1, o, v);
+      if (tile && live) lean_tl_store8(tile, trows, trow(p), o, v);
       if (feat) {   // the gated map replaces the patch in LDS for the class pool below
         *reinterpret_cast<f32x4*>(Zs + p * C + o * 8) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(Zs + p * C + o * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -1575,10 +1585,10 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
       const int it = lt + j * TPP;
       if (it >= CFG::ITEMS) continue;
       const int p = it / NO, o = it % NO;
-      lean_tl_store8(tile, CFG::QZ, (p / WZ + 1) * CFG::W2 + p % WZ + 1, o, z[j]);
+      lean_tl_store8(tile, trows, trow(p), o, z[j]);
     }
   }
-  if (tile && live) lean_tl_halo<T, CFG>(tile, lt);
+  if (tile && live && !a.a_compact) lean_tl_halo<T, CFG>(tile, lt);
 }
 
 // ------------------------------------------------------------------------------------------------

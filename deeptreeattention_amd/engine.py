@@ -248,11 +248,14 @@ class FusedTrainer:
                                              _lib.ptr(self.head_dscores[g, hd]) if want_grad else None,
                                              _lib.ptr(self.ce_scratch), st), "dta_weighted_ce")
                 k += 1
-        torch.sum(self.head_losses, dim=0, out=self.loss)
+        self.loss = torch.sum(self.head_losses, dim=0)
         return self.loss
 
     def _loss(self, logits, y, want_grad):
         L = _lib.lib()
+        # a fresh 0-d tensor per call (caching-allocator bookkeeping only, no device work): callers may keep every
+        # step's loss (Lightning collects them per epoch) without an extra copy kernel on the stream
+        self.loss = torch.empty((), dtype=torch.float32, device=self.device)
         _lib.check(L.dta_weighted_ce(_lib.ptr(logits), _lib.ptr(y), _lib.ptr(self.loss_weight), logits.shape[0],
                                      logits.shape[1], _lib.ptr(self.loss),
                                      _lib.ptr(self.dlogits) if want_grad else None, _lib.ptr(self.ce_scratch),
@@ -360,7 +363,7 @@ class FusedTrainer:
             self._loss(logits, y, True)
             self._backward(self.dlogits)
         self._adam()
-        return self.loss.clone()
+        return self.loss
 
     def training_step(self, batch, batch_idx=0):
         """The reference's TreeModel.training_step unpacking (src/main.py:71-80): batch = (individual, inputs, y),
@@ -377,7 +380,7 @@ class FusedTrainer:
         """Forward + loss only (validation_step, reference src/main.py:82-94); returns fresh (logits, loss) tensors."""
         logits = self._forward_scores(x)
         loss = self._loss_heads(self._labels(y), False) if self.three_head else self._loss(logits, self._labels(y), False)
-        return logits.clone(), loss.clone()
+        return logits.clone(), loss
 
 
 class EnsembleTrainer:
@@ -539,6 +542,7 @@ class EnsembleTrainer:
 
     def _ce(self, y, want_grad):
         L = _lib.lib()
+        self.loss = torch.empty((), dtype=torch.float32, device=self.device)      # fresh per step (see FusedTrainer._loss)
         _lib.check(L.dta_weighted_ce(_lib.ptr(self.scores), _lib.ptr(y), _lib.ptr(self.loss_weight),
                                      self.scores.shape[0], self.scores.shape[1], _lib.ptr(self.loss),
                                      _lib.ptr(self.dscores) if want_grad else None, _lib.ptr(self.ce_scratch),
@@ -571,7 +575,7 @@ class EnsembleTrainer:
             for i, t in enumerate(self.years):
                 if local[i]:
                     t._adam()
-            return self.loss.clone()
+            return self.loss
         # data-parallel: every rank issues the same collectives whatever it kept; skipped years send their zeros
         mask = sum(1 << i for i, k in enumerate(local) if k)
         if self.overlap:
@@ -587,14 +591,14 @@ class EnsembleTrainer:
         self.sync.finish()
         self.dev_steps.add_((self.flags > 0).to(torch.int32))
         self._adam_gated()
-        return self.loss.clone()
+        return self.loss
 
     def forward_loss(self, images, y, present=None):
         """validation_step of the level (multi_stage.py:290-304): ensemble scores + weighted CE, no update."""
         local = self._kept(images, present)
         self._forward(images, local)
         self._ce(self.years[0]._labels(y), False)
-        return self.scores.clone(), self.loss.clone()
+        return self.scores.clone(), self.loss
 
 
 class MultiStageTrainer:
