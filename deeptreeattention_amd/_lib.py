@@ -84,6 +84,15 @@ def lib():
         L.dta_net_backward.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p,
                                        C.POINTER(ScoreTable), C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p,
                                        C.c_int, C.c_void_p]
+        L.dta_net_forward_tiles.restype = C.c_int
+        L.dta_net_forward_tiles.argtypes = L.dta_net_forward.argtypes
+        L.dta_net_backward_tiles.restype = C.c_int
+        L.dta_net_backward_tiles.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.POINTER(ScoreTable), C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p,
+                                             C.c_int, C.c_void_p]
+        L.dta_preprocess_crops_tiles.restype = C.c_int
+        L.dta_preprocess_crops_tiles.argtypes = [C.POINTER(CropDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]
         L.dta_ensemble_workspace_bytes.restype = C.c_size_t
         L.dta_ensemble_workspace_bytes.argtypes = [C.POINTER(NetDesc), C.c_int]
         L.dta_ensemble_forward.restype = C.c_int

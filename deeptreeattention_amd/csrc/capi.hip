@@ -269,7 +269,13 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
 
 template <typename T>
 int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha,
-              const float* const* xs, void* ws, float* const (*scores)[3], float* joint, hipStream_t st) {
+              const float* const* xs, void* ws, float* const (*scores)[3], float* joint, hipStream_t st,
+              const void* x_tiles = nullptr) {
+  // x_tiles: the network input already as halo-free bf16 conv tiles (dta_preprocess_crops_tiles): no fp32 input at all
+  if (x_tiles && !(p.esz == 2 && p.x_compact && (p.shared_x || p.G == 1))) {
+    dta_set_error("input tiles need the bf16 mode, 11x11-class patches and a single input tensor");
+    return 1;
+  }
   const int G = p.G, B = p.B;
   GemmGroup heads;
   // ---- all weight re-layouts of the step in two launches (forward forms, and when training the transposed
@@ -304,7 +310,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     PrepArgs pa = {};
     // bf16, halo-free input tiles: the first conv reads the caller's fp32 tensor itself (and leaves the bf16 tiles
     // behind for the weight gradient), so there is no input-pack job
-    pa.nx = fused_input(p) ? 0 : (p.shared_x ? 1 : G); pa.x_tl_gs = p.x_tl_gs;
+    pa.nx = (x_tiles || fused_input(p)) ? 0 : (p.shared_x ? 1 : G); pa.x_tl_gs = p.x_tl_gs;
     for (int g = 0; g < pa.nx; ++g) pa.x[g] = xs[g];
     pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
     pa.x_compact = p.x_compact;
@@ -321,8 +327,8 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     ConvArgs ca;
     memset(&ca, 0, sizeof(ca));
     if (L == 0) {
-      ca.x_tl = at<char>(ws, p.x_tl); ca.x_gs = p.x_tl_gs / p.esz; ca.x_compact = p.x_compact;
-      if (fused_input(p)) {
+      ca.x_tl = x_tiles ? x_tiles : at<char>(ws, p.x_tl); ca.x_gs = p.x_tl_gs / p.esz; ca.x_compact = p.x_compact;
+      if (!x_tiles && fused_input(p)) {
         for (int g = 0; g < G; ++g) ca.x_nchw[g] = xs[p.shared_x ? 0 : g];
         ca.Cx = p.bands;
         ca.x_tl_out = (d->heads_mask & DTA_FORWARD_ONLY) ? nullptr : at<char>(ws, p.x_tl);   // only the backward reads the tiles
@@ -402,7 +408,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
 
 template <typename T>
 int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grads* grads, void* ws, int L,
-                     WgradReduceGroup& reduces, hipStream_t st) {
+                     WgradReduceGroup& reduces, hipStream_t st, const void* x_tiles = nullptr) {
   const int G = p.G, B = p.B, C = CH[L];
   const bool cat = L == 0 && p.shared_x;
   const int Nconv = cat ? 32 * G : C;
@@ -412,7 +418,7 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
   if (!want_w) return 0;
   WgradArgs wa;
   memset(&wa, 0, sizeof(wa));
-  if (L == 0) { wa.x_tl = at<char>(ws, p.x_tl); wa.x_gs = p.x_tl_gs / p.esz; wa.x_compact = p.x_compact; }
+  if (L == 0) { wa.x_tl = x_tiles ? x_tiles : at<char>(ws, p.x_tl); wa.x_gs = p.x_tl_gs / p.esz; wa.x_compact = p.x_compact; }
   else { wa.x_tl = at<char>(ws, p.a_tl[L - 1]); wa.x_gs = (size_t)B * p.NCin[L] * p.Rin[L] * 16; wa.x_compact = p.tl_compact; }
   wa.NCx = p.NCin[L];
   wa.dy_tl = at<char>(ws, p.dy_tl[L]);
@@ -436,12 +442,12 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
 template <typename T>
 int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, void* ws,
                const float* const (*dscores)[3], const float* djoint, const dta_subnet_grads* grads, double* dalpha,
-               int phases, hipStream_t st) {
+               int phases, hipStream_t st, const void* x_tiles = nullptr) {
   const int G = p.G, B = p.B;
   if (!(phases & 1)) {
     // phase 2 only: the first layer's weight gradient from tensors phase 1 left in the workspace
     WgradReduceGroup reduces;
-    if (conv_wgrad_layer<T>(p, d, grads, ws, 0, reduces, st)) return 1;
+    if (conv_wgrad_layer<T>(p, d, grads, ws, 0, reduces, st, x_tiles)) return 1;
     return launch_wgrad_reduce_group(reduces, st);
   }
   const float* dsc[MAXG][3] = {};
@@ -608,7 +614,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       deferred.n = 0;
     }
     if (L > 0 || (phases & 2))
-      if (conv_wgrad_layer<T>(p, d, grads, ws, L, reduces, st)) return 1;
+      if (conv_wgrad_layer<T>(p, d, grads, ws, L, reduces, st, x_tiles)) return 1;
     // ---- conv input gradient (feeds the previous stage's gated map) ----
     if (L > 0) {
       PackWArgs pw;
@@ -701,6 +707,26 @@ int dta_net_forward(const dta_net_desc* d, const dta_subnet_params* nets, const 
   if (d->dtype == DTA_F32) return forward_t<float>(p, d, nets, alpha, xs, workspace, scores, joint, st);
   dta_set_error("unknown dtype %d", d->dtype);
   return 1;
+}
+
+int dta_net_forward_tiles(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,
+                          void* workspace, float* const scores[2][3], float* joint, void* stream) {
+  Plan p;
+  if (!d || !nets || !x_tiles || !workspace) { dta_set_error("dta_net_forward_tiles: null argument"); return 1; }
+  if (build_plan(d, &p)) return 1;
+  if (d->dtype != DTA_BF16) { dta_set_error("dta_net_forward_tiles: bf16 mode only"); return 1; }
+  const float* xs[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+  return forward_t<bf16_t>(p, d, nets, alpha, xs, workspace, scores, joint, (hipStream_t)stream, x_tiles);
+}
+
+int dta_net_backward_tiles(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,
+                           void* workspace, const float* const dscores[2][3], const float* djoint,
+                           const dta_subnet_grads* grads, double* dalpha, int phases, void* stream) {
+  Plan p;
+  if (!d || !nets || !x_tiles || !workspace || !grads || !(phases & 3)) { dta_set_error("dta_net_backward_tiles: null argument"); return 1; }
+  if (build_plan(d, &p)) return 1;
+  if (d->dtype != DTA_BF16) { dta_set_error("dta_net_backward_tiles: bf16 mode only"); return 1; }
+  return backward_t<bf16_t>(p, d, nets, alpha, workspace, dscores, djoint, grads, dalpha, phases, (hipStream_t)stream, x_tiles);
 }
 
 // ---- year ensemble: `years` spectral networks as the groups of ONE set of launches ----

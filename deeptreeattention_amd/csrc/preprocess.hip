@@ -147,6 +147,84 @@ __global__ __launch_bounds__(256) void k_preprocess_crops(CropArgs a) {
   }
 }
 
+// Same preprocessing, output written straight as the bf16 conv tiles the first layer's kernels read
+// ([crop][chunk = band / 16][pixel][16], halo-free; bands past C are zero): the float32 NCHW batch (4 bytes per element
+// written here, read and converted again by the first conv) never exists.  Values are the float32 results above rounded
+// to bf16 (nearest even).  A thread owns (pixel, 16-band chunk) items: with pixel-interleaved crops its 16 bands are one
+// contiguous 32-byte run of the raw pixel.
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void k_preprocess_crops_tiles(CropArgs a, unsigned short* tiles) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x, t = threadIdx.x, S = a.S, SS = S * S, C = a.C, NC = (C + 15) / 16;
+  const int h = a.hs[b], w = a.ws[b];
+  unsigned short* out = tiles + (size_t)b * NC * SS * 16;
+  const int p0 = blockIdx.y * a.np, NP = min(a.np, SS - p0);
+  if (h <= 0 || w <= 0) {   // missing year: all zeros
+    for (int i = t; i < NC * NP * 2; i += 256) {
+      const int ch = i / (NP * 2), r = i % (NP * 2);
+      reinterpret_cast<u32x4*>(out + ((size_t)ch * SS + p0) * 16)[r] = u32x4{0u, 0u, 0u, 0u};
+    }
+    return;
+  }
+  const T* raw = reinterpret_cast<const T*>(a.raw) + a.off[b];
+  int* pix = reinterpret_cast<int*>(sm);
+  float* scl = sm + a.np;
+  float* mn = scl + a.np;
+  for (int p = t; p < NP; p += 256) {
+    int i = (p0 + p) / S, j = (p0 + p) - i * S;
+    if (a.flip) { i = S - 1 - i; j = S - 1 - j; }
+    pix[p] = nearest_src(i, h, S) * w + nearest_src(j, w, S);
+  }
+  __syncthreads();
+  const float tiny = 10.f * 1.1920928955078125e-07f;
+  const size_t plane = (size_t)h * w;
+  auto at = [&](int p, int c) -> float {
+    return LAYOUT == 0 ? to_f(raw[(size_t)(a.c0 + c) * plane + pix[p]]) : to_f(raw[(size_t)pix[p] * a.Craw + a.c0 + c]);
+  };
+  // per-pixel range: 256 / np lanes share a pixel when it pays, else one lane per pixel
+  {
+    const int lane = t & 63, wv = t >> 6;
+    for (int p = wv; p < NP; p += 4) {
+      float lo = __builtin_inff(), hi = -__builtin_inff();
+      for (int c = lane; c < C; c += 64) { const float v = at(p, c); lo = fminf(lo, v); hi = fmaxf(hi, v); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+      if (lane == 0) {
+        float rng = hi - lo;
+        if (rng < tiny) rng = 1.f;
+        const float s = 1.f / rng;
+        scl[p] = s; mn[p] = 0.f - mul_rounded(lo, s);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < NC * NP; i += 256) {
+    const int ch = LAYOUT == 0 ? i / NP : i % NC, p = LAYOUT == 0 ? i % NP : i / NC;   // consecutive lanes: consecutive raw bytes
+    const float s = scl[p], m = mn[p];
+    unsigned pk[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c0 = ch * 16 + 2 * e;
+      const float v0 = c0 < C ? mul_rounded(at(p, c0), s) + m : 0.f;
+      const float v1 = c0 + 1 < C ? mul_rounded(at(p, c0 + 1), s) + m : 0.f;
+      pk[e] = pack2_fmt(v0, v1, FMT_BF16);
+    }
+    u32x4* dst = reinterpret_cast<u32x4*>(out + ((size_t)ch * SS + p0 + p) * 16);
+    dst[0] = u32x4{pk[0], pk[1], pk[2], pk[3]};
+    dst[1] = u32x4{pk[4], pk[5], pk[6], pk[7]};
+  }
+}
+
+template <typename T>
+int launch_tiles_t(const CropArgs& a, int layout, unsigned short* tiles, hipStream_t st) {
+  const size_t lds = 3 * (size_t)a.np * 4;
+  const dim3 grid(a.B, (a.S * a.S + a.np - 1) / a.np);
+  if (layout == 0) hipLaunchKernelGGL((k_preprocess_crops_tiles<T, 0>), grid, dim3(256), lds, st, a, tiles);
+  else hipLaunchKernelGGL((k_preprocess_crops_tiles<T, 1>), grid, dim3(256), lds, st, a, tiles);
+  DTA_CHECK_LAUNCH("k_preprocess_crops_tiles");
+  return 0;
+}
+
 template <typename T>
 int launch_t(const CropArgs& a, int layout, size_t lds, hipStream_t st) {
   if (layout == 0) {
@@ -194,5 +272,28 @@ extern "C" int dta_preprocess_crops(const dta_crop_desc* d, const void* raw, con
     case DTA_CROP_I16: return launch_t<short>(a, d->layout, lds_floats * 4, st);
     case DTA_CROP_U8: return launch_t<unsigned char>(a, d->layout, lds_floats * 4, st);
     default: dta_set_error("dta_preprocess_crops: unknown raw dtype %d", d->dtype); return 1;
+  }
+}
+
+extern "C" int dta_preprocess_crops_tiles(const dta_crop_desc* d, const void* raw, const long long* offsets, const int* heights,
+                                          const int* widths, void* tiles, void* stream) {
+  if (!d || !raw || !offsets || !heights || !widths || !tiles) { dta_set_error("dta_preprocess_crops_tiles: null argument"); return 1; }
+  if (d->batch < 1 || d->bands_raw < 1 || d->size < 1 || d->clip < 0) { dta_set_error("dta_preprocess_crops_tiles: bad descriptor"); return 1; }
+  if (d->layout != DTA_CROP_CHW && d->layout != DTA_CROP_HWC) { dta_set_error("dta_preprocess_crops_tiles: unknown layout %d", d->layout); return 1; }
+  CropArgs a;
+  a.raw = raw; a.off = offsets; a.hs = heights; a.ws = widths; a.out = nullptr;
+  a.B = d->batch; a.Craw = d->bands_raw; a.S = d->size; a.flip = d->flip != 0;
+  a.c0 = d->bands_raw > 3 ? d->clip : 0;
+  a.C = dta_preprocess_out_bands(d->bands_raw, d->clip);
+  if (a.C < 1) { dta_set_error("dta_preprocess_crops_tiles: %d bands leave nothing after dropping 2 x %d", d->bands_raw, d->clip); return 1; }
+  const int SS = a.S * a.S, parts = (SS + 143) / 144;
+  a.np = (SS + parts - 1) / parts; a.pitch = 0; a.cc = 0;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* o = reinterpret_cast<unsigned short*>(tiles);
+  switch (d->dtype) {
+    case DTA_CROP_F32: return launch_tiles_t<float>(a, d->layout, o, st);
+    case DTA_CROP_I16: return launch_tiles_t<short>(a, d->layout, o, st);
+    case DTA_CROP_U8: return launch_tiles_t<unsigned char>(a, d->layout, o, st);
+    default: dta_set_error("dta_preprocess_crops_tiles: unknown raw dtype %d", d->dtype); return 1;
   }
 }

@@ -212,7 +212,13 @@ class FusedTrainer:
         mode: every head's scores in self.head_scores[net][head]; self.logits holds Hang2020's blended scores or the
         last head)."""
         L = _lib.lib()
-        x = H._check_input(x)
+        tiles = getattr(x, "tiles", None)        # preprocess.PatchTiles: the input already as the first conv's bf16 tiles
+        if tiles is not None:
+            if self.model.precision != "bf16":
+                raise RuntimeError("PatchTiles inputs need a bf16-mode network")
+        else:
+            x = H._check_input(x)
+        self._tiles = tiles                      # the backward reads them again (first conv's weight gradient)
         self._prepare(x)
         table = _lib.ScoreTable()
         joint = _lib.ptr(self.logits)
@@ -228,9 +234,10 @@ class FusedTrainer:
                                    "spatial network built with last_head_only=True, or three_head_loss=True")
             table[0][2] = self.logits.data_ptr()
             joint = None
-        _lib.check(L.dta_net_forward(C.byref(self.desc), self.nets, _lib.ptr(self.alpha) if self.hang else None,
-                                     _lib.ptr(x), _lib.ptr(self._ws), C.byref(table), joint,
-                                     _lib.current_stream_ptr()), "dta_net_forward")
+        fwd = L.dta_net_forward if tiles is None else L.dta_net_forward_tiles
+        _lib.check(fwd(C.byref(self.desc), self.nets, _lib.ptr(self.alpha) if self.hang else None,
+                       _lib.ptr(x if tiles is None else tiles), _lib.ptr(self._ws), C.byref(table), joint,
+                       _lib.current_stream_ptr()), "dta_net_forward")
         if self.three_head and not self.hang:
             self.logits = self.head_scores[0, 2]
         return self.logits
@@ -283,8 +290,13 @@ class FusedTrainer:
         self._zero_grads()             # C-ABI contract: gradient buffers (and dalpha) arrive zero-filled
 
         def run(phases):
-            _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table), djoint, self.grads,
-                                          dalpha, phases, st), "dta_net_backward")
+            if self._tiles is None:
+                _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table), djoint, self.grads,
+                                              dalpha, phases, st), "dta_net_backward")
+            else:
+                _lib.check(L.dta_net_backward_tiles(d, self.nets, alpha, _lib.ptr(self._tiles), _lib.ptr(self._ws),
+                                                    C.byref(table), djoint, self.grads, dalpha, phases, st),
+                           "dta_net_backward_tiles")
         ag, slot = (self.alpha_g, self.alpha_slot) if self.alpha_on_graph else (None, None)
         if self.world == 1:
             run(3)

@@ -21,11 +21,29 @@ def out_bands(bands_raw, clip=10):
     return bands_raw - 2 * clip if bands_raw > 3 else bands_raw
 
 
-def preprocess_batch(crops, image_size, train=False, pixel_interleaved=False, clip=10, device="cuda", out=None):
+class PatchTiles:
+    """A preprocessed batch stored as the first conv's bf16 tiles ([B][ceil(bands / 16)][H * W][16], halo-free) instead
+    of the float32 (B, bands, H, W) tensor: what `preprocess_batch(..., tiles=True)` returns and what
+    `engine.FusedTrainer.train_step / forward_loss` accept in bf16 mode.  `.float()` expands it back (bf16-rounded
+    values) for anything that wants the NCHW tensor."""
+
+    def __init__(self, tiles, batch, bands, height, width):
+        self.tiles, self.shape = tiles, (int(batch), int(bands), int(height), int(width))
+
+    def float(self):
+        B, C, Hh, Ww = self.shape
+        t = self.tiles.view(B, -1, Hh * Ww, 16).view(torch.bfloat16).float()       # [B][chunk][pixel][16]
+        return t.permute(0, 1, 3, 2).reshape(B, -1, Hh, Ww)[:, :C].contiguous()
+
+
+def preprocess_batch(crops, image_size, train=False, pixel_interleaved=False, clip=10, device="cuda", out=None,
+                     tiles=False):
     """crops: list of raw arrays (numpy or torch; all one dtype among float32 / int16 / uint8), each band-first
     (bands, h, w) as rasterio's read() / np.load return it, or (h, w, bands) when pixel_interleaved (the on-disk order); `None` marks a missing year (all-zero output, reference data.py:295-296).
     Returns a (len(crops), bands_out, image_size, image_size) float32 device tensor: the reference's
-    load_image(path, image_size) for every crop, followed by the training flips when train=True."""
+    load_image(path, image_size) for every crop, followed by the training flips when train=True.
+    tiles=True: returns a PatchTiles instead -- the same values rounded to bf16 and laid out as the first conv's tiles,
+    written by the same single launch (the float32 batch is never materialised; bf16-mode networks only)."""
     L = _lib.lib()
     channel_is_first = not pixel_interleaved
     dev = torch.device(device)
@@ -57,6 +75,14 @@ def preprocess_batch(crops, image_size, train=False, pixel_interleaved=False, cl
     meta = torch.tensor([offs], dtype=torch.int64).reshape(-1).to(dev)
     hw = torch.tensor([hs, ws], dtype=torch.int32).to(dev)
     B, Cout = len(crops), out_bands(bands, clip)
+    if tiles:
+        desc = _lib.CropDesc(B, bands, clip, image_size, 1 if train else 0,
+                             _lib.CROP_CHW if channel_is_first else _lib.CROP_HWC, _DTYPES[np.dtype(dt)])
+        t = torch.empty(B * ((Cout + 15) // 16) * image_size * image_size * 16, dtype=torch.int16, device=dev)
+        _lib.check(L.dta_preprocess_crops_tiles(C.byref(desc), _lib.ptr(raw), _lib.ptr(meta), _lib.ptr(hw[0]),
+                                                _lib.ptr(hw[1]), _lib.ptr(t), _lib.current_stream_ptr()),
+                   "dta_preprocess_crops_tiles")
+        return PatchTiles(t, B, Cout, image_size, image_size)
     if out is None:
         out = torch.empty(B, Cout, image_size, image_size, dtype=torch.float32, device=dev)
     elif tuple(out.shape) != (B, Cout, image_size, image_size) or out.dtype != torch.float32 or not out.is_contiguous():

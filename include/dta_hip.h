@@ -91,6 +91,16 @@ int dta_net_backward(const dta_net_desc* d, const dta_subnet_params* nets, const
                      const float* const dscores[2][3], const float* djoint, const dta_subnet_grads* grads,
                      double* dalpha, int phases, void* stream);
 
+/* The same two calls for a batch whose input is ALREADY the first conv's bf16 tiles (dta_preprocess_crops_tiles below:
+ * raw crops -> tiles in one launch): bf16 mode, one input tensor (every kind but the ensemble), patches whose tile is a
+ * single band (11x11-class).  x_tiles: bf16 [batch][ceil(bands / 16)][height * width][16], bands past `bands` zero; it
+ * must stay valid and unchanged until the matching backward, which reads it again for the first conv's weight gradient. */
+int dta_net_forward_tiles(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,
+                          void* workspace, float* const scores[2][3], float* joint, void* stream);
+int dta_net_backward_tiles(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,
+                           void* workspace, const float* const dscores[2][3], const float* djoint,
+                           const dta_subnet_grads* grads, double* dalpha, int phases, void* stream);
+
 /* ---- Year ensemble (reference src/models/year.py:9-33): `years` (1..DTA_MAX_YEARS) spectral_networks, each on its own
  * input, run as the groups of ONE set of launches (a third of the launches of `years` separate dta_net_* calls);
  * the returned scores are the mean over the years of each year's last-head scores (year.py:30,33).
@@ -132,6 +142,11 @@ typedef struct {
 int dta_preprocess_out_bands(int bands_raw, int clip);
 int dta_preprocess_crops(const dta_crop_desc* d, const void* raw, const long long* offsets, const int* heights,
                          const int* widths, float* out, void* stream);
+/* Same preprocessing, written straight as the bf16 conv tiles dta_net_forward_tiles takes (the float32 batch never
+ * exists): tiles bf16 [batch][ceil(out_bands / 16)][size * size][16] = the float32 results above rounded to bf16
+ * (nearest even), bands past out_bands zero. */
+int dta_preprocess_crops_tiles(const dta_crop_desc* d, const void* raw, const long long* offsets, const int* heights,
+                               const int* widths, void* tiles, void* stream);
 
 /* Replaces F.cross_entropy(logits, y, weight=w) forward+backward (src/main.py:78, multi_stage.py:285).
  * weight may be null (= ones, metadata.py:61).  scratch: batch+1 floats.  dlogits may be null.

@@ -141,3 +141,62 @@ def test_oracle_minmax_matches_sklearn_bit_exact_on_random_crops():
         got = P.minmax_over_bands(img)
         assert got.dtype == want.dtype == np.float32
         assert np.array_equal(got, want), trial
+
+
+def _bf16(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.gpu
+def test_hip_preprocess_writes_conv_tiles_directly(golden):
+    """tiles=True: the same launch writes the first conv's bf16 tiles instead of the float32 batch: bit-identical to
+    the reference's outputs rounded to bf16, for both raw layouts, 11x11 and 24x24, with a missing year."""
+    from deeptreeattention_amd import preprocess as PP
+    g = golden("preprocess.npz")
+    names = list(g["names"])
+    raws = [g[f"{n}/raw"] for n in names]
+    want = _bf16(np.stack([g[f"{n}/resized11"] for n in names]))
+    t = PP.preprocess_batch(raws, 11, train=False, tiles=True)
+    assert t.shape == (len(names), want.shape[1], 11, 11) and t.tiles.dtype == torch.int16
+    assert np.array_equal(t.float().cpu().numpy(), want)
+    hwc = [np.ascontiguousarray(np.moveaxis(r, 0, 2)) for r in raws]
+    t2 = PP.preprocess_batch(hwc, 11, train=False, pixel_interleaved=True, tiles=True)
+    assert torch.equal(t2.tiles, t.tiles)
+    # padded channels of the last chunk are zero; a missing crop is all zeros; flips act on the tiles too
+    C = want.shape[1]
+    full = t.tiles.view(len(names), -1, 121, 16).view(torch.bfloat16).float()
+    assert full.shape[1] * 16 >= C and float(full.permute(0, 1, 3, 2).reshape(len(names), -1, 121)[:, C:].abs().max()) == 0.0
+    t3 = PP.preprocess_batch([raws[0], None], 24, train=True, tiles=True)
+    want24 = _bf16(g[f"{names[0]}/resized24"])[:, ::-1, ::-1]
+    got24 = t3.float().cpu().numpy()
+    assert np.array_equal(got24[0], want24) and not got24[1].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [24, 440])      # 440: the batch size class where the float32 path fuses the conversion
+def test_train_step_from_tiles_equals_train_step_from_the_float_batch(B):
+    """bf16 mode rounds the network input to bf16 anyway, so a step fed with the preprocessed TILES must equal the step
+    fed with the float32 batch of the same crops (reference flow: load_image -> model), without ever building it."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd import preprocess as PP
+    from deeptreeattention_amd.engine import FusedTrainer
+    import copy
+    rng = np.random.RandomState(3)
+    crops = [rng.randint(0, 9000, size=(43, rng.randint(8, 20), rng.randint(8, 20))).astype(np.int16) for _ in range(B)]
+    y = torch.from_numpy(rng.randint(0, 6, size=B)).to(_dev())
+    x32 = PP.preprocess_batch(crops, 11, train=True)
+    xt = PP.preprocess_batch(crops, 11, train=True, tiles=True)
+    assert np.array_equal(xt.float().cpu().numpy(), _bf16(x32.cpu().numpy()))
+    torch.manual_seed(5)
+    m1 = H.Hang2020(23, 6, precision="bf16").to(_dev()).train()
+    m2 = copy.deepcopy(m1)
+    t1, t2 = FusedTrainer(m1, lr=1e-3), FusedTrainer(m2, lr=1e-3)
+    for _ in range(2):
+        l1, l2 = t1.train_step(x32, y), t2.train_step(xt, y)
+    assert abs(float(l1) - float(l2)) <= 1e-5 * abs(float(l1))
+    assert float((t1.logits - t2.logits).abs().max()) <= 1e-4 * float(t1.logits.abs().max())
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        if a.dtype.is_floating_point and not k.endswith("conv_layer.bias"):
+            assert float((a.double() - b.double()).norm()) <= 1e-4 * max(float(a.double().norm()), 1e-12), k
+    lg, lv = t2.forward_loss(xt, y)
+    assert torch.isfinite(lg).all() and np.isfinite(float(lv))
