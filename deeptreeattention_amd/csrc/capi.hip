@@ -146,6 +146,7 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
     }
     int Nconv = (L == 0 && p->shared_x) ? 32 * G : CH[L];
     p->MWG[L] = conv_mwg(Nconv);
+    if (d->dtype == DTA_BF16 && L > 0 && Nconv == 64) p->MWG[L] = 256;   // second conv: two 256-row workgroups per CU
     int ppw, spp;
     conv_geometry(p->HWc[L], p->MWG[L], B, &ppw, &spp, &p->nwg[L]);
     // weight-gradient split
@@ -337,7 +338,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     ca.wp = at<char>(ws, p.wp[L]);
     for (int g = 0; g < G; ++g) ca.bias[g] = nets[g].conv_b[L];
     ca.bias_mode = pack_mode[L]; ca.bias_split = 32;
-    ca.y = at<float>(ws, p.y[L]); ca.y_fmt = p.y_fmt;
+    ca.y = at<float>(ws, p.y[L]); ca.y_fmt = p.y_fmt; ca.mwg = p.MWG[L];
     if (cat) { ca.y_gs = 0; ca.y_rs = Nconv; } else { ca.y_gs = (size_t)B * p.HWc[L] * C; ca.y_rs = C; }
     ca.stats = d->training ? at<float>(ws, p.stats[L]) : nullptr;
     ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];

@@ -36,9 +36,20 @@ __device__ __forceinline__ bf16x8 lds_tr8w(const unsigned char* base, int off) {
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad conv
 // ------------------------------------------------------------------------------------------------
+// developer instrumentation (-DDTA_TICKS): cycle stamps of one workgroup of the few-chunk convs (conv2 forward: N == 64,
+// NC == 2, statistics on), wave 0: [0] entry, [1] tables + halo zero, [2] first chunk landed, [3] chunk loop done,
+// [4] output stored, [5] statistics done
+#ifdef DTA_TICKS
+__device__ long long g_cticks[16];
+extern "C" int dta_debug_cticks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cticks), sizeof(long long) * 16); }
+#define CTICK(i) do { if (!XN && a.N == 64 && a.NC == 2 && a.stats && blockIdx.x == 100 && blockIdx.y == 0 && threadIdx.x == 0) g_cticks[i] = clock64(); } while (0)
+#else
+#define CTICK(i)
+#endif
 template <int MT, int NT, bool XN>
 __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CTICK(0);
   constexpr int NW = 8, NTHR = 512;
   constexpr int MWG = NW * MT * 32;
   constexpr int N = NT * 32;
@@ -141,6 +152,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     wdst[u] = (v >> 1) * RB + (v & 1) * 16;
   }
   u32x4 rx[XV], rw[WV];
+  CTICK(1);
 #define DTA_FETCH(chunk_)                                                                             \
   {                                                                                                   \
     if (xn) {                                                                                         \
@@ -262,6 +274,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   DTA_STORE(sbuf, sbuf + xbytes, 0)
   if (a.NC > 1) DTA_FETCH(1)
   __syncthreads();
+  CTICK(2);
   for (int chunk = 0; chunk < a.NC; ++chunk) {
     unsigned char* cx = sbuf + ((dbuf && (chunk & 1)) ? stage : 0);
     unsigned char* nx = sbuf + ((dbuf && !(chunk & 1)) ? stage : 0);
@@ -289,6 +302,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
 #undef DTA_STORE
 #undef DTA_FETCH
 
+  CTICK(3);
   // ---- epilogue: bias, store, per-workgroup (mean, M2) per column ----
   float bias[NT];
 #pragma unroll
@@ -325,18 +339,22 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     }
   } else {
     // 16-bit output rows: a lane holds ONE column of 16 rows, so neighbouring lanes trade values (rows r and r + 1 are
-    // consecutive pixels): the even lane packs columns (n, n + 1) of row r, the odd lane the same pair of row r + 1 ->
-    // 4-byte stores, 64 contiguous bytes per row and half-wave, instead of 2-byte ones.  Statistics stay on the fp32 values
+    // consecutive pixels): the even lane packs columns (n, n + 1) of row r, the odd lane the same pair of row r + 1.
+    // The packed tile then goes through LDS (the staging buffers are free: the chunk loop ended on a barrier) and leaves
+    // as 16-byte vectors, 8 per thread, contiguous in HBM -- four times fewer, four times wider stores than 4-byte ones
+    // scattered from the accumulator layout (cycle stamps: 10.7 k -> the epilogue was 37 % of a few-chunk workgroup).
+    // Statistics stay on the fp32 values.
     unsigned short* y16 = reinterpret_cast<unsigned short*>(a.y) + (size_t)g * a.y_gs;
     const bool odd = lane & 1;
     const int ncol = (lane & 31) & ~1;
+    constexpr int EP = N * 2 + 16;                  // LDS row pitch in bytes (16-byte aligned, rows 4 apart miss banks)
+    unsigned char* E = sbuf;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const int lr0 = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int orow0 = rowtab[lr0], orow1 = rowtab[lr0 + 1];
-        const int orow = odd ? orow1 : orow0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const float v0 = acc[mt][nt][r] + bias[nt], v1 = acc[mt][nt][r + 1] + bias[nt];
@@ -345,11 +363,21 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
           if (orow1 >= 0) csum[nt] += v1;
           const float got = lane_xor1(odd ? v0 : v1);      // even lane <- neighbour's row r, odd lane <- neighbour's row r + 1
           const unsigned pk = odd ? pack2_fmt(got, v1, a.y_fmt) : pack2_fmt(v0, got, a.y_fmt);
-          if (orow >= 0) *reinterpret_cast<unsigned*>(y16 + (size_t)orow * a.y_rs + nt * 32 + ncol) = pk;
+          *reinterpret_cast<unsigned*>(E + (lr0 + (odd ? 1 : 0)) * EP + (nt * 32 + ncol) * 2) = pk;
         }
       }
     }
+    __syncthreads();
+    constexpr int VPR = N / 8;                      // 16-byte vectors per output row
+#pragma unroll
+    for (int u = 0; u < MWG * VPR / NTHR; ++u) {
+      const int v = tid + u * NTHR, row = v / VPR, part = v % VPR;
+      const int orow = rowtab[row];
+      if (orow >= 0)
+        *reinterpret_cast<u32x4*>(y16 + (size_t)orow * a.y_rs + part * 8) = *reinterpret_cast<const u32x4*>(E + row * EP + part * 16);
+    }
   }
+  CTICK(4);
   if (a.stats == nullptr) return;
   const int cnt = (a.spp == 1) ? npatch * HW : min(MWG, HW - split * MWG);
 #pragma unroll
@@ -391,6 +419,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     o[0] = cmean[tid];
     o[1] = m2;
   }
+  CTICK(5);
 }
 
 template <int MT, int NT>
@@ -403,6 +432,10 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   // each other's prologue / epilogue instead of double-buffering a two-iteration loop
   a.dbuf = tab + 2 * stage <= 160 * 1024 && a.NC > 4;   // measured: conv2's input-gradient conv 28 -> 22 us
   size_t lds = tab + (a.dbuf ? 2 : 1) * stage;
+  if (a.y_fmt != FMT_F32) {   // the 16-bit epilogue transposes the output tile through the staging area
+    const size_t epi = tab + (size_t)MWG * (N * 2 + 16);
+    if (epi > lds) lds = epi;
+  }
   if (lds > 160 * 1024) { dta_set_error("conv3x3(bf16): LDS need %zu B exceeds 160 KiB (H=%d W=%d)", lds, a.H, a.W); return 1; }
   if (a.ppw * a.Q * 2 > 4 * 512) { dta_set_error("conv3x3(bf16): %dx%d tile exceeds the staging plan", a.H, a.W); return 1; }
   static bool attr_done = false;
@@ -427,6 +460,9 @@ int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
       int ppw, spp, nwg;
       conv_geometry(a.HW, 512, a.B, &ppw, &spp, &nwg);
       if (a.stats == nullptr && nwg * G <= 128) return launch_conv_bf16_t<1, 2>(a, G, st);
+      // 256-row workgroups need 114 VGPRs against 184: two workgroups share a CU instead of one (the few-chunk layers are
+      // all prologue / epilogue, so the overlap of two workgroups is worth more than the larger tile)
+      if (a.mwg == 256) return launch_conv_bf16_t<1, 2>(a, G, st);
       return launch_conv_bf16_t<2, 2>(a, G, st);
     }
     case 128: return launch_conv_bf16_t<1, 4>(a, G, st);

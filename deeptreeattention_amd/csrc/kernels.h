@@ -19,6 +19,7 @@ struct ConvArgs {
   const float* bias[MAXG]; int bias_mode, bias_split;
   float* y; size_t y_gs; int y_rs;    // output rows [row][y_rs], group offset y_gs (elements); storage format y_fmt
   int y_fmt;                          // FMT_F32 (default) / FMT_F16 / FMT_BF16: bf16 kernels only
+  int mwg;                            // output rows per workgroup the plan chose (0 = conv_mwg(N)); bf16 kernels
   float* stats;                       // [G][nwg][N][2] (mean, M2) or null
   int B, H, W, NC, N, Q, HW, ppw, spp, dbuf;
   int x_compact;                      // bf16: input tiles are halo-free [patch][chunk][pixel][16] (network input only)

@@ -1,0 +1,16 @@
+# Round artifacts on one box: usage run_profiles.sh <tag>   (writes gpurun_out/<tag>/...)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O
+cd $R
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --site wgrad0 --no-cpu-baseline > $O/bench_wgrad0.json 2>> $O/bench_default.err
+python bench.py --precision fp32 --no-cpu-baseline > $O/bench_fp32.json 2>> $O/bench_default.err
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --no-cpu-baseline --steady-steps 0"
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B --steps 50 --warmup 10 > $O/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o f -- $B --steps 3 --warmup 2 > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o w -- $B --steps 3 --warmup 2 > $O/write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace -d $O/sq -o s -- $B --steps 3 --warmup 2 > $O/sq.log 2>&1
+cd $R
+python tools/prof_summary.py $O/kt/kt_results.db 60 > $O/kernel_trace.txt
+python tools/step_traffic.py --trace $O/kt/kt_results.db --fetch $O/fetch/f_results.db --write $O/write/w_results.db --sq $O/sq/s_results.db --trace-steps 60 --pmc-steps 5 --out $O/traffic_step.json > $O/traffic_step.txt
+head -5 $O/kernel_trace.txt; head -12 $O/traffic_step.txt; cut -c1-400 $O/bench_default.json

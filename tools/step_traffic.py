@@ -8,7 +8,7 @@ serialise the launches; durations are therefore taken from the plain --kernel-tr
 launches some kernels several times; `launches_per_step` says how often): mean bytes per launch = 2 x FETCH_SIZE
 (MI355X_MICROARCH.md: gfx950 reports half the bytes of wide coalesced reads) + WRITE_SIZE, mean duration, GB/s, and the
 step totals against the algorithmic bytes of SURVEY.md 8(d).  With --sq: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256
-CUs x GRBM_GUI_ACTIVE) = fraction of the matrix pipes' cycles that were busy.
+CUs x GRBM_GUI_ACTIVE / 8 XCDs) = fraction of the matrix pipes' cycles that were busy.
 """
 import argparse
 import json
@@ -69,7 +69,8 @@ def main():
         if k in sq:
             s = sq[k][0]
             if s.get("GRBM_GUI_ACTIVE"):
-                row["mfma_busy_frac"] = round(s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * s["GRBM_GUI_ACTIVE"]), 4)
+                # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (8 x kernel cycles); MFMA_BUSY over all 1024 SIMDs
+                row["mfma_busy_frac"] = round(s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * s["GRBM_GUI_ACTIVE"] / 8.0), 4)
             for name in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
                          "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES"):
                 if name in s:
