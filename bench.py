@@ -114,8 +114,12 @@ def main():
         local = local % torch.cuda.device_count()   # development only: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # DTA_FORCE_COLLECTIVES=1: a single rank still builds the RCCL process group and issues the step's collectives
+    # (development: the only RCCL exercise a one-GPU box allows; never a measured configuration)
+    dist_on = world > 1 or os.environ.get("DTA_FORCE_COLLECTIVES") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         # "nccl" is RCCL on ROCm.  DTA_BENCH_BACKEND=gloo exists only to exercise this multi-rank code path with
         # several ranks sharing ONE GPU (development boxes); it is never a measured configuration.
         backend = os.environ.get("DTA_BENCH_BACKEND", "nccl")
@@ -142,7 +146,7 @@ def main():
     SITE = {"fwd0": _lib.SITE_CONV_FWD, "wgrad0": _lib.SITE_CONV_WGRAD}
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
 
     for i in range(a.warmup):
@@ -159,7 +163,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
@@ -266,7 +270,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

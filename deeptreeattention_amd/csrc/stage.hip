@@ -1605,9 +1605,17 @@ struct LeanBwd {
   static constexpr int LDS = 4 * C + CFG::PPW * SLOT + CFG::RED + C + 2 * CFG::K * CFG::K;
 };
 
+#ifdef DTA_TICKS
+__device__ long long g_lticks[2][16];
+extern "C" int dta_debug_lticks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lticks), sizeof(long long) * 32); }
+#define LTICK(i) do { if (CFG::C == 32 && blockIdx.x == 300 && threadIdx.x == 0) g_lticks[blockIdx.y][i] = clock64(); } while (0)
+#else
+#define LTICK(i)
+#endif
 template <typename CFG>
 __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  LTICK(0);
   const StageArgs& a = ba.f;
   constexpr int C = CFG::C, NO = CFG::NO, NP = CFG::NP, TPP = CFG::TPP, IPT = CFG::IPT, PPW = CFG::PPW, WZ = CFG::WZ;
   constexpr int K = CFG::K, KK = K * K, R = CFG::R, WP = CFG::WP, NPAD = CFG::NPAD;
@@ -1675,7 +1683,9 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     for (int p = lt; p < NP; p += TPP) vec[2 * NPAD + p] = __builtin_nontemporal_load(save + 2 * a.vslot + p);   // s
   }
   const float* df = (ba.dfeat && live) ? ba.dfeat + (size_t)g * ba.dfeat_gs + (size_t)b * a.F[g] : nullptr;
+  LTICK(1);
   __syncthreads();
+  LTICK(2);
 
   // ---- recompute BN -> ReLU -> pool; keep z, the window position of the maximum and xhat there ----
   float z[IPT][8], xh[IPT][8];
@@ -1707,6 +1717,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     *reinterpret_cast<f32x4*>(Zx + p * C + o * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
   };
   float dv[IPT][8];
+  LTICK(3);
   if (kind == KIND_SPECTRAL) {
     float* pooled = vec; float* hL = vec + C; float* gL = vec + 2 * C;
     float* d2L = vec + 3 * C; float* d1L = vec + 4 * C; float* dpL = vec + 5 * C;
@@ -1727,6 +1738,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     }
     __syncthreads();
     lean_colsum<CFG>(red, sm0 + VOFF + 3 * C, SLOT, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + p * C + c]; });
+    LTICK(4);
     for (int c = lt; c < C; c += TPP) d2L[c] = d2L[c] * gL[c] * (1.f - gL[c]);
     __syncthreads();
     auto fin2 = [&](int s, int i, float v) {
@@ -1741,6 +1753,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
       lean_matvec<CFG>(a.att[g].p[5], sm0 + VOFF + 3 * C, SLOT, red, fin2);
       lean_matvec<CFG>(a.att[g].p[4], sm0 + VOFF + 4 * C, SLOT, red, fin1);
     }
+    LTICK(5);
     if (vout)
       for (int c = lt; c < C; c += TPP) { vout[c] = d2L[c]; vout[C + c] = hL[c]; vout[2 * C + c] = d1L[c]; vout[3 * C + c] = pooled[c]; }
 #pragma unroll
@@ -1771,6 +1784,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
       if (it < CFG::ITEMS && o == 0) { const float sp = sL[p]; d2L[(p / WZ + R) * WP + p % WZ + R] = acc * sp * (1.f - sp); }
     }
     __syncthreads();
+    LTICK(4);
     // d1 = (transposed k2 stencil of d2) masked by t1 > 0 ;  dm = (transposed k1 stencil of d1) masked by m > 0
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -1805,6 +1819,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
       }
       if (it < CFG::ITEMS && vout != nullptr) put8(Z1, p, o, w8);
     }
+    LTICK(5);
     if (ba.vec) {
       // [dwc (C) | dbc | dK1 (kk) | db1 | dK2 (kk) | db2]
       __syncthreads();
@@ -1857,6 +1872,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
       }
     }
   }
+  LTICK(6);
   // ---- outputs: dv (dense, or compact value + window position for pooled stages), BatchNorm partial sums ----
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
@@ -1917,6 +1933,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     }
   }
   __syncthreads();
+  LTICK(7);
   if (ba.bnpart) {
     float* s1L = red + PPW * CFG::NT + slot * 2 * C;     // (the head of red is the column-sum scratch)
     lean_colsum<CFG>(red, red + PPW * CFG::NT, 2 * C, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + p * C + c]; });
@@ -1924,6 +1941,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     if (bnp)
       for (int c = lt; c < C; c += TPP) *reinterpret_cast<f32x2*>(bnp + c * 2) = f32x2{s1L[c], s1L[C + c]};
   }
+  LTICK(8);
 }
 
 template <typename CFG>

@@ -8,6 +8,7 @@ BatchNorm statistics stay per-rank (the reference does not enable sync_batchnorm
 back-propagates is its own weighted mean (DDP semantics: gradients are averaged over ranks).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -60,7 +61,11 @@ class FusedTrainer:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
-        self.overlap = overlap_comm and self.world > 1
+        # DTA_FORCE_COLLECTIVES=1: a one-rank process group still goes through the collectives (the only way to run the
+        # RCCL code path -- streams, buckets, the alpha slot -- on a single-GPU box; tests/test_rccl_single_gpu.py)
+        self.comm = self.world > 1 or (os.environ.get("DTA_FORCE_COLLECTIVES") == "1" and torch.distributed.is_available()
+                                       and torch.distributed.is_initialized())
+        self.overlap = overlap_comm and self.comm
         self.hang = model._net_code == _lib.NET_HANG2020
         self.single_score = model._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
         self.three_head = bool(three_head_loss)
@@ -130,7 +135,7 @@ class FusedTrainer:
         self._desc_key = None
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self.sync = GradSync(self.world, self.pg, self._side)
-        if self.world > 1 and storage is None:
+        if self.comm and storage is None:
             self.broadcast_parameters()
 
     @staticmethod
@@ -298,7 +303,7 @@ class FusedTrainer:
                                                     C.byref(table), djoint, self.grads, dalpha, phases, st),
                            "dta_net_backward_tiles")
         ag, slot = (self.alpha_g, self.alpha_slot) if self.alpha_on_graph else (None, None)
-        if self.world == 1:
+        if not self.comm:
             run(3)
         elif self.overlap:
             # phase 1: everything but the first conv's weight gradient; its all-reduce (side stream) runs while
