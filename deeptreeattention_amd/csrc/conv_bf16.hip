@@ -40,6 +40,22 @@ __device__ __forceinline__ bf16x8 lds_tr8w(const unsigned char* base, int off) {
 // NC == 2, statistics on), wave 0: [0] entry, [1] tables + halo zero, [2] first chunk landed, [3] chunk loop done,
 // [4] output stored, [5] statistics done
 #ifdef DTA_TICKS
+// developer instrumentation: start / end time (100 MHz wall clock, common to all XCDs) of every workgroup of selected kernels
+__device__ long long g_wgstamp_conv[4][8192][2];
+extern "C" int dta_debug_wgstamps_conv(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgstamp_conv), sizeof(long long) * 4 * 8192 * 2); }
+struct WgStamp {
+  int id; long long t0;
+  __device__ WgStamp(int id_) : id(id_), t0(wall_clock64()) {}
+  __device__ ~WgStamp() {
+    const int w = blockIdx.x + gridDim.x * blockIdx.y;
+    if (threadIdx.x == 0 && id >= 0 && w < 8192) { g_wgstamp_conv[id][w][0] = t0; g_wgstamp_conv[id][w][1] = wall_clock64(); }
+  }
+};
+#define WGSTAMP(id) WgStamp _wgstamp(id)
+#else
+#define WGSTAMP(id)
+#endif
+#ifdef DTA_TICKS
 __device__ long long g_cticks[16];
 extern "C" int dta_debug_cticks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cticks), sizeof(long long) * 16); }
 #define CTICK(i) do { if (!XN && a.N == 64 && a.NC == 2 && a.stats && blockIdx.x == 100 && blockIdx.y == 0 && threadIdx.x == 0) g_cticks[i] = clock64(); } while (0)
@@ -48,6 +64,7 @@ extern "C" int dta_debug_cticks(long long* out) { return (int)hipMemcpyFromSymbo
 #endif
 template <int MT, int NT, bool XN>
 __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
+  WGSTAMP(XN ? 0 : (a.stats ? (a.N == 64 ? 1 : 2) : -1));      // first conv, second conv, third conv (forward launches)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   CTICK(0);
   constexpr int NW = 8, NTHR = 512;
@@ -68,24 +85,8 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   const int b0 = pg * a.ppw;
   const int npatch = min(a.ppw, a.B - b0);
 
-  for (int lr = tid; lr < MWG; lr += NTHR) {
-    int pl, pix;
-    bool valid;
-    if (a.spp == 1) { pl = lr / HW; pix = lr - pl * HW; valid = pl < npatch; }
-    else { pl = 0; pix = split * MWG + lr; valid = pix < HW; }
-    int h = valid ? pix / a.W : 0, w = valid ? pix - h * a.W : 0;
-    rowtab[lr] = valid ? (b0 + pl) * HW + pix : -1;
-    plq[lr] = valid ? ((pl << 16) | (h * W2 + w)) : 0;
-  }
-  __syncthreads();
-
   const int khalf16 = (lane >> 5) * 16;
   int abase[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int v = plq[(wave * MT + mt) * 32 + (lane & 31)];
-    abase[mt] = ((v >> 16) * Q + (v & 0xFFFF)) * RB + khalf16;
-  }
   const int bbase = (lane & 31) * RB + khalf16;
 
   f32x16 acc[MT][NT];
@@ -140,12 +141,30 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   }
   float rf[QV][4];
   bf16_t* xo = (XN && a.x_tl_out) ? (bf16_t*)a.x_tl_out + (size_t)g * a.x_gs : nullptr;
-  if (xc) {   // the halo rows of both LDS stages
-    u32x4* z = reinterpret_cast<u32x4*>(sbuf);
-    const u32x4 zero = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < xbytes / 16; i += NTHR) { z[i] = zero; if (dbuf) z[i + stage / 16] = zero; }
+  // row tables + the zero halo of halo-free inputs: LDS-only work, done while the first chunk's loads are in flight
+  // (cycle stamps of a two-chunk workgroup: tables 4.0 k cycles, then 2.3 k waiting for the first chunk)
+  auto tables = [&]() {
+    for (int lr = tid; lr < MWG; lr += NTHR) {
+      int pl, pix;
+      bool valid;
+      if (a.spp == 1) { pl = lr / HW; pix = lr - pl * HW; valid = pl < npatch; }
+      else { pl = 0; pix = split * MWG + lr; valid = pix < HW; }
+      int h = valid ? pix / a.W : 0, w = valid ? pix - h * a.W : 0;
+      rowtab[lr] = valid ? (b0 + pl) * HW + pix : -1;
+      plq[lr] = valid ? ((pl << 16) | (h * W2 + w)) : 0;
+    }
+    if (xc) {   // the halo rows of both LDS stages
+      u32x4* z = reinterpret_cast<u32x4*>(sbuf);
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < xbytes / 16; i += NTHR) { z[i] = zero; if (dbuf) z[i + stage / 16] = zero; }
+    }
     __syncthreads();
-  }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int v = plq[(wave * MT + mt) * 32 + (lane & 31)];
+      abase[mt] = ((v >> 16) * Q + (v & 0xFFFF)) * RB + khalf16;
+    }
+  };
 #pragma unroll
   for (int u = 0; u < WV; ++u) {
     int v = min(tid + u * NTHR, wvec - 1);
@@ -232,6 +251,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     }
     DTA_FETCH_XF(rf, 0)
     DTA_FETCH_W(0)
+    tables();
     DTA_STORE_XF(rf, sbuf)
     DTA_STORE_W(sbuf + xbytes)
     DTA_FETCH_XF(rf, 1)
@@ -271,6 +291,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   } else {
   // chunk k+1 sits in registers while chunk k is multiplied; with two LDS stages its ds_writes also overlap
   DTA_FETCH(0)
+  tables();
   DTA_STORE(sbuf, sbuf + xbytes, 0)
   if (a.NC > 1) DTA_FETCH(1)
   __syncthreads();
@@ -524,6 +545,7 @@ extern "C" int dta_debug_wticks(long long* out) { return (int)hipMemcpyFromSymbo
 #endif
 template <int CT, int NTT, bool BIGW>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
+  WGSTAMP(CT == 2 ? 3 : -1);      // first conv's weight gradient
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTHR = 512;
   // CT 32-channel input tiles x NTT 32-column tiles per workgroup = PAIRS wave tiles; the 8 waves are PAIRS tiles x

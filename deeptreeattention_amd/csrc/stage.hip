@@ -7,6 +7,22 @@
 #include "kernels.h"
 
 namespace dta {
+#ifdef DTA_TICKS
+// developer instrumentation: start / end time (100 MHz wall clock, common to all XCDs) of every workgroup of selected kernels
+__device__ long long g_wgstamp_stage[4][8192][2];
+extern "C" int dta_debug_wgstamps_stage(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgstamp_stage), sizeof(long long) * 4 * 8192 * 2); }
+struct WgStamp {
+  int id; long long t0;
+  __device__ WgStamp(int id_) : id(id_), t0(wall_clock64()) {}
+  __device__ ~WgStamp() {
+    const int w = blockIdx.x + gridDim.x * blockIdx.y;
+    if (threadIdx.x == 0 && id >= 0 && w < 8192) { g_wgstamp_stage[id][w][0] = t0; g_wgstamp_stage[id][w][1] = wall_clock64(); }
+  }
+};
+#define WGSTAMP(id) WgStamp _wgstamp(id)
+#else
+#define WGSTAMP(id)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm statistics: combine the conv workgroups' (mean, M2) partials (Chan et al.) in double.
@@ -1060,6 +1076,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
 // image of the patch (halo included) built in LDS, then one linear 16-byte-per-lane copy to HBM.
 template <typename T, int YF, int DVF>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
+  WGSTAMP(3);      // (the last launch of a step is the first stage's)
   extern __shared__ __attribute__((aligned(16))) char smem_apply[];
   // a workgroup = one patch x one slice of CS channels (blockIdx.z): small LDS images keep 8 workgroups on a CU
   const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = a.C, CS = a.cslice, c0 = blockIdx.z * CS;
@@ -1217,6 +1234,10 @@ struct LeanCfg {
   static constexpr int R = K / 2, WP = WZ + 2 * R, HPAD = HZ + 2 * R, NPAD = HPAD * WP;
   static constexpr int W2 = WZ + 2, QZ = (HZ + 2) * W2;   // haloed grid of the gated map's conv tiles
   static constexpr int NPART = NT / C;                    // matvec: input slices per output
+  // waves per SIMD the backward is compiled for (register budget 512 / MINW): two 512-thread or three 256-thread
+  // workgroups per CU; the 128-wide stage needs its 256 registers
+  static constexpr int MINW = C == 32 ? 4 : (C == 64 ? 3 : 2);
+  static constexpr bool PERSIST = C < 128;                // backward: persistent workgroups with next-batch prefetch
   // LDS floats per patch slot: the patch [NP][C], then vectors: spectral pooled|h|gate, spatial m|t1 (padded) | s
   static constexpr int VEC = 3 * C > 2 * NPAD + NP ? 3 * C : 2 * NPAD + NP;
   static constexpr int SLOT = NP * C + VEC;
@@ -1237,6 +1258,29 @@ __device__ __forceinline__ void lean_ld8(float (&v)[8], const void* base, size_t
     const u32x4 q = NT ? __builtin_nontemporal_load(p) : *p;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[2 * e] = unpack_lo(q[e], YF); v[2 * e + 1] = unpack_hi(q[e], YF); }
+  }
+}
+// the same eight channels as the raw bytes a prefetch keeps in registers until the previous patch is done with
+template <int YF> struct LeanRaw { u32x4 q; };
+template <> struct LeanRaw<FMT_F32> { f32x4 a, b; };
+template <int YF, bool NT>
+__device__ __forceinline__ void lean_ld8_raw(LeanRaw<YF>& r, const void* base, size_t i) {
+  if constexpr (YF == FMT_F32) {
+    const f32x4* p = (const f32x4*)((const float*)base + i);
+    r.a = NT ? __builtin_nontemporal_load(p) : p[0]; r.b = NT ? __builtin_nontemporal_load(p + 1) : p[1];
+  } else {
+    const u32x4* p = (const u32x4*)((const unsigned short*)base + i);
+    r.q = NT ? __builtin_nontemporal_load(p) : *p;
+  }
+}
+template <int YF>
+__device__ __forceinline__ void lean_unpack8(float (&v)[8], const LeanRaw<YF>& r) {
+  if constexpr (YF == FMT_F32) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = r.a[e]; v[4 + e] = r.b[e]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = unpack_lo(r.q[e], YF); v[2 * e + 1] = unpack_hi(r.q[e], YF); }
   }
 }
 // one octet of a tile row: channels 8 * (o & 1) .. + 8 of chunk o / 2 at haloed-grid row q
@@ -1301,6 +1345,47 @@ __device__ __forceinline__ void lean_colsum(float* red, float* out, int out_stri
   }
   __syncthreads();
 }
+// per-channel sums over the pixels straight from the owners' registers: part[v][e] is this thread's sum over its items
+// of value set v, channel 8 o + e (o = lt % NO is the same for all items of a thread: TPP % NO == 0; threads without an
+// item pass zeros).  The lanes of a wave that share o meet through DPP row rotations and two shuffles, the waves of a patch
+// through `red` (NV * PPW * NW * C floats).  out[v][slot * out_stride + c] = scale * sum.  All threads call it.
+template <int N>
+__device__ __forceinline__ float lean_row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N /* row_ror:N */, 0xF, 0xF, false));
+}
+template <typename CFG, int NV>
+__device__ __forceinline__ void lean_colsum_reg(float (&part)[NV][8], float* red, float* const (&out)[NV], int out_stride, float scale) {
+  constexpr int C = CFG::C, NO = CFG::NO, TPP = CFG::TPP, PPW = CFG::PPW, NW = TPP / 64;
+  static_assert(TPP % 64 == 0 && (NO == 4 || NO == 8 || NO == 16), "lean_colsum_reg: item ownership");
+  static_assert(NV * PPW * NW * C <= CFG::RED, "lean_colsum_reg: scratch");
+  const int t = threadIdx.x, slot = t / TPP, lt = t % TPP, lane = t & 63, wave = lt >> 6;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = part[v][e];
+      if (NO == 4) x += lean_row_ror<4>(x);
+      if (NO <= 8) x += lean_row_ror<8>(x);
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      part[v][e] = x;
+    }
+    if (lane < NO) {
+      float* r = red + ((v * PPW + slot) * NW + wave) * C + lane * 8;
+      *reinterpret_cast<f32x4*>(r) = f32x4{part[v][0], part[v][1], part[v][2], part[v][3]};
+      *reinterpret_cast<f32x4*>(r + 4) = f32x4{part[v][4], part[v][5], part[v][6], part[v][7]};
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < NV * PPW * C; i += CFG::NT) {
+    const int v = i / (PPW * C), sl = (i / C) % PPW, c = i % C;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) acc += red[((v * PPW + sl) * NW + k) * C + c];
+    out[v][sl * out_stride + c] = acc * scale;
+  }
+  __syncthreads();
+}
 // The scalar mat-vec in two halves, so that callers can fetch a thread's weight slice (C / NPART values) at kernel entry,
 // long before the vector it multiplies exists: the weights then cost no latency on the dependent chain.
 template <typename CFG>
@@ -1333,6 +1418,16 @@ __device__ __forceinline__ void lean_matvec_run(const float (&w)[CFG::C / CFG::N
     fin(s, oo, v);
   }
   __syncthreads();
+}
+// the same with the weight matrix staged in LDS (persistent workgroups: staged once, used for every patch batch)
+template <typename CFG, typename F>
+__device__ __forceinline__ void lean_matvec_lds(const float* WL, const float* x, int x_stride, float* red, F fin) {
+  constexpr int C = CFG::C, PER = C / CFG::NPART;
+  const int t = threadIdx.x, o = t % C, part = t / C;
+  float w[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) w[k] = WL[(part * PER + k) * C + o];
+  lean_matvec_run<CFG>(w, x, x_stride, red, fin);
 }
 // y[slot][o] = sum_i W[i * C + o] * x[slot][i] for every patch slot of the workgroup (W input-major, so lanes read
 // consecutive o): thread (o, part) covers C / NPART inputs for all slots, the parts meet in LDS.  `fin(slot, o, sum)`.
@@ -1393,6 +1488,7 @@ __device__ __forceinline__ float lean_octet_sum(float v) {
 
 template <typename T, typename CFG>
 __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
+  WGSTAMP(CFG::C == 32 ? 2 : -1);
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int C = CFG::C, NO = CFG::NO, NP = CFG::NP, TPP = CFG::TPP, IPT = CFG::IPT, PPW = CFG::PPW, WZ = CFG::WZ;
   constexpr int K = CFG::K, R = CFG::R, WP = CFG::WP, NPAD = CFG::NPAD;
@@ -1463,12 +1559,13 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
       }
       z[j][e] = (live && it < CFG::ITEMS) ? fmaxf(m, 0.f) : 0.f;
     }
-    if (it < CFG::ITEMS) {
+    // only the plain network's classifier flatten reads the un-gated patch back from LDS
+    if (it < CFG::ITEMS && kind != KIND_SPECTRAL && kind != KIND_SPATIAL) {
       *reinterpret_cast<f32x4*>(Zs + p * C + o * 8) = f32x4{z[j][0], z[j][1], z[j][2], z[j][3]};
       *reinterpret_cast<f32x4*>(Zs + p * C + o * 8 + 4) = f32x4{z[j][4], z[j][5], z[j][6], z[j][7]};
     }
   }
-  __syncthreads();
+  if (kind != KIND_SPECTRAL && kind != KIND_SPATIAL) __syncthreads();
   // tile rows per chunk: the haloed grid, or (a_compact) the pixels only -- the readers keep the halo in LDS
   const int trows = a.a_compact ? NP : CFG::QZ;
   T* tile = a.a_tl ? (T*)a.a_tl + (size_t)g * a.a_gs + ((size_t)(live ? b : 0) * a.a_nc + a.a_ch0) * trows * 16 : nullptr;
@@ -1478,7 +1575,17 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
   float* sm0 = sm + 2 * C;
   if (kind == KIND_SPECTRAL) {
     float* pooled = vec; float* hL = vec + C; float* gL = vec + 2 * C;
-    lean_colsum<CFG>(red, vec0, CFG::SLOT, 1.f / (float)NP, [&](int s, int p, int c) { return sm0[s * CFG::SLOT + p * C + c]; });
+    {
+      float part[1][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        part[0][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) part[0][e] += z[j][e];
+      }
+      float* const outs[1] = {vec0};
+      lean_colsum_reg<CFG, 1>(part, red, outs, CFG::SLOT, 1.f / (float)NP);
+    }
     const float* c1 = a.att[g].p[1]; const float* c2 = a.att[g].p[3];
     auto fin1 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + C + o] = fmaxf(v + c1[o], 0.f); };
     auto fin2 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + 2 * C + o] = sigmoidf_(v + c2[o]); };
@@ -1601,91 +1708,122 @@ template <typename CFG>
 struct LeanBwd {
   static constexpr int C = CFG::C, NP = CFG::NP, NPAD = CFG::NPAD;
   static constexpr int VEC = 8 * C > 4 * NPAD + 2 * NP + 3 * C ? 8 * C : 4 * NPAD + 2 * NP + 3 * C;
-  static constexpr int SLOT = 2 * NP * C + VEC;
-  static constexpr int LDS = 4 * C + CFG::PPW * SLOT + CFG::RED + C + 2 * CFG::K * CFG::K;
+  static constexpr int SLOT = VEC;                        // per-patch vectors only: the maps never leave the registers
+  static constexpr int LDS = 4 * C + CFG::PPW * SLOT + CFG::RED + C + 2 * CFG::K * CFG::K + 4 + (C < 128 ? 2 * C * C : 0);
 };
 
-#ifdef DTA_TICKS
-__device__ long long g_lticks[2][16];
-extern "C" int dta_debug_lticks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lticks), sizeof(long long) * 32); }
-#define LTICK(i) do { if (CFG::C == 32 && blockIdx.x == 300 && threadIdx.x == 0) g_lticks[blockIdx.y][i] = clock64(); } while (0)
-#else
-#define LTICK(i)
-#endif
 template <typename CFG>
-__global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
+__global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdArgs ba) {
+  WGSTAMP(CFG::C == 32 ? 0 : (CFG::C == 64 ? 1 : -1));
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  LTICK(0);
   const StageArgs& a = ba.f;
   constexpr int C = CFG::C, NO = CFG::NO, NP = CFG::NP, TPP = CFG::TPP, IPT = CFG::IPT, PPW = CFG::PPW, WZ = CFG::WZ;
   constexpr int K = CFG::K, KK = K * K, R = CFG::R, WP = CFG::WP, NPAD = CFG::NPAD;
-  constexpr int SLOT = LeanBwd<CFG>::SLOT;
-  const int g = blockIdx.y, t = threadIdx.x, slot = t / TPP, lt = t % TPP;
-  const int b = blockIdx.x * PPW + slot;
-  const bool live = b < a.B;
-  const int bb = live ? b : 0;
+  constexpr int SLOT = LeanBwd<CFG>::SLOT, NPOS = CFG::POOL ? 4 : 1;
+  // storage of the gradient maps follows the conv outputs': bf16 next to half outputs, fp32 next to fp32 (launcher checks)
+  constexpr int GF = CFG::YF == FMT_F16 ? FMT_BF16 : FMT_F32;
+  const int g = blockIdx.y, t = threadIdx.x, slot0 = t / TPP, lt0 = t % TPP;
   const int kind = a.kind[g];
   float* coefL = sm;                                   // [C][4] scale, shift, mean, rstd
   float* sm0 = sm + 4 * C;
-  float* Z1 = sm0 + slot * SLOT;                       // [NP][C]
-  float* Z2 = Z1 + NP * C;                             // [NP][C]
-  float* vec = Z2 + NP * C;
+  float* vec0 = sm0 + slot0 * SLOT;
   float* red = sm0 + PPW * SLOT;
-  constexpr int VOFF = 2 * NP * C;                     // vectors of slot s start at sm0 + s * SLOT + VOFF
+  constexpr int VOFF = 0;                              // vectors of slot s start at sm0 + s * SLOT + VOFF
 
-  // ---- loads in flight: conv output, incoming gradient ----
-  const size_t ypatch = (size_t)g * a.y_gs + (size_t)bb * CFG::HWC * a.y_rs;
-  float yraw[IPT][CFG::POOL ? 4 : 1][8];
+  // ---- once per workgroup: BatchNorm coefficients, attention weights (spectral mat-vec slices -> registers,
+  //      spatial stencils -> LDS), zero borders of the padded gradient maps ----
+  {
+    const float* coef = a.coef + (size_t)g * a.coef_gs;
+    for (int i = t; i < 4 * C; i += CFG::NT) coefL[i] = coef[i];
+  }
+  constexpr bool PRE = C < 128;                          // the two C x C mat-vec matrices fit in LDS
+  float* wL = sm0 + PPW * SLOT + CFG::RED;               // [C + 2 K K] wc | k1 | k2
+  float* W1L = wL + C + 2 * KK + ((4 - (C + 2 * KK) % 4) % 4);      // [C][C] each, 16-byte aligned
+  float* W2L = W1L + C * C;
+  if (PRE && kind == KIND_SPECTRAL) {
+    const f32x4* s1 = reinterpret_cast<const f32x4*>(a.att[g].p[4]); const f32x4* s2 = reinterpret_cast<const f32x4*>(a.att[g].p[5]);
+    for (int i = t; i < C * C / 4; i += CFG::NT) {
+      reinterpret_cast<f32x4*>(W1L)[i] = s1[i];
+      reinterpret_cast<f32x4*>(W2L)[i] = s2[i];
+    }
+  }
+  if (kind == KIND_SPATIAL) {
+    for (int i = t; i < C + 2 * KK; i += CFG::NT)
+      wL[i] = i < C ? a.att[g].p[0][i] : (i < C + KK ? a.att[g].p[2][i - C] : a.att[g].p[4][i - C - KK]);
+    for (int i = lt0; i < NPAD; i += TPP) { vec0[2 * NPAD + NP + i] = 0.f; vec0[3 * NPAD + NP + i] = 0.f; }   // d2, d1 (padded)
+  }
+
+  // ---- a workgroup walks patch batches blockIdx.x, + gridDim.x, ...; the next batch's conv output, incoming gradient
+  //      and saved attention state are fetched into registers (raw bytes) while the current one is worked on ----
+  constexpr int NSAVE = (3 * C > 2 * NPAD + NP ? 3 * C : 2 * NPAD + NP);
+  constexpr int NSV = (NSAVE + TPP - 1) / TPP;
+  LeanRaw<CFG::YF> yq[IPT][NPOS];
+  LeanRaw<GF> dq[IPT];
+  float sv[NSV];
+  const int nsave = kind == KIND_SPECTRAL ? 3 * C : (kind == KIND_SPATIAL ? 2 * NPAD + NP : 0);
+  auto fetch = [&](int bi) {
+    const int b = bi * PPW + slot0, bb = b < a.B ? b : 0;
+    const size_t ypatch = (size_t)g * a.y_gs + (size_t)bb * CFG::HWC * a.y_rs;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const int it = lt0 + j * TPP, itc = it < CFG::ITEMS ? it : 0;
+      const int p = itc / NO, o = itc % NO;
+      if (CFG::POOL) {
+        const int hz = p / WZ, wz = p % WZ, p00 = (2 * hz) * CFG::WC + 2 * wz;
+        const int po[4] = {p00, p00 + 1, p00 + CFG::WC, p00 + CFG::WC + 1};
+#pragma unroll
+        for (int k = 0; k < NPOS; ++k) lean_ld8_raw<CFG::YF, false>(yq[j][k], a.y, ypatch + (size_t)po[k] * a.y_rs + o * 8);
+      } else {
+        lean_ld8_raw<CFG::YF, false>(yq[j][0], a.y, ypatch + (size_t)p * a.y_rs + o * 8);
+      }
+      if (ba.da) lean_ld8_raw<GF, true>(dq[j], ba.da, (size_t)g * ba.da_gs + ((size_t)bb * NP + p) * C + o * 8);
+    }
+    const float* save = a.attsave + ((size_t)g * a.B + bb) * a.attsave_ld;
+#pragma unroll
+    for (int k = 0; k < NSV; ++k) {
+      const int i = lt0 + k * TPP;
+      if (i < nsave) {
+        // spectral: pooled | h | gate, contiguous; spatial: m | t1 (padded maps) | s, one slot of a.vslot floats each
+        const int src = kind == KIND_SPECTRAL ? i : (i < NPAD ? i : (i < 2 * NPAD ? a.vslot + i - NPAD : 2 * a.vslot + i - 2 * NPAD));
+        sv[k] = __builtin_nontemporal_load(save + src);
+      }
+    }
+  };
+  const int nb = (a.B + PPW - 1) / PPW;
+  // the 128-wide stage has no registers to spare (a loop costs it spills): one batch per workgroup, fetched at the top
+  constexpr bool PF = CFG::PERSIST;
+  if (PF && (int)blockIdx.x < nb) fetch(blockIdx.x);
+
+  for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
+  // the thread's place is re-derived from an opaque copy in every round: otherwise the compiler hoists every
+  // loop-invariant address out of the loop and pays ~50 registers (= a workgroup per CU) for it
+  int lt = lt0;
+  asm volatile("" : "+v"(lt));
+  const int slot = PPW > 1 ? (int)threadIdx.x / TPP : 0;
+  float* vec = sm0 + slot * SLOT;
+  const int b = bi * PPW + slot;
+  const bool live = b < a.B;
+  if (!PF) fetch(bi);
+  // ---- the fetched bytes -> floats; saved attention state -> LDS ----
+  float yraw[IPT][NPOS][8];
   float D[IPT][8];
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
-    const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0;
-    const int p = itc / NO, o = itc % NO;
-    if (CFG::POOL) {
-      const int hz = p / WZ, wz = p % WZ, p00 = (2 * hz) * CFG::WC + 2 * wz;
-      const int po[4] = {p00, p00 + 1, p00 + CFG::WC, p00 + CFG::WC + 1};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) lean_ld8<CFG::YF, false>(yraw[j][k], a.y, ypatch + (size_t)po[k] * a.y_rs + o * 8);
-    } else {
-      lean_ld8<CFG::YF, false>(yraw[j][0], a.y, ypatch + (size_t)p * a.y_rs + o * 8);
-    }
-    if (ba.da) {
-      const size_t di = (size_t)g * ba.da_gs + ((size_t)bb * NP + p) * C + o * 8;
-      if (ba.da_fmt == FMT_BF16) lean_ld8<FMT_BF16, true>(D[j], ba.da, di); else lean_ld8<FMT_F32, true>(D[j], ba.da, di);
-    }
+    for (int k = 0; k < NPOS; ++k) lean_unpack8<CFG::YF>(yraw[j][k], yq[j][k]);
+    if (ba.da) lean_unpack8<GF>(D[j], dq[j]);
     else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) D[j][e] = 0.f;
     }
   }
-  {
-    const float* coef = a.coef + (size_t)g * a.coef_gs;
-    for (int i = t; i < 4 * C; i += CFG::NT) coefL[i] = coef[i];
-  }
-  // attention weights in flight too: spectral mat-vec slices -> registers, spatial stencils -> LDS
-  constexpr bool PRE = C < 128;
-  float w1[C / CFG::NPART], w2[C / CFG::NPART];
-  if (PRE && kind == KIND_SPECTRAL) { lean_matvec_load<CFG>(a.att[g].p[5], w2); lean_matvec_load<CFG>(a.att[g].p[4], w1); }
-  float* wL = sm0 + PPW * SLOT + CFG::RED;               // [C + 2 K K] wc | k1 | k2
-  if (kind == KIND_SPATIAL)
-    for (int i = t; i < C + 2 * KK; i += CFG::NT)
-      wL[i] = i < C ? a.att[g].p[0][i] : (i < C + KK ? a.att[g].p[2][i - C] : a.att[g].p[4][i - C - KK]);
-  // saved attention state -> LDS
-  const float* save = a.attsave + ((size_t)g * a.B + bb) * a.attsave_ld;
-  if (kind == KIND_SPECTRAL) {
-    for (int i = lt; i < 3 * C; i += TPP) vec[i] = __builtin_nontemporal_load(save + i);        // pooled | h | gate
-  } else if (kind == KIND_SPATIAL) {
-    for (int i = lt; i < NPAD; i += TPP) {
-      vec[i] = __builtin_nontemporal_load(save + i);                                              // m (padded)
-      vec[NPAD + i] = __builtin_nontemporal_load(save + a.vslot + i);                             // t1 (padded)
-      vec[2 * NPAD + NP + i] = 0.f; vec[3 * NPAD + NP + i] = 0.f;                                 // d2, d1 (padded): borders
-    }
-    for (int p = lt; p < NP; p += TPP) vec[2 * NPAD + p] = __builtin_nontemporal_load(save + 2 * a.vslot + p);   // s
+#pragma unroll
+  for (int k = 0; k < NSV; ++k) {
+    const int i = lt + k * TPP;
+    if (i < nsave) vec[i] = sv[k];
   }
   const float* df = (ba.dfeat && live) ? ba.dfeat + (size_t)g * ba.dfeat_gs + (size_t)b * a.F[g] : nullptr;
-  LTICK(1);
   __syncthreads();
-  LTICK(2);
 
   // ---- recompute BN -> ReLU -> pool; keep z, the window position of the maximum and xhat there ----
   float z[IPT][8], xh[IPT][8];
@@ -1709,36 +1847,33 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
       xh[j][e] = (ys - q[2]) * q[3];
     }
   }
+  // the raw registers are free again: next batch in flight behind everything below
+  if (PF && bi + (int)gridDim.x < nb) fetch(bi + gridDim.x);
   float* bnp = (ba.bnpart && live) ? ba.bnpart + (size_t)g * ba.bnpart_gs + (size_t)b * C * 2 : nullptr;
   float* vout = (ba.vec && live) ? ba.vec + (size_t)g * ba.vec_gs + (size_t)b * ba.vec_ld : nullptr;
 
-  auto put8 = [&](float* Zx, int p, int o, const float (&v)[8]) {
-    *reinterpret_cast<f32x4*>(Zx + p * C + o * 8) = f32x4{v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(Zx + p * C + o * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
-  };
   float dv[IPT][8];
-  LTICK(3);
   if (kind == KIND_SPECTRAL) {
     float* pooled = vec; float* hL = vec + C; float* gL = vec + 2 * C;
     float* d2L = vec + 3 * C; float* d1L = vec + 4 * C; float* dpL = vec + 5 * C;
     const float inv = 1.f / (float)NP;
     // D += df / NP (the features are the pixel mean of the gated map), T_c = sum_p D z
+    {
+      float part[1][8];
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-      const int it = lt + j * TPP;
-      if (it >= CFG::ITEMS) continue;
-      const int p = it / NO, o = it % NO;
-      float pr[8];
+      for (int e = 0; e < 8; ++e) part[0][e] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (df) D[j][e] += df[o * 8 + e] * inv;
-        pr[e] = D[j][e] * z[j][e];
+      for (int j = 0; j < IPT; ++j) {
+        const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, o = itc % NO;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (df) D[j][e] += df[o * 8 + e] * inv;
+          part[0][e] += D[j][e] * z[j][e];            // z is zero for threads without an item
+        }
       }
-      put8(Z1, p, o, pr);
+      float* const outs[1] = {sm0 + VOFF + 3 * C};
+      lean_colsum_reg<CFG, 1>(part, red, outs, SLOT, 1.f);
     }
-    __syncthreads();
-    lean_colsum<CFG>(red, sm0 + VOFF + 3 * C, SLOT, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + p * C + c]; });
-    LTICK(4);
     for (int c = lt; c < C; c += TPP) d2L[c] = d2L[c] * gL[c] * (1.f - gL[c]);
     __syncthreads();
     auto fin2 = [&](int s, int i, float v) {
@@ -1747,13 +1882,12 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     };
     auto fin1 = [&](int s, int i, float v) { sm0[s * SLOT + VOFF + 5 * C + i] = v * inv; };
     if constexpr (PRE) {
-      lean_matvec_run<CFG>(w2, sm0 + VOFF + 3 * C, SLOT, red, fin2);
-      lean_matvec_run<CFG>(w1, sm0 + VOFF + 4 * C, SLOT, red, fin1);
+      lean_matvec_lds<CFG>(W2L, sm0 + VOFF + 3 * C, SLOT, red, fin2);
+      lean_matvec_lds<CFG>(W1L, sm0 + VOFF + 4 * C, SLOT, red, fin1);
     } else {
       lean_matvec<CFG>(a.att[g].p[5], sm0 + VOFF + 3 * C, SLOT, red, fin2);
       lean_matvec<CFG>(a.att[g].p[4], sm0 + VOFF + 4 * C, SLOT, red, fin1);
     }
-    LTICK(5);
     if (vout)
       for (int c = lt; c < C; c += TPP) { vout[c] = d2L[c]; vout[C + c] = hL[c]; vout[2 * C + c] = d1L[c]; vout[3 * C + c] = pooled[c]; }
 #pragma unroll
@@ -1784,7 +1918,6 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
       if (it < CFG::ITEMS && o == 0) { const float sp = sL[p]; d2L[(p / WZ + R) * WP + p % WZ + R] = acc * sp * (1.f - sp); }
     }
     __syncthreads();
-    LTICK(4);
     // d1 = (transposed k2 stencil of d2) masked by t1 > 0 ;  dm = (transposed k1 stencil of d1) masked by m > 0
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -1806,38 +1939,40 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
       }
       __syncthreads();
     }
+    float dwp[1][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dwp[0][e] = 0.f;
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
       const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, p = itc / NO, o = itc % NO;
       const float sp = sL[p], dm = dmL[p];
-      float w8[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float dz = D[j][e] * sp + dm * wc[o * 8 + e];
         dv[j][e] = z[j][e] > 0.f ? dz : 0.f;
-        w8[e] = dm * z[j][e];
+        dwp[0][e] += dm * z[j][e];                    // z is zero for threads without an item
       }
-      if (it < CFG::ITEMS && vout != nullptr) put8(Z1, p, o, w8);
     }
-    LTICK(5);
     if (ba.vec) {
       // [dwc (C) | dbc | dK1 (kk) | db1 | dK2 (kk) | db2]
-      __syncthreads();
       float* dwcL = dmL + NP;
-      lean_colsum<CFG>(red, sm0 + VOFF + (int)(dmL + NP - vec), SLOT, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + p * C + c]; });
+      float* const outs[1] = {sm0 + VOFF + (int)(dmL + NP - vec)};
+      lean_colsum_reg<CFG, 1>(dwp, red, outs, SLOT, 1.f);
       if (vout) {
         for (int c = lt; c < C; c += TPP) vout[c] = dwcL[c];
-        // stencil-weight gradients: task = (kernel, tap), NP products each
-        for (int task = lt >> 1; task < 2 * KK; task += TPP / 2) {      // a lane pair per (kernel, tap): rows split
+        // stencil-weight gradients: task = (kernel, tap), NP products each; LPT lanes per task split the rows
+        constexpr int LPT = TPP >= 8 * KK ? 4 : 2;
+        for (int task = lt / LPT; task < 2 * KK; task += TPP / LPT) {
           const bool fst = task < KK;
           const int jj = fst ? task : task - KK, ky = jj / K, kx = jj % K;
           const float* src = fst ? mL : t1L; const float* dd = fst ? d1L : d2L;
           float acc = 0.f;
-          for (int h = lt & 1; h < CFG::HZ; h += 2)
+          for (int h = lt % LPT; h < CFG::HZ; h += LPT)
 #pragma unroll
             for (int w = 0; w < WZ; ++w) acc += src[(h + ky) * WP + w + kx] * dd[(h + R) * WP + w + R];
           acc += lane_xor1(acc);
-          if (!(lt & 1)) vout[fst ? C + 1 + jj : C + 2 + KK + jj] = acc;
+          if (LPT == 4) acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
+          if (lt % LPT == 0) vout[fst ? C + 1 + jj : C + 2 + KK + jj] = acc;
         }
       }
       // bias gradients: sums of dm, d1, d2 (borders of the padded maps are zero): three waves, one map each
@@ -1857,7 +1992,6 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
           vout[lt == 0 ? C : (lt == 1 ? C + 1 + KK : C + 2 + 2 * KK)] = acc;
         }
       }
-      __syncthreads();
     }
   } else {
     // plain stage (vanilla_CNN): the gradient of the map is the incoming gradient (+ the classifier's, NCHW flatten)
@@ -1872,21 +2006,15 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
       }
     }
   }
-  LTICK(6);
   // ---- outputs: dv (dense, or compact value + window position for pooled stages), BatchNorm partial sums ----
+  constexpr bool h16 = GF == FMT_BF16;
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
     const int it = lt + j * TPP;
     if (it >= CFG::ITEMS) continue;
     const int p = it / NO, o = it % NO;
-    float w8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) w8[e] = dv[j][e] * xh[j][e];
-    put8(Z1, p, o, dv[j]);
-    put8(Z2, p, o, w8);
     if (live) {
       const size_t dvi = (size_t)g * ba.dv_gs + (size_t)b * CFG::HWC * C;          // element index of the patch
-      const bool h16 = ba.dv_fmt == FMT_BF16;
       auto st8 = [&](size_t i, const float (&q)[8]) {
         if (h16) {
           u32x4 u;
@@ -1927,28 +2055,59 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_bwd_lean(StageBwdArgs ba) {
     for (int i = lt; i < CFG::HWC * (C / 4); i += TPP) {
       const int pix = i / (C / 4), c4 = (i % (C / 4)) * 4, h = pix / CFG::WC, w = pix % CFG::WC;
       if ((h >> 1) >= CFG::HZ || (w >> 1) >= WZ) {
-        if (ba.dv_fmt == FMT_BF16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(ba.dv) + dvi + (size_t)pix * C + c4) = u32x2{0u, 0u};
+        if (h16) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(ba.dv) + dvi + (size_t)pix * C + c4) = u32x2{0u, 0u};
         else *reinterpret_cast<f32x4*>(ba.dv + dvi + (size_t)pix * C + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
-  __syncthreads();
-  LTICK(7);
   if (ba.bnpart) {
-    float* s1L = red + PPW * CFG::NT + slot * 2 * C;     // (the head of red is the column-sum scratch)
-    lean_colsum<CFG>(red, red + PPW * CFG::NT, 2 * C, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + p * C + c]; });
-    lean_colsum<CFG>(red, red + PPW * CFG::NT + C, 2 * C, 1.f, [&](int s, int p, int c) { return sm0[s * SLOT + NP * C + p * C + c]; });
+    // sum dv, sum dv xhat per channel (dv is zero for threads without an item and for dead patches)
+    float bp[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bp[0][e] = 0.f; bp[1][e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) { bp[0][e] += dv[j][e]; bp[1][e] += dv[j][e] * xh[j][e]; }
+    }
+    constexpr int S1 = 2 * PPW * (TPP / 64) * C;         // the head of red is the column-sum scratch
+    float* s1L = red + S1 + slot * 2 * C;
+    float* const outs[2] = {red + S1, red + S1 + C};
+    lean_colsum_reg<CFG, 2>(bp, red, outs, 2 * C, 1.f);
     if (bnp)
       for (int c = lt; c < C; c += TPP) *reinterpret_cast<f32x2*>(bnp + c * 2) = f32x2{s1L[c], s1L[C + c]};
   }
-  LTICK(8);
+  if (!PF) break;       // (compile-time single trip: straight-line code)
+  __syncthreads();      // the next batch reuses the vectors and the scratch
+  }
 }
 
+// workgroups of `kernel` one CU holds at once (queried once per instantiation)
+template <typename KERNEL>
+static int lean_wgs_per_cu(KERNEL kernel, int threads, size_t lds) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) n = 1;
+  return n;
+}
+// persistent grid: as many workgroups per group as stay resident, evened out so that no workgroup walks a batch more
+// than the others need to (nb batches over gx workgroups: ceil(nb / gx) rounds)
+static int lean_grid_x(int nb, int G, int wgs_per_cu) {
+  const int slots = wgs_per_cu * 256 / (G > 0 ? G : 1);
+  if (slots < 1 || nb <= slots) return nb;
+  const int rounds = (nb + slots - 1) / slots;
+  return (nb + rounds - 1) / rounds;
+}
 template <typename CFG>
 static int launch_stage_bwd_lean_c(const StageBwdArgs& a, int G, hipStream_t st) {
   const size_t lds = (size_t)LeanBwd<CFG>::LDS * 4;
   static_assert(LeanBwd<CFG>::LDS * 4 <= 64 * 1024, "lean stage backward: LDS plan exceeds the default 64 KiB limit");
-  hipLaunchKernelGGL((k_stage_bwd_lean<CFG>), dim3((a.f.B + CFG::PPW - 1) / CFG::PPW, G), dim3(CFG::NT), lds, st, a);
+  constexpr int GF = CFG::YF == FMT_F16 ? FMT_BF16 : FMT_F32;
+  if ((a.da && a.da_fmt != GF) || a.dv_fmt != GF) {     // gradient maps are stored like the conv outputs
+    dta_set_error("k_stage_bwd_lean: gradient-map storage format does not follow the conv outputs'");
+    return 1;
+  }
+  static const int wpc = lean_wgs_per_cu(k_stage_bwd_lean<CFG>, CFG::NT, lds);
+  const int nb = (a.f.B + CFG::PPW - 1) / CFG::PPW;
+  hipLaunchKernelGGL((k_stage_bwd_lean<CFG>), dim3(CFG::PERSIST ? lean_grid_x(nb, G, wpc) : nb, G), dim3(CFG::NT), lds, st, a);
   DTA_CHECK_LAUNCH("k_stage_bwd_lean");
   return 0;
 }
