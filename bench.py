@@ -50,6 +50,8 @@ def parse():
                          "first conv's weight gradient (the longest MFMA-bound kernel)")
     ap.add_argument("--steady-steps", type=int, default=200,
                     help="extra steps timed one by one after the contract's K steps (median reported); 0 = skip")
+    ap.add_argument("--tile-steps", type=int, default=100,
+                    help="extra steps fed with pre-tiled bf16 input (reported under tile_input; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
@@ -193,6 +195,36 @@ def main():
                   "median_patches_per_s_per_gpu": round(a.batch / (ms[len(ms) // 2] * 1e-3), 1),
                   "note": "per-step HIP events on this rank's stream after the contract's timed region"}
 
+    # the same step fed the way this framework's own loader delivers patches (preprocess -> the first conv's bf16 tiles,
+    # SURVEY 8 row n2): the first conv then reads 2 bytes per value and writes no tile by-product.  A side number: the
+    # headline above keeps the reference's input format (fp32 NCHW).
+    tile_in = None
+    if a.tile_steps > 0 and a.precision == "bf16" and not dist_on:      # (single process only: the steps would issue collectives)
+        from deeptreeattention_amd.preprocess import PatchTiles
+        nchunk = (BANDS + 15) // 16
+
+        def as_tiles(x):
+            pad = torch.zeros(a.batch, nchunk * 16, HW * HW, device=dev)
+            pad[:, :BANDS] = x.reshape(a.batch, BANDS, HW * HW)
+            t = pad.view(a.batch, nchunk, 16, HW * HW).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+            return PatchTiles(t.view(torch.int16).reshape(-1), a.batch, BANDS, HW, HW)
+        ts = [as_tiles(x) for x in xs]
+        for i in range(5):
+            trainer.train_step(ts[i % nb], ys[i % nb])
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.tile_steps)]
+        for i, (e0, e1) in enumerate(evs):
+            e0.record()
+            trainer.train_step(ts[i % nb], ys[i % nb])
+            e1.record()
+        torch.cuda.synchronize()
+        ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        tile_in = {"steps": a.tile_steps, "median_ms_per_step": round(ms[len(ms) // 2], 4),
+                   "median_patches_per_s_per_gpu": round(a.batch / (ms[len(ms) // 2] * 1e-3), 1),
+                   "note": "input handed over as the first conv's bf16 tiles (preprocess.preprocess_batch(tiles=True)); "
+                           "per-step HIP events, rank 0, after the contract's timed region"}
+        del ts
+    barrier()
+
     if rank == 0:
         # HBM bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of this
         # very command; tools/step_traffic.py): a constant of the configuration it was measured on, not a live counter
@@ -266,6 +298,7 @@ def main():
                 "hbm_frac_algorithmic": round(per_gpu * BYTES_PER_PATCH_STEP / 1e9 / PEAK_HBM_GBS, 4),
                 "traffic": traffic.get("step_total"), "traffic_source": tsrc},
             "steady_state": steady,
+            "tile_input": tile_in,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_seconds)

@@ -3,6 +3,7 @@
 // unswizzled for bf16), LDS addresses precomputed per lane so the tap loops are MFMA + ds_read only.
 //   k_conv3x3_bf16<MT,NT>   forward / input-gradient 3x3 conv (same contract as k_conv3x3 in conv.hip)
 //   k_conv_wgrad_bf16<NTT>  weight gradient (same contract as k_conv_wgrad in conv.hip)
+#include <type_traits>
 #include "kernels.h"
 
 namespace dta {
@@ -62,12 +63,12 @@ extern "C" int dta_debug_cticks(long long* out) { return (int)hipMemcpyFromSymbo
 #else
 #define CTICK(i)
 #endif
-template <int MT, int NT, bool XN>
-__global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
+template <int MT, int NT, bool XN, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, 1) void k_conv3x3_bf16(ConvArgs a) {
   WGSTAMP(XN ? 0 : (a.stats ? (a.N == 64 ? 1 : 2) : -1));      // first conv, second conv, third conv (forward launches)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   CTICK(0);
-  constexpr int NW = 8, NTHR = 512;
+  constexpr int NW = NWV, NTHR = NW * 64;       // eight waves, or four for maps so small that 256-row tiles leave CUs idle
   constexpr int MWG = NW * MT * 32;
   constexpr int N = NT * 32;
   int* rowtab = (int*)smem;                 // [MWG] global output row or -1
@@ -88,6 +89,33 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   const int khalf16 = (lane >> 5) * 16;
   int abase[MT];
   const int bbase = (lane & 31) * RB + khalf16;
+  const bool xc = a.x_compact != 0;
+  // row tables + the zero halo of halo-free inputs: LDS-only work, done while the first chunk's loads are in flight
+  // (cycle stamps of a two-chunk workgroup: tables 4.0 k cycles, then 2.3 k waiting for the first chunk)
+#define DTA_TABLES \
+  { \
+    for (int lr = tid; lr < MWG; lr += NTHR) { \
+      int pl, pix; \
+      bool valid; \
+      if (a.spp == 1) { pl = lr / HW; pix = lr - pl * HW; valid = pl < npatch; } \
+      else { pl = 0; pix = split * MWG + lr; valid = pix < HW; } \
+      int h = valid ? pix / a.W : 0, w = valid ? pix - h * a.W : 0; \
+      rowtab[lr] = valid ? (b0 + pl) * HW + pix : -1; \
+      plq[lr] = valid ? ((pl << 16) | (h * W2 + w)) : 0; \
+    } \
+    if (xc) { \
+      u32x4* z = reinterpret_cast<u32x4*>(sbuf); \
+      const u32x4 zero = {0u, 0u, 0u, 0u}; \
+      for (int i = tid; i < xbytes / 16; i += NTHR) { z[i] = zero; if (dbuf) z[i + stage / 16] = zero; } \
+    } \
+    __syncthreads(); \
+_Pragma("unroll") \
+    for (int mt = 0; mt < MT; ++mt) { \
+      int v = plq[(wave * MT + mt) * 32 + (lane & 31)]; \
+      abase[mt] = ((v >> 16) * Q + (v & 0xFFFF)) * RB + khalf16; \
+    } \
+  }
+  if (XN) DTA_TABLES    // (the fused-input kernel is at its register limit: tables first, nothing else live)
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -101,14 +129,14 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   constexpr int XV = 4, WV = (9 * N * 2 + NTHR - 1) / NTHR;
   // input tiles in HBM: haloed [q][16] rows, or (x_compact, the network input) halo-free [pixel][16] rows whose zero
   // halo exists only in LDS (zeroed once below, never overwritten)
-  const bool xc = a.x_compact != 0;
   const int trows = xc ? HW : Q;              // tile rows in HBM
   const int vpp = trows * 2;                  // vectors per patch tile
   const int nxv = npatch * vpp, wvec = 9 * N * 2;
-  const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs;
+  const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs + ((size_t)b0 * a.NC) * ((size_t)(a.x_compact ? HW : Q) * 16);
   const bf16_t* wg = (const bf16_t*)a.wp + (size_t)g * a.NC * 9 * N * 16;
   const size_t xchunk = (size_t)trows * 16;   // elements between consecutive chunks of one patch
-  size_t xsrc[XV];
+  // (offsets are 32-bit and relative to the workgroup's first patch: the 64-bit part is a scalar base, not a register pair per vector)
+  unsigned xsrc[XV];
   int xdst[XV], wdst[WV];
 #pragma unroll
   for (int u = 0; u < XV; ++u) {
@@ -116,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     int pl = v / vpp, o = v - pl * vpp;
     int row = o >> 1;
     if (xc) { const int hh = row / a.W; row = (hh + 1) * W2 + (row - hh * a.W) + 1; }   // pixel -> haloed-grid row
-    xsrc[u] = ((size_t)(b0 + pl) * a.NC) * xchunk + (size_t)o * 8;
+    xsrc[u] = (unsigned)(((size_t)pl * a.NC) * xchunk + (size_t)o * 8);
     xdst[u] = (pl * Q + row) * RB + (o & 1) * 16;
   }
   // ---- network input read directly as fp32 NCHW (no separate pack pass): thread t owns (patch, 4-channel group,
@@ -124,9 +152,9 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   // read consecutive floats.  Four channels of a pixel are converted and written to the LDS row as one 8-byte store.
   constexpr int QV = 4;
   constexpr bool xn = XN;
-  const float* xf = xn ? a.x_nchw[g] : nullptr;
+  const float* xf = xn ? a.x_nchw[g] + (size_t)b0 * a.Cx * HW : nullptr;
   const int nquad = xn ? npatch * 4 * HW : 0;
-  size_t qsrc[QV];
+  unsigned qsrc[QV];
   int qdst[QV], qch[QV];
 #pragma unroll
   for (int u = 0; u < QV; ++u) {
@@ -135,36 +163,12 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     int cq = rem / HW, px = rem - cq * HW;
     const int hh = px / a.W;
     const int row = (hh + 1) * W2 + (px - hh * a.W) + 1;
-    qsrc[u] = (size_t)(b0 + pl) * a.Cx * HW + px;    // channel 0 of the patch
+    qsrc[u] = (unsigned)((size_t)pl * a.Cx * HW + px);    // channel 0 of the patch, relative to the workgroup's first
     qdst[u] = (pl * Q + row) * RB + cq * 8;
     qch[u] = cq * 4;
   }
   float rf[QV][4];
-  bf16_t* xo = (XN && a.x_tl_out) ? (bf16_t*)a.x_tl_out + (size_t)g * a.x_gs : nullptr;
-  // row tables + the zero halo of halo-free inputs: LDS-only work, done while the first chunk's loads are in flight
-  // (cycle stamps of a two-chunk workgroup: tables 4.0 k cycles, then 2.3 k waiting for the first chunk)
-  auto tables = [&]() {
-    for (int lr = tid; lr < MWG; lr += NTHR) {
-      int pl, pix;
-      bool valid;
-      if (a.spp == 1) { pl = lr / HW; pix = lr - pl * HW; valid = pl < npatch; }
-      else { pl = 0; pix = split * MWG + lr; valid = pix < HW; }
-      int h = valid ? pix / a.W : 0, w = valid ? pix - h * a.W : 0;
-      rowtab[lr] = valid ? (b0 + pl) * HW + pix : -1;
-      plq[lr] = valid ? ((pl << 16) | (h * W2 + w)) : 0;
-    }
-    if (xc) {   // the halo rows of both LDS stages
-      u32x4* z = reinterpret_cast<u32x4*>(sbuf);
-      const u32x4 zero = {0u, 0u, 0u, 0u};
-      for (int i = tid; i < xbytes / 16; i += NTHR) { z[i] = zero; if (dbuf) z[i + stage / 16] = zero; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      int v = plq[(wave * MT + mt) * 32 + (lane & 31)];
-      abase[mt] = ((v >> 16) * Q + (v & 0xFFFF)) * RB + khalf16;
-    }
-  };
+  bf16_t* xo = (XN && a.x_tl_out) ? (bf16_t*)a.x_tl_out + (size_t)g * a.x_gs + ((size_t)b0 * a.NC) * ((size_t)(a.x_compact ? HW : Q) * 16) : nullptr;
 #pragma unroll
   for (int u = 0; u < WV; ++u) {
     int v = min(tid + u * NTHR, wvec - 1);
@@ -251,7 +255,6 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     }
     DTA_FETCH_XF(rf, 0)
     DTA_FETCH_W(0)
-    tables();
     DTA_STORE_XF(rf, sbuf)
     DTA_STORE_W(sbuf + xbytes)
     DTA_FETCH_XF(rf, 1)
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   } else {
   // chunk k+1 sits in registers while chunk k is multiplied; with two LDS stages its ds_writes also overlap
   DTA_FETCH(0)
-  tables();
+  if (!XN) DTA_TABLES
   DTA_STORE(sbuf, sbuf + xbytes, 0)
   if (a.NC > 1) DTA_FETCH(1)
   __syncthreads();
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   }
   }
 #undef DTA_COMPUTE
+#undef DTA_TABLES
 #undef DTA_STORE
 #undef DTA_FETCH
 
@@ -370,6 +374,10 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
     const int ncol = (lane & 31) & ~1;
     constexpr int EP = N * 2 + 16;                  // LDS row pitch in bytes (16-byte aligned, rows 4 apart miss banks)
     unsigned char* E = sbuf;
+    // (the format is a compile-time constant inside the unrolled packing loop: one uniform branch out here instead of
+    // one per packed pair)
+    auto pack_tile = [&](auto fmt_tag) {
+    constexpr int YFMT = decltype(fmt_tag)::value;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -383,11 +391,14 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
           if (orow0 >= 0) csum[nt] += v0;
           if (orow1 >= 0) csum[nt] += v1;
           const float got = lane_xor1(odd ? v0 : v1);      // even lane <- neighbour's row r, odd lane <- neighbour's row r + 1
-          const unsigned pk = odd ? pack2_fmt(got, v1, a.y_fmt) : pack2_fmt(v0, got, a.y_fmt);
+          const unsigned pk = odd ? pack2_fmt(got, v1, YFMT) : pack2_fmt(v0, got, YFMT);
           *reinterpret_cast<unsigned*>(E + (lr0 + (odd ? 1 : 0)) * EP + (nt * 32 + ncol) * 2) = pk;
         }
       }
     }
+    };
+    if (a.y_fmt == FMT_F16) pack_tile(std::integral_constant<int, FMT_F16>{});
+    else pack_tile(std::integral_constant<int, FMT_BF16>{});
     __syncthreads();
     constexpr int VPR = N / 8;                      // 16-byte vectors per output row
 #pragma unroll
@@ -443,9 +454,9 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_bf16(ConvArgs a) {
   CTICK(5);
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int NW = 8>
 static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
-  constexpr int MWG = 8 * MT * 32, N = NT * 32;
+  constexpr int MWG = NW * MT * 32, N = NT * 32;
   int nwg;
   conv_geometry(a.HW, MWG, a.B, &a.ppw, &a.spp, &nwg);
   size_t tab = (size_t)MWG * 8 + (size_t)9 * N * 4, stage = ((size_t)a.ppw * a.Q + (size_t)9 * N) * RB;
@@ -458,15 +469,19 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
     if (epi > lds) lds = epi;
   }
   if (lds > 160 * 1024) { dta_set_error("conv3x3(bf16): LDS need %zu B exceeds 160 KiB (H=%d W=%d)", lds, a.H, a.W); return 1; }
-  if (a.ppw * a.Q * 2 > 4 * 512) { dta_set_error("conv3x3(bf16): %dx%d tile exceeds the staging plan", a.H, a.W); return 1; }
+  if (a.ppw * a.Q * 2 > 4 * NW * 64) { dta_set_error("conv3x3(bf16): %dx%d tile exceeds the staging plan", a.H, a.W); return 1; }
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (NW == 8) hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  if (a.x_nchw[0]) hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, true>), dim3(nwg, G), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, false>), dim3(nwg, G), dim3(512), lds, st, a);
+  if (a.x_nchw[0]) {
+    if (NW != 8) { dta_set_error("conv3x3(bf16): the fused-input first conv runs eight-wave workgroups only"); return 1; }
+    hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, true, 8>), dim3(nwg, G), dim3(512), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, false, NW>), dim3(nwg, G), dim3(NW * 64), lds, st, a);
+  }
   DTA_CHECK_LAUNCH("k_conv3x3_bf16");
   return 0;
 }
@@ -486,7 +501,10 @@ int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
       if (a.mwg == 256) return launch_conv_bf16_t<1, 2>(a, G, st);
       return launch_conv_bf16_t<2, 2>(a, G, st);
     }
-    case 128: return launch_conv_bf16_t<1, 4>(a, G, st);
+    case 128:
+      // (four-wave, 128-row workgroups for the 5x5 maps were measured: every workgroup stages the full weight set, so
+      // halving the rows doubles that traffic -- third conv 18.9 -> 18.0 us, its input-gradient conv 17 -> 24 us; not used)
+      return launch_conv_bf16_t<1, 4>(a, G, st);
   }
   dta_set_error("conv3x3: unsupported output width %d", a.N);
   return 1;
