@@ -90,6 +90,14 @@ def lib():
         L.dta_net_backward_tiles.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.POINTER(ScoreTable), C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p,
                                              C.c_int, C.c_void_p]
+        L.dta_net_backward_dp.restype = C.c_int
+        L.dta_net_backward_dp.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(ScoreTable), C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_void_p]
+        L.dta_adam_step_dp.restype = C.c_int
+        L.dta_adam_step_dp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, C.c_int, C.c_void_p]
         L.dta_preprocess_crops_tiles.restype = C.c_int
         L.dta_preprocess_crops_tiles.argtypes = [C.POINTER(CropDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p]

@@ -443,7 +443,7 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
 template <typename T>
 int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, void* ws,
                const float* const (*dscores)[3], const float* djoint, const dta_subnet_grads* grads, double* dalpha,
-               int phases, hipStream_t st, const void* x_tiles = nullptr) {
+               int phases, hipStream_t st, const void* x_tiles = nullptr, float* dalpha32 = nullptr) {
   const int G = p.G, B = p.B;
   if (!(phases & 1)) {
     // phase 2 only: the first layer's weight gradient from tensors phase 1 left in the workspace
@@ -469,7 +469,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     // (GemmArgs::sig_mode); d(alpha) is reduced by one extra block of the first GEMM launch below
     BlendBwdArgs bb = {};
     bb.spec = at<float>(ws, p.scores[0][2]); bb.spat = at<float>(ws, p.scores[1][2]);
-    bb.alpha = alpha; bb.djoint = djoint; bb.dalpha = dalpha; bb.B = B; bb.classes = p.classes;
+    bb.alpha = alpha; bb.djoint = djoint; bb.dalpha = dalpha; bb.dalpha32 = dalpha32; bb.B = B; bb.classes = p.classes;
     if (dalpha == nullptr) { dta_set_error("Hang2020 backward needs a dalpha destination"); return 1; }
     blend_fin = bb; blend_fin_pending = true;
     dsc[0][2] = djoint; dsc[1][2] = djoint;
@@ -796,6 +796,20 @@ int dta_net_backward(const dta_net_desc* d, const dta_subnet_params* nets, const
   return 1;
 }
 
+int dta_net_backward_dp(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,
+                        void* workspace, const float* const dscores[2][3], const float* djoint,
+                        const dta_subnet_grads* grads, double* dalpha, float* dalpha_f32, int phases, void* stream) {
+  Plan p;
+  if (!d || !nets || !workspace || !grads || !(phases & 3)) { dta_set_error("dta_net_backward_dp: null argument"); return 1; }
+  if (build_plan(d, &p)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (x_tiles && d->dtype != DTA_BF16) { dta_set_error("dta_net_backward_dp: tile input is bf16 mode only"); return 1; }
+  if (d->dtype == DTA_BF16) return backward_t<bf16_t>(p, d, nets, alpha, workspace, dscores, djoint, grads, dalpha, phases, st, x_tiles, dalpha_f32);
+  if (d->dtype == DTA_F32) return backward_t<float>(p, d, nets, alpha, workspace, dscores, djoint, grads, dalpha, phases, st, nullptr, dalpha_f32);
+  dta_set_error("unknown dtype %d", d->dtype);
+  return 1;
+}
+
 int dta_weighted_ce(const float* logits, const long long* labels, const float* weight, int batch, int classes,
                     float* loss, float* dlogits, float* scratch, void* stream) {
   if (!logits || !labels || !loss || !scratch || batch < 1 || classes < 1) { dta_set_error("dta_weighted_ce: bad argument"); return 1; }
@@ -814,14 +828,15 @@ int dta_softmax_top2(const float* logits, int batch, int classes, float* probs, 
 static int adam_step_impl(float* p, const float* g, float* gz, float* m, float* v, size_t n, double* alpha_p,
                           const double* alpha_g, double* alpha_gz, double* alpha_m, double* alpha_v, int step, float lr,
                           float beta1, float beta2, float eps, float grad_scale, void* stream,
-                          const float* active = nullptr, const int* dev_step = nullptr) {
+                          const float* active = nullptr, const int* dev_step = nullptr, const float* alpha_g32 = nullptr) {
   if ((step < 1 && !active) || (n && (!p || !g || !m || !v))) { dta_set_error("dta_adam_step: bad argument"); return 1; }
   AdamArgs a;
   a.active = active; a.dev_step = dev_step;
   if (active && !dev_step) { dta_set_error("dta_adam_step_gated: needs a device step counter"); return 1; }
+  if (alpha_g32 && (alpha_g32 < g || alpha_g32 >= g + n)) { dta_set_error("dta_adam_step_dp: alpha's exchange slot must lie inside g"); return 1; }
   if (step < 1) step = 1;
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.gz = gz; a.alpha_gz = alpha_gz;
-  a.alpha_p = alpha_p; a.alpha_g = alpha_g; a.alpha_m = alpha_m; a.alpha_v = alpha_v;
+  a.alpha_p = alpha_p; a.alpha_g = alpha_g; a.alpha_m = alpha_m; a.alpha_v = alpha_v; a.alpha_g32 = alpha_g32;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));   // O(1): a long run must not become host-bound
   a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
@@ -847,6 +862,13 @@ int dta_adam_step_zero_grad(float* p, float* g, float* m, float* v, size_t n, do
                             float grad_scale, void* stream) {
   return adam_step_impl(p, g, g, m, v, n, alpha_p, alpha_g, alpha_g, alpha_m, alpha_v, step, lr, beta1, beta2, eps,
                         grad_scale, stream);
+}
+
+int dta_adam_step_dp(float* p, float* g, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,
+                     const float* alpha_g_f32, double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2,
+                     float eps, float grad_scale, int zero_grad, void* stream) {
+  return adam_step_impl(p, g, zero_grad ? g : nullptr, m, v, n, alpha_p, alpha_g, zero_grad ? alpha_g : nullptr, alpha_m, alpha_v,
+                        step, lr, beta1, beta2, eps, grad_scale, stream, nullptr, nullptr, alpha_g_f32);
 }
 
 }  // extern "C"

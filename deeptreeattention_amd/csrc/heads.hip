@@ -476,6 +476,7 @@ __device__ __forceinline__ void blend_bwd_fin_block(const BlendBwdArgs& a, doubl
   if (threadIdx.x == 0) {
     const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
     atomicAdd(a.dalpha, sd[0] * wd * (1.0 - wd));
+    if (a.dalpha32) atomicAdd(a.dalpha32, (float)(sd[0] * wd * (1.0 - wd)));
   }
 }
 __global__ __launch_bounds__(256) void k_blend_bwd_fin(BlendBwdArgs a) {
@@ -628,23 +629,29 @@ __global__ void k_adam(AdamArgs a) {
     bc1 = (float)(1.0 - pow((double)a.beta1, st)); bc2 = (float)(1.0 - pow((double)a.beta2, st));
   }
   const float ss = a.lr / bc1, rbc2 = rsqrtf(bc2);
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
-    // moments: touched once per step, by this kernel only -> nontemporal both ways (they would only evict useful lines)
-    float g = a.g[i] * a.grad_scale;
-    float m = a.beta1 * __builtin_nontemporal_load(a.m + i) + (1.f - a.beta1) * g;
-    float v = a.beta2 * __builtin_nontemporal_load(a.v + i) + (1.f - a.beta2) * g * g;
-    __builtin_nontemporal_store(m, a.m + i); __builtin_nontemporal_store(v, a.v + i);
-    a.p[i] -= ss * (m / (sqrtf(v) * rbc2 + a.eps));
-    if (a.gz) a.gz[i] = 0.f;
-  }
-  if (a.alpha_p && blockIdx.x == 0 && threadIdx.x == 0) {
-    double g = a.alpha_g[0] * (double)a.grad_scale;
+  auto alpha_update = [&](double graw) {
+    double g = graw * (double)a.grad_scale;
     double m = (double)a.beta1 * a.alpha_m[0] + (1.0 - (double)a.beta1) * g;
     double v = (double)a.beta2 * a.alpha_v[0] + (1.0 - (double)a.beta2) * g * g;
     a.alpha_m[0] = m; a.alpha_v[0] = v;
     a.alpha_p[0] -= ((double)a.lr / (double)bc1) * (m / (sqrt(v) / sqrt((double)bc2) + (double)a.eps));
     if (a.alpha_gz) a.alpha_gz[0] = 0.0;
+  };
+  // alpha's gradient in an exchange slot of g: the thread that owns that element steps alpha (it reads the slot before
+  // the pass clears it)
+  const bool slot_mode = a.alpha_p && a.alpha_g32;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+    // moments: touched once per step, by this kernel only -> nontemporal both ways (they would only evict useful lines)
+    const float graw = a.g[i];
+    float g = graw * a.grad_scale;
+    float m = a.beta1 * __builtin_nontemporal_load(a.m + i) + (1.f - a.beta1) * g;
+    float v = a.beta2 * __builtin_nontemporal_load(a.v + i) + (1.f - a.beta2) * g * g;
+    __builtin_nontemporal_store(m, a.m + i); __builtin_nontemporal_store(v, a.v + i);
+    a.p[i] -= ss * (m / (sqrtf(v) * rbc2 + a.eps));
+    if (slot_mode && a.g + i == a.alpha_g32) alpha_update((double)graw);
+    if (a.gz) a.gz[i] = 0.f;
   }
+  if (a.alpha_p && !a.alpha_g32 && blockIdx.x == 0 && threadIdx.x == 0) alpha_update(a.alpha_g[0]);
 }
 int launch_adam(const AdamArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_adam, dim3((unsigned)min((size_t)2048, (a.n + 255) / 256)), dim3(256), 0, st, a);

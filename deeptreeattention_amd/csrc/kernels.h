@@ -334,6 +334,8 @@ int launch_mean_scores(const MeanArgs& a, hipStream_t st);
 struct BlendBwdArgs {
   const float* spec; const float* spat; const double* alpha; const float* djoint;
   double* dalpha; int B, classes;
+  float* dalpha32;      // optional fp32 copy of d(alpha), accumulated alongside: the slot of the flat gradient buffer in
+                        // which alpha's gradient travels through a data-parallel exchange (no copy kernels around it)
 };
 // the blend's backward lives inside the head GEMMs (GemmArgs::sig_mode); its d(alpha) reduction rides as extra blocks
 // of a grouped GEMM launch
@@ -346,6 +348,7 @@ int launch_weighted_ce(const CeArgs& a, hipStream_t st);
 struct AdamArgs {
   float* p; const float* g; float* m; float* v; size_t n;
   double* alpha_p; const double* alpha_g; double* alpha_m; double* alpha_v;
+  const float* alpha_g32;              // non-null: alpha's gradient is read from this fp32 exchange slot instead
   float lr, beta1, beta2, eps, bc1, bc2; float grad_scale;
   float* gz; double* alpha_gz;         // non-null: gradients are cleared after use (step + zero_grad in one pass)
   // device-side gating (year ensembles under data parallelism): when `active` is non-null the step is applied only if

@@ -133,8 +133,7 @@ class FusedTrainer:
         self._ws = None
         self._ws_key = None
         self._desc_key = None
-        self._side = torch.cuda.Stream(device=dev) if self.overlap else None
-        self.sync = GradSync(self.world, self.pg, self._side)
+        self.sync = GradSync(self.world, self.pg)
         if self.comm and storage is None:
             self.broadcast_parameters()
 
@@ -294,34 +293,35 @@ class FusedTrainer:
             djoint = None
         self._zero_grads()             # C-ABI contract: gradient buffers (and dalpha) arrive zero-filled
 
+        # data-parallel: alpha's gradient is also accumulated (fp32) into its slot of the first bucket by the kernels
+        slot = _lib.ptr(self.alpha_slot) if (self.comm and self.alpha_on_graph) else None
+
         def run(phases):
-            if self._tiles is None:
-                _lib.check(L.dta_net_backward(d, self.nets, alpha, _lib.ptr(self._ws), C.byref(table), djoint, self.grads,
-                                              dalpha, phases, st), "dta_net_backward")
-            else:
-                _lib.check(L.dta_net_backward_tiles(d, self.nets, alpha, _lib.ptr(self._tiles), _lib.ptr(self._ws),
-                                                    C.byref(table), djoint, self.grads, dalpha, phases, st),
-                           "dta_net_backward_tiles")
-        ag, slot = (self.alpha_g, self.alpha_slot) if self.alpha_on_graph else (None, None)
+            tiles = None if self._tiles is None else _lib.ptr(self._tiles)
+            _lib.check(L.dta_net_backward_dp(d, self.nets, alpha, tiles, _lib.ptr(self._ws), C.byref(table), djoint,
+                                             self.grads, dalpha, slot, phases, st), "dta_net_backward_dp")
+        ag, slot_t = None, None        # (GradSync's copy-in / copy-out of alpha is for callers without the slot kernels)
         if not self.comm:
             run(3)
         elif self.overlap:
             # phase 1: everything but the first conv's weight gradient; its all-reduce (side stream) runs while
             # phase 2, the first conv's weight gradient, is computed: two collectives per step
             run(1)
-            self.sync.reduce_early(self.g_head, ag, slot)
+            self.sync.reduce_early(self.g_head, ag, slot_t)
             run(2)
             self.sync.reduce_late(self.g_tail)
             self.sync.finish()
         elif self.flat_g is not None:
             run(3)                     # no overlap: ONE collective over the whole flat gradient
-            self.sync.reduce_all(self.flat_g, ag, slot)
+            self.sync.reduce_all(self.flat_g, ag, slot_t)
             self.sync.finish()
         else:
             run(3)
-            self.sync.reduce_early(self.g_head, ag, slot)
+            self.sync.reduce_early(self.g_head, ag, slot_t)
             self.sync.reduce_late(self.g_tail)
             self.sync.finish()
+        if self.comm and self.alpha_on_graph and self.keep_grads:
+            self.alpha_g.copy_(self.alpha_slot[0])      # readable summed gradient (grad_of); the optimizer reads the slot
         self._grads_clear = False
 
     def _zero_grads(self):
@@ -339,8 +339,8 @@ class FusedTrainer:
         L = _lib.lib()
         self.step_count += 1
         # default: step + zero_grad in one pass, so the next backward finds its gradient buffers already cleared
-        adam = L.dta_adam_step if self.keep_grads else L.dta_adam_step_zero_grad
         al = self.alpha_on_graph
+        slot = _lib.ptr(self.alpha_slot) if (self.comm and al) else None
         if self.flat_p is not None:
             segs = [(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.n)]
         elif all(h.data_ptr() + 4 * self.split == t.data_ptr() for h, t in
@@ -352,11 +352,13 @@ class FusedTrainer:
                     (self.p_tail, self.g_tail, self.m_tail, self.v_tail, self.n_first)]
         for i, (p, g, m, v, n) in enumerate(segs):
             a = al and i == 0
-            _lib.check(adam(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n,
-                            _lib.ptr(self.alpha) if a else None, _lib.ptr(self.alpha_g) if a else None,
-                            _lib.ptr(self.alpha_m) if a else None, _lib.ptr(self.alpha_v) if a else None,
-                            self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
-                            self.sync.grad_scale, _lib.current_stream_ptr()), "dta_adam_step")
+            _lib.check(L.dta_adam_step_dp(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n,
+                                          _lib.ptr(self.alpha) if a else None, _lib.ptr(self.alpha_g) if a else None,
+                                          slot if a else None,
+                                          _lib.ptr(self.alpha_m) if a else None, _lib.ptr(self.alpha_v) if a else None,
+                                          self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                          self.sync.grad_scale, 0 if self.keep_grads else 1, _lib.current_stream_ptr()),
+                       "dta_adam_step_dp")
         self._grads_clear = not self.keep_grads
 
     def _labels(self, y):

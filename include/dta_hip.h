@@ -101,6 +101,15 @@ int dta_net_backward_tiles(const dta_net_desc* d, const dta_subnet_params* nets,
                            void* workspace, const float* const dscores[2][3], const float* djoint,
                            const dta_subnet_grads* grads, double* dalpha, int phases, void* stream);
 
+/* Data-parallel form of dta_net_backward / dta_net_backward_tiles (x_tiles NULL: the workspace's own tiles).  One extra
+ * destination: dalpha_f32 (may be NULL), a float32 copy of d(alpha) accumulated next to the float64 one.  A
+ * data-parallel caller points it at a (zeroed) slot of its flat float32 gradient buffer, so that alpha's gradient takes
+ * part in the buffer's all-reduce without copy kernels around the collective (reference train.py:89-98 lets Lightning's
+ * DDP all-reduce every parameter; here that is at most two collectives per step). */
+int dta_net_backward_dp(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,
+                        void* workspace, const float* const dscores[2][3], const float* djoint,
+                        const dta_subnet_grads* grads, double* dalpha, float* dalpha_f32, int phases, void* stream);
+
 /* ---- Year ensemble (reference src/models/year.py:9-33): `years` (1..DTA_MAX_YEARS) spectral_networks, each on its own
  * input, run as the groups of ONE set of launches (a third of the launches of `years` separate dta_net_* calls);
  * the returned scores are the mean over the years of each year's last-head scores (year.py:30,33).
@@ -172,6 +181,12 @@ int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double
 int dta_adam_step_zero_grad(float* p, float* g, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,
                             double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2, float eps,
                             float grad_scale, void* stream);
+
+/* Data-parallel form: alpha's gradient is read from alpha_g_f32 (the exchange slot dta_net_backward_dp filled and the
+ * all-reduce summed) when that is non-NULL, from alpha_g otherwise; zero_grad != 0 clears g and alpha_g after use. */
+int dta_adam_step_dp(float* p, float* g, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,
+                     const float* alpha_g_f32, double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2,
+                     float eps, float grad_scale, int zero_grad, void* stream);
 
 /* optimizer.step() + zero_grad() gated ON THE DEVICE (year ensembles under data parallelism, where whether a year is
  * stepped -- "some rank kept it", src/models/year.py:27 -- is only known on the device after the gradient exchange):
