@@ -233,7 +233,7 @@ def main():
         if os.path.exists(tpath) and a.batch == 1024 and a.precision == "bf16":
             tj = json.load(open(tpath))
             for row in tj.get("kernels", []):
-                if row["kernel"].startswith("k_conv3x3_bf16<2, 2, true>"):
+                if row["kernel"].startswith("k_conv3x3_bf16<2, 2, true"):
                     traffic["fwd0"] = row["hbm_bytes_per_launch"]
                 if row["kernel"].startswith("k_conv_wgrad_bf16<2, 2"):
                     traffic["wgrad0"] = row["hbm_bytes_per_launch"]

@@ -30,9 +30,14 @@ def _check(line, want_cpu):
     return d
 
 
-def test_committed_bench_artifact_has_the_contract_schema():
-    d = _check(open(os.path.join(REPO, "profiles", "r01_bench_bf16_default.json")).read(), True)
+@pytest.mark.parametrize("name", ["r01_bench_bf16_default.json", "r02_bench_bf16_default.json"])
+def test_committed_bench_artifact_has_the_contract_schema(name):
+    d = _check(open(os.path.join(REPO, "profiles", name)).read(), True)
     assert d["n_gpus"] == 1 and d["dtype"] == "bf16"
+    if name.startswith("r02"):      # round 2: both first-conv rooflines, the step's, the steady state, the core count
+        assert d["roofline_mfma"]["bound"] == "mfma" and d["roofline"]["bound"] == "hbm"
+        assert d["step_roofline"]["algorithmic_flop_per_patch"] == 154486824
+        assert d["steady_state"]["steps"] >= 200 and d["cpu_baseline"]["cores"] >= d["cpu_baseline"]["threads"]
 
 
 @pytest.mark.gpu
