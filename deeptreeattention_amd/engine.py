@@ -1,6 +1,6 @@
 """Fused train step for the Hang2020 hot path: forward + class-weighted cross-entropy + backward + Adam as four
 C-ABI calls on flat device buffers, optionally data-parallel (one process per GPU, RCCL all-reduce of the flat
-gradient on a side HIP stream overlapped with the first conv's weight gradient).
+gradient asynchronously, overlapped with the first conv's weight gradient).
 
 Replaces, for one model, the reference's TreeModel.training_step + loss.backward() + Adam.step()
 (/root/reference/src/main.py:71-80, :135-137) and Lightning's DDP wrapper (train.py:89-98, `gpus>1`).
@@ -304,7 +304,7 @@ class FusedTrainer:
         if not self.comm:
             run(3)
         elif self.overlap:
-            # phase 1: everything but the first conv's weight gradient; its all-reduce (side stream) runs while
+            # phase 1: everything but the first conv's weight gradient; its all-reduce (backend stream) runs while
             # phase 2, the first conv's weight gradient, is computed: two collectives per step
             run(1)
             self.sync.reduce_early(self.g_head, ag, slot_t)
