@@ -1,0 +1,62 @@
+"""The specialised stage kernels against the generic ones on the same inputs.
+
+The 11x11 networks run the "lean" stage kernels (persistent workgroups that walk patch batches with a register prefetch
+of the next one, register-level column sums, four patches per workgroup in the last stage); DTA_NO_LEAN=1 routes the same
+step through the generic per-patch kernels.  Both implement the same reference lines (Hang2020.py:24-31, :105-124,
+:149-168), so losses and gradients must agree -- exactly up to summation order in fp32 mode, up to the storage formats of
+the intermediate maps in bf16 mode -- at batch sizes that leave the persistent grid with ragged last rounds, a partly
+filled four-patch workgroup, or a single patch."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(m, x, y):
+    m.zero_grad(set_to_none=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.reset_running_stats()
+    out = m(x)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    return float(loss.detach()), out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("precision,B", [("fp32", 2), ("fp32", 5), ("fp32", 1031), ("bf16", 3), ("bf16", 257), ("bf16", 2051)])
+def test_lean_stage_kernels_match_generic_kernels(precision, B, monkeypatch):
+    from deeptreeattention_amd import Hang2020 as H, _lib
+    torch.manual_seed(B)
+    bands, classes = 24, 11
+    m = H.Hang2020(bands, classes, precision=precision).cuda().train()
+    x = torch.rand(B, bands, 11, 11, device="cuda")
+    y = torch.randint(0, classes, (B,), device="cuda")
+    L = _lib.lib()
+    monkeypatch.delenv("DTA_NO_LEAN", raising=False)
+    L.dta_dev_reload_switches()
+    l1, o1, g1 = _step(m, x, y)
+    monkeypatch.setenv("DTA_NO_LEAN", "1")
+    L.dta_dev_reload_switches()
+    try:
+        l2, o2, g2 = _step(m, x, y)
+    finally:
+        monkeypatch.delenv("DTA_NO_LEAN", raising=False)
+        L.dta_dev_reload_switches()
+    fp32 = precision == "fp32"
+    assert torch.isfinite(o1).all() and abs(l1 - l2) < (1e-5 if fp32 else 2e-3) * max(1.0, abs(l2))
+    assert rel_l2(o1.cpu().numpy(), o2.cpu().numpy()) < (1e-5 if fp32 else 5e-3)
+    assert g1.keys() == g2.keys()
+    for k in g2:
+        n2 = float(g2[k].norm())
+        # conv biases (zero under batch-statistics BatchNorm) and the gates' output biases are cancelling sums: noise
+        if n2 == 0 or k.endswith("conv_layer.bias") or k.endswith("attention_conv2.bias"):
+            continue
+        if not fp32 and g2[k].numel() == 1:     # one-element bias sums over bf16-stored maps: in the whole-vector check below
+            continue
+        assert rel_l2(g1[k].cpu().numpy(), g2[k].cpu().numpy()) < (2e-4 if fp32 else 3e-2), k
+    # the whole gradient as one vector
+    keep = [k for k in g2 if not (k.endswith("conv_layer.bias") or k.endswith("attention_conv2.bias"))]
+    a = torch.cat([g1[k].reshape(-1).double() for k in keep]); b = torch.cat([g2[k].reshape(-1).double() for k in keep])
+    assert float((a - b).norm() / b.norm()) < (5e-5 if fp32 else 1e-2)
