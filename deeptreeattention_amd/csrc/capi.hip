@@ -49,11 +49,12 @@ inline void prof_end(int site, hipStream_t st) {
 }
 
 // Developer switches (same-box A/B runs): the environment is read once per process, not per call.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles; };
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; };
 inline Switches read_switches() {
   return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr,
           getenv("DTA_FP32_ACT") != nullptr, getenv("DTA_NO_LEAN") != nullptr,
-          getenv("DTA_LEAN_MASK") ? atoi(getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, getenv("DTA_HALO_TILES") != nullptr};
+          getenv("DTA_LEAN_MASK") ? atoi(getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, getenv("DTA_HALO_TILES") != nullptr,
+          getenv("DTA_NO_WGRAD_NSPLIT") == nullptr};
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -78,7 +79,7 @@ struct Plan {
   int Cin[3], NCin[3];
   int F[MAXG][3], Fmax[3], vec_ld[3];
   int nwg[3], MWG[3];
-  int S[3], cgroups[3], CpadW[3];
+  int S[3], cgroups[3], ngroups[3], CpadW[3];
   size_t x_tl, wp[3], wd[3], y[3], stats[3], coef[3], a_tl[3], feat[3], attpk[MAXG][3], scores[MAXG][3];
   size_t dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart[3];
   size_t attsave[3]; int attsave_ld[3];
@@ -156,7 +157,8 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
     int launchG = (L == 0 && p->shared_x) ? 1 : G;
     // bf16 path: register-prefetch pipeline, 1 workgroup per CU; fp32 path: 2 workgroups per CU overlap each other
     int target = d->dtype == DTA_BF16 ? 256 : 512;
-    int S = target / (p->cgroups[L] * launchG);   // floor: never spill into a second round of workgroups
+    p->ngroups[L] = (switches().wgrad_nsplit ? wgrad_ngroups(Nconv, d->dtype == DTA_BF16) : 1);
+    int S = target / (p->cgroups[L] * p->ngroups[L] * launchG);   // floor: never spill into a second round of workgroups
     if (S >= 8) S &= ~7;                           // multiple of 8: whole batch splits per XCD (see k_conv_wgrad_bf16)
     p->S[L] = S < 1 ? 1 : (S > B ? B : S);
   }
@@ -425,7 +427,7 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
   wa.dy_tl = at<char>(ws, p.dy_tl[L]);
   wa.dy_gs = cat ? 0 : (size_t)B * (C / 16) * p.Rin[L] * 16;
   wa.y_compact = p.tl_compact;
-  wa.NCy = Nconv / 16; wa.ych0 = 0;
+  wa.NCy = Nconv / 16; wa.ych0 = 0; wa.ngroups = p.ngroups[L];
   wa.partial = at<float>(ws, p.wpart[L]);
   wa.B = B; wa.H = p.Hc[L]; wa.W = p.Wc[L]; wa.Q = p.Qin[L]; wa.N = Nconv; wa.Cpad = p.CpadW[L]; wa.S = p.S[L];
   prof_begin(DTA_SITE_CONV_WGRAD + L, st);

@@ -590,6 +590,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_group(WgradReduceGroup gr)
 }
 
 int wgrad_cpw(int N) { return (4 / (N / 32)) * 32; }
+// 128-column layers (bf16): two 64-column groups per (channel group, slab).  A workgroup's partial tile is written once
+// per slab whatever its width, so halving the tile and the slab count halves the split-K traffic (37.7 -> 18.9 MB written
+// and read back for the third conv) at the price of each X tile being staged by two workgroups.
+int wgrad_ngroups(int N, int bf16) { return (bf16 && N == 128) ? 2 : 1; }
 
 void wgrad_band_plan(int Q, int W, int wr_max, int* bl, int* wr, int* nbands) {
   const int span = Q - 2 * (W + 3);              // haloed-grid rows q0..q1

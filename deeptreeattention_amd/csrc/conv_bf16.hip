@@ -561,7 +561,7 @@ extern "C" int dta_debug_wticks(long long* out) { return (int)hipMemcpyFromSymbo
 #define WTICK(i)
 #define WTICK_DUMP
 #endif
-template <int CT, int NTT, bool BIGW>
+template <int CT, int NTT, bool BIGW, bool STACK = false>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   WGSTAMP(CT == 2 ? 3 : -1);      // first conv's weight gradient
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -582,11 +582,13 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   // XCD-aware placement: workgroup id b runs on XCD b % 8 (observed dispatch rule, speed only); consecutive LOGICAL
   // indices (the channel groups of one batch split, which all re-read the same dY tiles) are mapped to one XCD so
   // that those re-reads hit its L2.
-  const int total = a.cgroups * a.S * a.G;
+  const int ngr = a.ngroups > 0 ? a.ngroups : 1;      // column groups: this workgroup's N columns start at ng * N
+  const int total = a.cgroups * ngr * a.S * a.G;
   const int per_xcd = (total + 7) / 8;
   const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (logical >= total) return;
-  const int cg = logical % a.cgroups, s = (logical / a.cgroups) % a.S, g = logical / (a.cgroups * a.S);
+  const int cg = logical % a.cgroups, ng = (logical / a.cgroups) % ngr, s = (logical / (a.cgroups * ngr)) % a.S,
+            g = logical / (a.cgroups * ngr * a.S);
   // wave = ((c-tile, n-tile) pair, k slice): the KS waves of a pair split the k-steps (ks = slice, slice + KS, ...) and
   // hold partial sums of the same nine tap tiles; waves w and w+4 share a SIMD and belong to different slices
   const int pair = wave % PAIRS, khalf = wave / PAIRS;   // khalf: k-slice index 0 .. KS-1
@@ -625,49 +627,67 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   const int vpcx = xc ? HWp * 2 : vpc, xtrows = xc ? HWp : Q;
   const bool yc = a.y_compact != 0;            // likewise the dY tiles
   const int vpcy = yc ? HWp * 2 : vpc, ytrows = yc ? HWp : Q;
-  const int nxv = nxch * vpcx, nyv = YCH * vpcy;
+  // small maps (5x5): ppi patches of the workgroup's list are stacked Q rows apart in ONE window and swept by one run
+  // of k-steps -- a patch of 33 centre rows is two or three k-steps, i.e. less than one per wave and barrier (halo-free
+  // tiles only: the rows between the stacked patches are their zero halos, so the sweep may run across them)
+  // (a compile-time variant: the plain kernels are at their register limit and must not carry any of this)
+  const int ppi = STACK ? a.ppi : 1;
+  const int nxv1 = nxch * vpcx, nyv1 = YCH * vpcy;        // vectors of one patch
+  const int nxv = ppi * nxv1, nyv = ppi * nyv1;
   const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs;
   const bf16_t* yg = (const bf16_t*)a.dy_tl + (size_t)g * a.dy_gs;
   const size_t xpatch = (size_t)a.NCx * xtrows * 16, ypatch = (size_t)a.NCy * ytrows * 16;
   // per vector: element offset inside the patch's tile and window row.  (The LDS image is linear: vector v of a part
   // lives at byte 16*v.)  Vectors past the end of the part are not stored; their loads are pointed at a valid row.
   int xsrc[XV], ysrc[YV], xrow[XV], yrow[YV], xdst[XV], ydst[YV];
+  int xpp[STACK ? XV : 1], ypp[STACK ? YV : 1];   // which of the window's stacked patches a vector belongs to
 #pragma unroll
   for (int u = 0; u < XV; ++u) {
     int v = min(tid + u * NTHR, max(nxv, 1) - 1);
+    const int pp = (STACK && nxv1 > 0) ? v / nxv1 : 0;
+    v -= pp * nxv1;
     int ch = v / vpcx, o = v - ch * vpcx;
     int row = o >> 1;
     xsrc[u] = ((nxch > 0 ? chunk0 : 0) + ch) * xtrows * 16 + o * 8;
     if (xc) { const int hh = row / a.W; row = (hh + 1) * W2 + (row - hh * a.W) + 1; }   // pixel -> haloed-grid row
     xrow[u] = xc ? 0 : row;                    // compact rows always exist
-    xdst[u] = (ch * WR + row) * RW + (o & 1) * 16;
+    xdst[u] = (ch * WR + pp * Q + row) * RW + (o & 1) * 16;
+    if constexpr (STACK) { xpp[u] = pp; xsrc[u] += pp * a.S * (int)xpatch; }     // (small maps: fits 32 bits by far)
   }
 #pragma unroll
   for (int u = 0; u < YV; ++u) {
     int v = min(tid + u * NTHR, nyv - 1);
+    const int pp = STACK ? v / nyv1 : 0;
+    v -= pp * nyv1;
     int ch = v / vpcy, o = v - ch * vpcy;
     int row = o >> 1;
-    ysrc[u] = (a.ych0 + ch) * ytrows * 16 + o * 8;
+    ysrc[u] = (a.ych0 + ng * YCH + ch) * ytrows * 16 + o * 8;
     if (yc) { const int hh = row / a.W; row = (hh + 1) * W2 + (row - hh * a.W) + 1; }   // pixel -> haloed-grid row
     yrow[u] = yc ? 0 : row;
-    ydst[u] = (ch * WR + row) * RW + (o & 1) * 16;
+    ydst[u] = (ch * WR + pp * Q + row) * RW + (o & 1) * 16;
+    if constexpr (STACK) { ypp[u] = pp; ysrc[u] += pp * a.S * (int)ypatch; }
   }
   u32x4 rx[XV], ry[YV];
   // Branch-free fetch: wave-uniform base (patch, band) + per-lane 32-bit offset.  A window row that falls beyond the
   // tile (last band; rows Q..WR-1 of an 11x11 patch) is redirected to row 0 of its chunk, a halo row, i.e. zeros.
   // (LDS-DMA staging was measured slower here: its LDS writes stall the transposing fragment reads.)
+  /* a stacked patch beyond the workgroup's list (last window) is stored as zeros, not loaded */                   \
 #define DTA_FETCH(b_, band_)                                                                                      \
   {                                                                                                               \
     const int r0_ = (band_) * a.bl;                                                                               \
     const bf16_t* xb_ = xg + (size_t)(b_) * xpatch + (size_t)r0_ * 16;                                            \
     const bf16_t* yb_ = yg + (size_t)(b_) * ypatch + (size_t)r0_ * 16;                                            \
+    const int npi_ = STACK ? min(ppi, (a.B - (b_) + a.S - 1) / a.S) : 1;                                          \
+    const u32x4 zero_ = {0u, 0u, 0u, 0u};                                                                         \
     _Pragma("unroll") for (int u = 0; u < XV; ++u) {                                                              \
       const int off_ = (xrow[u] + r0_ < Q) ? xsrc[u] : xsrc[u] - (xrow[u] + r0_) * 16;                            \
-      rx[u] = *reinterpret_cast<const u32x4*>(xb_ + off_);                                                        \
+      if (!STACK || xpp[STACK ? u : 0] < npi_) rx[u] = *reinterpret_cast<const u32x4*>(xb_ + off_);               \
+      else rx[u] = zero_;                                                                                         \
     }                                                                                                             \
     _Pragma("unroll") for (int u = 0; u < YV; ++u) {                                                              \
       const int off_ = (yrow[u] + r0_ < Q) ? ysrc[u] : ysrc[u] - (yrow[u] + r0_) * 16;                            \
-      ry[u] = *reinterpret_cast<const u32x4*>(yb_ + off_);                                                        \
+      if (!STACK || ypp[STACK ? u : 0] < npi_) ry[u] = *reinterpret_cast<const u32x4*>(yb_ + off_);               \
+      else ry[u] = zero_;                                                                                         \
     }                                                                                                             \
   }
 #define DTA_STORE(base_)                                                                                          \
@@ -679,9 +699,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   }
   // flattened (patch, band) iteration space of this workgroup
   const int npb = (a.B - s + a.S - 1) / a.S;
-  const int niter = npb * a.nbands;
-#define DTA_ITER_B(it_) (s + ((it_) / a.nbands) * a.S)
-#define DTA_ITER_BAND(it_) ((it_) % a.nbands)
+  const int niter = ppi > 1 ? (npb + ppi - 1) / ppi : npb * a.nbands;      // (stacked windows: single-band patches only)
+#define DTA_ITER_B(it_) (ppi > 1 ? s + (it_) * ppi * a.S : s + ((it_) / a.nbands) * a.S)
+#define DTA_ITER_BAND(it_) (ppi > 1 ? 0 : (it_) % a.nbands)
   if (niter > 0) {
     DTA_FETCH(DTA_ITER_B(0), DTA_ITER_BAND(0))
     __syncthreads();                       // zero fill complete before the first window lands
@@ -696,7 +716,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     const bool more = it + 1 < niter;
     WTICK(0)
     const int rem = (q1 - q0) - DTA_ITER_BAND(it) * a.bl;
-    const int nks = (min(a.bl, rem) + 15) / 16;
+    // stacked window: the sweep runs from the first patch's first centre row to the last present patch's last one
+    const int nks = ppi > 1 ? ((min(ppi, npb - it * ppi) - 1) * Q + (q1 - q0) + 15) / 16 : (min(a.bl, rem) + 15) / 16;
     // The two waves of a SIMD (k halves 0 and 1) run their phases in opposite order: while one issues its LDS
     // writes and global loads for the next window, the other keeps the matrix core busy.
     const bool stage_now = dbuf && more;
@@ -758,13 +779,13 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   }
   if (khalf != 0) return;
   // partial[g][tap][c][s][n]: the S partial sums of one output row are contiguous for the reduction
-  float* out = a.partial + (size_t)g * 9 * a.Cpad * a.S * N + (size_t)s * N;
+  float* out = a.partial + (size_t)g * 9 * a.Cpad * a.S * a.N + (size_t)s * a.N + ng * N;     // (a.N = ngr * N columns per row)
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int c = cg * CT * 32 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (c < a.Cpad) __builtin_nontemporal_store(acc[j][r], &out[((size_t)j * a.Cpad + c) * a.S * N + nt * 32 + (lane & 31)]);
+      if (c < a.Cpad) __builtin_nontemporal_store(acc[j][r], &out[((size_t)j * a.Cpad + c) * a.S * a.N + nt * 32 + (lane & 31)]);
     }
   }
 }
@@ -786,9 +807,36 @@ static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream
     hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  a2.ppi = 1;
+  static const bool no_stack = getenv("DTA_NO_WGRAD_STACK") != nullptr;      // development A/B switch, read once
+  if (CT == 1 && a2.nbands == 1 && a.x_compact && a.y_compact && !no_stack) {
+    // stack patches while the window (rows: (p - 1) Q + first centre row + 16 k-step rows + tap reach, = 4 mod 8) stays
+    // within the staging plan's 192 rows and the per-thread vector registers (X: 3 XCH / 4, dY: 3 YCH / 4 per 512 threads)
+    constexpr int XV = (3 * CT * 2 + 3) / 4, YV = (3 * NTT * 2 + 3) / 4;
+    const int HWp = a.H * a.W, q0 = a.W + 3, span = a.Q - 2 * (a.W + 3);
+    for (int pp = 2; pp <= 8; ++pp) {
+      int wr = q0 + ((pp - 1) * a.Q + span + 15) / 16 * 16 + (a.W + 3);
+      while ((wr & 7) != 4) ++wr;
+      if (wr > 192 || pp * CT * 2 * HWp * 2 > XV * 512 || pp * NTT * 2 * HWp * 2 > YV * 512) break;
+      if ((size_t)2 * (CT * 2 + NTT * 2) * wr * RW > 160 * 1024) break;
+      a2.ppi = pp; a2.wr = wr;
+    }
+  }
+  stage = (size_t)(CT * 2 + NTT * 2) * a2.wr * RW;
+  a2.dbuf = 2 * stage <= 160 * 1024;
+  lds = (a2.dbuf ? 2 : 1) * stage;
+  if (lds < 48 * 1024) lds = 48 * 1024;
   a2.cgroups = cgroups; a2.G = G;
-  const int total = cgroups * a.S * G;
-  if (a2.wr <= 192) hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
+  a2.ngroups = a.N / (NTT * 32);
+  const int total = cgroups * a2.ngroups * a.S * G;
+  if (a2.ppi > 1) {
+    if constexpr (CT == 1) {      // (the layers with small maps: 64 -> 128 channels)
+      static bool attr2 = false;
+      if (!attr2) { hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
+      hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false, true>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
+    }
+  }
+  else if (a2.wr <= 192) hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
   else hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, true>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
   DTA_CHECK_LAUNCH("k_conv_wgrad_bf16");
   return 0;
@@ -804,7 +852,10 @@ int launch_conv_wgrad<bf16_t>(const WgradArgs& a, int G, hipStream_t st) {
       // a 32-channel input (conv2) fills only one of the two c-tiles: run one tile pair-wise over four k-slices
       if (a.Cpad <= 32 && cgroups == 1) return launch_wgrad_bf16_t<1, 2>(a, G, cgroups, st);
       return launch_wgrad_bf16_t<2, 2>(a, G, cgroups, st);
-    case 128: return launch_wgrad_bf16_t<1, 4>(a, G, cgroups, st);
+    case 128:
+      // two 64-column groups (wgrad_ngroups): the plan's slab count already accounts for them
+      if (a.ngroups == 2) return launch_wgrad_bf16_t<1, 2>(a, G, (a.Cpad + 31) / 32, st);
+      return launch_wgrad_bf16_t<1, 4>(a, G, cgroups, st);
   }
   dta_set_error("conv_wgrad: unsupported width %d", a.N);
   return 1;

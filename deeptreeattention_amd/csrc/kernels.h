@@ -33,6 +33,8 @@ struct WgradArgs {
   float* partial;                     // [G][9][Cpad][S][N]
   int B, H, W, Q, N, Cpad, S, dbuf, cgroups, G;
   int bl, wr, nbands;                 // K-band plan (rows per band, LDS window rows, bands per patch)
+  int ppi;                            // bf16, small halo-free maps: patches stacked per LDS window (0 / 1 = one)
+  int ngroups;                        // bf16: output-column groups per (channel group, slab): a workgroup covers N / ngroups columns (0 = 1)
   int x_compact;                      // bf16, single band: X tiles are halo-free [patch][chunk][pixel][16]
   int y_compact;                      // likewise the dY tiles
 };
@@ -117,6 +119,7 @@ __device__ __forceinline__ void wgrad_reduce_blocks(const WgradReduceArgs& a, in
 void conv_geometry(int HW, int MWG, int B, int* ppw, int* spp, int* nwg);
 int conv_mwg(int N);
 int wgrad_cpw(int N);
+int wgrad_ngroups(int N, int bf16);     // column groups of the bf16 weight-gradient kernel (the slab count divides by it)
 
 // ---- stage.hip (BatchNorm + ReLU + pool + attention, forward and backward) ------------------------
 struct BnFinalizeArgs {
