@@ -561,7 +561,7 @@ extern "C" int dta_debug_wticks(long long* out) { return (int)hipMemcpyFromSymbo
 #define WTICK(i)
 #define WTICK_DUMP
 #endif
-template <int CT, int NTT, bool BIGW, bool STACK = false>
+template <int CT, int NTT, bool BIGW, bool STACK = false, bool D2 = false>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   WGSTAMP(CT == 2 ? 3 : -1);      // first conv's weight gradient
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -596,12 +596,6 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   const int chunk0 = cg * XCH;
   const int nxch = max(0, min(XCH, a.NCx - chunk0));
 
-  {  // zero everything once: absent chunks stay zero for the whole kernel
-    u32x4 z = {0, 0, 0, 0};
-    u32x4* d = reinterpret_cast<u32x4*>(smem);
-    int tot = (dbuf ? 2 : 1) * stage / 16;
-    for (int v = tid; v < tot; v += NTHR) d[v] = z;
-  }
   f32x16 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -667,12 +661,16 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     ydst[u] = (ch * WR + pp * Q + row) * RW + (o & 1) * 16;
     if constexpr (STACK) { ypp[u] = pp; ysrc[u] += pp * a.S * (int)ypatch; }
   }
+  // D2: TWO windows in flight in registers (sets rx/ry and rx2/ry2).  With one set a load has one iteration (one patch:
+  // 1.1 us of MFMA work for the first conv, less for the others) to land before it is written to LDS -- shorter than the
+  // loaded-memory latency, so the waves stalled on vmcnt at their store phase; with two it has two iterations.
   u32x4 rx[XV], ry[YV];
+  u32x4 rx2[D2 ? XV : 1], ry2[D2 ? YV : 1];
   // Branch-free fetch: wave-uniform base (patch, band) + per-lane 32-bit offset.  A window row that falls beyond the
   // tile (last band; rows Q..WR-1 of an 11x11 patch) is redirected to row 0 of its chunk, a halo row, i.e. zeros.
   // (LDS-DMA staging was measured slower here: its LDS writes stall the transposing fragment reads.)
-  /* a stacked patch beyond the workgroup's list (last window) is stored as zeros, not loaded */                   \
-#define DTA_FETCH(b_, band_)                                                                                      \
+  // A stacked patch beyond the workgroup's list (last window) is stored as zeros, not loaded.
+#define DTA_FETCH(RX_, RY_, b_, band_)                                                                            \
   {                                                                                                               \
     const int r0_ = (band_) * a.bl;                                                                               \
     const bf16_t* xb_ = xg + (size_t)(b_) * xpatch + (size_t)r0_ * 16;                                            \
@@ -681,71 +679,95 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     const u32x4 zero_ = {0u, 0u, 0u, 0u};                                                                         \
     _Pragma("unroll") for (int u = 0; u < XV; ++u) {                                                              \
       const int off_ = (xrow[u] + r0_ < Q) ? xsrc[u] : xsrc[u] - (xrow[u] + r0_) * 16;                            \
-      if (!STACK || xpp[STACK ? u : 0] < npi_) rx[u] = *reinterpret_cast<const u32x4*>(xb_ + off_);               \
-      else rx[u] = zero_;                                                                                         \
+      if (!STACK || xpp[STACK ? u : 0] < npi_) RX_[u] = *reinterpret_cast<const u32x4*>(xb_ + off_);              \
+      else RX_[u] = zero_;                                                                                        \
     }                                                                                                             \
     _Pragma("unroll") for (int u = 0; u < YV; ++u) {                                                              \
       const int off_ = (yrow[u] + r0_ < Q) ? ysrc[u] : ysrc[u] - (yrow[u] + r0_) * 16;                            \
-      if (!STACK || ypp[STACK ? u : 0] < npi_) ry[u] = *reinterpret_cast<const u32x4*>(yb_ + off_);               \
-      else ry[u] = zero_;                                                                                         \
+      if (!STACK || ypp[STACK ? u : 0] < npi_) RY_[u] = *reinterpret_cast<const u32x4*>(yb_ + off_);              \
+      else RY_[u] = zero_;                                                                                        \
     }                                                                                                             \
   }
-#define DTA_STORE(base_)                                                                                          \
+#define DTA_STORE(RX_, RY_, base_)                                                                                \
   {                                                                                                               \
     _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                                \
-        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((base_) + xdst[u]) = rx[u];                           \
+        if (tid + u * NTHR < nxv) *reinterpret_cast<u32x4*>((base_) + xdst[u]) = RX_[u];                          \
     _Pragma("unroll") for (int u = 0; u < YV; ++u)                                                                \
-        if (tid + u * NTHR < nyv) *reinterpret_cast<u32x4*>((base_) + xbytes + ydst[u]) = ry[u];                  \
+        if (tid + u * NTHR < nyv) *reinterpret_cast<u32x4*>((base_) + xbytes + ydst[u]) = RY_[u];                 \
   }
   // flattened (patch, band) iteration space of this workgroup
   const int npb = (a.B - s + a.S - 1) / a.S;
   const int niter = ppi > 1 ? (npb + ppi - 1) / ppi : npb * a.nbands;      // (stacked windows: single-band patches only)
 #define DTA_ITER_B(it_) (ppi > 1 ? s + (it_) * ppi * a.S : s + ((it_) / a.nbands) * a.S)
 #define DTA_ITER_BAND(it_) (ppi > 1 ? 0 : (it_) % a.nbands)
+  // window it + 1 is written to LDS and the fetch of window it + AHEAD issued during iteration it; the register set
+  // that carries window w is set (w & 1) when D2 (rx2/ry2 for odd windows), rx/ry otherwise
+  constexpr int AHEAD = D2 ? 3 : 2;
+  if (niter > 0) DTA_FETCH(rx, ry, DTA_ITER_B(0), DTA_ITER_BAND(0))
+  {  // zero everything once (absent chunks and halo rows stay zero for the whole kernel) -- under the first loads
+    u32x4 z = {0, 0, 0, 0};
+    u32x4* d = reinterpret_cast<u32x4*>(smem);
+    int tot = (dbuf ? 2 : 1) * stage / 16;
+    for (int v = tid; v < tot; v += NTHR) d[v] = z;
+  }
   if (niter > 0) {
-    DTA_FETCH(DTA_ITER_B(0), DTA_ITER_BAND(0))
     __syncthreads();                       // zero fill complete before the first window lands
-    DTA_STORE(smem)
-    if (niter > 1) DTA_FETCH(DTA_ITER_B(1), DTA_ITER_BAND(1))
+    DTA_STORE(rx, ry, smem)
+    if (D2) {
+      if (niter > 1) DTA_FETCH(rx2, ry2, DTA_ITER_B(1), DTA_ITER_BAND(1))
+      if (niter > 2) DTA_FETCH(rx, ry, DTA_ITER_B(2), DTA_ITER_BAND(2))
+    } else {
+      if (niter > 1) DTA_FETCH(rx, ry, DTA_ITER_B(1), DTA_ITER_BAND(1))
+    }
   }
   __syncthreads();
   WTICK_DECL
-  for (int it = 0; it < niter; ++it) {
-    unsigned char* cur = smem + ((dbuf && (it & 1)) ? stage : 0);
-    unsigned char* nxt = smem + ((dbuf && !(it & 1)) ? stage : 0);
-    const bool more = it + 1 < niter;
-    WTICK(0)
-    const int rem = (q1 - q0) - DTA_ITER_BAND(it) * a.bl;
-    // stacked window: the sweep runs from the first patch's first centre row to the last present patch's last one
-    const int nks = ppi > 1 ? ((min(ppi, npb - it * ppi) - 1) * Q + (q1 - q0) + 15) / 16 : (min(a.bl, rem) + 15) / 16;
-    // The two waves of a SIMD (k halves 0 and 1) run their phases in opposite order: while one issues its LDS
-    // writes and global loads for the next window, the other keeps the matrix core busy.
-    const bool stage_now = dbuf && more;
-    if ((khalf & 1) == 1 && stage_now) {
-      DTA_STORE(nxt)
-      if (it + 2 < niter) DTA_FETCH(DTA_ITER_B(it + 2), DTA_ITER_BAND(it + 2))
-    }
-    WTICK(1)
-#pragma unroll 1
-    for (int ks = khalf; ks < nks; ks += KS) {
-      WgradFrags f;
-      wgrad_kstep9_load(f, cur, cur + xbytes, a_dy, b_off, ks * 16 * RW);
-      wgrad_kstep9_mma(f, acc);
-    }
-    WTICK(2)
-    if ((khalf & 1) == 0 && stage_now) {
-      DTA_STORE(nxt)
-      if (it + 2 < niter) DTA_FETCH(DTA_ITER_B(it + 2), DTA_ITER_BAND(it + 2))
-    }
-    WTICK(3)
-    __syncthreads();
-    WTICK(4)
-    if (!dbuf && more) {
-      DTA_STORE(nxt)
-      if (it + 2 < niter) DTA_FETCH(DTA_ITER_B(it + 2), DTA_ITER_BAND(it + 2))
-      __syncthreads();
-    }
+  // one iteration; RX_/RY_ = the register set that holds window it + 1 (and then receives window it + AHEAD)
+#define DTA_WGRAD_ITER(RX_, RY_, it)                                                                              \
+  {                                                                                                               \
+    unsigned char* cur = smem + ((dbuf && ((it) & 1)) ? stage : 0);                                               \
+    unsigned char* nxt = smem + ((dbuf && !((it) & 1)) ? stage : 0);                                              \
+    const bool more = (it) + 1 < niter;                                                                           \
+    WTICK(0)                                                                                                      \
+    const int rem = (q1 - q0) - DTA_ITER_BAND(it) * a.bl;                                                         \
+    /* stacked window: the sweep runs from the first patch's first centre row to the last present patch's last */ \
+    const int nks = ppi > 1 ? ((min(ppi, npb - (it) * ppi) - 1) * Q + (q1 - q0) + 15) / 16 : (min(a.bl, rem) + 15) / 16; \
+    /* The two waves of a SIMD (k halves 0 and 1) run their phases in opposite order: while one issues its LDS */  \
+    /* writes and global loads for the next window, the other keeps the matrix core busy. */                      \
+    const bool stage_now = dbuf && more;                                                                          \
+    if ((khalf & 1) == 1 && stage_now) {                                                                          \
+      DTA_STORE(RX_, RY_, nxt)                                                                                    \
+      if ((it) + AHEAD < niter) DTA_FETCH(RX_, RY_, DTA_ITER_B((it) + AHEAD), DTA_ITER_BAND((it) + AHEAD))        \
+    }                                                                                                             \
+    WTICK(1)                                                                                                      \
+    _Pragma("unroll 1") for (int ks = khalf; ks < nks; ks += KS) {                                                \
+      WgradFrags f;                                                                                               \
+      wgrad_kstep9_load(f, cur, cur + xbytes, a_dy, b_off, ks * 16 * RW);                                         \
+      wgrad_kstep9_mma(f, acc);                                                                                   \
+    }                                                                                                             \
+    WTICK(2)                                                                                                      \
+    if ((khalf & 1) == 0 && stage_now) {                                                                          \
+      DTA_STORE(RX_, RY_, nxt)                                                                                    \
+      if ((it) + AHEAD < niter) DTA_FETCH(RX_, RY_, DTA_ITER_B((it) + AHEAD), DTA_ITER_BAND((it) + AHEAD))        \
+    }                                                                                                             \
+    WTICK(3)                                                                                                      \
+    __syncthreads();                                                                                              \
+    WTICK(4)                                                                                                      \
+    if (!dbuf && more) {                                                                                          \
+      DTA_STORE(RX_, RY_, nxt)                                                                                    \
+      if ((it) + AHEAD < niter) DTA_FETCH(RX_, RY_, DTA_ITER_B((it) + AHEAD), DTA_ITER_BAND((it) + AHEAD))        \
+      __syncthreads();                                                                                            \
+    }                                                                                                             \
   }
+  if constexpr (D2) {
+    for (int it = 0; it < niter; it += 2) {
+      DTA_WGRAD_ITER(rx2, ry2, it)                       // window it + 1 is odd
+      if (it + 1 < niter) DTA_WGRAD_ITER(rx, ry, it + 1)
+    }
+  } else {
+    for (int it = 0; it < niter; ++it) DTA_WGRAD_ITER(rx, ry, it)
+  }
+#undef DTA_WGRAD_ITER
 #undef DTA_ITER_BAND
 #undef DTA_ITER_B
 #undef DTA_STORE
@@ -808,7 +830,8 @@ static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream
     attr_done = true;
   }
   a2.ppi = 1;
-  static const bool no_stack = getenv("DTA_NO_WGRAD_STACK") != nullptr;      // development A/B switch, read once
+  static const bool no_stack = getenv("DTA_NO_WGRAD_STACK") != nullptr;      // development A/B switches, read once
+  static const bool no_d2 = getenv("DTA_NO_WGRAD_D2") != nullptr;
   if (CT == 1 && a2.nbands == 1 && a.x_compact && a.y_compact && !no_stack) {
     // stack patches while the window (rows: (p - 1) Q + first centre row + 16 k-step rows + tap reach, = 4 mod 8) stays
     // within the staging plan's 192 rows and the per-thread vector registers (X: 3 XCH / 4, dY: 3 YCH / 4 per 512 threads)
@@ -834,6 +857,17 @@ static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream
       static bool attr2 = false;
       if (!attr2) { hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
       hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false, true>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
+    }
+  }
+  else if (a2.wr <= 192 && a2.dbuf && CT == 2 && NTT == 2 && !no_d2) {
+    // two windows in flight in registers: the first conv's <2,2> (cycle stamps: loop 119.9 k -> 116.7 k cycles; the
+    // second conv's <1,2> measured slower with it, 23.8 -> 24.9 us, and stays on one set)
+    if constexpr (CT == 2 && NTT == 2) {
+      static bool attr3 = false;
+      if (!attr3) { hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
+      hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false, false, true>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
+    } else {
+      hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
     }
   }
   else if (a2.wr <= 192) hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
