@@ -740,6 +740,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
       if ((it) + AHEAD < niter) DTA_FETCH(RX_, RY_, DTA_ITER_B((it) + AHEAD), DTA_ITER_BAND((it) + AHEAD))        \
     }                                                                                                             \
     WTICK(1)                                                                                                      \
+    /* (requesting k-step j + 1's fragments before k-step j's MFMAs -- straight-line, two fragment sets -- was */   \
+    /* measured twice: the scheduler and the wait-count pass re-serialise it and it spills: 66 -> 77 us) */        \
     _Pragma("unroll 1") for (int ks = khalf; ks < nks; ks += KS) {                                                \
       WgradFrags f;                                                                                               \
       wgrad_kstep9_load(f, cur, cur + xbytes, a_dy, b_off, ks * 16 * RW);                                         \
