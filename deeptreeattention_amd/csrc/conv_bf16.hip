@@ -741,7 +741,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
     }                                                                                                             \
     WTICK(1)                                                                                                      \
     /* (requesting k-step j + 1's fragments before k-step j's MFMAs -- straight-line, two fragment sets -- was */   \
-    /* measured twice: the scheduler and the wait-count pass re-serialise it and it spills: 66 -> 77 us) */        \
+    /* measured: as plain code the scheduler / wait-count pass re-serialise it and it spills, 66 -> 77 us; with the */ \
+    /* order pinned by empty asm blocks (next set's reads, then this set's MFMAs without waits) still 71 -> 75 us) */ \
     _Pragma("unroll 1") for (int ks = khalf; ks < nks; ks += KS) {                                                \
       WgradFrags f;                                                                                               \
       wgrad_kstep9_load(f, cur, cur + xbytes, a_dy, b_off, ks * 16 * RW);                                         \
