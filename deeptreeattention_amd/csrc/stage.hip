@@ -1110,6 +1110,61 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   if (!a.dy_compact)
     for (int i = t; i < nvec; i += 256) img4[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
+  // 16-bit everything (the bf16 networks' lean path): a thread item is 8 channels of a pixel -- one 16-byte load of the
+  // half conv output, one of the bf16 gradient, one 16-byte LDS store -- half the instructions of the 4-channel form
+  constexpr bool V8 = sizeof(T) == 2 && YF != FMT_F32 && DVF != FMT_F32;
+  if constexpr (V8) {
+    const int c8sh = c4sh - 1, total8 = HW << c8sh;
+    constexpr int UB8 = 2;
+    auto ld8 = [](float (&v)[8], const void* base, size_t idx, int fmt) {
+      const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(base) + idx));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = unpack_lo(q[e], fmt); v[2 * e + 1] = unpack_hi(q[e], fmt); }
+    };
+    for (int i0 = t; i0 < total8; i0 += 256 * UB8) {
+      float yv[UB8][8], dvv[UB8][8];
+      int lq[UB8];
+#pragma unroll
+      for (int u = 0; u < UB8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < total8) {
+          const int pix = i >> c8sh, c8 = (i - (pix << c8sh)) * 8;
+          ld8(yv[u], a.y, ybase + (size_t)pix * a.y_rs + c8, YF);            // last reader of the conv output
+          const int l = lut[pix];
+          lq[u] = l;
+          if (!a.dv_compact) ld8(dvv[u], a.dv, dvbase + (size_t)pix * C + c0 + c8, DVF);
+          else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dvv[u][j] = 0.f;
+            if (l >> 22) {
+              const int pz = (l >> 10) & 1023, k = (l >> 20) & 3;
+              float dc[8];
+              ld8(dc, a.dv, dvbase + (size_t)pz * C + c0 + c8, DVF);
+              const u32x2 fb = *(const u32x2*)(fpos + (size_t)pz * C + c8);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) dvv[u][j] = (int)((fb[j >> 2] >> (8 * (j & 3))) & 0xFFu) == k ? dc[j] : 0.f;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UB8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < total8) {
+          const int pix = i >> c8sh, c8 = (i - (pix << c8sh)) * 8;
+          const int q = a.dy_compact ? pix : (lq[u] & 1023);
+          u32x4 pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v0 = sk[c8 + 2 * j] * dvv[u][2 * j] + sk[CS + c8 + 2 * j] * yv[u][2 * j] + sk[2 * CS + c8 + 2 * j];
+            const float v1 = sk[c8 + 2 * j + 1] * dvv[u][2 * j + 1] + sk[CS + c8 + 2 * j + 1] * yv[u][2 * j + 1] + sk[2 * CS + c8 + 2 * j + 1];
+            pk[j] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+          }
+          *(u32x4*)(img + ((size_t)(c8 >> 4) * QI + q) * 16 + (c8 & 15)) = pk;
+        }
+      }
+    }
+  } else {
   const int total = HW * C4;
   constexpr int UB = 4;
   for (int i0 = t; i0 < total; i0 += 256 * UB) {
@@ -1163,6 +1218,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
         }
       }
     }
+  }
   }
   __syncthreads();
   u32x4* dst = (u32x4*)((T*)a.dy_tl + (size_t)g * a.dy_gs + ((size_t)b * a.dy_nc + a.dy_ch0 + c0 / 16) * QI * 16);
