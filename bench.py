@@ -50,6 +50,8 @@ def parse():
                          "first conv's weight gradient (the longest MFMA-bound kernel)")
     ap.add_argument("--steady-steps", type=int, default=200,
                     help="extra steps timed one by one after the contract's K steps (median reported); 0 = skip")
+    ap.add_argument("--other-steps", type=int, default=None,
+                    help="steps after the timed region in which the OTHER first-conv kernel is event-timed (default min(steps, 50))")
     ap.add_argument("--tile-steps", type=int, default=100,
                     help="extra steps fed with pre-tiled bf16 input (reported under tile_input; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,7 +183,7 @@ def main():
     site_ms = {a.site: collect(SITE[a.site])} if rank == 0 else {}
     if rank == 0:
         L.dta_profile_enable(-1)
-    n_other = min(a.steps, 50)
+    n_other = min(a.steps, 50) if a.other_steps is None else a.other_steps
     if rank == 0:
         L.dta_profile_enable(SITE[other])
     for i in range(n_other):                 # (every rank: the steps issue the collectives)

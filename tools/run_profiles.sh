@@ -8,7 +8,7 @@ DTA_FORCE_COLLECTIVES=1 MASTER_PORT=29561 python bench.py --no-cpu-baseline --ti
 python tools/ensemblebench.py > $O/ensemble.json 2>> $O/bench_default.err
 python tools/inferbench.py > $O/infer.txt 2>> $O/bench_default.err
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --steady-steps 0 --tile-steps 0"
+B="python $R/bench.py --no-cpu-baseline --steady-steps 0 --tile-steps 0 --other-steps 0"
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B --steps 50 --warmup 10 > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o f -- $B --steps 3 --warmup 2 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o w -- $B --steps 3 --warmup 2 > $O/write.log 2>&1
