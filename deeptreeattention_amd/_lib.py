@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libdta_hip.so")
 DTA_F32, DTA_BF16 = 0, 1
 MAX_YEARS = 4   # DTA_MAX_YEARS
 FORWARD_ONLY = 8   # DTA_FORWARD_ONLY (heads_mask flag)
+SKIP_BLEND = 16    # DTA_SKIP_BLEND (heads_mask flag): the blend is left to dta_net_loss
 NET_HANG2020, NET_SPECTRAL, NET_SPATIAL, NET_VANILLA = 0, 1, 2, 3
 SITE_CONV_FWD, SITE_CONV_WGRAD, SITE_CONV_DGRAD, SITE_STAGE_FWD, SITE_STAGE_BWD, SITE_GEMM = 0, 3, 6, 9, 12, 15
 _DTYPES = {"fp32": DTA_F32, "f32": DTA_F32, "float32": DTA_F32, "bf16": DTA_BF16, "bfloat16": DTA_BF16}
@@ -114,6 +115,9 @@ def lib():
         L.dta_preprocess_crops.restype = C.c_int
         L.dta_preprocess_crops.argtypes = [C.POINTER(CropDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
+        L.dta_net_loss.restype = C.c_int
+        L.dta_net_loss.argtypes = [C.POINTER(NetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dta_weighted_ce.restype = C.c_int
         L.dta_weighted_ce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]

@@ -398,7 +398,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
   prof_begin(DTA_SITE_GEMM, st);
   if (launch_gemm_group(heads, st)) return 1;   // all classifier heads of all branches in one launch
   prof_end(DTA_SITE_GEMM, st);
-  if (d->kind == DTA_NET_HANG2020) {
+  if (d->kind == DTA_NET_HANG2020 && !(d->heads_mask & DTA_SKIP_BLEND)) {
     if (!(d->heads_mask & 4) || !joint || !alpha) { dta_set_error("Hang2020 forward needs head 3, alpha and a joint output"); return 1; }
     BlendArgs ba;
     ba.spec = (scores && scores[0][2]) ? scores[0][2] : at<float>(ws, p.scores[0][2]);
@@ -810,6 +810,24 @@ int dta_net_backward_dp(const dta_net_desc* d, const dta_subnet_params* nets, co
   if (d->dtype == DTA_F32) return backward_t<float>(p, d, nets, alpha, workspace, dscores, djoint, grads, dalpha, phases, st, nullptr, dalpha_f32);
   dta_set_error("unknown dtype %d", d->dtype);
   return 1;
+}
+
+int dta_net_loss(const dta_net_desc* d, const double* alpha, void* workspace, const long long* labels, const float* weight,
+                 float* joint, float* loss, float* dlogits, float* scratch, void* stream) {
+  Plan p;
+  if (!d || !workspace || !labels || !loss || !scratch) { dta_set_error("dta_net_loss: null argument"); return 1; }
+  if (build_plan(d, &p)) return 1;
+  BlendCeArgs a;
+  memset(&a, 0, sizeof(a));
+  if (d->kind == DTA_NET_HANG2020) {
+    if (!alpha) { dta_set_error("dta_net_loss: Hang2020 needs alpha"); return 1; }
+    a.spec = at<float>(workspace, p.scores[0][2]); a.spat = at<float>(workspace, p.scores[1][2]); a.alpha = alpha; a.joint = joint;
+  } else {
+    if (!joint) { dta_set_error("dta_net_loss: the scores of a single-branch network are passed in `joint`"); return 1; }
+    a.spec = joint; a.joint = joint;
+  }
+  a.labels = labels; a.weight = weight; a.dlogits = dlogits; a.loss = loss; a.rowtmp = scratch; a.B = p.B; a.classes = p.classes;
+  return launch_blend_ce(a, (hipStream_t)stream);
 }
 
 int dta_weighted_ce(const float* logits, const long long* labels, const float* weight, int batch, int classes,

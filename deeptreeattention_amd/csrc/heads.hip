@@ -554,6 +554,79 @@ __global__ __launch_bounds__(256) void k_ce_fin(CeArgs a) {
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) a.loss[0] = (float)(sd[0] / (double)a.rowtmp[a.B]);
 }
+// The same cross-entropy with the Hang2020 blend folded in (the blended scores never make a round trip through HBM
+// before the loss reads them) and the loss finalised by the LAST block to arrive (a counter in the scratch, reset by
+// that block): one launch instead of k_blend + k_ce_rows + k_ce_fin.  The row terms cross workgroups / XCDs through
+// device-scope atomics (the per-XCD L2s are not coherent for plain accesses); the summation order of the loss is fixed.
+__global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
+  __shared__ float sc[4];
+  __shared__ double sd[256];
+  __shared__ int is_last;
+  const int t = threadIdx.x, lane = t & 63, row = blockIdx.x * 4 + (t >> 6);
+  float part = 0.f;
+  for (int i = t; i < a.B; i += 256) {
+    long long y = a.labels[i];
+    if (y >= 0 && y < a.classes) part += a.weight ? a.weight[y] : 1.f;
+  }
+  const float den = block_sum256(part, sc);
+  if (row < a.B) {
+    const float w = a.spat ? (float)(1.0 / (1.0 + exp(-a.alpha[0]))) : 1.f;
+    const float* zs = a.spec + (size_t)row * a.classes;
+    const float* zt = a.spat ? a.spat + (size_t)row * a.classes : nullptr;
+    float* jo = a.joint ? a.joint + (size_t)row * a.classes : nullptr;
+    auto zval = [&](int n) { return zt ? zs[n] * w + zt[n] * (1.f - w) : zs[n]; };
+    // the first 256 classes of the row live in registers (four per lane); wider rows re-read the rest
+    float zc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int n = lane + 64 * k; zc[k] = n < a.classes ? zval(n) : -3.4e38f; }
+    auto zget = [&](int n, int k) { return k < 4 ? zc[k] : zval(n); };
+    const long long y = a.labels[row];
+    const bool ok = y >= 0 && y < a.classes;
+    const float wy = ok ? (a.weight ? a.weight[y] : 1.f) : 0.f;
+    float mx = -3.4e38f;
+    for (int n = lane, k = 0; n < a.classes; n += 64, ++k) mx = fmaxf(mx, zget(n, k));
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int n = lane, k = 0; n < a.classes; n += 64, ++k) se += __expf(zget(n, k) - mx);
+    se = wave_sum(se);
+    const float lse = __logf(se);
+    const float poison = (ok || y == -100) ? 0.f : __builtin_nanf("");
+    if (lane == 0) {
+      // device-scope exchange: performed at the coherence point (the per-XCD L2s are not coherent for plain stores);
+      // consuming its return value makes this wave wait until it HAS been performed before it reaches the barrier
+      const float old = __hip_atomic_exchange(a.rowtmp + row, ok ? wy * (lse + mx - zval((int)y)) : poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(old));
+    }
+    const float sc2 = (den > 0.f ? wy / den : 0.f) + poison;
+    for (int n = lane, k = 0; n < a.classes; n += 64, ++k) {
+      const float z = zget(n, k);
+      if (jo && jo != zs) jo[n] = z;
+      if (a.dlogits) a.dlogits[(size_t)row * a.classes + n] = sc2 * (__expf(z - mx - lse) - ((ok && n == (int)y) ? 1.f : 0.f));
+    }
+  }
+  // the last block to arrive sums the row terms (fixed order) into the loss.  No fence: a device-scope release would
+  // write back this XCD's whole L2 (measured: 28 us for this kernel); the row terms and the counter are all device-scope
+  // atomics, ordered by the waits above and the barrier
+  __syncthreads();
+  unsigned* counter = reinterpret_cast<unsigned*>(a.rowtmp + a.B + 1);
+  if (t == 0) is_last = (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!is_last) return;
+  double acc = 0;
+  for (int r = t; r < a.B; r += 256) acc += (double)__hip_atomic_load(a.rowtmp + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  sd[t] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) sd[t] += sd[t + o]; __syncthreads(); }
+  if (t == 0) {
+    a.loss[0] = (float)(sd[0] / (double)den);
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+  }
+}
+int launch_blend_ce(const BlendCeArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_blend_ce, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  DTA_CHECK_LAUNCH("k_blend_ce");
+  return 0;
+}
 int launch_weighted_ce(const CeArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_ce_rows, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
   DTA_CHECK_LAUNCH("k_ce_rows");

@@ -348,6 +348,13 @@ struct CeArgs {
   float* dlogits; float* loss; float* rowtmp; int B, classes;
 };
 int launch_weighted_ce(const CeArgs& a, hipStream_t st);
+// blend (optional) + weighted CE + loss in ONE launch: logits = spat ? w spec + (1 - w) spat : spec, w = sigmoid(alpha);
+// rowtmp: B + 2 floats, word B + 1 is a block counter that must be zero on entry and is left zero
+struct BlendCeArgs {
+  const float* spec; const float* spat; const double* alpha; float* joint;   // joint may be null (or == spec when no blend)
+  const long long* labels; const float* weight; float* dlogits; float* loss; float* rowtmp; int B, classes;
+};
+int launch_blend_ce(const BlendCeArgs& a, hipStream_t st);
 struct AdamArgs {
   float* p; const float* g; float* m; float* v; size_t n;
   double* alpha_p; const double* alpha_g; double* alpha_m; double* alpha_v;

@@ -128,6 +128,8 @@ class FusedTrainer:
             self.alpha_m = torch.zeros((), dtype=torch.float64, device=dev)
             self.alpha_v = torch.zeros((), dtype=torch.float64, device=dev)
             self.alpha_slot = self.g_head[self.alpha_slot_off:self.alpha_slot_off + 1]
+        self.external_loss = False     # True: the caller computes its own loss from the scores (MetadataTrainer)
+        self.fused_loss = False
         self.loss_weight = None if loss_weight is None else loss_weight.to(dev, torch.float32).contiguous()
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self._ws = None
@@ -185,8 +187,11 @@ class FusedTrainer:
         key = (B, bands, Hh, Ww, m.precision, m.training)
         if key != self._desc_key:
             all_heads = self.three_head or not (self.single_score or self.last_head_only)
+            # single-score step: the blend (Hang2020) / the scores go straight into the fused loss launch (dta_net_loss)
+            self.fused_loss = self.single_score and not self.three_head and not self.external_loss
+            mask = (7 if all_heads else 4) | (_lib.SKIP_BLEND if (self.fused_loss and self.hang) else 0)
             self.desc = _lib.NetDesc(B, bands, Hh, Ww, m._classes, m._net_code, _lib.dtype_code(m.precision),
-                                     1 if m.training else 0, 7 if all_heads else 4, H.BN_MOMENTUM, H.BN_EPS)
+                                     1 if m.training else 0, mask, H.BN_MOMENTUM, H.BN_EPS)
             self.nets, self.grads = self._structs()
             self._desc_key = key
         return key
@@ -203,7 +208,7 @@ class FusedTrainer:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self.logits = torch.empty(B, m._classes, dtype=torch.float32, device=self.device)
             self.dlogits = torch.empty_like(self.logits)
-            self.ce_scratch = torch.empty(B + 1, dtype=torch.float32, device=self.device)
+            self.ce_scratch = torch.zeros(B + 2, dtype=torch.float32, device=self.device)     # (last word: dta_net_loss's block counter)
             if self.three_head:      # per-head scores / score gradients / losses: [net][head]
                 nn_ = 2 if self.hang else 1
                 self.head_scores = torch.empty(nn_, 3, B, m._classes, dtype=torch.float32, device=self.device)
@@ -238,6 +243,8 @@ class FusedTrainer:
                                    "spatial network built with last_head_only=True, or three_head_loss=True")
             table[0][2] = self.logits.data_ptr()
             joint = None
+        if self.fused_loss and self.hang:
+            joint = None                         # DTA_SKIP_BLEND: the blend happens inside the loss launch
         fwd = L.dta_net_forward if tiles is None else L.dta_net_forward_tiles
         _lib.check(fwd(C.byref(self.desc), self.nets, _lib.ptr(self.alpha) if self.hang else None,
                        _lib.ptr(x if tiles is None else tiles), _lib.ptr(self._ws), C.byref(table), joint,
@@ -267,6 +274,13 @@ class FusedTrainer:
         # a fresh 0-d tensor per call (caching-allocator bookkeeping only, no device work): callers may keep every
         # step's loss (Lightning collects them per epoch) without an extra copy kernel on the stream
         self.loss = torch.empty((), dtype=torch.float32, device=self.device)
+        if self.fused_loss:
+            # blend (Hang2020) + cross-entropy + loss in one launch; self.logits receives / holds the scores
+            _lib.check(L.dta_net_loss(C.byref(self.desc), _lib.ptr(self.alpha) if self.hang else None, _lib.ptr(self._ws),
+                                      _lib.ptr(y), _lib.ptr(self.loss_weight), _lib.ptr(self.logits), _lib.ptr(self.loss),
+                                      _lib.ptr(self.dlogits) if want_grad else None, _lib.ptr(self.ce_scratch),
+                                      _lib.current_stream_ptr()), "dta_net_loss")
+            return self.loss
         _lib.check(L.dta_weighted_ce(_lib.ptr(logits), _lib.ptr(y), _lib.ptr(self.loss_weight), logits.shape[0],
                                      logits.shape[1], _lib.ptr(self.loss),
                                      _lib.ptr(self.dlogits) if want_grad else None, _lib.ptr(self.ce_scratch),
@@ -668,6 +682,7 @@ class MetadataTrainer:
         self.small_sizes = [p.numel() for p in self.small]
         self.sensor = FusedTrainer(model.sensor_model, lr, None, betas, eps, process_group, overlap_comm, keep_grads,
                                    extra_grad_slots=sum(self.small_sizes))
+        self.sensor.external_loss = True         # the loss is taken on the fused (HSI + site) scores, by torch
         self.opt = torch.optim.Adam(self.small, lr=lr, betas=betas, eps=eps)
         self.world, self.pg = self.sensor.world, self.sensor.pg
         if self.world > 1:

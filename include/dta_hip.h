@@ -31,7 +31,8 @@ typedef struct dta_net_desc {
   int dtype;         /* DTA_F32 (exact fp32 MFMA) or DTA_BF16 (bf16 MFMA inputs, fp32 accumulate) */
   int training;      /* 1: BatchNorm batch statistics + running-stat update; 0: running statistics */
   int heads_mask;    /* bit L-1 set: compute classifier head L (Hang2020.forward only needs head 3 = 4);
-                        | DTA_FORWARD_ONLY: no dta_net_backward will follow on this workspace (inference) */
+                        | DTA_FORWARD_ONLY: no dta_net_backward will follow on this workspace (inference)
+                        | DTA_SKIP_BLEND: Hang2020 forward leaves the sigmoid(alpha) blend to dta_net_loss (joint unused) */
   float bn_momentum, bn_eps;
 } dta_net_desc;
 
@@ -58,6 +59,7 @@ typedef struct dta_subnet_grads {
 
 /* heads_mask flag: the forward skips what only a backward would read (saved attention state, the bf16 input tiles) */
 #define DTA_FORWARD_ONLY 8
+#define DTA_SKIP_BLEND 16
 
 int dta_abi_version(void);
 const char* dta_last_error(void);
@@ -109,6 +111,15 @@ int dta_net_backward_tiles(const dta_net_desc* d, const dta_subnet_params* nets,
 int dta_net_backward_dp(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,
                         void* workspace, const float* const dscores[2][3], const float* djoint,
                         const dta_subnet_grads* grads, double* dalpha, float* dalpha_f32, int phases, void* stream);
+
+/* Loss head of the network whose forward just ran on `workspace`: the Hang2020 blend (Hang2020.py:260-261; the forward
+ * was built with DTA_SKIP_BLEND), F.cross_entropy(scores, labels, weight) (src/main.py:78), d(loss)/d(scores) and the
+ * scalar loss in ONE launch (dta_net_forward + dta_weighted_ce take three for the same).
+ *  joint   : Hang2020: receives the blended scores [batch][classes] (may be NULL); other kinds: the scores to use (input)
+ *  dlogits : d(loss)/d(scores) [batch][classes], may be NULL (validation)
+ *  scratch : batch + 2 floats; the LAST 32-bit word must be zero on entry and is zero again on return (block counter) */
+int dta_net_loss(const dta_net_desc* d, const double* alpha, void* workspace, const long long* labels, const float* weight,
+                 float* joint, float* loss, float* dlogits, float* scratch, void* stream);
 
 /* ---- Year ensemble (reference src/models/year.py:9-33): `years` (1..DTA_MAX_YEARS) spectral_networks, each on its own
  * input, run as the groups of ONE set of launches (a third of the launches of `years` separate dta_net_* calls);
