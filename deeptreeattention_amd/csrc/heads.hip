@@ -563,10 +563,16 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
   __shared__ double sd[256];
   __shared__ int is_last;
   const int t = threadIdx.x, lane = t & 63, row = blockIdx.x * 4 + (t >> 6);
+  // normaliser sum_i w[y_i] (every block needs it for its gradient rows): label loads of four strides in flight at
+  // once, then their weight gathers -- two dependent round trips per 1024 labels instead of eight
   float part = 0.f;
-  for (int i = t; i < a.B; i += 256) {
-    long long y = a.labels[i];
-    if (y >= 0 && y < a.classes) part += a.weight ? a.weight[y] : 1.f;
+  for (int i0 = t; i0 < a.B; i0 += 1024) {
+    long long yy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) yy[k] = (i0 + 256 * k < a.B) ? a.labels[i0 + 256 * k] : -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (yy[k] >= 0 && yy[k] < a.classes) part += a.weight ? a.weight[yy[k]] : 1.f;
   }
   const float den = block_sum256(part, sc);
   if (row < a.B) {
