@@ -220,3 +220,28 @@ def test_fused_loss_launch_matches_blend_plus_cross_entropy(precision):
     # an out-of-range label poisons the loss (same contract as dta_weighted_ce)
     y[7] = 99
     assert torch.isnan(t1._loss(t1._forward_scores(x), t1._labels(y), True))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_train_steps_are_bit_reproducible(precision):
+    """No kernel of the step sums in a run-dependent order (split-K slabs and the small GEMMs are reduced in fixed order,
+    the loss by the last block over a fixed sequence, d(alpha)'s atomics add grid-aligned numbers exactly): the same
+    steps from the same state give the same bits -- weights, BatchNorm statistics, alpha, losses."""
+    import copy
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    torch.manual_seed(11)
+    m0 = H.Hang2020(40, 9, precision=precision).cuda().train()
+    x = [torch.rand(96, 40, 11, 11, device="cuda") for _ in range(2)]
+    y = [torch.randint(0, 9, (96,), device="cuda") for _ in range(2)]
+    runs = []
+    for rep in range(3):
+        m = copy.deepcopy(m0)
+        tr = FusedTrainer(m, lr=1e-3)
+        losses = [tr.train_step(x[i % 2], y[i % 2]) for i in range(6)]
+        torch.cuda.synchronize()
+        runs.append(({k: v.clone() for k, v in m.state_dict().items()}, [float(l) for l in losses]))
+    for sd, ls in runs[1:]:
+        assert ls == runs[0][1]
+        for k in sd:
+            assert torch.equal(sd[k], runs[0][0][k]), k
