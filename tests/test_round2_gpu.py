@@ -188,23 +188,24 @@ def test_vanilla_cnn_rejects_patches_its_head_cannot_take():
     assert b"512" in L.dta_last_error()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_fused_loss_launch_matches_blend_plus_cross_entropy(precision):
+@pytest.mark.parametrize("precision,classes", [("fp32", 13), ("bf16", 13), ("fp32", 300)])
+def test_fused_loss_launch_matches_blend_plus_cross_entropy(precision, classes):
     """dta_net_loss (blend + weighted CE + loss in one launch, last-block finalisation) against the three-launch route
-    (k_blend inside the forward, dta_weighted_ce) on the same network and batch: same scores, loss and score gradient;
+    (k_blend inside the forward, dta_weighted_ce) on the same network and batch: same scores, loss and score gradient
+    (300 classes: rows wider than the 256 scores a wave keeps in registers);
     repeated calls leave the block counter clean; ignored (-100) labels drop out of the mean."""
     import copy
     from deeptreeattention_amd import Hang2020 as H
     from deeptreeattention_amd.engine import FusedTrainer
     torch.manual_seed(3)
-    m1 = H.Hang2020(24, 13, precision=precision).cuda().train()
+    m1 = H.Hang2020(24, classes, precision=precision).cuda().train()
     m2 = copy.deepcopy(m1)
-    w = torch.rand(13) + 0.5
+    w = torch.rand(classes) + 0.5
     t1 = FusedTrainer(m1, lr=1e-3, loss_weight=w)
     t2 = FusedTrainer(m2, lr=1e-3, loss_weight=w)
     t2.external_loss = True                      # forward blends, the loss is the stand-alone dta_weighted_ce
     x = torch.rand(37, 24, 11, 11, device="cuda")
-    y = torch.randint(0, 13, (37,), device="cuda")
+    y = torch.randint(0, classes, (37,), device="cuda")
     y[5] = -100
     for rep in range(3):                         # the counter must come back to zero every time
         y1 = t1._labels(y)
@@ -218,7 +219,7 @@ def test_fused_loss_launch_matches_blend_plus_cross_entropy(precision):
         assert float(t1.dlogits[5].abs().max()) == 0.0
         assert int(t1.ce_scratch.view(torch.int32)[-1]) == 0
     # an out-of-range label poisons the loss (same contract as dta_weighted_ce)
-    y[7] = 99
+    y[7] = classes + 86
     assert torch.isnan(t1._loss(t1._forward_scores(x), t1._labels(y), True))
 
 
