@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libdta_hip.so")
 DTA_F32, DTA_BF16 = 0, 1
 MAX_YEARS = 4   # DTA_MAX_YEARS
 FORWARD_ONLY = 8   # DTA_FORWARD_ONLY (heads_mask flag)
+XCHG_HANDLE_BYTES = 128   # DTA_XCHG_HANDLE_BYTES
 SKIP_BLEND = 16    # DTA_SKIP_BLEND (heads_mask flag): the blend is left to dta_net_loss
 NET_HANG2020, NET_SPECTRAL, NET_SPATIAL, NET_VANILLA = 0, 1, 2, 3
 SITE_CONV_FWD, SITE_CONV_WGRAD, SITE_CONV_DGRAD, SITE_STAGE_FWD, SITE_STAGE_BWD, SITE_GEMM = 0, 3, 6, 9, 12, 15
@@ -160,6 +161,31 @@ def lib():
         L.dta_profile_collect_site.restype = C.c_int
         L.dta_profile_collect_site.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int]
         L.dta_dev_reload_switches.restype = C.c_int
+        # peer gradient exchange (opaque handle = void*)
+        L.dta_xchg_create.restype = C.c_int
+        L.dta_xchg_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.dta_xchg_grad_buffer.restype = C.c_void_p
+        L.dta_xchg_grad_buffer.argtypes = [C.c_void_p]
+        L.dta_xchg_grad_capacity.restype = C.c_size_t
+        L.dta_xchg_grad_capacity.argtypes = [C.c_void_p]
+        L.dta_xchg_export.restype = C.c_int
+        L.dta_xchg_export.argtypes = [C.c_void_p, C.c_void_p]
+        L.dta_xchg_connect.restype = C.c_int
+        L.dta_xchg_connect.argtypes = [C.c_void_p, C.c_void_p]
+        L.dta_xchg_set_timeout.restype = None
+        L.dta_xchg_set_timeout.argtypes = [C.c_void_p, C.c_double]
+        L.dta_xchg_set_max_workgroups.restype = None
+        L.dta_xchg_set_max_workgroups.argtypes = [C.c_void_p, C.c_int]
+        L.dta_xchg_allreduce.restype = C.c_int
+        L.dta_xchg_allreduce.argtypes = [C.c_void_p, C.c_void_p]
+        L.dta_xchg_adam_step.restype = C.c_int
+        L.dta_xchg_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                         C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.dta_xchg_status.restype = C.c_int
+        L.dta_xchg_status.argtypes = [C.c_void_p]
+        L.dta_xchg_destroy.restype = C.c_int
+        L.dta_xchg_destroy.argtypes = [C.c_void_p]
         if L.dta_abi_version() != 1:
             raise RuntimeError("libdta_hip.so ABI version mismatch")
         _lib = L

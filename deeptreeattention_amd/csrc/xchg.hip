@@ -1,0 +1,361 @@
+// Peer gradient exchange for the data-parallel train step (one process per GPU of ONE node): the sum of the flat
+// gradient over ranks + Adam in ONE launch on the compute stream, through IPC-mapped peer memory (xGMI), without a
+// collective library, side streams or stream-event hops.
+//
+// Replaces what Lightning's DDP does for the reference between loss.backward() and optimizer.step()
+// (/root/reference/train.py:89-98: every parameter's gradient is all-reduced; src/main.py:136 Adam).
+//
+// Protocol of one step (epoch e), every rank runs the same kernel with G workgroups:
+//   0. announce: rank r writes ready[r] = e into every peer's signal page.  The gradient buffer was completed by the
+//      kernels before this one on the same stream, so it is in memory (kernel-boundary write-back).
+//   1. every workgroup waits until all ready[*] >= e in its OWN page (peers write, the owner polls locally).
+//   A. reduce-scatter by pulling: rank r sums shard r of every rank's gradient buffer in rank order 0..N-1 (one fixed
+//      order for everybody: the sums, and so the replicas, are bit-identical) and stores the sums in its staging area
+//      (uncached memory of its signal allocation, system-scope stores).  The last workgroup to finish writes
+//      done[r] = e into every page.
+//   B. all-gather by pulling, fused with the optimizer: for every shard s (starting at r+1, so that the N ranks use the
+//      N-1 links of the mesh at the same time), wait for done[s] >= e, read the summed shard from rank s's staging
+//      area and apply Adam to the local parameters / moments (all ranks hold the full optimizer state, as under DDP);
+//      the gradient element is cleared (or replaced by the sum: keep_grads).  done[s] also says that rank s has
+//      finished reading this rank's gradients, so clearing is safe.
+// Only flags are ever written remotely, and only into uncached memory; bulk data is pulled with system-scope loads
+// (remote lines are never served from a stale local L2 line).  Every wait is bounded (wall clock): a missing peer ends
+// the kernel with a status word in pinned host memory instead of hanging the GPU.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/dta_hip.h"
+#include "common.h"
+
+namespace dta {
+
+constexpr int XCHG_MAX_WORLD = 8;
+constexpr int XCHG_SIG_BYTES = 512;      // ready[16] | done[16] | arrive (u64) ... then the staging area
+constexpr int XCHG_THREADS = 256;
+
+struct XchgSig {
+  unsigned ready[16];
+  unsigned done[16];
+  unsigned long long arrive;
+};
+
+struct XchgArgs {
+  const float* grads[XCHG_MAX_WORLD];    // every rank's gradient buffer (own entry: the local one)
+  char* sig[XCHG_MAX_WORLD];             // every rank's signal page + staging area
+  int rank, world;
+  unsigned epoch;
+  size_t n, shard;                       // floats; shard is a multiple of 4
+  long long timeout_ticks;               // wall_clock64 ticks (100 MHz)
+  int* status;                           // pinned host word: 0 ok, else (phase << 8) | peer
+  int mode;                              // 0: all-reduce only (g := sum), 1: fused Adam
+  int zero_grad;
+  float* p; float* g; float* m; float* v;
+  double* alpha_p; double* alpha_m; double* alpha_v; double* alpha_g;
+  long long alpha_slot;                  // index into g of alpha's fp32 exchange slot, or -1
+  float lr, beta1, beta2, eps, bc1, bc2, grad_scale;
+};
+
+__device__ __forceinline__ unsigned ld_sys32(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys32(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// 16-byte system-scope accesses (sc0 sc1: never served from / parked in a non-coherent cache line).  The compiler does not
+// track these loads: xchg_wait_loads() is the s_waitcnt that makes their results usable.
+__device__ __forceinline__ f32x4 ld_sys128(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void st_sys128(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+template <int K>
+__device__ __forceinline__ void xchg_wait_loads(f32x4 (&r)[K]) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < K; ++k) asm volatile("" : "+v"(r[k]));      // uses of r[k] stay below the wait
+}
+
+// spin on a flag of the local page until it reaches `epoch` (wrap-safe) or the budget runs out
+__device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned epoch, long long budget) {
+  const long long t0 = wall_clock64();
+  while ((int)(ld_sys32(flag) - epoch) < 0) {
+    if (wall_clock64() - t0 > budget) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
+  __shared__ int s_abort;
+  __shared__ int s_last;
+  const int t = threadIdx.x;
+  XchgSig* mine = (XchgSig*)a.sig[a.rank];
+  if (t == 0) { s_abort = 0; s_last = 0; }
+  __syncthreads();
+  // 0. announce (one workgroup), 1. wait for every rank's gradients
+  if (blockIdx.x == 0 && t < a.world) st_sys32(&((XchgSig*)a.sig[t])->ready[a.rank], a.epoch);
+  if (t < a.world && !wait_flag(&mine->ready[t], a.epoch, a.timeout_ticks)) {
+    s_abort = 1;
+    a.status[0] = (1 << 8) | t;
+  }
+  __syncthreads();
+  if (s_abort) return;
+  if (t < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // drop what this CU / L2 still holds of the peers' buffers
+  __syncthreads();
+
+  const size_t gthreads = (size_t)gridDim.x * XCHG_THREADS, gtid = (size_t)blockIdx.x * XCHG_THREADS + t;
+  // A. my shard: sum over ranks in rank order -> staging (one 16-byte load per rank in flight per thread)
+  {
+    const size_t lo = (size_t)a.rank * a.shard, hi = lo + a.shard < a.n ? lo + a.shard : a.n;
+    float* stage = (float*)(a.sig[a.rank] + XCHG_SIG_BYTES);
+    for (size_t i = lo + 4 * gtid; i < hi; i += 4 * gthreads) {
+      f32x4 part[XCHG_MAX_WORLD];
+#pragma unroll
+      for (int s = 0; s < XCHG_MAX_WORLD; ++s)
+        if (s < a.world) part[s] = ld_sys128(a.grads[s] + i);
+      xchg_wait_loads(part);
+      f32x4 acc = part[0];
+#pragma unroll
+      for (int s = 1; s < XCHG_MAX_WORLD; ++s)
+        if (s < a.world) acc += part[s];
+      st_sys128(stage + (i - lo), acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's staging stores have reached memory
+    __syncthreads();
+    if (t == 0) {
+      const unsigned long long old = __hip_atomic_fetch_add(&mine->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (old + 1 == (unsigned long long)gridDim.x * a.epoch);
+    }
+    __syncthreads();
+    if (s_last && t < a.world) st_sys32(&((XchgSig*)a.sig[t])->done[a.rank], a.epoch);
+  }
+  // B. every rank's sums are published (which also says: every rank has finished reading this rank's gradients)
+  if (t < a.world && !wait_flag(&mine->done[t], a.epoch, a.timeout_ticks)) {
+    s_abort = 1;
+    a.status[0] = (2 << 8) | t;
+  }
+  __syncthreads();
+  if (s_abort) return;
+  const float ss = a.lr / a.bc1, rbc2 = rsqrtf(a.bc2);
+  constexpr int U = 2;
+  const size_t nq = a.n / 4, shard_q = a.shard / 4;
+  // rank r starts with the quads of shard r+1: at any moment the N ranks pull over N different links
+  const size_t rot = ((size_t)((a.rank + 1) % a.world)) * shard_q;
+  for (size_t q0 = gtid; q0 < nq; q0 += U * gthreads) {
+    f32x4 gs[U];
+    size_t idx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      size_t q = q0 + u * gthreads;
+      idx[u] = nq;                                        // nq = nothing to do
+      if (q < nq) {
+        q += rot;
+        if (q >= nq) q -= nq;
+        const size_t s = q / shard_q;
+        idx[u] = q;
+        gs[u] = ld_sys128((const float*)(a.sig[s] + XCHG_SIG_BYTES) + 4 * (q - s * shard_q));
+      }
+    }
+    xchg_wait_loads(gs);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (idx[u] >= nq) continue;
+      const size_t i = 4 * idx[u];
+      if (a.mode == 1) {
+        const f32x4 mo = __builtin_nontemporal_load((const f32x4*)(a.m + i));
+        const f32x4 vo = __builtin_nontemporal_load((const f32x4*)(a.v + i));
+        f32x4 po = *(const f32x4*)(a.p + i), mn, vn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g = gs[u][j] * a.grad_scale;
+          mn[j] = a.beta1 * mo[j] + (1.f - a.beta1) * g;
+          vn[j] = a.beta2 * vo[j] + (1.f - a.beta2) * g * g;
+          po[j] -= ss * (mn[j] / (sqrtf(vn[j]) * rbc2 + a.eps));
+        }
+        __builtin_nontemporal_store(mn, (f32x4*)(a.m + i));
+        __builtin_nontemporal_store(vn, (f32x4*)(a.v + i));
+        *(f32x4*)(a.p + i) = po;
+        if (a.alpha_slot >= 0 && (size_t)(a.alpha_slot & ~3ll) == i) {      // the owner of alpha's slot steps alpha (float64)
+          const float graw = gs[u][a.alpha_slot & 3];
+          const double g = (double)graw * (double)a.grad_scale;
+          const double m2 = (double)a.beta1 * a.alpha_m[0] + (1.0 - (double)a.beta1) * g;
+          const double v2 = (double)a.beta2 * a.alpha_v[0] + (1.0 - (double)a.beta2) * g * g;
+          a.alpha_m[0] = m2; a.alpha_v[0] = v2;
+          a.alpha_p[0] -= ((double)a.lr / (double)a.bc1) * (m2 / (sqrt(v2) / sqrt((double)a.bc2) + (double)a.eps));
+          if (a.alpha_g) a.alpha_g[0] = a.zero_grad ? 0.0 : (double)graw;
+        }
+      }
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(a.g + i) = (a.mode == 1 && a.zero_grad) ? z : gs[u];
+    }
+  }
+}
+
+}  // namespace dta
+
+using namespace dta;
+
+struct dta_xchg {
+  int rank, world, device;
+  size_t n, n_pad, shard;
+  float* grads;
+  char* sig;
+  size_t sig_bytes;
+  float* peer_grads[XCHG_MAX_WORLD];
+  char* peer_sig[XCHG_MAX_WORLD];
+  bool connected;
+  unsigned epoch;
+  int* status_host;
+  int* status_dev;
+  double timeout_s;
+  int max_wgs;
+};
+
+extern "C" {
+
+int dta_xchg_create(int rank, int world, size_t n_floats, dta_xchg** out) {
+  if (!out || world < 1 || world > XCHG_MAX_WORLD || rank < 0 || rank >= world || n_floats == 0) {
+    dta_set_error("dta_xchg_create: bad argument (1 <= world <= %d ranks of one node)", XCHG_MAX_WORLD);
+    return 1;
+  }
+  dta_xchg* x = (dta_xchg*)calloc(1, sizeof(dta_xchg));
+  if (!x) { dta_set_error("dta_xchg_create: out of host memory"); return 1; }
+  x->rank = rank; x->world = world; x->n = n_floats;
+  x->n_pad = (n_floats + 3) & ~(size_t)3;
+  x->shard = (((x->n_pad + world - 1) / world) + 3) & ~(size_t)3;
+  x->sig_bytes = XCHG_SIG_BYTES + x->shard * sizeof(float);
+  x->timeout_s = 5.0;
+  x->max_wgs = 256;
+  const char* why = nullptr;
+  hipError_t e = hipGetDevice(&x->device);
+  if (e == hipSuccess) { e = hipMalloc((void**)&x->grads, x->n_pad * sizeof(float)); why = "hipMalloc(gradient buffer)"; }
+  if (e == hipSuccess) {
+    e = hipExtMallocWithFlags((void**)&x->sig, x->sig_bytes, hipDeviceMallocUncached);
+    why = "hipExtMallocWithFlags(uncached signal page)";
+  }
+  if (e == hipSuccess) { e = hipHostMalloc((void**)&x->status_host, 64, hipHostMallocMapped); why = "hipHostMalloc(status)"; }
+  if (e == hipSuccess) { e = hipHostGetDevicePointer((void**)&x->status_dev, x->status_host, 0); why = "hipHostGetDevicePointer"; }
+  if (e == hipSuccess) { x->status_host[0] = 0; e = hipMemset(x->grads, 0, x->n_pad * sizeof(float)); why = "hipMemset"; }
+  if (e == hipSuccess) e = hipMemset(x->sig, 0, x->sig_bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    dta_set_error("dta_xchg_create: %s: %s", why ? why : "hipGetDevice", hipGetErrorString(e));
+    if (x->grads) hipFree(x->grads);
+    if (x->sig) hipFree(x->sig);
+    if (x->status_host) hipHostFree(x->status_host);
+    free(x);
+    return 1;
+  }
+  x->peer_grads[rank] = x->grads;
+  x->peer_sig[rank] = x->sig;
+  x->connected = (world == 1);
+  *out = x;
+  return 0;
+}
+
+float* dta_xchg_grad_buffer(dta_xchg* x) { return x ? x->grads : nullptr; }
+size_t dta_xchg_grad_capacity(dta_xchg* x) { return x ? x->n_pad : 0; }
+
+int dta_xchg_export(dta_xchg* x, void* handles) {
+  if (!x || !handles) { dta_set_error("dta_xchg_export: bad argument"); return 1; }
+  hipIpcMemHandle_t h[2];
+  hipError_t e = hipIpcGetMemHandle(&h[0], x->grads);
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h[1], x->sig);
+  if (e != hipSuccess) { dta_set_error("dta_xchg_export: hipIpcGetMemHandle: %s", hipGetErrorString(e)); return 1; }
+  memcpy(handles, h, sizeof(h));
+  return 0;
+}
+
+int dta_xchg_connect(dta_xchg* x, const void* all_handles) {
+  if (!x || !all_handles) { dta_set_error("dta_xchg_connect: bad argument"); return 1; }
+  if (x->connected) return 0;
+  const hipIpcMemHandle_t* h = (const hipIpcMemHandle_t*)all_handles;
+  for (int s = 0; s < x->world; ++s) {
+    if (s == x->rank) continue;
+    hipError_t e = hipIpcOpenMemHandle((void**)&x->peer_grads[s], h[2 * s], hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) e = hipIpcOpenMemHandle((void**)&x->peer_sig[s], h[2 * s + 1], hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      dta_set_error("dta_xchg_connect: hipIpcOpenMemHandle(rank %d): %s", s, hipGetErrorString(e));
+      return 1;
+    }
+  }
+  x->connected = true;
+  return 0;
+}
+
+void dta_xchg_set_timeout(dta_xchg* x, double seconds) { if (x && seconds > 0) x->timeout_s = seconds; }
+void dta_xchg_set_max_workgroups(dta_xchg* x, int wgs) { if (x && wgs > 0 && x->epoch == 0) x->max_wgs = wgs; }
+
+static int xchg_launch(dta_xchg* x, XchgArgs& a, void* stream) {
+  if (!x->connected) { dta_set_error("dta_xchg: not connected (dta_xchg_connect)"); return 1; }
+  for (int s = 0; s < x->world; ++s) { a.grads[s] = x->peer_grads[s]; a.sig[s] = x->peer_sig[s]; }
+  a.rank = x->rank; a.world = x->world; a.n = x->n_pad; a.shard = x->shard;
+  a.epoch = ++x->epoch;
+  a.timeout_ticks = (long long)(x->timeout_s * 1e8);
+  a.status = x->status_dev;
+  a.g = x->grads;
+  // one workgroup per CU at most, never more than there are element pairs per shard
+  size_t wgs = (x->shard / 2 + XCHG_THREADS - 1) / XCHG_THREADS;
+  if (wgs > (size_t)x->max_wgs) wgs = x->max_wgs;
+  if (wgs < 1) wgs = 1;
+  hipLaunchKernelGGL(k_xchg_step, dim3((unsigned)wgs), dim3(XCHG_THREADS), 0, (hipStream_t)stream, a);
+  DTA_CHECK_LAUNCH("k_xchg_step");
+  return 0;
+}
+
+int dta_xchg_allreduce(dta_xchg* x, void* stream) {
+  if (!x) { dta_set_error("dta_xchg_allreduce: null exchange"); return 1; }
+  XchgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mode = 0; a.alpha_slot = -1;
+  return xchg_launch(x, a, stream);
+}
+
+int dta_xchg_adam_step(dta_xchg* x, float* p, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,
+                       long long alpha_slot, double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2,
+                       float eps, float grad_scale, int zero_grad, void* stream) {
+  if (!x || !p || !m || !v || step < 1) { dta_set_error("dta_xchg_adam_step: bad argument"); return 1; }
+  if (n != x->n && n != x->n_pad) { dta_set_error("dta_xchg_adam_step: n = %zu does not match the exchange's %zu elements", n, x->n); return 1; }
+  if (n != x->n_pad) { dta_set_error("dta_xchg_adam_step: flat buffers must be padded to a multiple of 4 elements"); return 1; }
+  if (alpha_p && (alpha_slot < 0 || (size_t)alpha_slot >= n || !alpha_m || !alpha_v)) {
+    dta_set_error("dta_xchg_adam_step: alpha needs its exchange slot inside the gradient buffer and its moments");
+    return 1;
+  }
+  XchgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mode = 1; a.zero_grad = zero_grad;
+  a.p = p; a.m = m; a.v = v;
+  a.alpha_p = alpha_p; a.alpha_m = alpha_m; a.alpha_v = alpha_v; a.alpha_g = alpha_g;
+  a.alpha_slot = alpha_p ? alpha_slot : -1;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  return xchg_launch(x, a, stream);
+}
+
+int dta_xchg_status(dta_xchg* x) {
+  if (!x) return -1;
+  const int s = ((volatile int*)x->status_host)[0];
+  if (s) dta_set_error("dta_xchg: timed out in phase %d waiting for rank %d (a peer is missing, stuck or not co-scheduled)", s >> 8, s & 255);
+  return s;
+}
+
+int dta_xchg_destroy(dta_xchg* x) {
+  if (!x) return 0;
+  for (int s = 0; s < x->world; ++s) {
+    if (s == x->rank || !x->connected) continue;
+    if (x->peer_grads[s]) hipIpcCloseMemHandle(x->peer_grads[s]);
+    if (x->peer_sig[s]) hipIpcCloseMemHandle(x->peer_sig[s]);
+  }
+  hipFree(x->grads);
+  hipFree(x->sig);
+  hipHostFree(x->status_host);
+  free(x);
+  return 0;
+}
+
+}  // extern "C"

@@ -82,10 +82,146 @@ class GradSync:
             dist.broadcast(t, src, group=self.group)
 
 
-def kept_anywhere(local, group=None, device="cpu"):
-    """Year-ensemble step under data parallelism: `local[i]` says whether THIS rank's shard of year i is non-zero;
-    returns, identically on every rank, whether ANY rank kept year i (those years are stepped everywhere; ranks
-    that skipped one contribute zero gradients, as DDP does for unused parameters)."""
-    flags = torch.tensor([1.0 if k else 0.0 for k in local], device=device)
-    dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
-    return [f > 0 for f in flags.tolist()]
+class _DeviceBlock:
+    """A device allocation owned by the library, shown to torch through __cuda_array_interface__ (zero copy)."""
+
+    def __init__(self, ptr, n, owner):
+        self._owner = owner            # keeps the exchange object alive as long as a tensor view exists
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class PeerExchange:
+    """Gradient exchange + optimizer step through IPC-mapped peer memory (csrc/xchg.hip, dta_xchg_*): one launch on the
+    compute stream per step, no collective library.  Ranks must be processes of ONE node (xGMI / same GPU in tests).
+
+    grad: the flat float32 gradient buffer (library-owned device memory, mapped by every peer) as a torch tensor; the
+    trainer points its gradient views into it.  Handles travel once, at start-up, through torch.distributed's object
+    collective of `group` (any backend)."""
+
+    def __init__(self, n_floats, group=None, timeout_s=None, max_workgroups=None):
+        """max_workgroups: grid bound of the exchange launch (default 256 = one per CU).  Processes that SHARE a GPU (the
+        multi-rank tests on a one-GPU box) must keep world x max_workgroups within what stays co-resident, since every
+        rank's launch waits inside the kernel for the others."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        self._L = L
+        self.group = group
+        if dist.is_available() and dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            self.rank, self.world = 0, 1         # single process: the same launch without peers
+        h = C.c_void_p()
+        _lib.check(L.dta_xchg_create(self.rank, self.world, int(n_floats), C.byref(h)), "dta_xchg_create")
+        self._h = h
+        if timeout_s:
+            L.dta_xchg_set_timeout(h, float(timeout_s))
+        if max_workgroups:
+            L.dta_xchg_set_max_workgroups(h, int(max_workgroups))
+        self.capacity = int(L.dta_xchg_grad_capacity(h))
+        mine = C.create_string_buffer(_lib.XCHG_HANDLE_BYTES)
+        _lib.check(L.dta_xchg_export(h, mine), "dta_xchg_export")
+        if self.world > 1:
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, mine.raw, group=group)
+            blob = C.create_string_buffer(b"".join(gathered), _lib.XCHG_HANDLE_BYTES * self.world)
+            _lib.check(L.dta_xchg_connect(h, blob), "dta_xchg_connect")
+            dist.barrier(group=group)            # every rank has mapped every peer before the first step
+        self.grad = torch.as_tensor(_DeviceBlock(L.dta_xchg_grad_buffer(h), self.capacity, self), device="cuda")
+        assert self.grad.data_ptr() == L.dta_xchg_grad_buffer(h), "torch copied the exchange buffer instead of wrapping it"
+        self.grad_scale = 1.0 / self.world
+        self.steps = 0
+
+    def allreduce(self):
+        """grad := sum over ranks (enqueued on the current stream)."""
+        from . import _lib
+        _lib.check(self._L.dta_xchg_allreduce(self._h, _lib.current_stream_ptr()), "dta_xchg_allreduce")
+        self.steps += 1
+
+    def adam_step(self, p, m, v, alpha, alpha_g, alpha_slot, alpha_m, alpha_v, step, lr, betas, eps, zero_grad):
+        from . import _lib
+        _lib.check(self._L.dta_xchg_adam_step(self._h, _lib.ptr(p), _lib.ptr(m), _lib.ptr(v), p.numel(), _lib.ptr(alpha),
+                                              _lib.ptr(alpha_g), -1 if alpha is None else int(alpha_slot), _lib.ptr(alpha_m),
+                                              _lib.ptr(alpha_v), int(step), lr, betas[0], betas[1], eps, self.grad_scale,
+                                              1 if zero_grad else 0, _lib.current_stream_ptr()), "dta_xchg_adam_step")
+        self.steps += 1
+
+    def check(self):
+        """Raise if a step timed out waiting for a peer (call after a stream synchronisation)."""
+        if self._L.dta_xchg_status(self._h) != 0:
+            raise RuntimeError(self._L.dta_last_error().decode())
+
+    def close(self):
+        """Collective: every rank stops using its peers' memory before anybody frees it."""
+        if self._h is not None:
+            torch.cuda.synchronize()
+            if self.world > 1 and dist.is_initialized():
+                dist.barrier(group=self.group)
+            self.grad = None
+            self._L.dta_xchg_destroy(self._h)
+            self._h = None
+
+
+class RcclDirect:
+    """ncclAllReduce called straight from librccl.so (ctypes) ON THE COMPUTE STREAM: no torch.distributed work object,
+    no communication stream, no event hops (each of which stalled the compute stream ~12 us in the torch path).  The
+    communicator is bootstrapped from a unique id that travels through torch.distributed's object broadcast."""
+
+    NCCL_FLOAT, NCCL_SUM = 7, 0
+
+    def __init__(self, group=None):
+        import ctypes as C
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        import glob
+        import os
+        lib = None
+        # the copy torch itself loaded comes first (one RCCL instance per process), then the ROCm installation's
+        cands = sorted(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")))
+        for name in cands + ["librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"]:
+            try:
+                lib = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if lib is None:
+            raise RuntimeError("librccl.so not found")
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        self._lib = lib
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        uid = UniqueId()
+        if self.rank == 0:
+            self._ok(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        box = [bytes(uid.internal) if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        C.memmove(C.byref(uid), box[0], 128)
+        comm = C.c_void_p()
+        self._ok(lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
+        self._comm = comm
+        self.collectives = 0
+
+    def _ok(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("{}: {}".format(what, self._lib.ncclGetErrorString(rc).decode()))
+
+    def all_reduce(self, t):
+        """In-place sum of a contiguous float32 device tensor, enqueued on the current stream."""
+        import ctypes as C
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        ptr = C.c_void_p(t.data_ptr())
+        self._ok(self._lib.ncclAllReduce(ptr, ptr, t.numel(), self.NCCL_FLOAT, self.NCCL_SUM, self._comm,
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ncclAllReduce")
+        self.collectives += 1
+
+    def close(self):
+        if self._comm is not None:
+            torch.cuda.synchronize()
+            self._lib.ncclCommDestroy(self._comm)
+            self._comm = None

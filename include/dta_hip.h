@@ -8,7 +8,7 @@
  * Conventions
  *  - plain C, no C++/torch types; every pointer is a DEVICE pointer unless said otherwise
  *  - every buffer is allocated by the caller (PyTorch caching allocator) and only borrowed for the call;
- *    the library allocates nothing on the device and keeps no state between calls
+ *    the library allocates nothing on the device (one documented exception: the peer-exchange object dta_xchg_*)
  *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no internal syncs
  *  - return 0 on success; otherwise non-zero and dta_last_error() describes the failure (thread-local text)
  *  - parameters/gradients use the reference's torch layouts and state_dict shapes
@@ -206,6 +206,44 @@ int dta_adam_step_dp(float* p, float* g, float* m, float* v, size_t n, double* a
  * passes over parameters whose grad is None).  No float64 alpha here (spectral networks have none). */
 int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const float* active, const int* dev_step,
                         float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* ---- Peer gradient exchange: data-parallel training with one process per GPU of ONE node (reference train.py:89-98:
+ * Lightning DDP all-reduces every parameter's gradient between loss.backward() and optimizer.step()).  Here the sum over
+ * ranks and the Adam step are ONE launch on the caller's compute stream: every rank pulls its shard of all ranks'
+ * gradient buffers through IPC-mapped peer memory (xGMI), publishes the sums in its staging area, and every rank then
+ * pulls all summed shards and steps its full (replicated) optimizer state -- no collective library, no side stream, no
+ * stream-event hops; sums are taken in rank order, so replicas stay bit-identical.  Waits inside the kernel are bounded:
+ * a missing peer sets a status word (dta_xchg_status) instead of hanging the GPU.
+ * EXCEPTION to the "allocates nothing" rule above: the exchange object owns device memory that peers map -- the flat
+ * float32 gradient buffer (dta_xchg_grad_buffer; the backward entry points write the step's gradients there) and an
+ * uncached signal + staging allocation.  Create it once per trainer, destroy it after a barrier over the ranks.
+ *  handles: DTA_XCHG_HANDLE_BYTES per rank (dta_xchg_export writes this rank's; dta_xchg_connect takes all ranks' in
+ *  rank order, gathered by the caller over any side channel, e.g. torch.distributed.all_gather_object). */
+typedef struct dta_xchg dta_xchg;
+#define DTA_XCHG_HANDLE_BYTES 128
+#define DTA_XCHG_MAX_WORLD 8
+int dta_xchg_create(int rank, int world, size_t n_floats, dta_xchg** out);
+float* dta_xchg_grad_buffer(dta_xchg* x);          /* device pointer, dta_xchg_grad_capacity(x) floats, zero-filled */
+size_t dta_xchg_grad_capacity(dta_xchg* x);        /* n_floats rounded up to a multiple of 4 */
+int dta_xchg_export(dta_xchg* x, void* handles);
+int dta_xchg_connect(dta_xchg* x, const void* all_handles);
+void dta_xchg_set_timeout(dta_xchg* x, double seconds);   /* bound of every in-kernel wait (default 5 s) */
+/* Grid bound of the exchange launch (default 256, one workgroup per CU); only before the first step.  Ranks that share
+ * one GPU (tests) must keep world x workgroups co-resident: every rank's launch waits in-kernel for the others. */
+void dta_xchg_set_max_workgroups(dta_xchg* x, int workgroups);
+/* g := sum over ranks of g (all ranks end with the same bits). */
+int dta_xchg_allreduce(dta_xchg* x, void* stream);
+/* Sum over ranks + dta_adam_step_dp's update in one launch.  p / m / v: this rank's flat buffers of
+ * dta_xchg_grad_capacity(x) floats; alpha_slot: index (in floats) of alpha's exchange slot inside the gradient buffer
+ * (dta_net_backward_dp's dalpha_f32), or -1 with alpha_p NULL; alpha_g (may be NULL) receives the summed gradient
+ * (zero_grad = 0) or is cleared.  zero_grad != 0: the gradient buffer is cleared for the next backward; else it holds the sum. */
+int dta_xchg_adam_step(dta_xchg* x, float* p, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,
+                       long long alpha_slot, double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2,
+                       float eps, float grad_scale, int zero_grad, void* stream);
+/* 0 = every step so far completed; otherwise (phase << 8 | rank waited for) of the first timed-out wait (host-side read of
+ * a pinned word: meaningful once the stream has been synchronised). */
+int dta_xchg_status(dta_xchg* x);
+int dta_xchg_destroy(dta_xchg* x);
 
 /* ---- stand-alone building blocks (same kernels as the network-level path) ------------------------------------ */
 
