@@ -58,6 +58,12 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "rccl", "torch"],
+                    help="gradient exchange when data-parallel: peer = sum over ranks + Adam in one launch through "
+                         "IPC-mapped peer memory (csrc/xchg.hip), rccl = one ncclAllReduce on the compute stream, torch = "
+                         "torch.distributed buckets; auto = peer when its crash-isolated probe passes on every rank, else "
+                         "rccl.  (A one-rank DTA_FORCE_COLLECTIVES run defaults to torch, the round-2 path.)")
+    ap.add_argument("--traffic-file", default=None, help="profiles/*_traffic_step.json whose PMC counters are quoted")
     return ap.parse_args()
 
 
@@ -139,7 +145,8 @@ def main():
     torch.manual_seed(1234)                      # same initial weights on every rank (then broadcast anyway)
     model = H.Hang2020(BANDS, CLASSES, precision=a.precision).to(dev)
     model.train()
-    trainer = FusedTrainer(model, lr=1e-4, loss_weight=torch.ones(CLASSES), overlap_comm=not a.no_overlap)
+    trainer = FusedTrainer(model, lr=1e-4, loss_weight=torch.ones(CLASSES), overlap_comm=not a.no_overlap,
+                           exchange=None if a.exchange == "auto" else a.exchange)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)                   # each rank owns a different shard of the global batch
     nb = 2
@@ -170,6 +177,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     el = time.perf_counter() - t0
+    trainer.check_exchange()                 # a peer-exchange step that timed out waiting for a rank raises here
     if dist_on:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -244,16 +252,28 @@ def main():
         # HBM bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of this
         # very command; tools/step_traffic.py): a constant of the configuration it was measured on, not a live counter
         traffic = {}
-        tpath = os.path.join(REPO, "profiles", "r02_traffic_step.json")
+        build_id = L.dta_build_id().decode()
+        tpath = a.traffic_file
+        if tpath is None:
+            import glob
+            cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic_step.json")))
+            tpath = cands[-1] if cands else ""
+        tsrc = None
         if os.path.exists(tpath) and a.batch == 1024 and a.precision == "bf16":
             tj = json.load(open(tpath))
-            for row in tj.get("kernels", []):
-                if row["kernel"].startswith("k_conv3x3_bf16<2, 2, true"):
-                    traffic["fwd0"] = row["hbm_bytes_per_launch"]
-                if row["kernel"].startswith("k_conv_wgrad_bf16<2, 2"):
-                    traffic["wgrad0"] = row["hbm_bytes_per_launch"]
-            traffic["step_total"] = int(tj.get("hbm_mb_per_step", 0) * 1e6) or None
-        tsrc = "committed PMC passes (profiles/r02_traffic_step.json), valid for batch 1024 bf16 only"
+            if tj.get("library_build_id") == build_id:
+                for row in tj.get("kernels", []):
+                    if row["kernel"].startswith("k_conv3x3_bf16<2, 2, true"):
+                        traffic["fwd0"] = row["hbm_bytes_per_launch"]
+                    if row["kernel"].startswith("k_conv_wgrad_bf16<2, 2"):
+                        traffic["wgrad0"] = row["hbm_bytes_per_launch"]
+                traffic["step_total"] = int(tj.get("hbm_mb_per_step", 0) * 1e6) or None
+                tsrc = (f"PMC passes of this very build ({os.path.relpath(tpath, REPO)}, library_build_id {build_id}), "
+                        "batch 1024 bf16: 2 x FETCH_SIZE + WRITE_SIZE in separate rocprofv3 runs")
+            else:
+                # counters taken on another build of the kernels say nothing about this one: traffic stays null
+                tsrc = (f"none: {os.path.relpath(tpath, REPO)} was measured on library build "
+                        f"{tj.get('library_build_id')}, this run is build {build_id}")
         flops = CONV1_FLOP_PER_PATCH * a.batch
         roofs = {}
         if site_ms.get("wgrad0"):
@@ -273,11 +293,12 @@ def main():
                  "launches": len(site_ms["fwd0"]), "algorithmic_flop_per_launch": flops}
             if a.precision == "bf16":
                 # the bf16 conv1 forward reads the fp32 NCHW input itself and leaves the bf16 tiles behind for the
-                # weight gradient: per patch 369*121*4 B in, 384*121*2 B of tiles + 64*121*4 B of output out.
-                # That makes it HBM-bound (its MFMA floor is ~21 us, its HBM floor ~39 us at 8 TB/s).  Against the
-                # strictly compulsory bytes (input in + output out, the tiles being a by-product) the fraction is lower:
-                nbytes = a.batch * (BANDS * HW * HW * 4 + 384 * HW * HW * 2 + 64 * HW * HW * 4)
-                compulsory = a.batch * (BANDS * HW * HW * 4 + 64 * HW * HW * 4)
+                # weight gradient: per patch 369*121*4 B in, 384*121*2 B of tiles + 64*121*2 B of output (IEEE half) out
+                # = 287,012 B.  That makes it HBM-bound (its MFMA floor is ~21 us, its HBM floor ~37 us at 8 TB/s).
+                # Against the strictly compulsory bytes (input in + output out, the tiles being a by-product) the
+                # fraction is lower:
+                nbytes = a.batch * (BANDS * HW * HW * 4 + 384 * HW * HW * 2 + 64 * HW * HW * 2)
+                compulsory = a.batch * (BANDS * HW * HW * 4 + 64 * HW * HW * 2)
                 gbs = nbytes / (avg_ms * 1e-3) / 1e9
                 r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
@@ -297,8 +318,11 @@ def main():
             "config": {"workload": "Hang2020 spectral+spatial attention train step (fwd + weighted CE + bwd + Adam"
                                    + (" + RCCL grad all-reduce" if world > 1 else "") + "), bands=369 11x11 classes=200",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "overlap_comm": bool(world > 1 and not a.no_overlap),
-                       "collectives_per_step": (0 if world == 1 else (1 if a.no_overlap else 2))},
+                       "parallelism": f"dp{world}", "exchange": trainer.exchange,
+                       "overlap_comm": bool(trainer.overlap),
+                       "collectives_per_step": (0 if trainer.exchange in (None, "peer") else (2 if trainer.overlap else 1)),
+                       "exchange_launches_per_step": (1 if trainer.exchange == "peer" else 0)},
+            "library_build_id": build_id,
             "achieved_tflops_step": round(value * FLOP_PER_PATCH_STEP / 1e12, 2),
             "achieved_hbm_gbs_algorithmic": round(value * BYTES_PER_PATCH_STEP / 1e9, 1),
             "final_loss": round(final_loss, 5),
@@ -321,6 +345,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist_on:
+        trainer.close()
         torch.distributed.destroy_process_group()
 
 

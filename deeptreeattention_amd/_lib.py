@@ -77,6 +77,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.dta_abi_version.restype = C.c_int
         L.dta_last_error.restype = C.c_char_p
+        L.dta_build_id.restype = C.c_char_p
         L.dta_net_workspace_bytes.restype = C.c_size_t
         L.dta_net_workspace_bytes.argtypes = [C.POINTER(NetDesc)]
         L.dta_net_forward.restype = C.c_int
@@ -177,13 +178,15 @@ def lib():
         L.dta_xchg_set_max_workgroups.restype = None
         L.dta_xchg_set_max_workgroups.argtypes = [C.c_void_p, C.c_int]
         L.dta_xchg_allreduce.restype = C.c_int
-        L.dta_xchg_allreduce.argtypes = [C.c_void_p, C.c_void_p]
+        L.dta_xchg_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
         L.dta_xchg_adam_step.restype = C.c_int
         L.dta_xchg_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_int, C.c_void_p]
         L.dta_xchg_status.restype = C.c_int
         L.dta_xchg_status.argtypes = [C.c_void_p]
+        L.dta_xchg_last_timing.restype = C.c_int
+        L.dta_xchg_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.dta_xchg_destroy.restype = C.c_int
         L.dta_xchg_destroy.argtypes = [C.c_void_p]
         if L.dta_abi_version() != 1:

@@ -28,11 +28,25 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_digest():
+    """Hash of every source / header the library is built from: compiled into capi.hip (dta_build_id) so that
+    measurement artifacts (profiles/*.json) can name the exact build they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + sorted(HEADERS):
+        h.update(f.encode())
+        h.update(open(os.path.normpath(os.path.join(CSRC, f)), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    digest = source_digest()
+    idstamp = os.path.join(objdir, "build_id.txt")
+    id_stale = not os.path.exists(idstamp) or open(idstamp).read() != digest
     objs, procs = [], []
     extra = os.environ.get("DTA_EXTRA_HIPCC_FLAGS", "").split()
     stamp = os.path.join(objdir, "flags.txt")   # objects built with other flags (developer -D switches) are stale
@@ -42,8 +56,8 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
+        if force or _stale(o, [s] + hdrs) or (src == "capi.hip" and id_stale):
+            cmd = [hipcc] + FLAGS + extra + (['-DDTA_BUILD_ID="%s"' % digest] if src == "capi.hip" else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -57,6 +71,8 @@ def build(force=False, verbose=True):
         raise RuntimeError("hipcc failed")
     with open(stamp, "w") as f:
         f.write(" ".join(FLAGS + extra))
+    with open(idstamp, "w") as f:
+        f.write(digest)
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -646,6 +646,10 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
 extern "C" {
 
 int dta_abi_version(void) { return DTA_ABI_VERSION; }
+#ifndef DTA_BUILD_ID
+#define DTA_BUILD_ID "unknown"
+#endif
+const char* dta_build_id(void) { return DTA_BUILD_ID; }
 
 int dta_dev_reload_switches(void) { g_switches = read_switches(); return 0; }
 

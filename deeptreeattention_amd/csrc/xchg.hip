@@ -11,13 +11,13 @@
 //   1. every workgroup waits until all ready[*] >= e in its OWN page (peers write, the owner polls locally).
 //   A. reduce-scatter by pulling: rank r sums shard r of every rank's gradient buffer in rank order 0..N-1 (one fixed
 //      order for everybody: the sums, and so the replicas, are bit-identical) and stores the sums in its staging area
-//      (uncached memory of its signal allocation, system-scope stores).  The last workgroup to finish writes
-//      done[r] = e into every page.
-//   B. all-gather by pulling, fused with the optimizer: for every shard s (starting at r+1, so that the N ranks use the
-//      N-1 links of the mesh at the same time), wait for done[s] >= e, read the summed shard from rank s's staging
-//      area and apply Adam to the local parameters / moments (all ranks hold the full optimizer state, as under DDP);
-//      the gradient element is cleared (or replaced by the sum: keep_grads).  done[s] also says that rank s has
-//      finished reading this rank's gradients, so clearing is safe.
+//      (uncached memory of its signal allocation, system-scope stores).  Workgroup j owns the same relative slice of
+//      every shard in both phases, so it publishes done[r][j] = e to every page as soon as ITS slice is stored.
+//   B. all-gather by pulling, fused with the optimizer: workgroup j waits for done[s][j] >= e of every rank s, pulls
+//      slice j of every summed shard (one load per rank in flight, starting at rank r+1 so that the N ranks use the
+//      N-1 links of the mesh at the same time) and applies Adam to the local parameters / moments (all ranks hold the
+//      full optimizer state, as under DDP); the gradient elements are cleared (or replaced by the sum: keep_grads).
+//      done[s][j] also says that rank s has finished reading this rank's gradients of that slice, so clearing is safe.
 // Only flags are ever written remotely, and only into uncached memory; bulk data is pulled with system-scope loads
 // (remote lines are never served from a stale local L2 line).  Every wait is bounded (wall clock): a missing peer ends
 // the kernel with a status word in pinned host memory instead of hanging the GPU.
@@ -31,14 +31,16 @@
 namespace dta {
 
 constexpr int XCHG_MAX_WORLD = 8;
-constexpr int XCHG_SIG_BYTES = 512;      // ready[16] | done[16] | arrive (u64) ... then the staging area
+constexpr int XCHG_MAX_WGS = 256;
+constexpr int XCHG_SIG_BYTES = 16384;    // signal page (XchgSig), then the staging area
 constexpr int XCHG_THREADS = 256;
 
 struct XchgSig {
-  unsigned ready[16];
-  unsigned done[16];
-  unsigned long long arrive;
+  unsigned ready[16];                               // ready[s]: rank s's gradients of this epoch are complete
+  unsigned pad[48];
+  unsigned done[XCHG_MAX_WORLD][XCHG_MAX_WGS];      // done[s][j]: workgroup j of rank s has published its sums
 };
+static_assert(sizeof(XchgSig) <= XCHG_SIG_BYTES, "signal page overflow");
 
 struct XchgArgs {
   const float* grads[XCHG_MAX_WORLD];    // every rank's gradient buffer (own entry: the local one)
@@ -62,21 +64,19 @@ __device__ __forceinline__ unsigned ld_sys32(const unsigned* p) {
 __device__ __forceinline__ void st_sys32(unsigned* p, unsigned v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// 16-byte system-scope accesses (sc0 sc1: never served from / parked in a non-coherent cache line).  The compiler does not
-// track these loads: xchg_wait_loads() is the s_waitcnt that makes their results usable.
-__device__ __forceinline__ f32x4 ld_sys128(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
+// 16-byte system-scope accesses (sc0 sc1: never served from / parked in a non-coherent cache line) as raw buffer
+// operations: the compiler tracks their completion like any other load (hand-written global_load asm is not tracked, and
+// a register copy the compiler places before a hand-placed s_waitcnt reads the destination too early).
+typedef __amdgpu_buffer_rsrc_t xrsrc_t;
+__device__ __forceinline__ xrsrc_t xchg_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ void st_sys128(float* p, f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+constexpr int XCHG_SYS = 1 | 16;      // cache policy bits: sc0 | sc1 = system scope
+__device__ __forceinline__ f32x4 ld_sys128(xrsrc_t r, size_t float_index) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(float_index * 4), 0, XCHG_SYS));
 }
-template <int K>
-__device__ __forceinline__ void xchg_wait_loads(f32x4 (&r)[K]) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int k = 0; k < K; ++k) asm volatile("" : "+v"(r[k]));      // uses of r[k] stay below the wait
+__device__ __forceinline__ void st_sys128(xrsrc_t r, size_t float_index, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (unsigned)(float_index * 4), 0, XCHG_SYS);
 }
 
 // spin on a flag of the local page until it reaches `epoch` (wrap-safe) or the budget runs out
@@ -91,13 +91,19 @@ __device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned epoch, 
 
 __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
   __shared__ int s_abort;
-  __shared__ int s_last;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, j = blockIdx.x;
   XchgSig* mine = (XchgSig*)a.sig[a.rank];
-  if (t == 0) { s_abort = 0; s_last = 0; }
+  if (t == 0) s_abort = 0;
+  const long long tk0 = wall_clock64();
+  // alpha's float64 gradient enters the exchange as one float32 slot of the gradient buffer: converted here, once, from
+  // the (order-independently accumulated) double, so the slot does not depend on the order of any float atomics
+  if (j == 0 && t == 0 && a.alpha_slot >= 0 && a.alpha_g) {
+    st_sys32((unsigned*)(a.g + a.alpha_slot), __float_as_uint((float)a.alpha_g[0]));
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+  }
   __syncthreads();
   // 0. announce (one workgroup), 1. wait for every rank's gradients
-  if (blockIdx.x == 0 && t < a.world) st_sys32(&((XchgSig*)a.sig[t])->ready[a.rank], a.epoch);
+  if (j == 0 && t < a.world) st_sys32(&((XchgSig*)a.sig[t])->ready[a.rank], a.epoch);
   if (t < a.world && !wait_flag(&mine->ready[t], a.epoch, a.timeout_ticks)) {
     s_abort = 1;
     a.status[0] = (1 << 8) | t;
@@ -106,75 +112,74 @@ __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
   if (s_abort) return;
   if (t < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // drop what this CU / L2 still holds of the peers' buffers
   __syncthreads();
+  const long long tk1 = wall_clock64();
 
-  const size_t gthreads = (size_t)gridDim.x * XCHG_THREADS, gtid = (size_t)blockIdx.x * XCHG_THREADS + t;
-  // A. my shard: sum over ranks in rank order -> staging (one 16-byte load per rank in flight per thread)
-  {
-    const size_t lo = (size_t)a.rank * a.shard, hi = lo + a.shard < a.n ? lo + a.shard : a.n;
-    float* stage = (float*)(a.sig[a.rank] + XCHG_SIG_BYTES);
-    for (size_t i = lo + 4 * gtid; i < hi; i += 4 * gthreads) {
+  // Workgroup j owns the same relative slice {j*256 + t + k*G*256} (in 16-byte quads) of EVERY shard, in both phases:
+  // its phase-B reads of rank s's sums depend only on workgroup j of rank s, so the "sums published" flags are per
+  // (rank, workgroup) and no rank-wide counter or last-workgroup election sits on the critical path.
+  const size_t nq = a.n / 4, shard_q = a.shard / 4, stride = (size_t)gridDim.x * XCHG_THREADS;
+  auto len_q = [&](int s) -> size_t {
+    const size_t lo = (size_t)s * shard_q;
+    return lo >= nq ? 0 : (nq - lo < shard_q ? nq - lo : shard_q);
+  };
+  // A. my shard: sum over ranks in rank order -> staging (one 16-byte load per rank in flight per thread).
+  //    A single rank has nothing to sum or publish: phase B reads its gradient buffer directly.
+  if (a.world > 1) {
+    const size_t lo = (size_t)a.rank * a.shard, mylen = len_q(a.rank);
+    const xrsrc_t stage = xchg_rsrc(a.sig[a.rank] + XCHG_SIG_BYTES);
+    for (size_t q = (size_t)j * XCHG_THREADS + t; q < mylen; q += stride) {
       f32x4 part[XCHG_MAX_WORLD];
 #pragma unroll
       for (int s = 0; s < XCHG_MAX_WORLD; ++s)
-        if (s < a.world) part[s] = ld_sys128(a.grads[s] + i);
-      xchg_wait_loads(part);
+        if (s < a.world) part[s] = ld_sys128(xchg_rsrc(a.grads[s]), lo + 4 * q);
       f32x4 acc = part[0];
 #pragma unroll
       for (int s = 1; s < XCHG_MAX_WORLD; ++s)
         if (s < a.world) acc += part[s];
-      st_sys128(stage + (i - lo), acc);
+      st_sys128(stage, 4 * q, acc);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's staging stores have reached memory
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's staging stores have reached memory
     __syncthreads();
-    if (t == 0) {
-      const unsigned long long old = __hip_atomic_fetch_add(&mine->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (old + 1 == (unsigned long long)gridDim.x * a.epoch);
-    }
-    __syncthreads();
-    if (s_last && t < a.world) st_sys32(&((XchgSig*)a.sig[t])->done[a.rank], a.epoch);
+    if (t < a.world) st_sys32(&((XchgSig*)a.sig[t])->done[a.rank][j], a.epoch);
   }
-  // B. every rank's sums are published (which also says: every rank has finished reading this rank's gradients)
-  if (t < a.world && !wait_flag(&mine->done[t], a.epoch, a.timeout_ticks)) {
+  // B. every rank's workgroup j has published its sums (which also says: it has finished reading this rank's gradients
+  //    of that slice, so the slice may be cleared)
+  if (a.world > 1 && t < a.world && !wait_flag(&mine->done[t][j], a.epoch, a.timeout_ticks)) {
     s_abort = 1;
     a.status[0] = (2 << 8) | t;
   }
   __syncthreads();
   if (s_abort) return;
   const float ss = a.lr / a.bc1, rbc2 = rsqrtf(a.bc2);
-  constexpr int U = 2;
-  const size_t nq = a.n / 4, shard_q = a.shard / 4;
-  // rank r starts with the quads of shard r+1: at any moment the N ranks pull over N different links
-  const size_t rot = ((size_t)((a.rank + 1) % a.world)) * shard_q;
-  for (size_t q0 = gtid; q0 < nq; q0 += U * gthreads) {
-    f32x4 gs[U];
-    size_t idx[U];
+  for (size_t q = (size_t)j * XCHG_THREADS + t; q < shard_q; q += stride) {
+    // one load per shard in flight; rank r starts with shard r+1, so the N ranks pull over N different links at a time
+    f32x4 gs[XCHG_MAX_WORLD];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      size_t q = q0 + u * gthreads;
-      idx[u] = nq;                                        // nq = nothing to do
-      if (q < nq) {
-        q += rot;
-        if (q >= nq) q -= nq;
-        const size_t s = q / shard_q;
-        idx[u] = q;
-        gs[u] = ld_sys128((const float*)(a.sig[s] + XCHG_SIG_BYTES) + 4 * (q - s * shard_q));
+    for (int u = 0; u < XCHG_MAX_WORLD; ++u) {
+      if (u < a.world) {
+        int s = a.rank + 1 + u;
+        if (s >= a.world) s -= a.world;
+        if (q < len_q(s))
+          gs[u] = ld_sys128(xchg_rsrc(a.world > 1 ? (const void*)(a.sig[s] + XCHG_SIG_BYTES) : (const void*)a.grads[0]), 4 * q);
       }
     }
-    xchg_wait_loads(gs);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (idx[u] >= nq) continue;
-      const size_t i = 4 * idx[u];
+    for (int u = 0; u < XCHG_MAX_WORLD; ++u) {
+      if (u >= a.world) continue;
+      int s = a.rank + 1 + u;
+      if (s >= a.world) s -= a.world;
+      if (q >= len_q(s)) continue;
+      const size_t i = (size_t)s * a.shard + 4 * q;
       if (a.mode == 1) {
         const f32x4 mo = __builtin_nontemporal_load((const f32x4*)(a.m + i));
         const f32x4 vo = __builtin_nontemporal_load((const f32x4*)(a.v + i));
         f32x4 po = *(const f32x4*)(a.p + i), mn, vn;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float g = gs[u][j] * a.grad_scale;
-          mn[j] = a.beta1 * mo[j] + (1.f - a.beta1) * g;
-          vn[j] = a.beta2 * vo[j] + (1.f - a.beta2) * g * g;
-          po[j] -= ss * (mn[j] / (sqrtf(vn[j]) * rbc2 + a.eps));
+        for (int c = 0; c < 4; ++c) {
+          const float g = gs[u][c] * a.grad_scale;
+          mn[c] = a.beta1 * mo[c] + (1.f - a.beta1) * g;
+          vn[c] = a.beta2 * vo[c] + (1.f - a.beta2) * g * g;
+          po[c] -= ss * (mn[c] / (sqrtf(vn[c]) * rbc2 + a.eps));
         }
         __builtin_nontemporal_store(mn, (f32x4*)(a.m + i));
         __builtin_nontemporal_store(vn, (f32x4*)(a.v + i));
@@ -193,6 +198,8 @@ __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
       *(f32x4*)(a.g + i) = (a.mode == 1 && a.zero_grad) ? z : gs[u];
     }
   }
+  // workgroup 0's view of the launch, in 10 ns ticks: [2] waiting for the ranks to arrive, [3] the exchange proper
+  if (j == 0 && t == 0) { a.status[2] = (int)(tk1 - tk0); a.status[3] = (int)(wall_clock64() - tk1); }
 }
 
 }  // namespace dta
@@ -288,7 +295,7 @@ int dta_xchg_connect(dta_xchg* x, const void* all_handles) {
 }
 
 void dta_xchg_set_timeout(dta_xchg* x, double seconds) { if (x && seconds > 0) x->timeout_s = seconds; }
-void dta_xchg_set_max_workgroups(dta_xchg* x, int wgs) { if (x && wgs > 0 && x->epoch == 0) x->max_wgs = wgs; }
+void dta_xchg_set_max_workgroups(dta_xchg* x, int wgs) { if (x && wgs > 0 && x->epoch == 0) x->max_wgs = wgs < XCHG_MAX_WGS ? wgs : XCHG_MAX_WGS; }
 
 static int xchg_launch(dta_xchg* x, XchgArgs& a, void* stream) {
   if (!x->connected) { dta_set_error("dta_xchg: not connected (dta_xchg_connect)"); return 1; }
@@ -299,19 +306,23 @@ static int xchg_launch(dta_xchg* x, XchgArgs& a, void* stream) {
   a.status = x->status_dev;
   a.g = x->grads;
   // one workgroup per CU at most, never more than there are element pairs per shard
-  size_t wgs = (x->shard / 2 + XCHG_THREADS - 1) / XCHG_THREADS;
+  size_t wgs = (x->shard / 4 + XCHG_THREADS - 1) / XCHG_THREADS;
   if (wgs > (size_t)x->max_wgs) wgs = x->max_wgs;
+  if (wgs > XCHG_MAX_WGS) wgs = XCHG_MAX_WGS;
   if (wgs < 1) wgs = 1;
   hipLaunchKernelGGL(k_xchg_step, dim3((unsigned)wgs), dim3(XCHG_THREADS), 0, (hipStream_t)stream, a);
   DTA_CHECK_LAUNCH("k_xchg_step");
   return 0;
 }
 
-int dta_xchg_allreduce(dta_xchg* x, void* stream) {
+int dta_xchg_allreduce(dta_xchg* x, const double* alpha_g, long long alpha_slot, void* stream) {
   if (!x) { dta_set_error("dta_xchg_allreduce: null exchange"); return 1; }
+  if (alpha_g && (alpha_slot < 0 || (size_t)alpha_slot >= x->n_pad)) { dta_set_error("dta_xchg_allreduce: alpha's slot lies outside the buffer"); return 1; }
   XchgArgs a;
   memset(&a, 0, sizeof(a));
-  a.mode = 0; a.alpha_slot = -1;
+  a.mode = 0;
+  a.alpha_g = (double*)alpha_g;          // read only in this mode
+  a.alpha_slot = alpha_g ? alpha_slot : -1;
   return xchg_launch(x, a, stream);
 }
 
@@ -342,6 +353,15 @@ int dta_xchg_status(dta_xchg* x) {
   const int s = ((volatile int*)x->status_host)[0];
   if (s) dta_set_error("dta_xchg: timed out in phase %d waiting for rank %d (a peer is missing, stuck or not co-scheduled)", s >> 8, s & 255);
   return s;
+}
+
+/* Development aid: the last launch as workgroup 0 saw it, in microseconds (host read of pinned words; synchronise first). */
+int dta_xchg_last_timing(dta_xchg* x, float* wait_us, float* exchange_us) {
+  if (!x) return 1;
+  const volatile int* s = (const volatile int*)x->status_host;
+  if (wait_us) *wait_us = s[2] * 0.01f;
+  if (exchange_us) *exchange_us = s[3] * 0.01f;
+  return 0;
 }
 
 int dta_xchg_destroy(dta_xchg* x) {

@@ -41,16 +41,29 @@ class GradSync:
     (dta_net_backward_dp / dta_adam_step_dp), so nothing runs around the collective; callers without those kernels pass
     (alpha_grad, alpha_slot) and get the two copies done here."""
 
-    def __init__(self, world, group=None, side_stream=None):
+    def __init__(self, world, group=None, side_stream=None, rccl=None):
+        """rccl: a RcclDirect -> every reduction is one ncclAllReduce enqueued on the compute stream itself (nothing to
+        wait for afterwards); None -> torch.distributed work objects on the backend's stream."""
         self.world, self.group = int(world), group
+        self.rccl = rccl
         self.grad_scale = 1.0 / self.world
         self.collectives = 0          # all-reduces issued so far (tests: <= 2 per step)
         self._pending, self._post = [], []
 
+    _warned_skip = False
+
     def _ar(self, t):
         if os.environ.get("DTA_SKIP_ALLREDUCE") == "1":      # development: the phase split without the collectives
+            if not GradSync._warned_skip:
+                import warnings
+                warnings.warn("DTA_SKIP_ALLREDUCE=1: gradient all-reduces are being DROPPED (replicas diverge); "
+                              "development measurement switch, never set it in a training job")
+                GradSync._warned_skip = True
             return
-        self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.rccl is not None:
+            self.rccl.all_reduce(t)
+        else:
+            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.collectives += 1
 
     def reduce_early(self, flat_head, alpha_grad=None, alpha_slot=None):
@@ -132,10 +145,12 @@ class PeerExchange:
         self.grad_scale = 1.0 / self.world
         self.steps = 0
 
-    def allreduce(self):
-        """grad := sum over ranks (enqueued on the current stream)."""
+    def allreduce(self, alpha_g=None, alpha_slot=-1):
+        """grad := sum over ranks (enqueued on the current stream).  alpha_g: this rank's float64 d(alpha), which enters
+        the sum through slot `alpha_slot` of the buffer."""
         from . import _lib
-        _lib.check(self._L.dta_xchg_allreduce(self._h, _lib.current_stream_ptr()), "dta_xchg_allreduce")
+        _lib.check(self._L.dta_xchg_allreduce(self._h, _lib.ptr(alpha_g), int(alpha_slot) if alpha_g is not None else -1,
+                                              _lib.current_stream_ptr()), "dta_xchg_allreduce")
         self.steps += 1
 
     def adam_step(self, p, m, v, alpha, alpha_g, alpha_slot, alpha_m, alpha_v, step, lr, betas, eps, zero_grad):
@@ -188,7 +203,7 @@ class RcclDirect:
             raise RuntimeError("librccl.so not found")
 
         class UniqueId(C.Structure):
-            _fields_ = [("internal", C.c_char * 128)]
+            _fields_ = [("internal", C.c_ubyte * 128)]
         self._lib = lib
         lib.ncclGetErrorString.restype = C.c_char_p
         lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
@@ -198,7 +213,7 @@ class RcclDirect:
         uid = UniqueId()
         if self.rank == 0:
             self._ok(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [bytes(uid.internal) if self.rank == 0 else None]
+        box = [C.string_at(C.byref(uid), 128) if self.rank == 0 else None]      # all 128 bytes (the id holds NULs)
         if self.world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         C.memmove(C.byref(uid), box[0], 128)
@@ -225,3 +240,49 @@ class RcclDirect:
             torch.cuda.synchronize()
             self._lib.ncclCommDestroy(self._comm)
             self._comm = None
+
+
+def probe_peer_exchange(group=None, budget_s=90.0):
+    """Collective over `group`: run the crash-isolated self-test of the peer exchange (peer_probe.py, one subprocess per
+    rank on this rank's device) and agree on the outcome.  True = every rank's probe mapped its peers and summed
+    correctly; a fault in a probe (e.g. no peer access between two devices) costs only that subprocess."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [tempfile.mkdtemp(prefix="dta_peer_probe_") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    here = os.path.dirname(os.path.abspath(__file__))
+    ok = False
+    try:
+        proc = subprocess.run([sys.executable, os.path.join(here, "peer_probe.py"), box[0], str(rank), str(world),
+                               str(torch.cuda.current_device())], timeout=budget_s, capture_output=True, text=True)
+        ok = proc.returncode == 0
+        why = (proc.stderr or "").strip().splitlines()[-1:] if not ok else []
+    except Exception as e:         # timeout, missing interpreter, ...
+        why = [repr(e)]
+    votes = [None] * world
+    dist.all_gather_object(votes, (ok, why), group=group)
+    if rank == 0:
+        shutil.rmtree(box[0], ignore_errors=True)
+    return all(v[0] for v in votes), [v[1] for v in votes]
+
+
+def choose_exchange(prefer=None, group=None):
+    """Which gradient exchange a trainer uses for world > 1: "peer" (csrc/xchg.hip, fused with Adam), "rccl" (ncclAllReduce
+    on the compute stream) or "torch" (torch.distributed work objects: the portable path, gloo in the CPU tests).
+    prefer=None: peer when the crash-isolated probe passes on every rank, else rccl on an RCCL process group, else torch."""
+    if prefer in ("peer", "rccl", "torch"):
+        return prefer
+    if prefer not in (None, "auto"):
+        raise ValueError("exchange must be one of None / 'auto' / 'peer' / 'rccl' / 'torch'")
+    if not torch.cuda.is_available():
+        return "torch"
+    ok, why = probe_peer_exchange(group)
+    if ok:
+        return "peer"
+    if dist.get_rank(group) == 0:
+        import warnings
+        warnings.warn("peer gradient exchange unavailable on this node ({}); using the RCCL / torch.distributed path".format(why))
+    return "rccl" if dist.get_backend(group) == "nccl" else "torch"

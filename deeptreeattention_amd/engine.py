@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from . import Hang2020 as H
-from .dist import GradSync, kept_anywhere
+from .dist import GradSync, PeerExchange, RcclDirect, choose_exchange
 
 
 def _round4(n):
@@ -42,7 +42,7 @@ class FusedTrainer:
 
     def __init__(self, model, lr, loss_weight=None, betas=(0.9, 0.999), eps=1e-8, process_group=None,
                  overlap_comm=True, keep_grads=False, last_head_only=False, three_head_loss=False,
-                 extra_grad_slots=0, storage=None):
+                 extra_grad_slots=0, storage=None, exchange=None, exchange_opts=None):
         """three_head_loss: train on the SUM of the class-weighted cross-entropies of every classifier head (the Hang
         et al. recipe BASELINE.json's north_star words as "three-head weighted cross-entropy"): three heads for a
         spectral / spatial network, all six for Hang2020 (whose sigmoid(alpha) blend is then not on the graph, so
@@ -50,7 +50,13 @@ class FusedTrainer:
         step, which keeps the last head only (Hang2020.py:256-257, src/main.py:78).
         extra_grad_slots: fp32 slots appended to the first gradient bucket for a caller's own small gradients
         (MetadataTrainer: the site MLP / fusion layer travel in the same collective).
-        storage: (p, g, m, v) flat fp32 tensors to carve the buffers from (EnsembleTrainer: one buffer for all years)."""
+        storage: (p, g, m, v) flat fp32 tensors to carve the buffers from (EnsembleTrainer: one buffer for all years).
+        exchange: how gradients cross the ranks when data-parallel -- "peer": the sum over ranks and Adam are ONE launch
+        on the compute stream through IPC-mapped peer memory (csrc/xchg.hip; ranks = processes of one node); "rccl":
+        one ncclAllReduce of the flat buffer enqueued on the compute stream (librccl called directly); "torch":
+        torch.distributed all-reduces (two buckets overlapped with the first conv's weight gradient when
+        overlap_comm); None: peer if the crash-isolated probe passes on every rank, else rccl / torch.
+        exchange_opts: keyword arguments of dist.PeerExchange (timeout_s, max_workgroups)."""
         if not isinstance(model, H._Net):
             raise TypeError("FusedTrainer needs a deeptreeattention_amd network module")
         self.model = model
@@ -65,7 +71,10 @@ class FusedTrainer:
         # RCCL code path -- streams, buckets, the alpha slot -- on a single-GPU box; tests/test_rccl_single_gpu.py)
         self.comm = self.world > 1 or (os.environ.get("DTA_FORCE_COLLECTIVES") == "1" and torch.distributed.is_available()
                                        and torch.distributed.is_initialized())
-        self.overlap = overlap_comm and self.comm
+        self.exchange = None           # "peer" / "rccl" / "torch" when this trainer exchanges gradients itself
+        if self.comm and storage is None:
+            self.exchange = choose_exchange(exchange, process_group) if self.world > 1 else (exchange or "torch")
+        self.overlap = overlap_comm and self.comm and self.exchange in (None, "torch")
         self.hang = model._net_code == _lib.NET_HANG2020
         self.single_score = model._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
         self.three_head = bool(three_head_loss)
@@ -95,9 +104,16 @@ class FusedTrainer:
         self.alpha_slot_off = n_rest + self.extra_n
         n = self.split + n_first
         self.n, self.n_first = n, n_first
+        self.ex = None
         if storage is None:
             self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
-            self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+            if self.exchange == "peer":
+                # the gradient buffer is the exchange's: library-owned device memory every peer has mapped
+                self.ex = PeerExchange(n, process_group, **(exchange_opts or {}))
+                assert self.ex.capacity == n
+                self.flat_g = self.ex.grad
+            else:
+                self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
             self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
             self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
             head = tuple(t[:self.split] for t in (self.flat_p, self.flat_g, self.flat_m, self.flat_v))
@@ -135,7 +151,8 @@ class FusedTrainer:
         self._ws = None
         self._ws_key = None
         self._desc_key = None
-        self.sync = GradSync(self.world, self.pg)
+        self._reduced = False          # peer exchange: the gradient buffer already holds the sum (reduce_now)
+        self.sync = GradSync(self.world, self.pg, rccl=RcclDirect(self.pg) if self.exchange == "rccl" else None)
         if self.comm and storage is None:
             self.broadcast_parameters()
 
@@ -151,7 +168,31 @@ class FusedTrainer:
     # ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src=0):
         """DDP start-up semantics: every rank starts from rank `src`'s parameters and buffers."""
-        self.sync.broadcast([self.p_head, self.p_tail] + ([self.alpha.data] if self.hang else []) + list(self.model.buffers()), src)
+        if self.world > 1:
+            self.sync.broadcast([self.p_head, self.p_tail] + ([self.alpha.data] if self.hang else []) + list(self.model.buffers()), src)
+
+    def reduce_now(self):
+        """Peer exchange only: sum the gradient buffer over the ranks NOW (one launch) instead of inside the optimizer
+        launch -- for callers that read summed gradients before the step (MetadataTrainer's spare slots)."""
+        al = self.alpha_on_graph
+        self.ex.allreduce(self.alpha_g if al else None, self.alpha_slot_off)
+        self._reduced = True
+
+    def check_exchange(self):
+        """Raise if a peer-exchange step timed out (call after synchronising the stream; free otherwise)."""
+        if self.ex is not None:
+            self.ex.check()
+
+    def close(self):
+        """Collective: release the peer exchange / RCCL communicator (every rank calls it)."""
+        if self.ex is not None:
+            self.flat_g = self.g_head = self.g_tail = None
+            self._gview = {}
+            self.ex.close()
+            self.ex = None
+        if self.sync.rccl is not None:
+            self.sync.rccl.close()
+            self.sync.rccl = None
 
     def grad_of(self, param):
         """Gradient view (inside the flat gradient buffer) of one of the model's fp32 parameters.  After train_step
@@ -308,15 +349,16 @@ class FusedTrainer:
         self._zero_grads()             # C-ABI contract: gradient buffers (and dalpha) arrive zero-filled
 
         # data-parallel: alpha's gradient is also accumulated (fp32) into its slot of the first bucket by the kernels
-        slot = _lib.ptr(self.alpha_slot) if (self.comm and self.alpha_on_graph) else None
+        # (peer exchange: the exchange launch itself converts the float64 d(alpha) into the slot)
+        slot = _lib.ptr(self.alpha_slot) if (self.comm and self.alpha_on_graph and self.ex is None) else None
 
         def run(phases):
             tiles = None if self._tiles is None else _lib.ptr(self._tiles)
             _lib.check(L.dta_net_backward_dp(d, self.nets, alpha, tiles, _lib.ptr(self._ws), C.byref(table), djoint,
                                              self.grads, dalpha, slot, phases, st), "dta_net_backward_dp")
         ag, slot_t = None, None        # (GradSync's copy-in / copy-out of alpha is for callers without the slot kernels)
-        if not self.comm:
-            run(3)
+        if not self.comm or self.ex is not None:
+            run(3)                     # peer exchange: the sum over ranks happens inside the optimizer launch
         elif self.overlap:
             # phase 1: everything but the first conv's weight gradient; its all-reduce (backend stream) runs while
             # phase 2, the first conv's weight gradient, is computed: two collectives per step
@@ -334,7 +376,7 @@ class FusedTrainer:
             self.sync.reduce_early(self.g_head, ag, slot_t)
             self.sync.reduce_late(self.g_tail)
             self.sync.finish()
-        if self.comm and self.alpha_on_graph and self.keep_grads:
+        if self.comm and self.alpha_on_graph and self.keep_grads and self.ex is None:
             self.alpha_g.copy_(self.alpha_slot[0])      # readable summed gradient (grad_of); the optimizer reads the slot
         self._grads_clear = False
 
@@ -354,6 +396,15 @@ class FusedTrainer:
         self.step_count += 1
         # default: step + zero_grad in one pass, so the next backward finds its gradient buffers already cleared
         al = self.alpha_on_graph
+        if self.ex is not None and not self._reduced:
+            # sum over ranks + Adam (+ zero_grad) in one launch; with keep_grads the buffer holds the summed gradient after
+            self.ex.adam_step(self.flat_p, self.flat_m, self.flat_v, self.alpha if al else None,
+                              self.alpha_g if al else None, self.alpha_slot_off, self.alpha_m if al else None,
+                              self.alpha_v if al else None, self.step_count, self.lr, self.betas, self.eps,
+                              zero_grad=not self.keep_grads)
+            self._grads_clear = not self.keep_grads
+            return
+        self._reduced = False
         slot = _lib.ptr(self.alpha_slot) if (self.comm and al) else None
         if self.flat_p is not None:
             segs = [(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.n)]
@@ -438,7 +489,9 @@ class EnsembleTrainer:
     years' first-conv weight gradients), one otherwise."""
 
     def __init__(self, model, lr, loss_weight=None, betas=(0.9, 0.999), eps=1e-8, process_group=None,
-                 overlap_comm=True, keep_grads=False):
+                 overlap_comm=True, keep_grads=False, exchange=None, exchange_opts=None):
+        """exchange / exchange_opts: as for FusedTrainer ("peer": one all-reduce launch through peer memory before the
+        gated optimizer passes; "rccl": one ncclAllReduce on the compute stream; "torch": two overlapped buckets)."""
         from .year import learned_ensemble
         if not isinstance(model, learned_ensemble):
             raise TypeError("EnsembleTrainer needs a deeptreeattention_amd.year.learned_ensemble")
@@ -454,6 +507,13 @@ class EnsembleTrainer:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             world = torch.distributed.get_world_size(process_group)
         self.flat = [torch.zeros(_round4(n_head + Y) + n_tail, dtype=torch.float32, device=dev) for _ in range(4)]   # p g m v
+        self.ex, self.exchange = None, None
+        if world > 1:
+            self.exchange = choose_exchange(exchange, process_group)
+            if self.exchange == "peer":
+                self.ex = PeerExchange(self.flat[1].numel(), process_group, **(exchange_opts or {}))
+                assert self.ex.capacity == self.flat[1].numel()
+                self.flat[1] = self.ex.grad           # the gradient buffer every peer has mapped
         self.years = []
         if world == 1:
             # no exchange: each year's two segments adjacent, so its optimizer pass is one launch; flags unused
@@ -477,9 +537,9 @@ class EnsembleTrainer:
                 to += t
         first = self.years[0]
         self.device, self.world, self.pg = first.device, first.world, first.pg
-        self.overlap, self.keep_grads = first.overlap, bool(keep_grads)
+        self.overlap, self.keep_grads = first.overlap and self.exchange in (None, "torch"), bool(keep_grads)
         self.betas, self.eps = betas, float(eps)
-        self.sync = first.sync
+        self.sync = first.sync if self.exchange != "rccl" else GradSync(world, process_group, rccl=RcclDirect(process_group))
         self.loss_weight = first.loss_weight
         self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self._shape = None
@@ -611,7 +671,11 @@ class EnsembleTrainer:
             return self.loss
         # data-parallel: every rank issues the same collectives whatever it kept; skipped years send their zeros
         mask = sum(1 << i for i, k in enumerate(local) if k)
-        if self.overlap:
+        if self.ex is not None:
+            self._backward(kept, 3)
+            self.flags.copy_(self._flag_table[mask])
+            self.ex.allreduce()                 # gradients and year flags summed over the ranks in one launch
+        elif self.overlap:
             self._backward(kept, 1)
             self.flags.copy_(self._flag_table[mask])
             self.sync.reduce_early(self.g_head)
@@ -625,6 +689,20 @@ class EnsembleTrainer:
         self.dev_steps.add_((self.flags > 0).to(torch.int32))
         self._adam_gated()
         return self.loss
+
+    def close(self):
+        """Collective: release the peer exchange / RCCL communicator (every rank calls it)."""
+        if self.ex is not None:
+            for t in self.years:
+                t._gview = {}
+                t.g_head = t.g_tail = None
+            self.g_head = self.g_tail = self.flags = None
+            self.flat[1] = None
+            self.ex.close()
+            self.ex = None
+        if self.sync.rccl is not None:
+            self.sync.rccl.close()
+            self.sync.rccl = None
 
     def forward_loss(self, images, y, present=None):
         """validation_step of the level (multi_stage.py:290-304): ensemble scores + weighted CE, no update."""
@@ -673,7 +751,7 @@ class MetadataTrainer:
     still exchanges gradients in at most two collectives per step."""
 
     def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, process_group=None, overlap_comm=True,
-                 keep_grads=False):
+                 keep_grads=False, exchange=None, exchange_opts=None):
         from .metadata import metadata_sensor_fusion
         if not isinstance(model, metadata_sensor_fusion):
             raise TypeError("MetadataTrainer needs a deeptreeattention_amd.metadata.metadata_sensor_fusion")
@@ -681,7 +759,7 @@ class MetadataTrainer:
         self.small = list(model.metadata_model.parameters()) + list(model.fc1.parameters())
         self.small_sizes = [p.numel() for p in self.small]
         self.sensor = FusedTrainer(model.sensor_model, lr, None, betas, eps, process_group, overlap_comm, keep_grads,
-                                   extra_grad_slots=sum(self.small_sizes))
+                                   extra_grad_slots=sum(self.small_sizes), exchange=exchange, exchange_opts=exchange_opts)
         self.sensor.external_loss = True         # the loss is taken on the fused (HSI + site) scores, by torch
         self.opt = torch.optim.Adam(self.small, lr=lr, betas=betas, eps=eps)
         self.world, self.pg = self.sensor.world, self.sensor.pg
@@ -716,6 +794,8 @@ class MetadataTrainer:
             torch.cat([g.reshape(-1) for g in grads], out=self.sensor.extra_g)     # ride in the first bucket
         self.sensor._backward(scores.grad.contiguous())
         if self.world > 1:
+            if self.sensor.ex is not None:
+                self.sensor.reduce_now()                  # peer exchange: sums (incl. the spare slots) before they are read
             chunks = self.sensor.extra_g.split(self.small_sizes)
             for p, g, c in zip(self.small, grads, chunks):
                 p.grad = g

@@ -1,0 +1,89 @@
+"""Crash-isolated self-test of the peer gradient exchange (csrc/xchg.hip), run as ONE SUBPROCESS PER RANK before a
+trainer trusts the exchange on an unknown node:
+
+    python deeptreeattention_amd/peer_probe.py <rendezvous dir> <rank> <world> <device ordinal>
+
+The ranks' probes find each other through files in the rendezvous directory (IPC handles, two barriers), map each
+other's buffers, run three all-reduces over 256 Ki floats with known contents and compare the result bit for bit with
+the sum in rank order.  Exit code 0 = the exchange works between these devices.  A GPU memory fault, a missing peer
+mapping or a wrong sum ends only the probe process; the parent (dist.probe_peer_exchange) then falls back to RCCL.
+No torch import here: ctypes on libdta_hip.so and libamdhip64.so only, so a probe starts in well under a second."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+N = 1 << 18
+
+
+def _pattern(rank, step, n):
+    i = np.arange(n, dtype=np.int64)
+    return (((i * 2654435761 + rank * 40503 + step * 9973) % 2001 - 1000).astype(np.float32) / 1024.0)
+
+
+def _wait_files(d, prefix, world, deadline):
+    while True:
+        if all(os.path.exists(os.path.join(d, f"{prefix}{r}")) for r in range(world)):
+            return
+        if time.time() > deadline:
+            raise TimeoutError(f"peer probe: ranks missing at '{prefix}'")
+        time.sleep(0.01)
+
+
+def _put(d, name, data=b"1"):
+    tmp = os.path.join(d, name + ".tmp")
+    with open(tmp, "wb") as f:
+        f.write(data)
+    os.rename(tmp, os.path.join(d, name))
+
+
+def main(d, rank, world, device, budget_s=60.0):
+    import _lib          # the package's ctypes binding, imported by path: the package itself would pull in torch
+    deadline = time.time() + budget_s
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    if hip.hipSetDevice(int(device)) != 0:
+        raise RuntimeError("hipSetDevice failed")
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.dta_xchg_create(rank, world, N, C.byref(h)), "dta_xchg_create")
+    L.dta_xchg_set_timeout(h, 10.0)
+    L.dta_xchg_set_max_workgroups(h, 32)          # the probes of a shared-GPU test box must stay co-resident
+    mine = C.create_string_buffer(_lib.XCHG_HANDLE_BYTES)
+    _lib.check(L.dta_xchg_export(h, mine), "dta_xchg_export")
+    _put(d, f"h{rank}", mine.raw)
+    _wait_files(d, "h", world, deadline)
+    blob = b"".join(open(os.path.join(d, f"h{r}"), "rb").read() for r in range(world))
+    _lib.check(L.dta_xchg_connect(h, C.create_string_buffer(blob, len(blob))), "dta_xchg_connect")
+    _put(d, f"c{rank}")
+    _wait_files(d, "c", world, deadline)
+    g = L.dta_xchg_grad_buffer(h)
+    out = np.empty(N, np.float32)
+    ok = True
+    for step in range(3):
+        src = _pattern(rank, step, N)
+        if hip.hipMemcpy(g, src.ctypes.data, 4 * N, 1) != 0:
+            raise RuntimeError("hipMemcpy H2D failed")
+        hip.hipDeviceSynchronize()
+        _lib.check(L.dta_xchg_allreduce(h, None), "dta_xchg_allreduce")
+        if hip.hipDeviceSynchronize() != 0:
+            raise RuntimeError("exchange kernel failed")
+        if L.dta_xchg_status(h) != 0:
+            raise RuntimeError(L.dta_last_error().decode())
+        if hip.hipMemcpy(out.ctypes.data, g, 4 * N, 2) != 0:
+            raise RuntimeError("hipMemcpy D2H failed")
+        want = _pattern(0, step, N)
+        for r in range(1, world):
+            want = want + _pattern(r, step, N)
+        ok = ok and np.array_equal(out, want)
+    _put(d, f"d{rank}")
+    _wait_files(d, "d", world, deadline)        # nobody unmaps while a peer may still read
+    L.dta_xchg_destroy(h)
+    return 0 if ok else 3
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.exit(main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])))

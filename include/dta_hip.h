@@ -62,6 +62,9 @@ typedef struct dta_subnet_grads {
 #define DTA_SKIP_BLEND 16
 
 int dta_abi_version(void);
+/* Hash of the sources this library was built from (python -m deeptreeattention_amd.build): measurement artifacts record
+ * it, bench.py refuses to quote counters taken on another build. */
+const char* dta_build_id(void);
 const char* dta_last_error(void);
 
 /* Bytes of scratch + saved-activation workspace dta_net_forward/backward need for `d` (same blob for both;
@@ -231,18 +234,23 @@ void dta_xchg_set_timeout(dta_xchg* x, double seconds);   /* bound of every in-k
 /* Grid bound of the exchange launch (default 256, one workgroup per CU); only before the first step.  Ranks that share
  * one GPU (tests) must keep world x workgroups co-resident: every rank's launch waits in-kernel for the others. */
 void dta_xchg_set_max_workgroups(dta_xchg* x, int workgroups);
-/* g := sum over ranks of g (all ranks end with the same bits). */
-int dta_xchg_allreduce(dta_xchg* x, void* stream);
+/* g := sum over ranks of g (all ranks end with the same bits).  alpha_g (may be NULL): this rank's float64 d(alpha); the
+ * launch first stores it, rounded to float32, in slot alpha_slot of the gradient buffer, so that it takes part in the sum. */
+int dta_xchg_allreduce(dta_xchg* x, const double* alpha_g, long long alpha_slot, void* stream);
 /* Sum over ranks + dta_adam_step_dp's update in one launch.  p / m / v: this rank's flat buffers of
- * dta_xchg_grad_capacity(x) floats; alpha_slot: index (in floats) of alpha's exchange slot inside the gradient buffer
- * (dta_net_backward_dp's dalpha_f32), or -1 with alpha_p NULL; alpha_g (may be NULL) receives the summed gradient
- * (zero_grad = 0) or is cleared.  zero_grad != 0: the gradient buffer is cleared for the next backward; else it holds the sum. */
+ * dta_xchg_grad_capacity(x) floats; alpha_slot: index (in floats) of alpha's exchange slot inside the gradient buffer, or
+ * -1 with alpha_p NULL; alpha_g: this rank's float64 d(alpha) as the backward left it -- the launch rounds it to float32
+ * into the slot before the sum (no float atomics anywhere: replicas and reruns are bit-identical) and afterwards stores
+ * the summed gradient there (zero_grad = 0) or clears it.  zero_grad != 0: the gradient buffer is cleared for the next backward; else it holds the sum. */
 int dta_xchg_adam_step(dta_xchg* x, float* p, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,
                        long long alpha_slot, double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2,
                        float eps, float grad_scale, int zero_grad, void* stream);
 /* 0 = every step so far completed; otherwise (phase << 8 | rank waited for) of the first timed-out wait (host-side read of
  * a pinned word: meaningful once the stream has been synchronised). */
 int dta_xchg_status(dta_xchg* x);
+/* Development aid: how long workgroup 0 of the LAST exchange launch waited for the ranks to arrive and how long the
+ * exchange proper took afterwards, in microseconds (pinned host words: synchronise the stream first). */
+int dta_xchg_last_timing(dta_xchg* x, float* wait_us, float* exchange_us);
 int dta_xchg_destroy(dta_xchg* x);
 
 /* ---- stand-alone building blocks (same kernels as the network-level path) ------------------------------------ */

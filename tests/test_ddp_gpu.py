@@ -44,7 +44,7 @@ def _worker(rank, world, port, overlap, out):
             for prm in m.parameters():
                 prm.add_(0.5)
     m = m.to(dev).train()
-    tr = FusedTrainer(m, lr=1e-3, overlap_comm=overlap)
+    tr = FusedTrainer(m, lr=1e-3, overlap_comm=overlap, exchange="torch")
     assert tr.world == world
     x = prng.uniform01(100 + rank, 1, (B, BANDS, 11, 11))
     y = prng.randint(100 + rank, 2, (B,), CLASSES)
@@ -106,7 +106,7 @@ def _ensemble_worker(rank, world, port, out):
     torch.cuda.set_device(0)
     torch.manual_seed(5 + rank)                       # different start per rank: the start-up broadcast must fix it
     m = learned_ensemble(3, CLASSES, {"pretrain_state_dict": None, "bands": BANDS}).to(dev).train()
-    tr = EnsembleTrainer(m, lr=1e-3)
+    tr = EnsembleTrainer(m, lr=1e-3, exchange="torch")
     losses = []
     for step in range(2):
         imgs = [torch.from_numpy(prng.uniform01(200 + 10 * step + rank, yy, (B, BANDS, 11, 11))).to(dev) for yy in range(3)]
@@ -163,7 +163,7 @@ def _metadata_worker(rank, world, port, out):
     torch.manual_seed(9 + rank)
     m = metadata_sensor_fusion(bands=BANDS, sites=4, classes=CLASSES).to(dev).train()
     m.metadata_model.dropout.p = 0.0
-    tr = MetadataTrainer(m, lr=1e-3)
+    tr = MetadataTrainer(m, lr=1e-3, exchange="torch")
     for step in range(2):
         x = torch.from_numpy(prng.uniform01(300 + 10 * step + rank, 1, (B, BANDS, 11, 11))).to(dev)
         site = torch.from_numpy(prng.randint(300 + rank, 2, (B,), 4)).to(dev)

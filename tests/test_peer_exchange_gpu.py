@@ -29,6 +29,10 @@ def _grad(rank, step, n):
     return (((i * 2654435761 + rank * 40503 + step * 9973) % 2001 - 1000).astype(np.float32) / 1024.0)
 
 
+def _alpha_grad(rank, step):
+    return 1e-3 * (rank + 1) * step + 1e-11        # (not representable in float32: the slot carries its rounding)
+
+
 def _adam_np(p, m, v, g, step, lr, b1, b2, eps, scale):
     f = np.float32
     g = (g * f(scale)).astype(f)
@@ -78,6 +82,7 @@ def _worker(rank, world, port, out):
     slot = 12345
     for step in range(1, 4):
         ex.grad.copy_(torch.from_numpy(np.resize(_grad(rank, 10 + step, N), n)).to(dev))
+        ag.fill_(_alpha_grad(rank, step))          # this rank's float64 d(alpha): enters the sum through the slot
         ex.adam_step(p, m, v, alpha, ag, slot, am, av, step, 1e-3, (0.9, 0.999), 1e-8, zero_grad=(step != 3))
     torch.cuda.synchronize()
     ex.check()
@@ -108,8 +113,12 @@ def test_peer_allreduce_and_adam(world):
         g = _grad(0, 10 + step, N)
         for r in range(1, world):
             g = g + _grad(r, 10 + step, N)
+        gsum = np.float32(_alpha_grad(0, step))
+        for r in range(1, world):
+            gsum = np.float32(gsum + np.float32(_alpha_grad(r, step)))
+        g[12345] = gsum                                # the slot's gradient-buffer content is replaced by d(alpha)
         p, m, v = _adam_np(p, m, v, g, step, 1e-3, 0.9, 0.999, 1e-8, 1.0 / world)
-        ga = float(g[12345]) / world
+        ga = float(gsum) / world
         am = 0.9 * am + 0.1 * ga
         av = 0.999 * av + 0.001 * ga * ga
         alpha -= (1e-3 / (1 - 0.9 ** step)) * (am / (np.sqrt(av) / np.sqrt(1 - 0.999 ** step) + 1e-8))

@@ -1,0 +1,191 @@
+"""Data-parallel train steps at bench-scale batch (B = 530 / 1024, bf16: the fused fp32-input first conv and the
+persistent stage kernels bench.py times) with N ranks sharing ONE GPU, against the NumPy oracle run with the bf16 mode's
+roundings: the peer exchange (csrc/xchg.hip: sum over ranks + Adam in one launch) and the phased two-bucket path over
+torch.distributed (backward phases 1 / 2, alpha's exchange slot, dta_adam_step_dp).  Expected: the gradient every rank
+steps with is the MEAN over ranks of the per-rank gradients (DDP semantics, reference train.py:89-98: per-rank BatchNorm
+statistics, per-rank loss normalisation), replicas stay bit-identical."""
+import datetime
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+BANDS, CLASSES, SEED = 48, 11, 9
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _batch(rank, B):
+    from oracle import prng
+    return prng.uniform01(300 + rank, 1, (B, BANDS, 11, 11)), prng.randint(300 + rank, 2, (B,), CLASSES)
+
+
+def _weights():
+    return (0.1 + (np.arange(CLASSES) % 7)).astype(np.float32)
+
+
+def _worker(rank, world, port, B, exchange, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from oracle import hang2020_np as O
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    p = O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=SEED)
+    m = H.Hang2020(BANDS, CLASSES, precision="bf16")
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in p.items()})
+    m = m.to(dev).train()
+    tr = FusedTrainer(m, lr=1e-3, loss_weight=torch.from_numpy(_weights()), keep_grads=True, exchange=exchange,
+                      exchange_opts={"max_workgroups": 32, "timeout_s": 30.0} if exchange == "peer" else None)
+    assert tr.exchange == exchange and tr.world == world
+    x, y = _batch(rank, B)
+    loss = tr.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    torch.cuda.synchronize()
+    tr.check_exchange()
+    res = {"loss": float(loss), "alpha_g": float(tr.alpha_g),
+           "grads": {k: tr.grad_of(q).detach().cpu().numpy().copy() for k, q in m.named_parameters() if q.dtype == torch.float32},
+           "state": {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}}
+    # a second step with the summed gradients left in the buffer (keep_grads): the backward must start from zeros again
+    tr.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    torch.cuda.synchronize()
+    tr.check_exchange()
+    res["state2"] = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    out[rank] = res
+    tr.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange,world,B", [("peer", 2, 530), ("peer", 4, 530), ("peer", 2, 1024), ("torch", 2, 530),
+                                              ("torch", 2, 1024)])
+def test_dp_step_at_bench_batch_vs_oracle(exchange, world, B):
+    from conftest import rel_l2
+    from oracle import hang2020_np as O
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), B, exchange, out), nprocs=world, join=True)
+    p = O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=SEED)
+    w = _weights()
+    grads, losses, upds = [], [], []
+    O.bf16_mode(True)
+    try:
+        for rank in range(world):
+            x, y = _batch(rank, B)
+            logits, cache, upd = O.hang2020_fwd(p, x, True, np.float64)
+            loss, dl = O.weighted_cross_entropy(logits, y, w)
+            grads.append(O.hang2020_bwd(p, cache, dl, np.float64))
+            losses.append(loss)
+            upds.append(upd)
+    finally:
+        O.bf16_mode(False)
+    mean_g = {k: sum(np.asarray(g[k], np.float64) for g in grads) / world for k in grads[0]}
+    num = den = 0.0
+    for k, v in mean_g.items():
+        if k.endswith("conv_layer.bias") or k == "alpha" or not np.any(v):
+            continue
+        got = np.asarray(out[0]["grads"][k], np.float64) / world       # the buffer holds the SUM over ranks
+        num += float(((got - v) ** 2).sum())
+        den += float((v ** 2).sum())
+        if v.size >= 1000:
+            assert abs(np.linalg.norm(got) - np.linalg.norm(v)) <= 1e-2 * np.linalg.norm(v), k
+    whole = float(np.sqrt(num / den))
+    print(f"{exchange} world={world} B={B}: whole-gradient rel-L2 vs bf16-mode oracle mean gradient {whole:.2e}")
+    assert whole < 1e-2
+    ga = float(mean_g["alpha"])
+    assert abs(out[0]["alpha_g"] / world - ga) <= 1e-2 * abs(ga) + 1e-7
+    for rank in range(world):
+        assert abs(out[rank]["loss"] - losses[rank]) / losses[rank] < 1e-3          # per-rank loss (own shard)
+        for k, v in upds[rank].items():                                            # per-rank BatchNorm buffers
+            assert rel_l2(out[rank]["state"][k], v) < 1e-3, (rank, k)
+        for k in mean_g:                                                           # replicas: identical bits
+            assert np.array_equal(out[rank]["state"][k], out[0]["state"][k]), (rank, k)
+            assert np.array_equal(out[rank]["state2"][k], out[0]["state2"][k]), (rank, k)
+    # the first Adam step moves every parameter with a gradient by about lr against the sign of the mean gradient
+    moved = out[0]["state"]["spectral_network.conv2.conv_layer.weight"] - np.asarray(p["spectral_network.conv2.conv_layer.weight"])
+    g = mean_g["spectral_network.conv2.conv_layer.weight"]
+    big = np.abs(g) > 0.05 * np.abs(g).max()        # (elements near zero may change sign under bf16 rounding)
+    assert np.all(np.sign(moved[big]) == -np.sign(g[big]))
+    assert np.allclose(np.abs(moved[big]), 1e-3, rtol=2e-2)
+
+
+def _pair_worker(rank, world, port, kind, exchange, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from oracle import prng
+    from deeptreeattention_amd.engine import EnsembleTrainer, MetadataTrainer
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    torch.manual_seed(11)
+    opts = {"max_workgroups": 32, "timeout_s": 30.0} if exchange == "peer" else None
+    B, bands, classes = 6, 20, 7
+    losses = []
+    if kind == "ensemble":
+        from deeptreeattention_amd.year import learned_ensemble
+        m = learned_ensemble(3, classes, {"pretrain_state_dict": None, "bands": bands}).to(dev).train()
+        tr = EnsembleTrainer(m, lr=1e-3, exchange=exchange, exchange_opts=opts)
+        for step in range(3):
+            imgs = [torch.from_numpy(prng.uniform01(500 + 10 * step + rank, yy, (B, bands, 11, 11))).to(dev) for yy in range(3)]
+            if rank == 0:
+                imgs[1].zero_()            # missing on rank 0 only: still stepped everywhere
+            if step == 1:
+                imgs[2].zero_()            # missing everywhere in the second step: untouched
+            y = torch.from_numpy(prng.randint(500 + rank, 2, (B,), classes)).to(dev)
+            losses.append(float(tr.train_step(imgs, y)))
+        steps = tr.step_counts()
+    else:
+        from deeptreeattention_amd.metadata import metadata_sensor_fusion
+        m = metadata_sensor_fusion(bands, 4, classes).to(dev).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        tr = MetadataTrainer(m, lr=1e-3, exchange=exchange, exchange_opts=opts)
+        for step in range(3):
+            x = torch.from_numpy(prng.uniform01(600 + 10 * step + rank, 1, (B, bands, 11, 11))).to(dev)
+            site = torch.from_numpy(prng.randint(600 + rank, 3, (B,), 4)).to(dev)
+            y = torch.from_numpy(prng.randint(600 + rank, 2, (B,), classes)).to(dev)
+            losses.append(float(tr.train_step(x, site, y)))
+        steps = None
+    torch.cuda.synchronize()
+    (tr if kind == "ensemble" else tr.sensor).close()
+    out[(exchange, rank)] = ({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, losses, steps)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["ensemble", "metadata"])
+def test_peer_exchange_matches_collective_path(kind):
+    """Year ensemble (device-gated optimizer passes, year flags riding in the gradient buffer) and the metadata fusion
+    model (small parameters in spare slots) under the peer exchange: same results as over torch.distributed, and (two
+    ranks: a + b in either order) the same bits."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    for exchange in ("torch", "peer"):
+        mp.spawn(_pair_worker, args=(2, _free_port(), kind, exchange, out), nprocs=2, join=True)
+    for rank in range(2):
+        a, b = out[("torch", rank)], out[("peer", rank)]
+        assert a[1] == b[1] and a[2] == b[2]
+        for k in a[0]:
+            if kind == "metadata":
+                # the torch.distributed path accumulates alpha's float32 exchange slot with float atomics (last-bit
+                # run-to-run differences in alpha, which the later steps pick up); the peer path has none
+                assert np.allclose(a[0][k], b[0][k], rtol=1e-5, atol=1e-7), (rank, k)
+            else:
+                assert np.array_equal(a[0][k], b[0][k]), (rank, k)
+    if kind == "ensemble":
+        assert out[("peer", 0)][2] == [3, 3, 2]

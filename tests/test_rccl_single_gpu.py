@@ -26,7 +26,8 @@ from deeptreeattention_amd import Hang2020 as H
 from deeptreeattention_amd.engine import FusedTrainer
 torch.manual_seed(5)
 m = H.Hang2020(40, 9, precision=os.environ["DTA_PREC"]).to(dev).train()
-tr = FusedTrainer(m, lr=1e-3, overlap_comm=os.environ["DTA_OVERLAP"] == "1")
+exch = os.environ.get("DTA_EXCH") or None
+tr = FusedTrainer(m, lr=1e-3, overlap_comm=os.environ["DTA_OVERLAP"] == "1", exchange=exch)
 g = torch.Generator(device=dev); g.manual_seed(7)
 x = torch.rand(24, 40, 11, 11, device=dev, generator=g)
 y = torch.randint(0, 9, (24,), device=dev, generator=g)
@@ -34,19 +35,23 @@ for _ in range(3):
     loss = tr.train_step(x, y)
 torch.cuda.synchronize()
 if force:
-    assert tr.comm and tr.sync.collectives == 3 * (2 if tr.overlap else 1), tr.sync.collectives
+    assert tr.comm and tr.exchange == (exch or "torch")
+    want = 0 if tr.exchange == "peer" else 3 * (2 if tr.overlap else 1)
+    assert tr.sync.collectives == want, tr.sync.collectives
+    tr.check_exchange()
     # broadcast + the collectives really went through RCCL
     assert torch.distributed.get_backend() == "nccl"
 torch.save({k: v.cpu() for k, v in m.state_dict().items()}, os.environ["DTA_OUT"])
 print("loss", float(loss))
 if force:
+    tr.close()
     torch.distributed.destroy_process_group()
 """
 
 
-def _run(tmp_path, name, force, overlap, prec):
+def _run(tmp_path, name, force, overlap, prec, exch=""):
     out = str(tmp_path / (name + ".pt"))
-    env = dict(os.environ, DTA_ROOT=ROOT, DTA_OUT=out, DTA_OVERLAP="1" if overlap else "0", DTA_PREC=prec,
+    env = dict(os.environ, DTA_ROOT=ROOT, DTA_OUT=out, DTA_OVERLAP="1" if overlap else "0", DTA_PREC=prec, DTA_EXCH=exch,
                MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("DTA_FORCE_COLLECTIVES", None)
     if force:
@@ -66,6 +71,19 @@ def test_one_rank_rccl_step_matches_plain_step(tmp_path, overlap, prec):
         if k == "alpha":      # its float64 gradient rides through the exchange in an fp32 slot (dist.py)
             assert abs(float(ref[k]) - float(got[k])) < 1e-7
         else:                 # ... so later steps see an alpha that differs in the 8th digit
+            assert torch.allclose(ref[k].float(), got[k].float(), rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("exch", ["rccl", "peer"])
+def test_one_rank_direct_exchanges_match_plain_step(tmp_path, exch):
+    """ncclAllReduce called straight from librccl on the compute stream ("rccl") and the peer-exchange launch ("peer"),
+    one rank each: the updated weights equal the plain single-process step."""
+    ref = _run(tmp_path, "plain", False, False, "bf16")
+    got = _run(tmp_path, exch, True, False, "bf16", exch)
+    for k in ref:
+        if k == "alpha":
+            assert abs(float(ref[k]) - float(got[k])) < 1e-7
+        else:
             assert torch.allclose(ref[k].float(), got[k].float(), rtol=1e-4, atol=1e-6), k
 
 

@@ -12,6 +12,8 @@ CUs x GRBM_GUI_ACTIVE / 8 XCDs) = fraction of the matrix pipes' cycles that were
 """
 import argparse
 import json
+import sys
+import os
 import sqlite3
 from collections import defaultdict
 
@@ -80,7 +82,10 @@ def main():
         tot_us += avg_us * per_step
     rows.sort(key=lambda r: -r["us_per_step"])
     algo = ALGO_BYTES_PER_PATCH * a.batch + PARAM_STATE_BYTES
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deeptreeattention_amd import _lib
     out = {"note": __doc__.split("\n\n")[2].replace("\n", " ").strip(),
+           "library_build_id": _lib.lib().dta_build_id().decode(),      # bench.py quotes these counters only on this build
            "batch": a.batch, "launches_per_step": round(sum(r["launches_per_step"] for r in rows), 1),
            "kernel_us_per_step": round(tot_us, 1), "hbm_mb_per_step": round(tot_bytes / 1e6, 1),
            "algorithmic_mb_per_step": round(algo / 1e6, 1), "traffic_over_algorithmic": round(tot_bytes / algo, 2),
