@@ -507,6 +507,60 @@ def case_metadata():
     print("metadata.npz", len(out))
 
 
+def case_metadata_full():
+    """BASELINE configs[3] at its real size: metadata_sensor_fusion(bands=369, sites=23, classes=200)
+    (src/models/metadata.py:26-44), B=64: eval forward, and the unweighted-CE train step (metadata.py:52-63) with the
+    site branch's Dropout at p=0: outputs, loss, every gradient norm, d(loss)/d(HSI scores) and the small layers' own
+    gradients.  The small layers' torch-default init is stored as float16-exact values (they are rounded to half
+    before loading, in the reference too, so the fixture stays small)."""
+    _stub_missing_packages()
+    from src.models import metadata as RM
+    out = {}
+    bands, classes, sites, B = 369, 200, 23, 64
+    torch.manual_seed(23)
+    m = RM.metadata_sensor_fusion(bands=bands, sites=sites, classes=classes)
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=21)
+    load(m.sensor_model, p)
+    small = {}
+    for k, v in m.state_dict().items():
+        if not k.startswith("sensor_model."):
+            if v.dtype.is_floating_point:
+                v = v.half().float()
+            small[k] = v
+            out[f"init/{k}"] = (v.numpy().astype(np.float16) if v.dtype.is_floating_point else v.numpy().copy())
+    m.load_state_dict({**{k: v for k, v in m.state_dict().items() if k.startswith("sensor_model.")}, **small})
+    x = torch.from_numpy(prng.uniform01(30, 1, (B, bands, 11, 11)))
+    site = torch.from_numpy(prng.randint(30, 2, (B,), sites))
+    y = torch.from_numpy(prng.randint(30, 3, (B,), classes))
+    m.eval()
+    with torch.no_grad():
+        out["eval/out"] = m(x, site).numpy()
+        out["eval/hsi"] = m.sensor_model(x).numpy()
+    m.train()
+    m.metadata_model.dropout.p = 0.0
+    hsi = {}
+    hook = m.sensor_model.register_forward_hook(lambda mod, inp, o: (o.retain_grad(), hsi.__setitem__("scores", o)) and None)
+    yhat = m(x, site)
+    loss = F.cross_entropy(yhat, y)
+    loss.backward()
+    hook.remove()
+    out["train/out"] = yhat.detach().numpy()
+    out["train/hsi"] = hsi["scores"].detach().numpy()
+    out["train/dhsi"] = hsi["scores"].grad.numpy().copy()
+    out["train/loss"] = np.float64(loss.item())
+    none = []
+    for k, prm in m.named_parameters():
+        if prm.grad is None:
+            none.append(k)
+        else:
+            out[f"train/gnorm/{k}"] = np.float64(prm.grad.double().norm().item())
+            if not k.startswith("sensor_model.") and prm.numel() <= 4096:
+                out[f"train/g/{k}"] = prm.grad.numpy().copy()
+    out["train/none"] = np.array(none)
+    np.savez_compressed(os.path.join(OUT, "metadata_full.npz"), **out)
+    print("metadata_full.npz", len(out))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:      # regenerate only the named cases, e.g. `make_golden.py case_ensemble_steps`
         for name in sys.argv[1:]:
@@ -520,3 +574,4 @@ if __name__ == "__main__":
     case_preprocess()
     case_hang_full()
     case_metadata()          # last: it stubs packages process-wide
+    case_metadata_full()

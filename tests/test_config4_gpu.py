@@ -1,0 +1,144 @@
+"""BASELINE configs[3] at its real size: metadata_sensor_fusion(bands=369, sites=23, classes=200), B=64, against the
+reference's own outputs (tests/golden/metadata_full.npz, made by importing src/models/metadata.py), in fp32 and in the
+bf16 mode; the HSI branch's bf16 gradients against the oracle run with the bf16 mode's roundings; MetadataTrainer in bf16
+against the module-level step (autograd through the same HIP branch + torch Adam over every parameter)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import hang2020_np as O
+from oracle import prng
+
+pytestmark = pytest.mark.gpu
+
+BANDS, CLASSES, SITES, B = 369, 200, 23, 64
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _model(g, precision):
+    from deeptreeattention_amd.metadata import metadata_sensor_fusion
+    m = metadata_sensor_fusion(bands=BANDS, sites=SITES, classes=CLASSES, precision=precision)
+    sd = {"sensor_model." + k: torch.from_numpy(np.array(v)) for k, v in
+          O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=21).items()}
+    for k in g.files:
+        if k.startswith("init/"):
+            a = g[k]
+            sd[k[len("init/"):]] = torch.from_numpy(a.astype(np.float32) if a.dtype == np.float16 else a)
+    m.load_state_dict(sd)
+    return m.to(dev())
+
+
+def _batch():
+    x = torch.from_numpy(prng.uniform01(30, 1, (B, BANDS, 11, 11))).to(dev())
+    site = torch.from_numpy(prng.randint(30, 2, (B,), SITES)).to(dev())
+    y = torch.from_numpy(prng.randint(30, 3, (B,), CLASSES)).to(dev())
+    return x, site, y
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 1e-2)])
+def test_metadata_fusion_full_size_vs_reference_golden(golden, precision, tol):
+    g = golden("metadata_full.npz")
+    m = _model(g, precision)
+    x, site, y = _batch()
+    m.eval()
+    with torch.no_grad():
+        assert rel_l2(m.sensor_model(x).cpu().numpy(), g["eval/hsi"]) < tol
+        assert rel_l2(m(x, site).cpu().numpy(), g["eval/out"]) < tol
+    m.train()
+    m.metadata_model.dropout.p = 0.0
+    out = m(x, site)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    assert rel_l2(out.detach().cpu().numpy(), g["train/out"]) < tol
+    assert abs(float(loss.detach()) - float(g["train/loss"])) < tol * abs(float(g["train/loss"]))
+    none = set(g["train/none"].tolist())
+    tot = ref_tot = 0.0
+    for k, prm in m.named_parameters():
+        if k in none:
+            assert prm.grad is None, k
+            continue
+        if k.endswith("conv_layer.bias"):
+            continue
+        ref = float(g[f"train/gnorm/{k}"])
+        got = float(prm.grad.double().norm())
+        tot += got ** 2
+        ref_tot += ref ** 2
+        if precision == "bf16" and prm.numel() >= 1000:
+            print(f"bf16 vs reference: {k:70s} {prm.numel():7d} norm rel err {abs(got - ref) / ref:.2e}")
+        # bf16 against the EXACT reference at batch 64: the conv and classifier weights (96 % of the parameters) and the
+        # total keep the 1e-2 budget; the spectral-attention matrices are mat-vecs on 32..128 pooled values whose
+        # gradients cancel heavily, and operand rounding upstream moves their norms by 1-3 % in ANY implementation --
+        # the oracle with the same roundings is as far (the next test pins the kernels to it at 1e-2): 5e-2 here
+        if precision == "fp32" or k.endswith("conv_layer.weight") or k.endswith("fc1.weight") or k.endswith("mlp.weight"):
+            assert abs(got - ref) <= tol * max(ref, 1e-9), (k, got, ref)
+        elif prm.numel() >= 1000:
+            assert abs(got - ref) <= 5e-2 * ref, (k, got, ref)
+        if f"train/g/{k}" in g.files and precision == "fp32":
+            assert rel_l2(prm.grad.cpu().numpy(), g[f"train/g/{k}"]) < tol, k
+    assert abs(np.sqrt(tot) - np.sqrt(ref_tot)) <= tol * np.sqrt(ref_tot)
+
+
+def test_metadata_hsi_branch_bf16_vs_bf16_mode_oracle(golden):
+    """The HSI branch at 369 / 200 / B=64 in bf16 against the oracle with the same roundings, driven by the reference's
+    own d(loss)/d(HSI scores): logits 1e-3; every >= 1000-element gradient tensor's norm 1e-2; whole gradient vector
+    1.5e-2 (two float accumulations of the SAME rounded step are 8e-3 apart at this width, tools/bf16diag2.py)."""
+    from deeptreeattention_amd import Hang2020 as H
+    g = golden("metadata_full.npz")
+    p = O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=21)
+    m = H.Hang2020(BANDS, CLASSES, precision="bf16")
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in p.items()})
+    m = m.to(dev()).train()
+    x = prng.uniform01(30, 1, (B, BANDS, 11, 11))
+    scores = m(torch.from_numpy(x).to(dev()))
+    scores.backward(torch.from_numpy(g["train/dhsi"]).to(dev()))
+    O.bf16_mode(True)
+    try:
+        logits, cache, _ = O.hang2020_fwd(p, x, True, np.float64)
+        want = O.hang2020_bwd(p, cache, g["train/dhsi"].astype(np.float64), np.float64)
+    finally:
+        O.bf16_mode(False)
+    assert rel_l2(scores.detach().cpu().numpy(), logits) < 1e-3
+    num = den = 0.0
+    for k, prm in m.named_parameters():
+        v = np.asarray(want.get(k), np.float64) if k in want else None
+        if prm.grad is None or v is None or k.endswith("conv_layer.bias") or not np.any(v):
+            continue
+        got = prm.grad.detach().double().cpu().numpy()
+        num += float(((got - v) ** 2).sum())
+        den += float((v ** 2).sum())
+        if v.size >= 1000:
+            assert abs(np.linalg.norm(got) - np.linalg.norm(v)) <= 1e-2 * np.linalg.norm(v), k
+    whole = np.sqrt(num / den)
+    print(f"config 4 HSI branch bf16 vs bf16-mode oracle: whole-gradient rel-L2 {whole:.2e}")
+    assert whole < 1.5e-2
+
+
+def test_metadata_trainer_bf16_full_size_vs_module_level_step(golden):
+    from deeptreeattention_amd.engine import MetadataTrainer
+    g = golden("metadata_full.npz")
+    a = _model(g, "bf16").train()
+    a.metadata_model.dropout.p = 0.0
+    b = copy.deepcopy(a)
+    lr = 1e-3
+    opt = torch.optim.Adam(b.parameters(), lr=lr)
+    tr = MetadataTrainer(a, lr=lr)
+    x, site, y = _batch()
+    for step in range(2):
+        la = tr.training_step((["id"] * B, {"HSI": x, "site": site}, y))
+        opt.zero_grad(set_to_none=True)
+        lb = torch.nn.functional.cross_entropy(b(x, site), y)
+        lb.backward()
+        opt.step()
+        assert abs(float(la) - float(lb.detach())) < 1e-3 * abs(float(lb.detach())), step
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sb:
+        if k.endswith("conv_layer.bias") or k.endswith("num_batches_tracked"):
+            continue
+        assert rel_l2(sa[k].float().cpu().numpy(), sb[k].float().cpu().numpy()) < 2e-3, k

@@ -65,8 +65,13 @@ def test_one_year_of_the_grouped_launch_vs_oracle(ensemble):
         a, b = prm.grad.double().cpu().numpy(), np.asarray(g[k], np.float64)
         num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum())
         worst = max(worst, (rel_l2(a, b), k))
+        if b.size >= 1000:      # north_star's bf16 budget (1e-2) is on the gradient NORMS
+            assert abs(np.linalg.norm(a) - np.linalg.norm(b)) <= 1e-2 * np.linalg.norm(b), k
     whole = np.sqrt(num / den)
     print(f"config 5 (24x24, 369 bands, B={B}): year 0 whole-gradient rel-L2 vs bf16-mode oracle {whole:.2e}, worst {worst}")
+    # element-wise: fixed 2e-2 (observed 1.46e-2): the resolution of two float accumulations of the same rounded step at
+    # 369 bands is 8e-3 on 11x11 maps (tests/test_hip_benched_path.py explains the figure) and grows with the 576-pixel
+    # maps' longer BatchNorm sums; the 1e-2 budget is asserted on every tensor's norm above
     assert whole < 2e-2
     sd = m.state_dict()
     for k, v in upd.items():

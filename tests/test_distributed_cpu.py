@@ -85,17 +85,20 @@ def _ensemble_worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # single node: no hostname resolution in the rendezvous
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
-    from deeptreeattention_amd.dist import GradSync, kept_anywhere
-    # year 0 kept by both ranks, year 1 only by rank 1, year 2 by nobody
+    from deeptreeattention_amd.dist import GradSync
+    # year 0 kept by both ranks, year 1 only by rank 1, year 2 by nobody.  As in EnsembleTrainer, each rank's 0/1 year
+    # flags ride in slots of the first gradient bucket: the SUM all-reduce tells every rank which years were kept anywhere
     local = [True, rank == 1, False]
-    anywhere = kept_anywhere(local)
     sync = GradSync(world=world)
     # the year only rank 1 kept: rank 0 joins the same two-phase reduction with its zero-filled buffer
     g = torch.full((10,), 3.0) if local[1] else torch.zeros(10)
-    sync.reduce_early(g[:6])
-    sync.reduce_late(g[6:])
+    head = torch.cat([g[:6], torch.tensor([1.0 if k else 0.0 for k in local])])
+    tail = g[6:].clone()
+    sync.reduce_early(head)
+    sync.reduce_late(tail)
     sync.finish()
-    out[rank] = (anywhere, g.tolist(), sync.grad_scale)
+    anywhere = [f > 0 for f in head[6:].tolist()]
+    out[rank] = (anywhere, head[:6].tolist() + tail.tolist(), sync.grad_scale)
     dist.destroy_process_group()
 
 

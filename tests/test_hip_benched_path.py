@@ -85,27 +85,39 @@ def test_fused_input_bf16_step_vs_oracle(bands, classes, B):
     assert abs(loss.item() - q_loss) / q_loss < 1e-3
     whole, worst = _whole(got, q_g)
     print(f"B={B}: bf16 HIP vs bf16-operand oracle: whole-gradient rel-L2 {whole:.2e}, worst tensor {worst}")
-    bound = 1e-2
-    if whole >= 5e-3:
-        # wide contractions (K = 9 x 369): the HIP path accumulates the products of the rounded operands in fp32, the
-        # oracle above in fp64; values that land on different sides of a bf16 rounding boundary of the NEXT operand
-        # (gated maps, output gradients) differ by a whole bf16 ulp.  The oracle itself, run in float32, is equally far
-        # from its float64 run -- that distance, not the 1e-2 budget, is the resolution of this comparison
-        O.bf16_mode(True)
-        try:
-            l32, c32, _ = O.hang2020_fwd(p, x, True, np.float32)
-            _, dl32 = O.weighted_cross_entropy(l32, y, w)
-            g32 = O.hang2020_bwd(p, c32, dl32, np.float32)
-        finally:
-            O.bf16_mode(False)
-        self_noise, _ = _whole(g32, q_g)
-        print(f"B={B}: float32 oracle vs float64 oracle (same rounded operands): whole-gradient rel-L2 {self_noise:.2e}")
-        bound = max(bound, 1.5 * self_noise)
-    assert whole < bound
+    # Fixed tolerances.  north_star's bf16 budget names logits, loss and gradient NORMS: every tensor of >= 1000 elements
+    # must keep its norm within 1e-2 (observed <= 3.1e-3 at 369 bands), and so must the total.  Element-wise, the whole
+    # gradient vector is held to 1.5e-2: two float accumulations (float32 vs float64) of the SAME rounded step -- the
+    # oracle against itself -- are 8.0e-3 apart at 369 bands (1.3e-3 at 48), because ~2 % of the half-precision conv
+    # outputs round the other way and BatchNorm's backward cancels all but ~1 % of the weight-gradient sums
+    # (tools/bf16diag2.py prints the three pairwise distances); 48 bands keep the 1e-2 of the budget.
+    assert whole < (1.5e-2 if bands > 100 else 1e-2)
+    tot_q = tot_g = 0.0
     for k, v in q_g.items():        # per-tensor gradient norms (tensors that are more than a handful of scalars)
+        if k.endswith("conv_layer.bias") or not np.any(v):
+            continue
+        n_q, n_g = np.linalg.norm(np.asarray(v, np.float64)), np.linalg.norm(np.asarray(got[k], np.float64))
+        tot_q += n_q ** 2
+        tot_g += n_g ** 2
+        if np.asarray(v).size >= 1000:
+            assert abs(n_g - n_q) <= 1e-2 * n_q, (k, n_g, n_q)
+    assert abs(np.sqrt(tot_g) - np.sqrt(tot_q)) <= 1e-2 * np.sqrt(tot_q)
+    # same-precision comparison: the oracle accumulating in float32 like the kernels (bf16-mode roundings in both)
+    O.bf16_mode(True)
+    try:
+        l32, c32, _ = O.hang2020_fwd(p, x, True, np.float32)
+        _, dl32 = O.weighted_cross_entropy(l32, y, w)
+        g32 = O.hang2020_bwd(p, c32, dl32, np.float32)
+    finally:
+        O.bf16_mode(False)
+    whole32, _ = _whole(got, g32)
+    self32, _ = _whole(g32, q_g)
+    print(f"B={B}: bf16 HIP vs float32-accumulating oracle {whole32:.2e}; that oracle vs its float64 run {self32:.2e}")
+    assert whole32 < (1.5e-2 if bands > 100 else 1e-2)
+    for k, v in g32.items():
         if np.asarray(v).size >= 1000 and not k.endswith("conv_layer.bias") and np.any(v):
             n_q, n_g = np.linalg.norm(np.asarray(v, np.float64)), np.linalg.norm(np.asarray(got[k], np.float64))
-            assert abs(n_g - n_q) <= bound * n_q, (k, n_g, n_q)
+            assert abs(n_g - n_q) <= 1e-2 * n_q, (k, n_g, n_q)
     sd = m.state_dict()
     for k, v in q_upd.items():      # BatchNorm running statistics / counters after one train-mode forward
         assert rel_l2(sd[k].cpu().numpy(), v) < 1e-3, k
@@ -216,10 +228,16 @@ def test_full_size_bf16_gradients_vs_fp32(full):
     # element-wise the bf16-operand gradient sits ~0.1 away from the fp32 one at this width (K = 3321 products of
     # rounded operands feeding cancelling sums; test_fused_input_bf16_step_vs_oracle pins the SAME shape to the
     # rounded-operand oracle at 1e-2): here the norms carry the budget
-    big = [k for k, v in g32.items() if v.size >= 50000]      # conv weights, classifier and spectral-attention matrices
-    for k in big:
-        assert abs(np.linalg.norm(g16[k]) - np.linalg.norm(g32[k])) <= 2e-2 * np.linalg.norm(g32[k]), k
-    assert whole < 0.25
+    for k, v in g32.items():
+        if v.size < 1000 or k.endswith("conv_layer.bias"):
+            continue
+        # conv / classifier weights: 1e-2; the spectral-attention matrices (cancelling mat-vec gradients on pooled
+        # values): 5e-2 against the unrounded computation, see tests/test_config4_gpu.py
+        tol = 1e-2 if (k.endswith("conv_layer.weight") or k.endswith("fc1.weight")) else 5e-2
+        assert abs(np.linalg.norm(g16[k]) - np.linalg.norm(g32[k])) <= tol * np.linalg.norm(g32[k]), k
+    # (a consistency check of the two precision modes of the SAME kernels, not parity: bf16-vs-oracle parity at this
+    # shape is test_fused_input_bf16_step_vs_oracle; the element-wise distance is what operand rounding costs)
+    assert whole < 0.15
     for k in b32:
         assert rel_l2(b16[k], b32[k]) < 1e-2, k
 

@@ -367,3 +367,28 @@ def test_three_head_loss_oracle_vs_reference_golden(golden):
                 continue
             ref = float(g[f"{tag}p2_norm/{name}"])
             assert abs(np.sqrt((np.asarray(p[name], np.float64) ** 2).sum()) - ref) <= 2e-4 * max(ref, 1e-12), (tag, name)
+
+
+def test_oracle_metadata_sensor_branch_at_full_size_vs_reference_golden(golden):
+    """BASELINE configs[3] at its real size (369 bands, 200 classes, 23 sites, B=64): the NumPy oracle's Hang2020 branch
+    against what the reference's metadata_sensor_fusion produced -- the HSI scores in eval and train mode, and, from the
+    reference's own d(loss)/d(HSI scores), every sensor gradient norm."""
+    g = golden("metadata_full.npz")
+    bands, classes, B = 369, 200, 64
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=21)
+    x = prng.uniform01(30, 1, (B, bands, 11, 11))
+    logits, _, _ = O.hang2020_fwd(p, x, False, np.float64)
+    assert rel_l2(logits, g["eval/hsi"]) < TOL
+    logits, cache, _ = O.hang2020_fwd(p, x, True, np.float64)
+    assert rel_l2(logits, g["train/hsi"]) < TOL
+    grads = O.hang2020_bwd(p, cache, g["train/dhsi"].astype(np.float64), np.float64)
+    checked = 0
+    for k, v in grads.items():
+        key = f"train/gnorm/sensor_model.{k}"
+        if key not in g.files or k.endswith("conv_layer.bias"):
+            continue
+        ref = float(g[key])
+        # (+2e-9: the reference's float32 run leaves that much noise on single-scalar gradients of size 1e-6)
+        assert abs(np.linalg.norm(np.asarray(v, np.float64)) - ref) <= 1e-4 * ref + 2e-9, k
+        checked += 1
+    assert checked >= 50
