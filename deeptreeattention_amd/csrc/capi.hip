@@ -875,9 +875,9 @@ int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double
 }
 
 int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const float* active, const int* dev_step,
-                        float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                        float lr, float beta1, float beta2, float eps, float grad_scale, int zero_grad, void* stream) {
   if (!active) { dta_set_error("dta_adam_step_gated: null gate"); return 1; }
-  return adam_step_impl(p, g, g, m, v, n, nullptr, nullptr, nullptr, nullptr, nullptr, 0, lr, beta1, beta2, eps,
+  return adam_step_impl(p, g, zero_grad ? g : nullptr, m, v, n, nullptr, nullptr, nullptr, nullptr, nullptr, 0, lr, beta1, beta2, eps,
                         grad_scale, stream, active, dev_step);
 }
 

@@ -32,7 +32,11 @@ typedef _Float16 hw_f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 hw_f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned pack2_fmt(float lo, float hi, int fmt) {
   if (fmt == FMT_F16) {   // saturating: a value beyond the half range must not become inf (and NaN after BatchNorm)
-    hw_f16x2 h = {(_Float16)__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+    // (fminf / fmaxf return the non-NaN operand, v_med3 the minimum: clamp only ordered values, so a NaN stays a NaN
+    // and nodata pixels propagate through eval-mode BatchNorm as they do in the reference)
+    const float l = lo != lo ? lo : __builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f);
+    const float h2 = hi != hi ? hi : __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f);
+    hw_f16x2 h = {(_Float16)l, (_Float16)h2};
     return __builtin_bit_cast(unsigned, h);
   }
   unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);     // bf16, round to nearest even
@@ -72,7 +76,7 @@ __device__ __forceinline__ void ld4_fmt(float (&v)[4], const void* base, size_t 
 }
 __device__ __forceinline__ void st_fmt(void* base, size_t i, float v, int fmt) {
   if (fmt == FMT_F32) ((float*)base)[i] = v;
-  else if (fmt == FMT_F16) ((_Float16*)base)[i] = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  else if (fmt == FMT_F16) ((_Float16*)base)[i] = (_Float16)(v != v ? v : __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f));
   else ((unsigned short*)base)[i] = (unsigned short)(pack2_fmt(v, 0.f, FMT_BF16) & 0xFFFFu);
 }
 // exchange with the neighbouring lane (lane ^ 1) without touching LDS
@@ -130,6 +134,10 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
+// ReLU and the pooling maximum as torch computes them: a NaN operand stays a NaN (v_max_f32 would return the other
+// operand), so nodata pixels reach the scores exactly as they do in the reference
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float max_nan(float a, float b) { return (a >= b || a != a) ? a : b; }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // Block-wide sum for 256-thread blocks (4 waves); scratch must hold 4 floats.  All threads get the sum.
@@ -142,6 +150,19 @@ __device__ __forceinline__ float block_sum256(float v, float* scratch) {
 }
 
 }  // namespace dta
+
+// hipFuncSetAttribute is a per-device setting: a launch site remembers per device ordinal whether it has made it (one
+// process may drive several devices; a process-wide flag would leave the second device with the 64 KiB default).
+#include <atomic>
+struct DevOnce {
+  std::atomic<unsigned long long> done{0};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return true;
+    const unsigned long long bit = 1ull << (d & 63);
+    return (done.fetch_or(bit) & bit) == 0;
+  }
+};
 
 // Error plumbing: kernels launch asynchronously on the caller's stream; launch errors are caught here
 // and surfaced through dta_last_error() (no exceptions cross the C ABI).

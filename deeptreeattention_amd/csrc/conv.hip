@@ -436,10 +436,9 @@ static int launch_conv_t(ConvArgs a, int G, hipStream_t st) {
   conv_geometry(a.HW, MWG, a.B, &a.ppw, &a.spp, &nwg);
   size_t lds = (size_t)MWG * 8 + (size_t)5 * N * 4 + ((size_t)a.ppw * a.Q * 16 + (size_t)9 * N * 16) * sizeof(T);
   if (lds > 160 * 1024) { dta_set_error("conv3x3: LDS need %zu B exceeds 160 KiB (H=%d W=%d)", lds, a.H, a.W); return 1; }
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DevOnce attr_once;      // (function attributes are per device)
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_conv3x3<T, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   hipLaunchKernelGGL((k_conv3x3<T, MT, NT>), dim3(nwg, G), dim3(256), lds, st, a);
   DTA_CHECK_LAUNCH("k_conv3x3");
@@ -615,10 +614,9 @@ static int launch_wgrad_t(const WgradArgs& a, int G, int cgroups, hipStream_t st
   wgrad_band_plan(a.Q, a.W, wr_max, &a2.bl, &a2.wr, &a2.nbands);
   if (a2.bl < 16) { dta_set_error("conv_wgrad: %dx%d patch is too wide for the band plan", a.H, a.W); return 1; }
   size_t lds = (size_t)NCH * a2.wr * 16 * sizeof(T);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DevOnce attr_once;      // (function attributes are per device)
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_conv_wgrad<T, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   hipLaunchKernelGGL((k_conv_wgrad<T, NTT>), dim3(cgroups, a.S, G), dim3(256), lds, st, a2);
   DTA_CHECK_LAUNCH("k_conv_wgrad");

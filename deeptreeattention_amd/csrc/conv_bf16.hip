@@ -470,11 +470,10 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   }
   if (lds > 160 * 1024) { dta_set_error("conv3x3(bf16): LDS need %zu B exceeds 160 KiB (H=%d W=%d)", lds, a.H, a.W); return 1; }
   if (a.ppw * a.Q * 2 > 4 * NW * 64) { dta_set_error("conv3x3(bf16): %dx%d tile exceeds the staging plan", a.H, a.W); return 1; }
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DevOnce attr_once;      // (function attributes are per device)
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (NW == 8) hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   if (a.x_nchw[0]) {
     if (NW != 8) { dta_set_error("conv3x3(bf16): the fused-input first conv runs eight-wave workgroups only"); return 1; }
@@ -826,11 +825,10 @@ static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream
   size_t lds = (a2.dbuf ? 2 : 1) * stage;
   if (lds < 48 * 1024) lds = 48 * 1024;   // the final reduction passes up to 6 x 2 tiles (8 KiB each) through LDS
   if (lds > 160 * 1024) { dta_set_error("conv_wgrad(bf16): LDS need %zu B exceeds 160 KiB", lds); return 1; }
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DevOnce attr_once;      // (function attributes are per device)
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   a2.ppi = 1;
   static const bool no_stack = getenv("DTA_NO_WGRAD_STACK") != nullptr;      // development A/B switches, read once

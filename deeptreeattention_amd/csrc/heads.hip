@@ -619,7 +619,15 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
   // atomics, ordered by the waits above and the barrier
   __syncthreads();
   unsigned* counter = reinterpret_cast<unsigned*>(a.rowtmp + a.B + 1);
-  if (t == 0) is_last = (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+  // (-DDTA_STRICT_ORDER: the same hand-over by the letter of the memory model -- a release/acquire pair on the counter,
+  //  i.e. an L2 write-back per block; for ports to targets whose device-scope atomics are not performed at a common
+  //  coherence point.  tests/test_round2_gpu.py compares the fused loss with the three-launch route over many launches.)
+#ifdef DTA_STRICT_ORDER
+  constexpr int CNT_ORDER = __ATOMIC_ACQ_REL;
+#else
+  constexpr int CNT_ORDER = __ATOMIC_RELAXED;
+#endif
+  if (t == 0) is_last = (__hip_atomic_fetch_add(counter, 1u, CNT_ORDER, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
   __syncthreads();
   if (!is_last) return;
   double acc = 0;

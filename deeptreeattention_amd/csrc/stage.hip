@@ -333,7 +333,7 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
 #pragma unroll 8
       for (int p = p0; p < s.HWc; p += pstep) {      // unrolled: independent global loads in flight per thread
         float v = ldy((size_t)p * a.y_rs + c) * sc + sh;
-        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.relu) v = relu_nan(v);
         Z[p * ld + c] = v;
       }
     } else {
@@ -343,8 +343,8 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
         const size_t y0 = (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
         float v0_ = ldy(y0) * sc + sh, v1_ = ldy(y0 + a.y_rs) * sc + sh;
         float v2_ = ldy(y0 + (size_t)s.Wc * a.y_rs) * sc + sh, v3_ = ldy(y0 + (size_t)(s.Wc + 1) * a.y_rs) * sc + sh;
-        float m = fmaxf(fmaxf(v0_, v1_), fmaxf(v2_, v3_));
-        if (a.relu) m = fmaxf(m, 0.f);
+        float m = max_nan(max_nan(v0_, v1_), max_nan(v2_, v3_));
+        if (a.relu) m = relu_nan(m);
         Z[pz * ld + c] = m;
       }
     }
@@ -358,10 +358,10 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
       else {
         int hz = p / s.Wz, wz = p - hz * s.Wz;
         const size_t y0 = (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs + c;
-        v = fmaxf(fmaxf(ldy(y0) * sc + sh, ldy(y0 + a.y_rs) * sc + sh),
-                  fmaxf(ldy(y0 + (size_t)s.Wc * a.y_rs) * sc + sh, ldy(y0 + (size_t)(s.Wc + 1) * a.y_rs) * sc + sh));
+        v = max_nan(max_nan(ldy(y0) * sc + sh, ldy(y0 + a.y_rs) * sc + sh),
+                  max_nan(ldy(y0 + (size_t)s.Wc * a.y_rs) * sc + sh, ldy(y0 + (size_t)(s.Wc + 1) * a.y_rs) * sc + sh));
       }
-      if (a.relu) v = fmaxf(v, 0.f);
+      if (a.relu) v = relu_nan(v);
       Z[p * ld + c] = v;
     }
   }
@@ -379,7 +379,7 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
     const float* a2t = a.att[g].p[2]; const float* c2 = a.att[g].p[3];
     colreduce(C, s.HWz, scratch, v0, 1.f / (float)s.HWz, [&](int c, int i) { return Z[i * ld + c]; });
     colreduce(C, C, scratch, v1, 1.f, [&](int o, int i) { return a1t[i * C + o] * v0[i]; });
-    if (t < C) v1[t] = fmaxf(v1[t] + c1[t], 0.f);
+    if (t < C) v1[t] = relu_nan(v1[t] + c1[t]);
     __syncthreads();
     colreduce(C, C, scratch, v2, 1.f, [&](int o, int i) { return a2t[i * C + o] * v1[i]; });
     if (t < C) v2[t] = sigmoidf_(v2[t] + c2[t]);
@@ -392,12 +392,12 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
     pixreduce(s.HWz, C, [&](int p, int c) { return wc[c] * Z[p * ld + c]; },
               [&](int p, float acc) {
                 int h = p / s.Wz, w = p - h * s.Wz;
-                v0[(h + r) * Wp + w + r] = fmaxf(acc + bc, 0.f);
+                v0[(h + r) * Wp + w + r] = relu_nan(acc + bc);
               });
     __syncthreads();
     for (int p = t; p < s.HWz; p += 256) {
       int h = p / s.Wz, w = p - h * s.Wz;
-      v1[(h + r) * Wp + w + r] = fmaxf(b1 + stencil_at(v0, k1, k, Wp, h, w, false), 0.f);
+      v1[(h + r) * Wp + w + r] = relu_nan(b1 + stencil_at(v0, k1, k, Wp, h, w, false));
     }
     __syncthreads();
     for (int p = t; p < s.HWz; p += 256) {
@@ -442,7 +442,7 @@ __device__ __forceinline__ void stage_fwd_patch(const StageArgs& a, const StageG
         for (int dy = 0; dy < ps; ++dy)
           for (int dx = 0; dx < ps; ++dx) {
             int p = (ph * ps + dy) * s.Wz + pw * ps + dx;
-            m = fmaxf(m, Z[p * ld + c] * v2[p]);
+            m = max_nan(m, Z[p * ld + c] * v2[p]);
           }
         f[i] = m;
       }
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
 #define DTA_STAGE_LAND()                                                                             \
     _Pragma("unroll") for (int u = 0; u < NQ; ++u) {                                                 \
       const int i = t + u * 256;                                                                     \
-      if (i < NEL) Z[(i / CQ) * ld + (i % CQ)] = fmaxf(ry[u] * psc + psh, 0.f);                      \
+      if (i < NEL) Z[(i / CQ) * ld + (i % CQ)] = relu_nan(ry[u] * psc + psh);                      \
     }
     const int b0 = blockIdx.x, b1 = blockIdx.x + gridDim.x;
     DTA_STAGE_ISSUE(b0)          // the first patch's conv output is in flight while the statistics are combined
@@ -538,10 +538,9 @@ __global__ __launch_bounds__(256) void k_stage_fwd(StageArgs a) {
 
 template <typename T, typename CFG>
 static int launch_stage_fwd_c(const StageArgs& a, int G, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DevOnce attr_once;      // (function attributes are per device)
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_stage_fwd<T, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   const bool pipe = CFG::fixed && CFG::P == 0 && a.apply_bn && a.relu && a.B >= 512;   // two patches per workgroup
   hipLaunchKernelGGL((k_stage_fwd<T, CFG>), dim3(pipe ? (a.B + 1) / 2 : a.B, G), dim3(256), lds, st, a);
@@ -869,7 +868,7 @@ __global__ __launch_bounds__(256, (CFG::fixed && CFG::P == 0) ? 4 : 1) void k_st
         const int i = t + u * 256;                                                                   \
         if (i < NEL) {                                                                               \
           const int p = i / CQ, c = i % CQ;                                                          \
-          Z[p * ld + c] = fmaxf(ry[u] * psc + psh, 0.f);                                             \
+          Z[p * ld + c] = relu_nan(ry[u] * psc + psh);                                             \
           D[p * ld + c] = rq[u];                                                                     \
         }                                                                                            \
       }                                                                                              \
@@ -903,10 +902,9 @@ extern "C" int dta_debug_ticks(long long* out) { return (int)hipMemcpyFromSymbol
 
 template <typename CFG>
 static int launch_stage_bwd_c(const StageBwdArgs& a, int G, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DevOnce attr_once;      // (function attributes are per device)
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_stage_bwd<CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   // (11x11x32 network stage with saved attention state: two patches per workgroup, see the kernel)
   const bool pipe = CFG::fixed && CFG::P == 0 && a.da && a.f.attsave && a.f.apply_bn && a.f.relu && a.f.B >= 512;
@@ -1611,9 +1609,9 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
       float m = yraw[j][0][e] * sc[e] + sh[e];
       if (CFG::POOL) {
 #pragma unroll
-        for (int k = 1; k < 4; ++k) m = fmaxf(m, yraw[j][k][e] * sc[e] + sh[e]);
+        for (int k = 1; k < 4; ++k) m = max_nan(m, yraw[j][k][e] * sc[e] + sh[e]);
       }
-      z[j][e] = (live && it < CFG::ITEMS) ? fmaxf(m, 0.f) : 0.f;
+      z[j][e] = (live && it < CFG::ITEMS) ? relu_nan(m) : 0.f;
     }
     // only the plain network's classifier flatten reads the un-gated patch back from LDS
     if (it < CFG::ITEMS && kind != KIND_SPECTRAL && kind != KIND_SPATIAL) {
@@ -1643,7 +1641,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
       lean_colsum_reg<CFG, 1>(part, red, outs, CFG::SLOT, 1.f / (float)NP);
     }
     const float* c1 = a.att[g].p[1]; const float* c2 = a.att[g].p[3];
-    auto fin1 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + C + o] = fmaxf(v + c1[o], 0.f); };
+    auto fin1 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + C + o] = relu_nan(v + c1[o]); };
     auto fin2 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + 2 * C + o] = sigmoidf_(v + c2[o]); };
     if constexpr (PRE) {
       lean_matvec_run<CFG>(w1, vec0, CFG::SLOT, red, fin1);
@@ -1679,7 +1677,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc += wc[o * 8 + e] * z[j][e];
       acc = lean_octet_sum<NO>(acc);
-      if (it < CFG::ITEMS && o == 0) mL[(p / WZ + R) * WP + p % WZ + R] = fmaxf(acc + bc, 0.f);
+      if (it < CFG::ITEMS && o == 0) mL[(p / WZ + R) * WP + p % WZ + R] = relu_nan(acc + bc);
     }
     __syncthreads();
     // the two k x k stencils: the NO lanes of a pixel split the kernel rows
@@ -1696,7 +1694,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
         }
         acc = lean_octet_sum<NO>(acc);
         if (it < CFG::ITEMS && o == 0) {
-          if (pass == 0) t1L[(h + R) * WP + w + R] = fmaxf(acc + b1, 0.f);
+          if (pass == 0) t1L[(h + R) * WP + w + R] = relu_nan(acc + b1);
           else sL[p] = sigmoidf_(acc + b2);
         }
       }
@@ -1734,7 +1732,7 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
 #pragma unroll
           for (int dy = 0; dy < PS; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < PS; ++dx) m = fmaxf(m, Zs[((ph * PS + dy) * WZ + pw * PS + dx) * C + c]);
+            for (int dx = 0; dx < PS; ++dx) m = max_nan(m, Zs[((ph * PS + dy) * WZ + pw * PS + dx) * C + c]);
           feat[i] = m;
         }
       }
@@ -1899,7 +1897,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
           if (v > m) { m = v; ys = yraw[j][k][e]; first[j] = (first[j] & ~(3u << (2 * e))) | ((unsigned)k << (2 * e)); }
         }
       }
-      z[j][e] = (live && it < CFG::ITEMS) ? fmaxf(m, 0.f) : 0.f;
+      z[j][e] = (live && it < CFG::ITEMS) ? relu_nan(m) : 0.f;
       xh[j][e] = (ys - q[2]) * q[3];
     }
   }

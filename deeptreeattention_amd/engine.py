@@ -151,6 +151,7 @@ class FusedTrainer:
         self._ws = None
         self._ws_key = None
         self._desc_key = None
+        self._desc_cache, self._ws_cache = {}, {}      # the last two (shape, mode) keys: descriptors / device buffers
         self._reduced = False          # peer exchange: the gradient buffer already holds the sum (reduce_now)
         self.sync = GradSync(self.world, self.pg, rccl=RcclDirect(self.pg) if self.exchange == "rccl" else None)
         if self.comm and storage is None:
@@ -222,18 +223,30 @@ class FusedTrainer:
         return nets, grads
 
     def _describe(self, x):
-        """Descriptor + parameter / gradient pointer structs for this input shape (no device allocation)."""
+        """Descriptor + parameter / gradient pointer structs for this input shape (no device allocation).  The last two
+        shapes stay cached: an epoch's ragged last batch does not rebuild the full batch's tables (or workspace) twice."""
         B, bands, Hh, Ww = x.shape
         m = self.model
         key = (B, bands, Hh, Ww, m.precision, m.training)
         if key != self._desc_key:
-            all_heads = self.three_head or not (self.single_score or self.last_head_only)
-            # single-score step: the blend (Hang2020) / the scores go straight into the fused loss launch (dta_net_loss)
-            self.fused_loss = self.single_score and not self.three_head and not self.external_loss
-            mask = (7 if all_heads else 4) | (_lib.SKIP_BLEND if (self.fused_loss and self.hang) else 0)
-            self.desc = _lib.NetDesc(B, bands, Hh, Ww, m._classes, m._net_code, _lib.dtype_code(m.precision),
-                                     1 if m.training else 0, mask, H.BN_MOMENTUM, H.BN_EPS)
-            self.nets, self.grads = self._structs()
+            hit = self._desc_cache.get(key)
+            if hit is None:
+                all_heads = self.three_head or not (self.single_score or self.last_head_only)
+                # single-score step: the blend (Hang2020) / the scores go straight into the fused loss launch (dta_net_loss)
+                fused_loss = self.single_score and not self.three_head and not self.external_loss
+                mask = (7 if all_heads else 4) | (_lib.SKIP_BLEND if (fused_loss and self.hang) else 0)
+                desc = _lib.NetDesc(B, bands, Hh, Ww, m._classes, m._net_code, _lib.dtype_code(m.precision),
+                                    1 if m.training else 0, mask, H.BN_MOMENTUM, H.BN_EPS)
+                nets, grads = self._structs()
+                hit = (desc, nets, grads, fused_loss, self.external_loss)
+                if len(self._desc_cache) >= 2:
+                    self._desc_cache.pop(next(iter(self._desc_cache)))
+                self._desc_cache[key] = hit
+            if hit[4] != self.external_loss:          # (MetadataTrainer flips the flag right after construction)
+                self._desc_cache.pop(key)
+                self._desc_key = None
+                return self._describe(x)
+            self.desc, self.nets, self.grads, self.fused_loss = hit[:4]
             self._desc_key = key
         return key
 
@@ -242,19 +255,26 @@ class FusedTrainer:
         m = self.model
         key = self._describe(x)
         if key != self._ws_key:
-            L = _lib.lib()
-            nbytes = L.dta_net_workspace_bytes(C.byref(self.desc))
-            if nbytes == 0:
-                raise RuntimeError("dta_net_workspace_bytes: " + L.dta_last_error().decode())
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self.logits = torch.empty(B, m._classes, dtype=torch.float32, device=self.device)
-            self.dlogits = torch.empty_like(self.logits)
-            self.ce_scratch = torch.zeros(B + 2, dtype=torch.float32, device=self.device)     # (last word: dta_net_loss's block counter)
-            if self.three_head:      # per-head scores / score gradients / losses: [net][head]
-                nn_ = 2 if self.hang else 1
-                self.head_scores = torch.empty(nn_, 3, B, m._classes, dtype=torch.float32, device=self.device)
-                self.head_dscores = torch.empty_like(self.head_scores)
-                self.head_losses = torch.zeros(nn_ * 3, dtype=torch.float32, device=self.device)
+            bufs = self._ws_cache.get(key)
+            if bufs is None:
+                L = _lib.lib()
+                nbytes = L.dta_net_workspace_bytes(C.byref(self.desc))
+                if nbytes == 0:
+                    raise RuntimeError("dta_net_workspace_bytes: " + L.dta_last_error().decode())
+                bufs = {"_ws": torch.empty(nbytes, dtype=torch.uint8, device=self.device),
+                        "logits": torch.empty(B, m._classes, dtype=torch.float32, device=self.device),
+                        "ce_scratch": torch.zeros(B + 2, dtype=torch.float32, device=self.device)}     # (last word: dta_net_loss's block counter)
+                bufs["dlogits"] = torch.empty_like(bufs["logits"])
+                if self.three_head:      # per-head scores / score gradients / losses: [net][head]
+                    nn_ = 2 if self.hang else 1
+                    bufs["head_scores"] = torch.empty(nn_, 3, B, m._classes, dtype=torch.float32, device=self.device)
+                    bufs["head_dscores"] = torch.empty_like(bufs["head_scores"])
+                    bufs["head_losses"] = torch.zeros(nn_ * 3, dtype=torch.float32, device=self.device)
+                if len(self._ws_cache) >= 2:
+                    self._ws_cache.pop(next(iter(self._ws_cache)))
+                self._ws_cache[key] = bufs
+            for k, v in bufs.items():
+                setattr(self, k, v)
             self._ws_key = key
 
     def _forward_scores(self, x):
@@ -652,8 +672,8 @@ class EnsembleTrainer:
                                   (t.p_tail, t.g_tail, t.m_tail, t.v_tail, t.n_first)):
                 _lib.check(L.dta_adam_step_gated(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, active, step,
                                                  t.lr, self.betas[0], self.betas[1], self.eps, self.sync.grad_scale,
-                                                 st), "dta_adam_step_gated")
-            t._grads_clear = True
+                                                 0 if self.keep_grads else 1, st), "dta_adam_step_gated")
+            t._grads_clear = not self.keep_grads
 
     def train_step(self, images, y, present=None):
         """images: list of (B, bands, H, W) float32 device tensors, one per year; y: int64 labels.  Returns the loss

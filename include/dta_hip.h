@@ -9,6 +9,11 @@
  *  - plain C, no C++/torch types; every pointer is a DEVICE pointer unless said otherwise
  *  - every buffer is allocated by the caller (PyTorch caching allocator) and only borrowed for the call;
  *    the library allocates nothing on the device (one documented exception: the peer-exchange object dta_xchg_*)
+ *  - host-side state the library keeps (all of it per process): the thread-local text of dta_last_error(); the
+ *    developer switches read from the environment once at load time (dta_dev_reload_switches); per launch site, a bit per
+ *    device ordinal saying that the function's dynamic-LDS attribute has been set on that device; the optional
+ *    profiling event pool of dta_profile_* (one device at a time); peer-exchange objects the caller created.  Nothing
+ *    else survives a call: no caches keyed on shapes or pointers, no device allocations
  *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no internal syncs
  *  - return 0 on success; otherwise non-zero and dta_last_error() describes the failure (thread-local text)
  *  - parameters/gradients use the reference's torch layouts and state_dict shapes
@@ -205,10 +210,10 @@ int dta_adam_step_dp(float* p, float* g, float* m, float* v, size_t n, double* a
 /* optimizer.step() + zero_grad() gated ON THE DEVICE (year ensembles under data parallelism, where whether a year is
  * stepped -- "some rank kept it", src/models/year.py:27 -- is only known on the device after the gradient exchange):
  * active[0] > 0: Adam step with bias corrections taken from the device counter dev_step[0] (1-based, already advanced
- * by the caller for this step); otherwise nothing but the gradient clear happens (no moment decay, as torch's Adam
+ * by the caller for this step); otherwise nothing but the gradient clear (zero_grad != 0) happens (no moment decay, as torch's Adam
  * passes over parameters whose grad is None).  No float64 alpha here (spectral networks have none). */
 int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const float* active, const int* dev_step,
-                        float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+                        float lr, float beta1, float beta2, float eps, float grad_scale, int zero_grad, void* stream);
 
 /* ---- Peer gradient exchange: data-parallel training with one process per GPU of ONE node (reference train.py:89-98:
  * Lightning DDP all-reduces every parameter's gradient between loss.backward() and optimizer.step()).  Here the sum over

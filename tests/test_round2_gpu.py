@@ -246,3 +246,47 @@ def test_train_steps_are_bit_reproducible(precision):
         assert ls == runs[0][1]
         for k in sd:
             assert torch.equal(sd[k], runs[0][0][k]), k
+
+
+def test_fused_loss_over_many_launches_on_a_multi_xcd_grid():
+    """The fused loss launch hands its row terms to the last block through device-scope atomics without a fence
+    (csrc/heads.hip k_blend_ce).  300 back-to-back launches at B = 1024 (256 workgroups, spread over all eight XCDs) with
+    fresh scores every time: each loss must equal the stand-alone dta_weighted_ce of the same blended scores -- a stale
+    row term picked up by the finalising block would show as a mismatch of the order 1/B."""
+    import ctypes as C
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd import _lib
+    from deeptreeattention_amd.engine import FusedTrainer
+    torch.manual_seed(21)
+    B, classes = 1024, 200
+    m = H.Hang2020(16, classes, precision="bf16").cuda().train()
+    tr = FusedTrainer(m, lr=1e-3, loss_weight=torch.rand(classes) + 0.5)
+    L = _lib.lib()
+    losses, refs = [], []
+    ref_loss = torch.zeros(300, device="cuda")
+    scratch = torch.zeros(B + 1, device="cuda")
+    for i in range(300):
+        x = torch.rand(B, 16, 11, 11, device="cuda")
+        y = torch.randint(0, classes, (B,), device="cuda")
+        lg = tr._forward_scores(x)
+        losses.append(tr._loss(lg, y, True))
+        _lib.check(L.dta_weighted_ce(_lib.ptr(tr.logits), _lib.ptr(y), _lib.ptr(tr.loss_weight), B, classes,
+                                     C.c_void_p(ref_loss.data_ptr() + 4 * i), None, _lib.ptr(scratch),
+                                     _lib.current_stream_ptr()), "dta_weighted_ce")
+    torch.cuda.synchronize()
+    got = torch.stack(losses)
+    assert torch.allclose(got, ref_loss, rtol=2e-6, atol=0), float((got - ref_loss).abs().max())
+
+
+def test_nan_input_propagates_through_bf16_inference():
+    """A NaN pixel (nodata) must reach the scores in eval mode as it does in the reference: the saturating half store of
+    the conv outputs clamps only ordered values (csrc/common.h pack2_fmt / st_fmt)."""
+    from deeptreeattention_amd import Hang2020 as H
+    torch.manual_seed(2)
+    m = H.Hang2020(24, 7, precision="bf16").cuda().eval()
+    x = torch.rand(5, 24, 11, 11, device="cuda")
+    x[3, 7, 4, 4] = float("nan")
+    with torch.no_grad():
+        out = m(x)
+    assert torch.isnan(out[3]).all()
+    assert torch.isfinite(out[[0, 1, 2, 4]]).all()
