@@ -63,6 +63,9 @@ def parse():
                          "IPC-mapped peer memory (csrc/xchg.hip), rccl = one ncclAllReduce on the compute stream, torch = "
                          "torch.distributed buckets; auto = peer when its crash-isolated probe passes on every rank, else "
                          "rccl.  (A one-rank DTA_FORCE_COLLECTIVES run defaults to torch, the round-2 path.)")
+    ap.add_argument("--workload", default="hang2020", choices=["hang2020", "ensemble24"],
+                    help="hang2020 = BASELINE configs[1]/[2] (the headline); ensemble24 = BASELINE configs[4]: the year ensemble "
+                         "(3 x spectral_network over 369-band 24x24 crops), a side workload with its own roofline object")
     ap.add_argument("--traffic-file", default=None, help="profiles/*_traffic_step.json whose PMC counters are quoted")
     return ap.parse_args()
 
@@ -110,8 +113,81 @@ def cpu_baseline(batch, seconds):
                       f"hardware threads (oneDNN does not scale this small model further), {el:.1f} s"}
 
 
+def main_ensemble24(a):
+    """BASELINE configs[4]: train step of the year ensemble (3 x spectral_network(369, 200) over 24x24 crops, mean of the
+    last heads, weighted CE, backward, one Adam per year), bf16 convs / fp32 BN + loss, per-GPU batch 256 unless --batch
+    says otherwise.  Single process (the data-parallel form of this step is covered by tests/test_ddp_gpu.py)."""
+    from deeptreeattention_amd import _lib
+    from deeptreeattention_amd.engine import EnsembleTrainer
+    from deeptreeattention_amd.year import learned_ensemble
+    import deeptreeattention_amd
+    YEARS, CROP = 3, 24
+    B = a.batch if a.batch != 1024 else 256
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    deeptreeattention_amd.set_default_precision(a.precision)
+    torch.manual_seed(1234)
+    m = learned_ensemble(YEARS, CLASSES, {"pretrain_state_dict": None, "bands": BANDS}).to(dev).train()
+    tr = EnsembleTrainer(m, lr=1e-4, loss_weight=torch.ones(CLASSES))
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    imgs = [torch.rand(B, BANDS, CROP, CROP, device=dev, generator=g) for _ in range(YEARS)]
+    y = torch.randint(0, CLASSES, (B,), device=dev, generator=g)
+    present = [True] * YEARS                 # the loader knows which years exist (src/data.py zero-fills the others)
+    L = _lib.lib()
+    for _ in range(a.warmup):
+        tr.train_step(imgs, y, present)
+    torch.cuda.synchronize()
+    sites = {"fwd0": _lib.SITE_CONV_FWD, "wgrad0": _lib.SITE_CONV_WGRAD}
+    L.dta_profile_enable(sites[a.site])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.train_step(imgs, y, present)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    buf = (C.c_float * 512)()
+    n = L.dta_profile_collect_site(sites[a.site], buf, 512)
+    ms = [buf[i] for i in range(max(n, 0))]
+    L.dta_profile_enable(-1)
+    # algorithmic FLOPs (2 per MAC; conv layers only, as torch's FlopCounterMode counts the reference): per crop-year
+    px = CROP * CROP
+    conv_fwd = [2 * BANDS * 32 * 9 * px, 2 * 32 * 64 * 9 * px, 2 * 64 * 128 * 9 * (px // 4)]
+    fwd = sum(conv_fwd) + 2 * 128 * CLASSES
+    step_flop = fwd + sum(conv_fwd) + conv_fwd[1] + conv_fwd[2]        # + weight gradients + two input gradients
+    bytes_step = 2 * BANDS * px * 4                                     # fp32 crop read by the forward and by conv1's weight gradient
+    value = a.steps * B / el
+    roof = None
+    if ms:
+        avg = sum(ms) / len(ms)
+        flops = conv_fwd[0] * B * YEARS
+        ach = flops / (avg * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": ("conv1 forward" if a.site == "fwd0" else "conv1 weight gradient") + " of the three years (one grouped launch)",
+                "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_TFLOPS[a.precision], 4), "traffic": None, "avg_launch_ms": round(avg, 4),
+                "launches": len(ms), "algorithmic_flop_per_launch": flops,
+                "measured_in": "HIP events around every launch of the timed steps"}
+    out = {"metric": "crops/sec (train step) year-ensemble 3 x spectral_network 369-band 24x24", "value": round(value, 1),
+           "unit": "crops/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+           "config": {"workload": "year-ensemble train step (BASELINE configs[4]): 3 years x spectral_network(369, 200) on 24x24 crops, "
+                                  "mean of last heads + weighted CE + bwd + Adam per year", "per_gpu_batch": B, "years": YEARS,
+                      "crop": CROP, "parallelism": "dp1", "zero_year_test": "present flags from the loader (no host sync)"},
+           "library_build_id": L.dta_build_id().decode(), "final_loss": round(float(loss), 5), "roofline": roof,
+           "step_roofline": {"bound": "mfma", "achieved": round(value * YEARS * step_flop / 1e12, 2), "peak": PEAK_TFLOPS[a.precision],
+                             "unit": "TFLOP/s", "frac": round(value * YEARS * step_flop / 1e12 / PEAK_TFLOPS[a.precision], 4),
+                             "algorithmic_flop_per_crop_year": step_flop,
+                             "hbm_gbs_algorithmic": round(value * YEARS * bytes_step / 1e9, 1),
+                             "hbm_frac_algorithmic": round(value * YEARS * bytes_step / 1e9 / PEAK_HBM_GBS, 4)}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
+    if a.workload == "ensemble24":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+        return main_ensemble24(a)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

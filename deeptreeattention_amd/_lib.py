@@ -123,6 +123,9 @@ def lib():
         L.dta_weighted_ce.restype = C.c_int
         L.dta_weighted_ce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_weighted_ce_scaled.restype = C.c_int
+        L.dta_weighted_ce_scaled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.dta_adam_step.restype = C.c_int
         L.dta_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
@@ -131,7 +134,8 @@ def lib():
         L.dta_adam_step_zero_grad.argtypes = L.dta_adam_step.argtypes
         L.dta_adam_step_gated.restype = C.c_int
         L.dta_adam_step_gated.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
-                                          C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]
+                                          C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                          C.c_void_p]
         L.dta_ensemble_backward_phased.restype = C.c_int
         L.dta_ensemble_backward_phased.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams), C.c_void_p,
                                                    C.c_void_p, C.POINTER(SubnetGrads), C.c_int, C.c_void_p]

@@ -823,6 +823,7 @@ int dta_net_loss(const dta_net_desc* d, const double* alpha, void* workspace, co
   if (build_plan(d, &p)) return 1;
   BlendCeArgs a;
   memset(&a, 0, sizeof(a));
+  a.gscale = 1.f;
   if (d->kind == DTA_NET_HANG2020) {
     if (!alpha) { dta_set_error("dta_net_loss: Hang2020 needs alpha"); return 1; }
     a.spec = at<float>(workspace, p.scores[0][2]); a.spat = at<float>(workspace, p.scores[1][2]); a.alpha = alpha; a.joint = joint;
@@ -843,6 +844,16 @@ int dta_weighted_ce(const float* logits, const long long* labels, const float* w
   return launch_weighted_ce(a, (hipStream_t)stream);
 }
 
+int dta_weighted_ce_scaled(const float* logits, const long long* labels, const float* weight, int batch, int classes,
+                           float grad_scale, float* loss, float* dlogits, float* scratch, void* stream) {
+  if (!logits || !labels || !loss || !scratch || batch < 1 || classes < 1) { dta_set_error("dta_weighted_ce_scaled: bad argument"); return 1; }
+  BlendCeArgs a;
+  a.spec = logits; a.spat = nullptr; a.alpha = nullptr; a.joint = nullptr;
+  a.labels = labels; a.weight = weight; a.dlogits = dlogits; a.loss = loss; a.rowtmp = scratch;
+  a.B = batch; a.classes = classes; a.gscale = grad_scale;
+  return launch_blend_ce(a, (hipStream_t)stream);
+}
+
 int dta_softmax_top2(const float* logits, int batch, int classes, float* probs, long long* top_idx, float* top_score,
                      void* stream) {
   if (!logits || !top_idx || !top_score || batch < 1 || classes < 2) { dta_set_error("dta_softmax_top2: bad argument"); return 1; }
@@ -852,10 +863,11 @@ int dta_softmax_top2(const float* logits, int batch, int classes, float* probs, 
 static int adam_step_impl(float* p, const float* g, float* gz, float* m, float* v, size_t n, double* alpha_p,
                           const double* alpha_g, double* alpha_gz, double* alpha_m, double* alpha_v, int step, float lr,
                           float beta1, float beta2, float eps, float grad_scale, void* stream,
-                          const float* active = nullptr, const int* dev_step = nullptr, const float* alpha_g32 = nullptr) {
+                          const float* active = nullptr, const int* dev_step = nullptr, const float* alpha_g32 = nullptr,
+                          int* dev_step_out = nullptr) {
   if ((step < 1 && !active) || (n && (!p || !g || !m || !v))) { dta_set_error("dta_adam_step: bad argument"); return 1; }
   AdamArgs a;
-  a.active = active; a.dev_step = dev_step;
+  a.active = active; a.dev_step = dev_step; a.dev_step_out = dev_step_out;
   if (active && !dev_step) { dta_set_error("dta_adam_step_gated: needs a device step counter"); return 1; }
   if (alpha_g32 && (alpha_g32 < g || alpha_g32 >= g + n)) { dta_set_error("dta_adam_step_dp: alpha's exchange slot must lie inside g"); return 1; }
   if (step < 1) step = 1;
@@ -875,10 +887,12 @@ int dta_adam_step(float* p, const float* g, float* m, float* v, size_t n, double
 }
 
 int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const float* active, const int* dev_step,
-                        float lr, float beta1, float beta2, float eps, float grad_scale, int zero_grad, void* stream) {
+                        int* dev_step_next, float lr, float beta1, float beta2, float eps, float grad_scale, int zero_grad,
+                        void* stream) {
   if (!active) { dta_set_error("dta_adam_step_gated: null gate"); return 1; }
+  if (dev_step_next == dev_step) { dta_set_error("dta_adam_step_gated: dev_step_next must be a different word than dev_step"); return 1; }
   return adam_step_impl(p, g, zero_grad ? g : nullptr, m, v, n, nullptr, nullptr, nullptr, nullptr, nullptr, 0, lr, beta1, beta2, eps,
-                        grad_scale, stream, active, dev_step);
+                        grad_scale, stream, active, dev_step, nullptr, dev_step_next);
 }
 
 int dta_adam_step_zero_grad(float* p, float* g, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,

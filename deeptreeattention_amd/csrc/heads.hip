@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
       const float old = __hip_atomic_exchange(a.rowtmp + row, ok ? wy * (lse + mx - zval((int)y)) : poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("" ::"v"(old));
     }
-    const float sc2 = (den > 0.f ? wy / den : 0.f) + poison;
+    const float sc2 = (den > 0.f ? wy / den : 0.f) * a.gscale + poison;
     for (int n = lane, k = 0; n < a.classes; n += 64, ++k) {
       const float z = zget(n, k);
       if (jo && jo != zs) jo[n] = z;
@@ -711,12 +711,15 @@ int launch_softmax_top2(const float* logits, int B, int classes, float* probs, l
 __global__ void k_adam(AdamArgs a) {
   float bc1 = a.bc1, bc2 = a.bc2;
   if (a.active) {
+    // the step count advances on the device too: dev_step = steps taken so far, dev_step_out (a DIFFERENT word, read
+    // by nobody during this launch) receives the count after this step
+    if (a.dev_step_out && blockIdx.x == 0 && threadIdx.x == 0) a.dev_step_out[0] = a.dev_step[0] + (a.active[0] > 0.f ? 1 : 0);
     if (!(a.active[0] > 0.f)) {      // skipped everywhere: only optimizer.zero_grad()'s part of the pass
       if (a.gz)
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) a.gz[i] = 0.f;
       return;
     }
-    const double st = (double)a.dev_step[0];
+    const double st = (double)(a.dev_step[0] + 1);
     bc1 = (float)(1.0 - pow((double)a.beta1, st)); bc2 = (float)(1.0 - pow((double)a.beta2, st));
   }
   const float ss = a.lr / bc1, rbc2 = rsqrtf(bc2);

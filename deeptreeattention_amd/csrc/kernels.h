@@ -353,6 +353,7 @@ int launch_weighted_ce(const CeArgs& a, hipStream_t st);
 struct BlendCeArgs {
   const float* spec; const float* spat; const double* alpha; float* joint;   // joint may be null (or == spec when no blend)
   const long long* labels; const float* weight; float* dlogits; float* loss; float* rowtmp; int B, classes;
+  float gscale = 1.f;      // factor on dlogits only (year ensemble: d(mean over kept years) / d(year score))
 };
 int launch_blend_ce(const BlendCeArgs& a, hipStream_t st);
 struct AdamArgs {
@@ -364,8 +365,8 @@ struct AdamArgs {
   // device-side gating (year ensembles under data parallelism): when `active` is non-null the step is applied only if
   // active[0] > 0 (otherwise the moments do not decay and the parameters stay, exactly as torch's Adam passes over a
   // parameter whose grad is None; the gradient buffer is still cleared), and the bias corrections come from the
-  // DEVICE step counter dev_step[0] (already advanced by the caller for this step) instead of bc1 / bc2
-  const float* active; const int* dev_step;
+  // DEVICE step counter (dev_step[0] = steps taken so far; this one is step dev_step[0] + 1) instead of bc1 / bc2
+  const float* active; const int* dev_step; int* dev_step_out = nullptr;
 };
 int launch_adam(const AdamArgs& a, hipStream_t st);
 int launch_softmax_top2(const float* logits, int B, int classes, float* probs, long long* top_idx, float* top_score,

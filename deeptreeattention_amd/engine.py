@@ -567,7 +567,9 @@ class EnsembleTrainer:
         self._ws_key = None
         if self.world > 1:
             self.sync.broadcast([self.flat[0]] + list(model.buffers()), 0)
-            self.dev_steps = torch.zeros(Y, dtype=torch.int32, device=dev)     # per-year optimizer step counts
+            # per-year optimizer step counts, two banks used alternately (the gated launches read one, write the other)
+            self.dev_steps = torch.zeros(2, Y, dtype=torch.int32, device=dev)
+            self._bank = 0
             # the 2^Y possible flag vectors, resident on the device: setting the flags is a device-to-device copy
             self._flag_table = torch.tensor([[(mask >> i) & 1 for i in range(Y)] for mask in range(1 << Y)],
                                             dtype=torch.float32, device=dev)
@@ -584,7 +586,7 @@ class EnsembleTrainer:
     def step_counts(self):
         """Optimizer steps taken per year (data-parallel: read back from the device counters, one host sync)."""
         if self.world > 1:
-            return [int(v) for v in self.dev_steps.tolist()]
+            return [int(v) for v in self.dev_steps[self._bank].tolist()]
         return [t.step_count for t in self.years]
 
     def grad_of(self, param):
@@ -608,7 +610,7 @@ class EnsembleTrainer:
         if self._shape != (B, classes):
             self.scores = torch.empty(B, classes, dtype=torch.float32, device=self.device)
             self.dscores = torch.empty_like(self.scores)
-            self.ce_scratch = torch.empty(B + 1, dtype=torch.float32, device=self.device)
+            self.ce_scratch = torch.zeros(B + 2, dtype=torch.float32, device=self.device)   # (last word: block counter)
             self._shape = (B, classes)
 
     def _forward(self, images, local):
@@ -653,27 +655,32 @@ class EnsembleTrainer:
         for i in kept:
             self.years[i]._grads_clear = False
 
-    def _ce(self, y, want_grad):
+    def _ce(self, y, want_grad, kept_years=1):
+        """Loss of the mean scores and, in the same launch, d(loss)/d(one year's scores) = d(loss)/d(mean) / kept years."""
         L = _lib.lib()
         self.loss = torch.empty((), dtype=torch.float32, device=self.device)      # fresh per step (see FusedTrainer._loss)
-        _lib.check(L.dta_weighted_ce(_lib.ptr(self.scores), _lib.ptr(y), _lib.ptr(self.loss_weight),
-                                     self.scores.shape[0], self.scores.shape[1], _lib.ptr(self.loss),
-                                     _lib.ptr(self.dscores) if want_grad else None, _lib.ptr(self.ce_scratch),
-                                     _lib.current_stream_ptr()), "dta_weighted_ce")
+        _lib.check(L.dta_weighted_ce_scaled(_lib.ptr(self.scores), _lib.ptr(y), _lib.ptr(self.loss_weight),
+                                            self.scores.shape[0], self.scores.shape[1], 1.0 / kept_years, _lib.ptr(self.loss),
+                                            _lib.ptr(self.dscores) if want_grad else None, _lib.ptr(self.ce_scratch),
+                                            _lib.current_stream_ptr()), "dta_weighted_ce_scaled")
 
     def _adam_gated(self):
         """One gated optimizer pass per year and bucket, driven by the reduced flags / device step counters."""
         L = _lib.lib()
         st = _lib.current_stream_ptr()
+        Y = len(self.years)
+        cur, nxt = self._bank, 1 - self._bank
         for i, t in enumerate(self.years):
             active = C.c_void_p(self.flags.data_ptr() + 4 * i)
-            step = C.c_void_p(self.dev_steps.data_ptr() + 4 * i)
-            for p, g, m, v, n in ((t.p_head, t.g_head, t.m_head, t.v_head, t.split),
-                                  (t.p_tail, t.g_tail, t.m_tail, t.v_tail, t.n_first)):
+            step = C.c_void_p(self.dev_steps.data_ptr() + 4 * (cur * Y + i))
+            step_next = C.c_void_p(self.dev_steps.data_ptr() + 4 * (nxt * Y + i))
+            for k, (p, g, m, v, n) in enumerate(((t.p_head, t.g_head, t.m_head, t.v_head, t.split),
+                                                 (t.p_tail, t.g_tail, t.m_tail, t.v_tail, t.n_first))):
                 _lib.check(L.dta_adam_step_gated(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, active, step,
-                                                 t.lr, self.betas[0], self.betas[1], self.eps, self.sync.grad_scale,
+                                                 step_next if k == 0 else None, t.lr, self.betas[0], self.betas[1], self.eps, self.sync.grad_scale,
                                                  0 if self.keep_grads else 1, st), "dta_adam_step_gated")
             t._grads_clear = not self.keep_grads
+        self._bank = nxt
 
     def train_step(self, images, y, present=None):
         """images: list of (B, bands, H, W) float32 device tensors, one per year; y: int64 labels.  Returns the loss
@@ -681,8 +688,7 @@ class EnsembleTrainer:
         local = self._kept(images, present)
         y = self.years[0]._labels(y)
         kept = self._forward(images, local)
-        self._ce(y, True)
-        self.dscores.mul_(1.0 / len(kept))      # d(mean over kept years)/d(year score)
+        self._ce(y, True, len(kept))
         if self.world == 1:
             self._backward(kept)
             for i, t in enumerate(self.years):
@@ -706,7 +712,6 @@ class EnsembleTrainer:
             self.flags.copy_(self._flag_table[mask])
             self.sync.reduce_all(self.flat[1])
         self.sync.finish()
-        self.dev_steps.add_((self.flags > 0).to(torch.int32))
         self._adam_gated()
         return self.loss
 

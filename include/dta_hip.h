@@ -183,6 +183,13 @@ int dta_preprocess_crops_tiles(const dta_crop_desc* d, const void* raw, const lo
 int dta_weighted_ce(const float* logits, const long long* labels, const float* weight, int batch, int classes,
                     float* loss, float* dlogits, float* scratch, void* stream);
 
+/* The same loss in ONE launch (the last block to arrive finalises it) with a factor on the gradient only: dlogits =
+ * grad_scale * d(loss)/d(logits).  The year ensemble's step uses it with grad_scale = 1 / kept years, the derivative of
+ * the mean over the kept years' scores (src/models/year.py:33), so no elementwise pass follows the loss.
+ * scratch: batch + 2 floats whose LAST 32-bit word is zero on entry (block counter; left zero). */
+int dta_weighted_ce_scaled(const float* logits, const long long* labels, const float* weight, int batch, int classes,
+                           float grad_scale, float* loss, float* dlogits, float* scratch, void* stream);
+
 /* Inference epilogue: replaces F.softmax(pred, dim=1) (src/models/multi_stage.py:302,315; src/main.py:190) and the
  * top-1/top-2 label+score extraction of src/main.py:192-205.  probs [batch][classes] may be null.
  * top_idx [batch][2] int64, top_score [batch][2] float32. */
@@ -209,11 +216,14 @@ int dta_adam_step_dp(float* p, float* g, float* m, float* v, size_t n, double* a
 
 /* optimizer.step() + zero_grad() gated ON THE DEVICE (year ensembles under data parallelism, where whether a year is
  * stepped -- "some rank kept it", src/models/year.py:27 -- is only known on the device after the gradient exchange):
- * active[0] > 0: Adam step with bias corrections taken from the device counter dev_step[0] (1-based, already advanced
- * by the caller for this step); otherwise nothing but the gradient clear (zero_grad != 0) happens (no moment decay, as torch's Adam
- * passes over parameters whose grad is None).  No float64 alpha here (spectral networks have none). */
+ * active[0] > 0: Adam step number dev_step[0] + 1 (dev_step[0] = steps this parameter group has taken so far, a device
+ * counter); otherwise nothing but the gradient clear (zero_grad != 0) happens (no moment decay, as torch's Adam passes
+ * over parameters whose grad is None).  dev_step_next (may be NULL; must not alias dev_step): receives the count after
+ * this step, dev_step[0] + (active ? 1 : 0) -- callers ping-pong two counter words, so the count advances without any
+ * launch of their own; pass it in ONE of the launches that share a counter.  No float64 alpha here. */
 int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const float* active, const int* dev_step,
-                        float lr, float beta1, float beta2, float eps, float grad_scale, int zero_grad, void* stream);
+                        int* dev_step_next, float lr, float beta1, float beta2, float eps, float grad_scale, int zero_grad,
+                        void* stream);
 
 /* ---- Peer gradient exchange: data-parallel training with one process per GPU of ONE node (reference train.py:89-98:
  * Lightning DDP all-reduces every parameter's gradient between loss.backward() and optimizer.step()).  Here the sum over
