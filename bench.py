@@ -167,6 +167,15 @@ def main_ensemble24(a):
                 "frac": round(ach / PEAK_TFLOPS[a.precision], 4), "traffic": None, "avg_launch_ms": round(avg, 4),
                 "launches": len(ms), "algorithmic_flop_per_launch": flops,
                 "measured_in": "HIP events around every launch of the timed steps"}
+        if a.site == "fwd0" and a.precision == "bf16":
+            # the bf16 first conv reads the fp32 crops itself and leaves the (haloed) bf16 tiles behind for the weight
+            # gradient: per crop-year 369*576*4 B in, 384*676*2 B of tiles + 32*576*2 B of half output out -> HBM-bound
+            nbytes = B * YEARS * (BANDS * px * 4 + 384 * (CROP + 2) * (CROP + 2) * 2 + 32 * px * 2)
+            gbs = nbytes / (avg * 1e-3) / 1e9
+            roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes, "mfma_tflops": round(ach, 2),
+                         "kernel": "k_conv3x3_bf16<3,1,XN,6> (conv1 forward of the three years, one grouped launch; converts "
+                                   "the fp32 crops and emits the bf16 tiles)"})
     out = {"metric": "crops/sec (train step) year-ensemble 3 x spectral_network 369-band 24x24", "value": round(value, 1),
            "unit": "crops/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",

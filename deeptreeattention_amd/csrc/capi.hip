@@ -146,7 +146,7 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
       if (vl > p->vec_ld[L]) p->vec_ld[L] = (vl + 3) & ~3;   // rows 16-byte aligned: the batch GEMMs over them use vector loads
     }
     int Nconv = (L == 0 && p->shared_x) ? 32 * G : CH[L];
-    p->MWG[L] = conv_mwg(Nconv);
+    p->MWG[L] = d->dtype == DTA_BF16 ? conv_mwg_bf16(Nconv, p->HWc[L]) : conv_mwg(Nconv);
     if (d->dtype == DTA_BF16 && L > 0 && Nconv == 64) p->MWG[L] = 256;   // second conv: two 256-row workgroups per CU
     int ppw, spp;
     conv_geometry(p->HWc[L], p->MWG[L], B, &ppw, &spp, &p->nwg[L]);
@@ -227,7 +227,8 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
 // faster (measured crossover: ~100 first-conv workgroups, B ~ 450 for Hang2020)
 inline bool fused_input(const Plan& p) {
   const int launchG = p.shared_x ? 1 : p.G;
-  return p.esz == 2 && p.x_compact && p.nwg[0] * launchG >= 100 && !switches().no_fused_input;
+  // (tiles that keep their halo -- 24x24-class crops -- take the same route as long as a workgroup owns whole patches)
+  return p.esz == 2 && p.HWc[0] <= p.MWG[0] && p.nwg[0] * launchG >= 100 && !switches().no_fused_input;
 }
 
 template <typename T> inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }

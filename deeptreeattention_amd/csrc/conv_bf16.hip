@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_conv3x3_bf16(ConvArgs a) {
       rowtab[lr] = valid ? (b0 + pl) * HW + pix : -1; \
       plq[lr] = valid ? ((pl << 16) | (h * W2 + w)) : 0; \
     } \
-    if (xc) { \
+    if (xc || XN) {   /* (the fused-input kernel writes interior pixels only, whatever the HBM tile format) */ \
       u32x4* z = reinterpret_cast<u32x4*>(sbuf); \
       const u32x4 zero = {0u, 0u, 0u, 0u}; \
       for (int i = tid; i < xbytes / 16; i += NTHR) { z[i] = zero; if (dbuf) z[i + stage / 16] = zero; } \
@@ -150,7 +150,7 @@ _Pragma("unroll") \
   // ---- network input read directly as fp32 NCHW (no separate pack pass): thread t owns (patch, 4-channel group,
   // pixel) quads t, t+512, ...; the 16 channel planes of a chunk are one contiguous run per patch, so consecutive lanes
   // read consecutive floats.  Four channels of a pixel are converted and written to the LDS row as one 8-byte store.
-  constexpr int QV = 4;
+  constexpr int QV = 2 * MT;                 // quads per thread: a workgroup's MWG rows x 4 channel groups over NTHR threads
   constexpr bool xn = XN;
   const float* xf = xn ? a.x_nchw[g] + (size_t)b0 * a.Cx * HW : nullptr;
   const int nquad = xn ? npatch * 4 * HW : 0;
@@ -473,11 +473,11 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   static DevOnce attr_once;      // (function attributes are per device)
   if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (NW == 8) hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   if (a.x_nchw[0]) {
-    if (NW != 8) { dta_set_error("conv3x3(bf16): the fused-input first conv runs eight-wave workgroups only"); return 1; }
-    hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, true, 8>), dim3(nwg, G), dim3(512), lds, st, a);
+    if (a.spp != 1) { dta_set_error("conv3x3(bf16): the fused-input first conv needs whole patches per workgroup"); return 1; }
+    hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, true, NW>), dim3(nwg, G), dim3(NW * 64), lds, st, a);
   } else {
     hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, false, NW>), dim3(nwg, G), dim3(NW * 64), lds, st, a);
   }
@@ -485,10 +485,21 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   return 0;
 }
 
+int conv_mwg_bf16(int N, int HW) {
+  if (N == 32 && HW > 512) {
+    const int r512 = (HW + 511) / 512 * 512, r576 = (HW + 575) / 576 * 576;
+    if (r576 < r512) return 576;
+  }
+  return conv_mwg(N);
+}
+
 template <>
 int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
-  switch (a.N) {     // workgroup rows must match conv_mwg(N): 512 for N<=64, 256 for N=128
-    case 32: return launch_conv_bf16_t<2, 1>(a, G, st);
+  switch (a.N) {     // workgroup rows must match the plan's choice (conv_mwg_bf16): 512 or 576 for N<=64, 256 for N=128
+    case 32:
+      // (an input-gradient conv has no BN partials, so the plan's geometry is not binding: pick the tighter tile here)
+      if (a.mwg == 576 || (a.stats == nullptr && conv_mwg_bf16(32, a.HW) == 576)) return launch_conv_bf16_t<3, 1, 6>(a, G, st);
+      return launch_conv_bf16_t<2, 1>(a, G, st);
     case 64: {
       // an input-gradient conv (no BN partials, so the plan's workgroup geometry is not binding) over few rows:
       // 256-row workgroups double the number of busy CUs

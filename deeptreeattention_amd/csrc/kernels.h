@@ -118,6 +118,9 @@ __device__ __forceinline__ void wgrad_reduce_blocks(const WgradReduceArgs& a, in
 #endif
 void conv_geometry(int HW, int MWG, int B, int* ppw, int* spp, int* nwg);
 int conv_mwg(int N);
+// bf16 kernels: output rows per workgroup for an HW-pixel map -- 576 (six waves x three 32-row tiles) when that wastes
+// fewer rows than 512 (a 24x24 map is exactly one 576-row workgroup instead of 512 + 64 rows of two)
+int conv_mwg_bf16(int N, int HW);
 int wgrad_cpw(int N);
 int wgrad_ngroups(int N, int bf16);     // column groups of the bf16 weight-gradient kernel (the slab count divides by it)
 
