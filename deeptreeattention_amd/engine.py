@@ -42,7 +42,7 @@ class FusedTrainer:
 
     def __init__(self, model, lr, loss_weight=None, betas=(0.9, 0.999), eps=1e-8, process_group=None,
                  overlap_comm=True, keep_grads=False, last_head_only=False, three_head_loss=False,
-                 extra_grad_slots=0, storage=None, exchange=None, exchange_opts=None):
+                 extra_grad_slots=0, storage=None, exchange=None, exchange_opts=None, broadcast_buffers=False):
         """three_head_loss: train on the SUM of the class-weighted cross-entropies of every classifier head (the Hang
         et al. recipe BASELINE.json's north_star words as "three-head weighted cross-entropy"): three heads for a
         spectral / spatial network, all six for Hang2020 (whose sigmoid(alpha) blend is then not on the graph, so
@@ -56,7 +56,12 @@ class FusedTrainer:
         one ncclAllReduce of the flat buffer enqueued on the compute stream (librccl called directly); "torch":
         torch.distributed all-reduces (two buckets overlapped with the first conv's weight gradient when
         overlap_comm); None: peer if the crash-isolated probe passes on every rank, else rccl / torch.
-        exchange_opts: keyword arguments of dist.PeerExchange (timeout_s, max_workgroups)."""
+        exchange_opts: keyword arguments of dist.PeerExchange (timeout_s, max_workgroups).
+        broadcast_buffers: Lightning's DDP wrapper (torch DDP default broadcast_buffers=True) copies rank 0's BatchNorm
+        running statistics / counters to every rank before each forward, so all ranks' buffers -- and a checkpoint
+        written by any rank -- equal rank 0's view.  They never enter a training-mode forward or a gradient, so the
+        default here is False (per-rank statistics, one collective less per step); True reproduces the reference's
+        buffers exactly at the cost of one small broadcast per step (data-parallel only)."""
         if not isinstance(model, H._Net):
             raise TypeError("FusedTrainer needs a deeptreeattention_amd network module")
         self.model = model
@@ -152,6 +157,7 @@ class FusedTrainer:
         self._ws_key = None
         self._desc_key = None
         self._desc_cache, self._ws_cache = {}, {}      # the last two (shape, mode) keys: descriptors / device buffers
+        self.broadcast_buffers = bool(broadcast_buffers)
         self._reduced = False          # peer exchange: the gradient buffer already holds the sum (reduce_now)
         self.sync = GradSync(self.world, self.pg, rccl=RcclDirect(self.pg) if self.exchange == "rccl" else None)
         if self.comm and storage is None:
@@ -171,6 +177,21 @@ class FusedTrainer:
         """DDP start-up semantics: every rank starts from rank `src`'s parameters and buffers."""
         if self.world > 1:
             self.sync.broadcast([self.p_head, self.p_tail] + ([self.alpha.data] if self.hang else []) + list(self.model.buffers()), src)
+
+    def sync_buffers(self, src=0):
+        """Every rank's BatchNorm running statistics / counters := rank `src`'s (one packed float64 broadcast: int64
+        counters and float32 statistics are exact in it)."""
+        if self.world <= 1:
+            return
+        bufs = list(self.model.buffers())
+        flat = torch.cat([b.detach().reshape(-1).to(torch.float64) for b in bufs])
+        torch.distributed.broadcast(flat, src, group=self.pg)
+        off = 0
+        with torch.no_grad():
+            for b in bufs:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view(b.shape).to(b.dtype))
+                off += n
 
     def reduce_now(self):
         """Peer exchange only: sum the gradient buffer over the ranks NOW (one launch) instead of inside the optimizer
@@ -459,6 +480,8 @@ class FusedTrainer:
                                "three_head_loss=True, or a spectral/spatial network with last_head_only=True; a year "
                                "ensemble of spectral networks trains through EnsembleTrainer")
         y = self._labels(y)
+        if self.broadcast_buffers and self.world > 1:
+            self.sync_buffers()            # DDP's per-forward buffer broadcast from rank 0
         logits = self._forward_scores(x)
         if self.three_head:
             self._loss_heads(y, True)

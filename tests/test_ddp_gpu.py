@@ -192,3 +192,39 @@ def test_two_rank_metadata_step_keeps_replicas_identical():
         if "running_" in k or "num_batches_tracked" in k:
             continue
         assert rel_l2(sd0[k], sd1[k]) < 1e-6, k
+
+
+def _bb_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    from oracle import prng
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    torch.manual_seed(3)
+    m = H.Hang2020(BANDS, CLASSES).to(dev).train()
+    tr = FusedTrainer(m, lr=1e-3, exchange="torch", broadcast_buffers=True)
+    for step in range(3):
+        x = torch.from_numpy(prng.uniform01(400 + 10 * step + rank, 1, (B, BANDS, 11, 11))).to(dev)
+        y = torch.from_numpy(prng.randint(400 + rank, 2, (B,), CLASSES)).to(dev)
+        tr.train_step(x, y)
+    tr.sync_buffers()                      # what a checkpoint hook would call before saving on any rank
+    torch.cuda.synchronize()
+    out[rank] = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    dist.destroy_process_group()
+
+
+def test_broadcast_buffers_option_gives_every_rank_rank0s_batchnorm_state():
+    """Lightning DDP's broadcast_buffers semantics as an option: with it, the running statistics
+    every rank holds are rank 0's; without it (default) they are per rank, which the other tests of this file pin."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bb_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
+    assert int(out[1]["spectral_network.conv1.bn1.num_batches_tracked"]) == 3

@@ -4,7 +4,9 @@ cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --site wgrad0 --no-cpu-baseline > $O/bench_wgrad0.json 2>> $O/bench_default.err
 python bench.py --precision fp32 --no-cpu-baseline > $O/bench_fp32.json 2>> $O/bench_default.err
-DTA_FORCE_COLLECTIVES=1 MASTER_PORT=29561 python bench.py --no-cpu-baseline --tile-steps 0 > $O/bench_rccl_one_rank.json 2>> $O/bench_default.err
+bash tools/dp_probe.sh > $O/dp_one_rank.txt 2>> $O/bench_default.err
+python bench.py --workload ensemble24 --steps 100 --warmup 10 > $O/bench_ensemble24.json 2>> $O/bench_default.err
+python bench.py --workload ensemble24 --steps 100 --warmup 10 --site wgrad0 > $O/bench_ensemble24_wgrad0.json 2>> $O/bench_default.err
 python tools/ensemblebench.py > $O/ensemble.json 2>> $O/bench_default.err
 python tools/inferbench.py > $O/infer.txt 2>> $O/bench_default.err
 cd /tmp && export TMPDIR=/tmp
@@ -13,7 +15,9 @@ rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B --steps 50 --warmup 10 > $
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o f -- $B --steps 3 --warmup 2 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o w -- $B --steps 3 --warmup 2 > $O/write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace -d $O/sq -o s -- $B --steps 3 --warmup 2 > $O/sq.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt_e24 -o kt -- python $R/bench.py --workload ensemble24 --steps 30 --warmup 5 > $O/kt_e24.log 2>&1
 cd $R
+python tools/prof_summary.py $O/kt_e24/kt_results.db 35 > $O/kernel_trace_ensemble24.txt
 python tools/prof_summary.py $O/kt/kt_results.db 60 > $O/kernel_trace.txt
 python tools/step_traffic.py --trace $O/kt/kt_results.db --fetch $O/fetch/f_results.db --write $O/write/w_results.db --sq $O/sq/s_results.db --trace-steps 60 --pmc-steps 5 --out $O/traffic_step.json > $O/traffic_step.txt
 head -5 $O/kernel_trace.txt; head -12 $O/traffic_step.txt; cut -c1-400 $O/bench_default.json
