@@ -40,6 +40,8 @@ class FusedTrainer:
     process_group: torch.distributed group (None = single process)
     """
 
+    _warned_force = False
+
     def __init__(self, model, lr, loss_weight=None, betas=(0.9, 0.999), eps=1e-8, process_group=None,
                  overlap_comm=True, keep_grads=False, last_head_only=False, three_head_loss=False,
                  extra_grad_slots=0, storage=None, exchange=None, exchange_opts=None, broadcast_buffers=False):
@@ -76,6 +78,11 @@ class FusedTrainer:
         # RCCL code path -- streams, buckets, the alpha slot -- on a single-GPU box; tests/test_rccl_single_gpu.py)
         self.comm = self.world > 1 or (os.environ.get("DTA_FORCE_COLLECTIVES") == "1" and torch.distributed.is_available()
                                        and torch.distributed.is_initialized())
+        if self.comm and self.world == 1 and not FusedTrainer._warned_force:
+            import warnings
+            warnings.warn("DTA_FORCE_COLLECTIVES=1: a one-rank process group still issues the gradient exchange "
+                          "(development measurement switch)")
+            FusedTrainer._warned_force = True
         self.exchange = None           # "peer" / "rccl" / "torch" when this trainer exchanges gradients itself
         if self.comm and storage is None:
             self.exchange = choose_exchange(exchange, process_group) if self.world > 1 else (exchange or "torch")
