@@ -250,7 +250,12 @@ def probe_peer_exchange(group=None, budget_s=90.0):
     import subprocess
     import sys
     import tempfile
+    import socket
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    hosts = [None] * world
+    dist.all_gather_object(hosts, socket.gethostname(), group=group)
+    if len(set(hosts)) > 1:            # peers are mapped through HIP IPC: one node only
+        return False, ["ranks span {} hosts".format(len(set(hosts)))] * world
     box = [tempfile.mkdtemp(prefix="dta_peer_probe_") if rank == 0 else None]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     here = os.path.dirname(os.path.abspath(__file__))
