@@ -161,6 +161,8 @@ def lib():
         L.dta_softmax_top2.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
         L.dta_profile_enable.restype = C.c_int
         L.dta_profile_enable.argtypes = [C.c_int]
+        L.dta_profile_set_stride.restype = C.c_int
+        L.dta_profile_set_stride.argtypes = [C.c_int]
         L.dta_profile_collect.restype = C.c_int
         L.dta_profile_collect.argtypes = [C.POINTER(C.c_float), C.c_int]
         L.dta_profile_collect_site.restype = C.c_int

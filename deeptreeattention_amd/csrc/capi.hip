@@ -29,6 +29,8 @@ constexpr int DTA_LEAN_DEFAULT = 15;
 struct Prof {
   static constexpr int SLOTS = 4, CAP = 512;
   int site[SLOTS] = {-1, -1, -1, -1}, n[SLOTS] = {0, 0, 0, 0}, nslots = 0;
+  int stride = 1, seen[SLOTS] = {0, 0, 0, 0};      // every stride-th launch of a site is timed (an event pair costs ~5 us of stream time)
+  bool armed[SLOTS] = {false, false, false, false};
   bool created = false;
   hipEvent_t ev[SLOTS][CAP][2];
 } g_prof;
@@ -40,12 +42,14 @@ inline int prof_slot(int site) {
 inline void prof_begin(int site, hipStream_t st) {
   if (g_prof.nslots == 0) return;
   const int s = prof_slot(site);
-  if (s >= 0 && g_prof.n[s] < Prof::CAP) hipEventRecord(g_prof.ev[s][g_prof.n[s]][0], st);
+  if (s < 0) return;
+  g_prof.armed[s] = (g_prof.seen[s]++ % g_prof.stride) == 0 && g_prof.n[s] < Prof::CAP;
+  if (g_prof.armed[s]) hipEventRecord(g_prof.ev[s][g_prof.n[s]][0], st);
 }
 inline void prof_end(int site, hipStream_t st) {
   if (g_prof.nslots == 0) return;
   const int s = prof_slot(site);
-  if (s >= 0 && g_prof.n[s] < Prof::CAP) { hipEventRecord(g_prof.ev[s][g_prof.n[s]][1], st); ++g_prof.n[s]; }
+  if (s >= 0 && g_prof.armed[s]) { hipEventRecord(g_prof.ev[s][g_prof.n[s]][1], st); ++g_prof.n[s]; g_prof.armed[s] = false; }
 }
 
 // Developer switches (same-box A/B runs): the environment is read once per process, not per call.
@@ -660,6 +664,12 @@ const char* dta_build_id(void) { return DTA_BUILD_ID; }
 
 int dta_dev_reload_switches(void) { g_switches = read_switches(); return 0; }
 
+int dta_profile_set_stride(int stride) {
+  if (stride < 1) { dta_set_error("dta_profile_set_stride: stride must be >= 1"); return 1; }
+  g_prof.stride = stride;
+  return 0;
+}
+
 int dta_profile_enable(int site) {
   if (site < 0) {   // stop timing, forget every site
     g_prof.nslots = 0;
@@ -679,7 +689,7 @@ int dta_profile_enable(int site) {
     s = g_prof.nslots++;
     g_prof.site[s] = site;
   }
-  g_prof.n[s] = 0;
+  g_prof.n[s] = 0; g_prof.seen[s] = 0; g_prof.armed[s] = false;
   return 0;
 }
 

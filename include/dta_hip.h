@@ -319,6 +319,9 @@ enum { DTA_SITE_CONV_FWD = 0, DTA_SITE_CONV_WGRAD = 3, DTA_SITE_CONV_DGRAD = 6, 
        DTA_SITE_STAGE_BWD = 12,
        DTA_SITE_GEMM = 15 /* +0 classifier heads forward, +1 head input gradients, +2 parameter-gradient group */ };
 int dta_profile_enable(int site);
+/* Time only every stride-th launch of an enabled site (default 1): an event pair costs ~5 us of stream time per launch,
+ * which a throughput measurement running beside the timing should not pay on every step. */
+int dta_profile_set_stride(int stride);
 int dta_profile_collect(float* ms, int max);
 int dta_profile_collect_site(int site, float* ms, int max);
 /* Development aid: the library reads its developer environment switches (DTA_NO_FUSED_INPUT, DTA_NO_TAIL_MERGE,
