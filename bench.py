@@ -261,16 +261,18 @@ def main():
 
     primed = 0
     t_prime = time.perf_counter()
-    while time.perf_counter() - t_prime < a.prime_seconds:      # same count on every rank is not needed: a barrier follows
+    while a.prime_seconds > 0:
         for i in range(50):
             trainer.train_step(xs[i % nb], ys[i % nb])
         torch.cuda.synchronize()
         primed += 50
-        if dist_on:      # ranks must issue the same number of exchanges: agree on stopping
-            flag = torch.tensor([1.0 if time.perf_counter() - t_prime < a.prime_seconds else 0.0], device=dev)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-            if flag.item() == 0.0:
-                break
+        stop = time.perf_counter() - t_prime >= a.prime_seconds
+        if dist_on:      # every rank must issue the same number of exchanges: any rank's "enough" ends it for all
+            flag = torch.tensor([1.0 if stop else 0.0], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            stop = flag.item() > 0.0
+        if stop:
+            break
     for i in range(a.warmup):
         trainer.train_step(xs[i % nb], ys[i % nb])
     torch.cuda.synchronize()
