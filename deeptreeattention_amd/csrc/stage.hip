@@ -325,6 +325,48 @@ __device__ __forceinline__ void stage_forward(const StageArgs& a, const StageGeo
   auto ldy = [&](size_t i_) { return use_saved ? ld_fmt<false>(a.y, ybase + i_, yf) : ld_fmt<true>(a.y, ybase + i_, yf); };
   if (z_ready) {
     // the caller already built Z from prefetched registers
+  } else if (CT > 0 && CT % 8 == 0 && yf != FMT_F32 && (a.y_rs & 7) == 0 && (ybase & 7) == 0) {
+    // 16-bit conv output with 16-byte aligned rows: a thread owns one 8-channel octet (256 % (C / 8) == 0, so the octet
+    // and its BN coefficients are fixed per thread) and fetches it as ONE 16-byte load per pixel -- the scalar form below
+    // issues eight 2-byte loads and eight address computations for the same bytes, and these generic kernels are
+    // instruction-issue bound (24x24 crops: 72 -> 9 fetch iterations per thread)
+    constexpr int NO = (CT > 0 ? CT : 8) / 8;
+    const int o = t % NO, p0 = t / NO, pstep = 256 / NO;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = a.apply_bn ? coef[(o * 8 + e) * 4 + 0] : 1.f;
+      sh[e] = a.apply_bn ? coef[(o * 8 + e) * 4 + 1] : 0.f;
+    }
+    const unsigned short* y16 = (const unsigned short*)a.y + ybase + o * 8;
+    auto ld8 = [&](size_t i_, float (&v)[8]) {
+      const u32x4* pq = (const u32x4*)(y16 + i_);
+      const u32x4 q = use_saved ? *pq : __builtin_nontemporal_load(pq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = unpack_lo(q[e], yf) * sc[2 * e] + sh[2 * e]; v[2 * e + 1] = unpack_hi(q[e], yf) * sc[2 * e + 1] + sh[2 * e + 1]; }
+    };
+    if (!pool) {
+#pragma unroll 4
+      for (int p = p0; p < s.HWc; p += pstep) {
+        float v[8];
+        ld8((size_t)p * a.y_rs, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Z[p * ld + o * 8 + e] = a.relu ? relu_nan(v[e]) : v[e];
+      }
+    } else {
+#pragma unroll 2
+      for (int pz = p0; pz < s.HWz; pz += pstep) {
+        const int hz = pz / s.Wz, wz = pz - hz * s.Wz;
+        const size_t y0 = (size_t)((2 * hz) * s.Wc + 2 * wz) * a.y_rs;
+        float v0_[8], v1_[8], v2_[8], v3_[8];
+        ld8(y0, v0_); ld8(y0 + a.y_rs, v1_); ld8(y0 + (size_t)s.Wc * a.y_rs, v2_); ld8(y0 + (size_t)(s.Wc + 1) * a.y_rs, v3_);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float m = max_nan(max_nan(v0_[e], v1_[e]), max_nan(v2_[e], v3_[e]));
+          Z[pz * ld + o * 8 + e] = a.relu ? relu_nan(m) : m;
+        }
+      }
+    }
   } else if (CT > 0) {
     // 256 % C == 0: every thread keeps one channel, its BN coefficients live in registers
     const int c = t % C, p0 = t / C, pstep = 256 / C;
