@@ -10,12 +10,12 @@ python bench.py --workload ensemble24 --steps 100 --warmup 10 --site wgrad0 > $O
 python tools/ensemblebench.py > $O/ensemble.json 2>> $O/bench_default.err
 python tools/inferbench.py > $O/infer.txt 2>> $O/bench_default.err
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --steady-steps 0 --tile-steps 0 --other-steps 0"
+B="python $R/bench.py --no-cpu-baseline --steady-steps 0 --tile-steps 0 --other-steps 0 --prime-seconds 0"
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B --steps 50 --warmup 10 > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o f -- $B --steps 3 --warmup 2 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o w -- $B --steps 3 --warmup 2 > $O/write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace -d $O/sq -o s -- $B --steps 3 --warmup 2 > $O/sq.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/kt_e24 -o kt -- python $R/bench.py --workload ensemble24 --steps 30 --warmup 5 > $O/kt_e24.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt_e24 -o kt -- python $R/bench.py --workload ensemble24 --steps 30 --warmup 5 --prime-seconds 0 > $O/kt_e24.log 2>&1
 cd $R
 python tools/prof_summary.py $O/kt_e24/kt_results.db 35 > $O/kernel_trace_ensemble24.txt
 python tools/prof_summary.py $O/kt/kt_results.db 60 > $O/kernel_trace.txt
