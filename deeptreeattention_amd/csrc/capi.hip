@@ -558,7 +558,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     // operand they become is bf16 anyway); `da` was written by the NEXT layer's input-gradient conv in the format that
     // layer chose from lean_lvl[L] (same predicate, evaluated before the loop)
     sb.da_fmt = (L < 2 && lean_lvl[L] && g16) ? FMT_BF16 : FMT_F32;
-    sb.dv_fmt = (lean_lvl[L] && g16) ? FMT_BF16 : FMT_F32;
+    sb.dv_fmt = g16 ? FMT_BF16 : FMT_F32;      // (the generic stage kernels store it in bf16 too)
     sb.bnpart = at<float>(ws, p.bnpart[L]); sb.bnpart_gs = (size_t)B * C * 2;
     sb.vec = at<float>(ws, p.vec[L]); sb.vec_gs = (size_t)B * p.vec_ld[L]; sb.vec_ld = p.vec_ld[L];
     prof_begin(DTA_SITE_STAGE_BWD + L, st);

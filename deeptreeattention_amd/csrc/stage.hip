@@ -800,7 +800,17 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
 
   TICK(3);
   // pool + ReLU backward, write dv and the per-patch BatchNorm-backward partial sums
-  float* dv = ba.dv + (size_t)g * ba.dv_gs + (size_t)b * s.HWc * C;
+  // the gradient map leaves in fp32 or (bf16 mode) in bf16, like the lean kernels' (half the bytes here and in the
+  // BatchNorm-backward apply that reads it); element index dvi, stores through st_dv
+  const int dvf = ba.dv_fmt;
+  const size_t dvi = (size_t)g * ba.dv_gs + (size_t)b * s.HWc * C;
+  // (bf16: lanes t, t ^ 1 own channels c, c + 1 of the same pixel -- the even lane stores the packed pair as one dword;
+  //  2-byte stores per lane were measured 19 % slower for the whole kernel)
+  auto st_dv = [&](size_t i_, float v_) {
+    if (dvf == FMT_F32) { const_cast<float*>(ba.dv)[dvi + i_] = v_; return; }
+    const float nb_ = lane_xor1(v_);
+    if (!(t & 1)) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(const_cast<float*>(ba.dv)) + dvi + i_) = pack2_fmt(v_, nb_, FMT_BF16);
+  };
   const size_t ybase = (size_t)g * a.y_gs + (size_t)b * s.HWc * a.y_rs;
   const float* coef = a.coef ? a.coef + (size_t)g * a.coef_gs : nullptr;
   const int c = t % C, sl = t / C, nsl = 256 / C;
@@ -817,7 +827,7 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
       for (int p = sl; p < s.HWc; p += nsl) {
         float d = D[p * ld + c], r = Z[p * ld + c];
         if (a.relu && r <= 0.f) d = 0.f;
-        dv[(size_t)p * C + c] = d;
+        st_dv((size_t)p * C + c, d);
         if (a.apply_bn) {
           float xh = recover ? (r - bet) * inv_gam : (ld_fmt(a.y, ybase + (size_t)p * a.y_rs + c, CFG::YF) - mean) * rstd;
           s1 += d; s2 += d * xh;
@@ -825,7 +835,7 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
       }
     } else {
       // one pooled element per iteration: re-read its 2x2 window, route the gradient to the first maximum
-      unsigned char* fpos = reinterpret_cast<unsigned char*>(dv + (size_t)s.HWz * C);   // compact form: positions
+      unsigned char* fpos = reinterpret_cast<unsigned char*>(const_cast<float*>(ba.dv)) + (dvi + (size_t)s.HWz * C) * fmt_bytes(dvf);   // compact form: positions
       for (int pz = sl; pz < s.HWz; pz += nsl) {
         int hz = pz / s.Wz, wz = pz - hz * s.Wz;
         const int p00 = (2 * hz) * s.Wc + 2 * wz;
@@ -840,10 +850,10 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
         }
         float d = D[pz * ld + c];
         if (a.relu && m <= 0.f) d = 0.f;
-        if (ba.dv_compact) { dv[(size_t)pz * C + c] = d; fpos[(size_t)pz * C + c] = (unsigned char)first; }
+        if (ba.dv_compact) { st_dv((size_t)pz * C + c, d); fpos[(size_t)pz * C + c] = (unsigned char)first; }
         else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) dv[(size_t)po[k] * C + c] = (k == first) ? d : 0.f;
+          for (int k = 0; k < 4; ++k) st_dv((size_t)po[k] * C + c, (k == first) ? d : 0.f);
         }
         if (a.apply_bn) { s1 += d; s2 += d * (yv[first] - mean) * rstd; }
       }
@@ -851,7 +861,7 @@ __device__ __forceinline__ void stage_bwd_patch(const StageBwdArgs& ba, const St
       if (!ba.dv_compact)
         for (int p = sl; p < s.HWc; p += nsl) {
           int h = p / s.Wc, w = p - h * s.Wc;
-          if ((h >> 1) >= s.Hz || (w >> 1) >= s.Wz) dv[(size_t)p * C + c] = 0.f;
+          if ((h >> 1) >= s.Hz || (w >> 1) >= s.Wz) st_dv((size_t)p * C + c, 0.f);
         }
     }
   }
@@ -971,7 +981,8 @@ int launch_stage_bwd(const StageBwdArgs& a_in, int G, hipStream_t st) {
   StageBwdArgs a = a_in;
   a.f.vslot = stage_vslot_for(a.f, G);
   if (stage_bwd_is_lean(a, G)) return launch_stage_bwd_lean(a, G, st);
-  if (a.da_fmt != FMT_F32 || a.dv_fmt != FMT_F32) { dta_set_error("stage_bwd: 16-bit gradient maps need the lean kernels"); return 1; }
+  if (a.da_fmt != FMT_F32) { dta_set_error("stage_bwd: a 16-bit incoming gradient map needs the lean kernels"); return 1; }
+  if (a.dv_fmt != FMT_F32 && a.dv_fmt != FMT_BF16) { dta_set_error("stage_bwd: unsupported gradient-map format %d", a.dv_fmt); return 1; }
   size_t lds = stage_lds_floats(a.f, true) * 4;
   if (lds > 160 * 1024) { dta_set_error("stage_bwd: %dx%dx%d patch needs %zu B of LDS", a.f.Hc, a.f.Wc, a.f.C, lds); return 1; }
   const bool net = a.f.apply_bn && a.f.relu && stage_net_cfg(a.f);
