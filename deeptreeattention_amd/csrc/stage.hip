@@ -601,9 +601,23 @@ static bool stage_net_cfg(const StageArgs& a) {
   return true;
 }
 
+// true when (C, Hc, Wc, pool) are those of one of the three stages of a spectral network on 24x24 crops (BASELINE
+// configs[4]: year ensembles) and no group is a spatial network (the reference's spatial branch is 11x11-only)
+static bool stage_net24_cfg(const StageArgs& a) {
+  int lvl = a.C == 32 ? 0 : a.C == 64 ? 1 : a.C == 128 ? 2 : -1;
+  if (lvl < 0) return false;
+  const int H[3] = {24, 24, 12}, P[3] = {0, 1, 1};
+  if (a.Hc != H[lvl] || a.Wc != H[lvl] || (a.pool != 0) != (P[lvl] != 0)) return false;
+  for (int g = 0; g < MAXG; ++g)
+    if (a.kind[g] != KIND_SPECTRAL) return false;      // (unused entries are zero = KIND_SPECTRAL)
+  return true;
+}
+
 template <typename T> int launch_stage_fwd_lean(const StageArgs& a, int G, hipStream_t st);
 bool stage_fwd_is_lean(const StageArgs& a) {
-  return (a.lean & 1) && a.apply_bn && a.relu && stage_net_cfg(a) && !a.a_nchw && (a.y_fmt == FMT_F32 || a.y_fmt == FMT_F16);
+  if (!((a.lean & 1) && a.apply_bn && a.relu && !a.a_nchw)) return false;
+  if (stage_net_cfg(a)) return a.y_fmt == FMT_F32 || a.y_fmt == FMT_F16;
+  return stage_net24_cfg(a) && a.y_fmt == FMT_F16;      // (bf16 mode only: the configuration BASELINE names)
 }
 
 template <typename T>
@@ -970,7 +984,8 @@ int launch_stage_bwd_lean(const StageBwdArgs& a, int G, hipStream_t st);
 // spatial groups with a classifier gradient, the un-pooled class pool of the last stage
 bool stage_bwd_is_lean(const StageBwdArgs& a, int G) {
   const int lbit = a.f.C == 32 ? 2 : (a.f.C == 64 ? 4 : 8);
-  bool ok = (a.f.lean & lbit) && a.f.apply_bn && a.f.relu && stage_net_cfg(a.f) && a.f.attsave && !a.da_nchw && a.dv &&
+  const bool net24 = stage_net24_cfg(a.f) && a.f.y_fmt == FMT_F16;      // 24x24 spectral networks, bf16 mode
+  bool ok = (a.f.lean & lbit) && a.f.apply_bn && a.f.relu && (stage_net_cfg(a.f) || net24) && a.f.attsave && !a.da_nchw && a.dv &&
             (a.f.y_fmt == FMT_F32 || a.f.y_fmt == FMT_F16);
   for (int g = 0; g < G; ++g)
     if (a.f.kind[g] == KIND_SPATIAL && a.dfeat && a.f.C != 128) ok = false;
@@ -1343,11 +1358,14 @@ struct LeanCfg {
   static constexpr int NPART = NT / C;                    // matvec: input slices per output
   // waves per SIMD the backward is compiled for (register budget 512 / MINW): two 512-thread or three 256-thread
   // workgroups per CU; the 128-wide stage needs its 256 registers
-  static constexpr int MINW = C == 32 ? 4 : (C == 64 ? 3 : 2);
-  static constexpr bool PERSIST = C < 128;                // backward: persistent workgroups with next-batch prefetch
+  static constexpr int MINW = HC > 11 ? 2 : (C == 32 ? 4 : (C == 64 ? 3 : 2));      // (24x24 crops: 3-5 items per thread)
+  static constexpr bool PERSIST = C < 128 && HC <= 11;    // backward: persistent workgroups with next-batch prefetch
   // LDS floats per patch slot: the patch [NP][C], then vectors: spectral pooled|h|gate, spatial m|t1 (padded) | s
   static constexpr int VEC = 3 * C > 2 * NPAD + NP ? 3 * C : 2 * NPAD + NP;
-  static constexpr int SLOT = NP * C + VEC;
+  // the [NP][C] patch image in LDS serves the spatial class pool and the plain network's flatten only: the 24x24
+  // configurations (spectral networks only) do without it (73 KiB for the 32-channel stage)
+  static constexpr int ZF = HC > 11 ? 0 : NP * C;
+  static constexpr int SLOT = ZF + VEC;
   static constexpr int RED = C >= 128 ? 4608 : (1536 > PPW * NT + 2 * C * PPW ? 1536 : PPW * NT + 2 * C * PPW);                        // reduction scratch shared by the workgroup (>= 4 C + 516, >= 256 + 2 C PPW)
   static constexpr int LDS_FWD = 2 * C + PPW * SLOT + RED + C + 2 * K * K;
 };
@@ -1605,9 +1623,9 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
   const int kind = a.kind[g];
   float* coefL = sm;                                   // [C][2] scale, shift
   float* Zs = sm + 2 * C + slot * CFG::SLOT;           // [NP][C]
-  float* vec = Zs + NP * C;                            // spectral: pooled | h | gate ; spatial: m | t1 (padded maps) | s
+  float* vec = Zs + CFG::ZF;                           // spectral: pooled | h | gate ; spatial: m | t1 (padded maps) | s
   float* red = sm + 2 * C + PPW * CFG::SLOT;           // [RED]
-  float* vec0 = sm + 2 * C + NP * C;                   // slot 0's vectors (matvec operands are addressed with a slot stride)
+  float* vec0 = sm + 2 * C + CFG::ZF;                  // slot 0's vectors (matvec operands are addressed with a slot stride)
 
   // ---- conv output of this thread's items in flight first ----
   float z[IPT][8];
@@ -1694,8 +1712,8 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
       lean_colsum_reg<CFG, 1>(part, red, outs, CFG::SLOT, 1.f / (float)NP);
     }
     const float* c1 = a.att[g].p[1]; const float* c2 = a.att[g].p[3];
-    auto fin1 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + C + o] = relu_nan(v + c1[o]); };
-    auto fin2 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + NP * C + 2 * C + o] = sigmoidf_(v + c2[o]); };
+    auto fin1 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + CFG::ZF + C + o] = relu_nan(v + c1[o]); };
+    auto fin2 = [&](int s, int o, float v) { sm0[s * CFG::SLOT + CFG::ZF + 2 * C + o] = sigmoidf_(v + c2[o]); };
     if constexpr (PRE) {
       lean_matvec_run<CFG>(w1, vec0, CFG::SLOT, red, fin1);
       lean_matvec_run<CFG>(w2, vec0 + C, CFG::SLOT, red, fin2);
@@ -2220,6 +2238,11 @@ static int launch_stage_bwd_lean_c(const StageBwdArgs& a, int G, hipStream_t st)
 }
 int launch_stage_bwd_lean(const StageBwdArgs& a, int G, hipStream_t st) {
   const bool h = a.f.y_fmt == FMT_F16;
+  if (a.f.Hc != 11 && a.f.Hc != 5) {      // 24x24 crops (spectral networks, bf16 mode)
+    if (a.f.C == 32) return launch_stage_bwd_lean_c<LeanCfg<32, 24, 24, 0, FMT_F16>>(a, G, st);
+    if (a.f.C == 64) return launch_stage_bwd_lean_c<LeanCfg<64, 24, 24, 1, FMT_F16>>(a, G, st);
+    return launch_stage_bwd_lean_c<LeanCfg<128, 12, 12, 1, FMT_F16>>(a, G, st);
+  }
   if (a.f.C == 32) return h ? launch_stage_bwd_lean_c<LeanCfg<32, 11, 11, 0, FMT_F16>>(a, G, st) : launch_stage_bwd_lean_c<LeanCfg<32, 11, 11, 0, FMT_F32>>(a, G, st);
   if (a.f.C == 64) return h ? launch_stage_bwd_lean_c<LeanCfg<64, 11, 11, 1, FMT_F16>>(a, G, st) : launch_stage_bwd_lean_c<LeanCfg<64, 11, 11, 1, FMT_F32>>(a, G, st);
   return h ? launch_stage_bwd_lean_c<LeanCfg<128, 5, 5, 1, FMT_F16>>(a, G, st) : launch_stage_bwd_lean_c<LeanCfg<128, 5, 5, 1, FMT_F32>>(a, G, st);
@@ -2227,7 +2250,11 @@ int launch_stage_bwd_lean(const StageBwdArgs& a, int G, hipStream_t st) {
 
 template <typename T, typename CFG>
 static int launch_stage_fwd_lean_c(const StageArgs& a, int G, hipStream_t st) {
-  const size_t lds = (size_t)CFG::LDS_FWD * 4;     // < 24 KiB: no attribute needed
+  const size_t lds = (size_t)CFG::LDS_FWD * 4;     // < 24 KiB for the 11x11 networks
+  if (lds > 64 * 1024) {
+    static DevOnce attr_once;
+    if (attr_once.first()) hipFuncSetAttribute((const void*)k_stage_fwd_lean<T, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
   hipLaunchKernelGGL((k_stage_fwd_lean<T, CFG>), dim3((a.B + CFG::PPW - 1) / CFG::PPW, G), dim3(CFG::NT), lds, st, a);
   DTA_CHECK_LAUNCH("k_stage_fwd_lean");
   return 0;
@@ -2235,6 +2262,11 @@ static int launch_stage_fwd_lean_c(const StageArgs& a, int G, hipStream_t st) {
 template <typename T>
 int launch_stage_fwd_lean(const StageArgs& a, int G, hipStream_t st) {
   const bool h = a.y_fmt == FMT_F16;
+  if (a.Hc != 11 && a.Hc != 5) {      // 24x24 crops (spectral networks, bf16 mode): several items per thread
+    if (a.C == 32) return launch_stage_fwd_lean_c<T, LeanCfg<32, 24, 24, 0, FMT_F16>>(a, G, st);
+    if (a.C == 64) return launch_stage_fwd_lean_c<T, LeanCfg<64, 24, 24, 1, FMT_F16>>(a, G, st);
+    return launch_stage_fwd_lean_c<T, LeanCfg<128, 12, 12, 1, FMT_F16>>(a, G, st);
+  }
   if (a.C == 32) return h ? launch_stage_fwd_lean_c<T, LeanCfg<32, 11, 11, 0, FMT_F16>>(a, G, st) : launch_stage_fwd_lean_c<T, LeanCfg<32, 11, 11, 0, FMT_F32>>(a, G, st);
   if (a.C == 64) return h ? launch_stage_fwd_lean_c<T, LeanCfg<64, 11, 11, 1, FMT_F16>>(a, G, st) : launch_stage_fwd_lean_c<T, LeanCfg<64, 11, 11, 1, FMT_F32>>(a, G, st);
   return h ? launch_stage_fwd_lean_c<T, LeanCfg<128, 5, 5, 1, FMT_F16>>(a, G, st) : launch_stage_fwd_lean_c<T, LeanCfg<128, 5, 5, 1, FMT_F32>>(a, G, st);

@@ -60,3 +60,49 @@ def test_lean_stage_kernels_match_generic_kernels(precision, B, monkeypatch):
     keep = [k for k in g2 if not (k.endswith("conv_layer.bias") or k.endswith("attention_conv2.bias"))]
     a = torch.cat([g1[k].reshape(-1).double() for k in keep]); b = torch.cat([g2[k].reshape(-1).double() for k in keep])
     assert float((a - b).norm() / b.norm()) < (5e-5 if fp32 else 1e-2)
+
+
+@pytest.mark.parametrize("B", [1, 3, 130])
+def test_lean_stage_kernels_for_24x24_crops_match_generic_kernels(B, monkeypatch):
+    """BASELINE configs[4] geometry (spectral network on 24x24 crops, bf16 mode): the lean stage kernels run with several
+    (pixel, octet) items per thread (5 / 3 / 2 for the three stages) and without the patch image in LDS; the generic
+    kernels on the same step must give the same loss, head scores and gradients up to the bf16 storage of the
+    intermediate maps.  B = 130 also takes the fused fp32-input first conv (>= 100 workgroups)."""
+    from deeptreeattention_amd import Hang2020 as H, _lib
+    torch.manual_seed(40 + B)
+    bands, classes = 24, 9
+    m = H.spectral_network(bands, classes, precision="bf16").cuda().train()
+    x = torch.rand(B, bands, 24, 24, device="cuda")
+    y = torch.randint(0, classes, (B,), device="cuda")
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.reset_running_stats()
+        heads = m(x)
+        loss = sum(torch.nn.functional.cross_entropy(h, y) for h in heads)      # all three heads: every stage's feature path
+        loss.backward()
+        return float(loss.detach()), [h.detach().clone() for h in heads], {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    L = _lib.lib()
+    monkeypatch.delenv("DTA_NO_LEAN", raising=False)
+    L.dta_dev_reload_switches()
+    l1, o1, g1 = step()
+    monkeypatch.setenv("DTA_NO_LEAN", "1")
+    L.dta_dev_reload_switches()
+    try:
+        l2, o2, g2 = step()
+    finally:
+        monkeypatch.delenv("DTA_NO_LEAN", raising=False)
+        L.dta_dev_reload_switches()
+    assert abs(l1 - l2) < 2e-3 * max(1.0, abs(l2))
+    for a, b in zip(o1, o2):
+        assert torch.isfinite(a).all() and rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 5e-3
+    assert g1.keys() == g2.keys()
+    keep = [k for k in g2 if not (k.endswith("conv_layer.bias") or k.endswith("attention_conv2.bias"))]
+    a = torch.cat([g1[k].reshape(-1).double() for k in keep]); b = torch.cat([g2[k].reshape(-1).double() for k in keep])
+    assert float((a - b).norm() / b.norm()) < (1e-2 if B > 1 else 3e-2)
+    for k in keep:
+        if g2[k].numel() >= 1000:
+            assert abs(float(g1[k].norm()) - float(g2[k].norm())) <= 1e-2 * float(g2[k].norm()), k
