@@ -126,6 +126,14 @@ def lib():
         L.dta_weighted_ce_scaled.restype = C.c_int
         L.dta_weighted_ce_scaled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_weighted_ce_scaled_dev.restype = C.c_int
+        L.dta_weighted_ce_scaled_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_year_flags.restype = C.c_int
+        L.dta_year_flags.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_ensemble_forward_gated.restype = C.c_int
+        L.dta_ensemble_forward_gated.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams), C.POINTER(C.c_void_p),
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dta_adam_step.restype = C.c_int
         L.dta_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,

@@ -284,7 +284,7 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
 template <typename T>
 int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha,
               const float* const* xs, void* ws, float* const (*scores)[3], float* joint, hipStream_t st,
-              const void* x_tiles = nullptr) {
+              const void* x_tiles = nullptr, const float* gate = nullptr) {
   // x_tiles: the network input already as halo-free bf16 conv tiles (dta_preprocess_crops_tiles): no fp32 input at all
   if (x_tiles && !(p.esz == 2 && p.x_compact && (p.shared_x || p.G == 1))) {
     dta_set_error("input tiles need the bf16 mode, 11x11-class patches and a single input tensor");
@@ -368,6 +368,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     }
     bf.cat_mode = (cat && G == 2); bf.nsplit = 32;
     bf.coef = at<float>(ws, p.coef[L]); bf.training = d->training; bf.momentum = d->bn_momentum; bf.eps = d->bn_eps;
+    bf.gate = gate;      // (year ensembles: a year the step skips keeps its running statistics)
     // BN + ReLU + pool + attention
     StageArgs sa = stage_args(p, d, nets, ws, L);
     // eval mode: the coefficients are a function of the running statistics only, so every stage workgroup derives
@@ -768,8 +769,8 @@ size_t dta_ensemble_workspace_bytes(const dta_net_desc* d, int years) {
   return p.total;
 }
 
-int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
-                         void* workspace, float* mean_scores, void* stream) {
+static int ensemble_forward_impl(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
+                                 const float* gate, void* workspace, float* mean_scores, float* kept, void* stream) {
   Plan p; dta_net_desc dd;
   if (!nets || !x || !workspace || !mean_scores) { dta_set_error("dta_ensemble_forward: null argument"); return 1; }
   if (ensemble_desc(d, years, &dd, &p, "dta_ensemble_forward")) return 1;
@@ -777,14 +778,32 @@ int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_para
     if (!x[g]) { dta_set_error("dta_ensemble_forward: null input for year %d", g); return 1; }
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (dd.dtype == DTA_BF16) rc = forward_t<bf16_t>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st);
-  else if (dd.dtype == DTA_F32) rc = forward_t<float>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st);
+  if (dd.dtype == DTA_BF16) rc = forward_t<bf16_t>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st, nullptr, gate);
+  else if (dd.dtype == DTA_F32) rc = forward_t<float>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st, nullptr, gate);
   else { dta_set_error("unknown dtype %d", dd.dtype); return 1; }
   if (rc) return rc;
   MeanArgs ma = {};
   for (int g = 0; g < years; ++g) ma.src[g] = at<float>(workspace, p.scores[g][2]);
-  ma.n = years; ma.dst = mean_scores; ma.count = (size_t)p.B * p.classes;
+  ma.n = years; ma.dst = mean_scores; ma.count = (size_t)p.B * p.classes; ma.gate = gate; ma.kept = kept;
   return launch_mean_scores(ma, st);
+}
+
+int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
+                         void* workspace, float* mean_scores, void* stream) {
+  return ensemble_forward_impl(d, years, nets, x, nullptr, workspace, mean_scores, nullptr, stream);
+}
+
+int dta_ensemble_forward_gated(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
+                               const float* gate, void* workspace, float* mean_scores, float* kept, void* stream) {
+  if (!gate) { dta_set_error("dta_ensemble_forward_gated: null gate"); return 1; }
+  return ensemble_forward_impl(d, years, nets, x, gate, workspace, mean_scores, kept, stream);
+}
+
+int dta_year_flags(const float* const* x, int years, size_t n_per_year, float* flags, float* clear_next, void* stream) {
+  if (!x || !flags || flags == clear_next || years < 1 || years > MAXG || n_per_year == 0) { dta_set_error("dta_year_flags: bad argument (1..%d years)", MAXG); return 1; }
+  for (int g = 0; g < years; ++g)
+    if (!x[g] || ((size_t)x[g] & 15)) { dta_set_error("dta_year_flags: year %d: null or not 16-byte aligned", g); return 1; }
+  return launch_year_flags(x, years, n_per_year, flags, clear_next, (hipStream_t)stream);
 }
 
 int dta_ensemble_backward(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
@@ -861,14 +880,24 @@ int dta_weighted_ce(const float* logits, const long long* labels, const float* w
   return launch_weighted_ce(a, (hipStream_t)stream);
 }
 
-int dta_weighted_ce_scaled(const float* logits, const long long* labels, const float* weight, int batch, int classes,
-                           float grad_scale, float* loss, float* dlogits, float* scratch, void* stream) {
+static int weighted_ce_scaled_impl(const float* logits, const long long* labels, const float* weight, int batch, int classes,
+                                   float grad_scale, const float* grad_scale_dev, float* loss, float* dlogits, float* scratch,
+                                   void* stream) {
   if (!logits || !labels || !loss || !scratch || batch < 1 || classes < 1) { dta_set_error("dta_weighted_ce_scaled: bad argument"); return 1; }
   BlendCeArgs a;
   a.spec = logits; a.spat = nullptr; a.alpha = nullptr; a.joint = nullptr;
   a.labels = labels; a.weight = weight; a.dlogits = dlogits; a.loss = loss; a.rowtmp = scratch;
-  a.B = batch; a.classes = classes; a.gscale = grad_scale;
+  a.B = batch; a.classes = classes; a.gscale = grad_scale; a.gscale_dev = grad_scale_dev;
   return launch_blend_ce(a, (hipStream_t)stream);
+}
+int dta_weighted_ce_scaled(const float* logits, const long long* labels, const float* weight, int batch, int classes,
+                           float grad_scale, float* loss, float* dlogits, float* scratch, void* stream) {
+  return weighted_ce_scaled_impl(logits, labels, weight, batch, classes, grad_scale, nullptr, loss, dlogits, scratch, stream);
+}
+int dta_weighted_ce_scaled_dev(const float* logits, const long long* labels, const float* weight, int batch, int classes,
+                               const float* grad_scale_dev, float* loss, float* dlogits, float* scratch, void* stream) {
+  if (!grad_scale_dev) { dta_set_error("dta_weighted_ce_scaled_dev: null scale"); return 1; }
+  return weighted_ce_scaled_impl(logits, labels, weight, batch, classes, 1.f, grad_scale_dev, loss, dlogits, scratch, stream);
 }
 
 int dta_softmax_top2(const float* logits, int batch, int classes, float* probs, long long* top_idx, float* top_score,
@@ -885,6 +914,7 @@ static int adam_step_impl(float* p, const float* g, float* gz, float* m, float* 
   if ((step < 1 && !active) || (n && (!p || !g || !m || !v))) { dta_set_error("dta_adam_step: bad argument"); return 1; }
   AdamArgs a;
   a.active = active; a.dev_step = dev_step; a.dev_step_out = dev_step_out;
+  a.g_inactive = active ? const_cast<float*>(g) : nullptr;
   if (active && !dev_step) { dta_set_error("dta_adam_step_gated: needs a device step counter"); return 1; }
   if (alpha_g32 && (alpha_g32 < g || alpha_g32 >= g + n)) { dta_set_error("dta_adam_step_dp: alpha's exchange slot must lie inside g"); return 1; }
   if (step < 1) step = 1;

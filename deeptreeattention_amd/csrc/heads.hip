@@ -437,12 +437,45 @@ int launch_blend(const BlendArgs& a, hipStream_t st) {
 // Year ensemble: scores = mean over the years' last-head scores (reference src/models/year.py:33).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_mean_scores(MeanArgs a) {
-  const float inv = 1.f / (float)a.n;
+  float kept = 0.f;
+  bool use[MAXG];
+  for (int k = 0; k < a.n; ++k) { use[k] = !a.gate || a.gate[k] > 0.f; kept += use[k] ? 1.f : 0.f; }
+  const float inv = 1.f / kept;                       // nothing kept: inf, and 0 * inf = NaN below -- an empty mean
+  if (a.kept && blockIdx.x == 0 && threadIdx.x == 0) { a.kept[0] = kept; a.kept[1] = inv; }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.count; i += (size_t)gridDim.x * blockDim.x) {
-    float acc = a.src[0][i];
-    for (int k = 1; k < a.n; ++k) acc += a.src[k][i];
+    float acc = 0.f;
+    for (int k = 0; k < a.n; ++k)
+      if (use[k]) acc += a.src[k][i];                 // (selected, not multiplied: a skipped year's scores may be anything)
     a.dst[i] = acc * inv;
   }
+}
+// flags[y] = 1 when year y's tensor has a non-zero element (NaN counts), else 0: the reference's `x.sum() == 0` test of a
+// missing year (year.py:27) for the non-negative crops its loader produces (a sum of non-negative floats is zero exactly
+// when all of them are), decided on the device.  flags arrive zeroed; a block stops at its first hit.
+struct YearPtrs { const float* x[MAXG]; };
+__global__ __launch_bounds__(256) void k_year_flags(YearPtrs px, size_t n, float* flags, float* clear_next) {
+  const int y = blockIdx.y;
+  const float* p = px.x[y];
+  const size_t n4 = n / 4;
+  if (clear_next && blockIdx.x == 0 && threadIdx.x == 0) clear_next[y] = 0.f;      // the bank the NEXT call sets
+  bool hit = false;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+    hit = !(v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f);
+    if (__any(hit)) break;                            // this wave has its answer
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) hit = hit || !(p[i] == 0.f);
+  if (hit) flags[y] = 1.f;
+}
+int launch_year_flags(const float* const* x, int years, size_t n, float* flags, float* clear_next, hipStream_t st) {
+  YearPtrs px = {};
+  for (int y = 0; y < years; ++y) px.x[y] = x[y];
+  // flags must be zero on entry: cleared here, unless the caller alternates two banks and lets each call clear the other
+  if (!clear_next && hipMemsetAsync(flags, 0, sizeof(float) * years, st) != hipSuccess) { dta_set_error("year flags: memset failed"); return 1; }
+  hipLaunchKernelGGL(k_year_flags, dim3(64, years), dim3(256), 0, st, px, n, flags, clear_next);
+  DTA_CHECK_LAUNCH("k_year_flags");
+  return 0;
 }
 int launch_mean_scores(const MeanArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_mean_scores, dim3((unsigned)min((size_t)1024, (a.count + 255) / 256)), dim3(256), 0, st, a);
@@ -607,7 +640,7 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
       const float old = __hip_atomic_exchange(a.rowtmp + row, ok ? wy * (lse + mx - zval((int)y)) : poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("" ::"v"(old));
     }
-    const float sc2 = (den > 0.f ? wy / den : 0.f) * a.gscale + poison;
+    const float sc2 = (den > 0.f ? wy / den : 0.f) * (a.gscale_dev ? a.gscale_dev[0] : a.gscale) + poison;
     for (int n = lane, k = 0; n < a.classes; n += 64, ++k) {
       const float z = zget(n, k);
       if (jo && jo != zs) jo[n] = z;
@@ -715,12 +748,19 @@ __global__ void k_adam(AdamArgs a) {
     // by nobody during this launch) receives the count after this step
     if (a.dev_step_out && blockIdx.x == 0 && threadIdx.x == 0) a.dev_step_out[0] = a.dev_step[0] + (a.active[0] > 0.f ? 1 : 0);
     if (!(a.active[0] > 0.f)) {      // skipped everywhere: only optimizer.zero_grad()'s part of the pass
-      if (a.gz)
-        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) a.gz[i] = 0.f;
+      float* z = a.gz ? a.gz : a.g_inactive;
+      if (z)
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) z[i] = 0.f;
       return;
     }
-    const double st = (double)(a.dev_step[0] + 1);
-    bc1 = (float)(1.0 - pow((double)a.beta1, st)); bc2 = (float)(1.0 - pow((double)a.beta2, st));
+    // (one thread per block takes the two double-precision powers: per thread they cost more than the update itself)
+    __shared__ float s_bc[2];
+    if (threadIdx.x == 0) {
+      const double st = (double)(a.dev_step[0] + 1);
+      s_bc[0] = (float)(1.0 - pow((double)a.beta1, st)); s_bc[1] = (float)(1.0 - pow((double)a.beta2, st));
+    }
+    __syncthreads();
+    bc1 = s_bc[0]; bc2 = s_bc[1];
   }
   const float ss = a.lr / bc1, rbc2 = rsqrtf(bc2);
   auto alpha_update = [&](double graw) {

@@ -132,6 +132,7 @@ struct BnFinalizeArgs {
   int cat_mode, nsplit;                                // 1: G==1 launch whose columns are [branch0|branch1]
   float* coef;                                         // [G][N][4] = scale, shift, mean, rstd
   int training; float momentum, eps;
+  const float* gate = nullptr;                         // device, per group: <= 0 -> this group's running statistics / counter stay untouched
 };
 int launch_bn_finalize(const BnFinalizeArgs& a, int G, hipStream_t st);
 // kernel-side form of the above (group offsets resolved)
@@ -141,6 +142,7 @@ struct BnFinK {
   const float* gamma[MAXG]; const float* beta[MAXG];
   float* rmean[MAXG]; float* rvar[MAXG]; long long* nbt[MAXG];
   float* coef; int training; float momentum, eps;
+  const float* gate;
 };
 BnFinK bn_finalize_kargs(const BnFinalizeArgs& b);
 // the stage kernels can combine the conv partials themselves (every workgroup, redundantly and in the same order, so
@@ -335,7 +337,10 @@ struct BlendArgs {
   const float* spec; const float* spat; const double* alpha; float* joint; int B, classes;
 };
 int launch_blend(const BlendArgs& a, hipStream_t st);
-struct MeanArgs { const float* src[MAXG]; int n; float* dst; size_t count; };
+// gate (device, per source; may be null = all): sources with gate <= 0 are left out of the mean; kept (device, may be null)
+// receives {number of sources kept, 1 / that number}; nothing kept -> NaN scores, as an empty mean is
+struct MeanArgs { const float* src[MAXG]; int n; float* dst; size_t count; const float* gate = nullptr; float* kept = nullptr; };
+int launch_year_flags(const float* const* x, int years, size_t n, float* flags, float* clear_next, hipStream_t st);
 int launch_mean_scores(const MeanArgs& a, hipStream_t st);
 struct BlendBwdArgs {
   const float* spec; const float* spat; const double* alpha; const float* djoint;
@@ -357,6 +362,7 @@ struct BlendCeArgs {
   const float* spec; const float* spat; const double* alpha; float* joint;   // joint may be null (or == spec when no blend)
   const long long* labels; const float* weight; float* dlogits; float* loss; float* rowtmp; int B, classes;
   float gscale = 1.f;      // factor on dlogits only (year ensemble: d(mean over kept years) / d(year score))
+  const float* gscale_dev = nullptr;   // non-null: the factor is read from the device (decided there: kept years)
 };
 int launch_blend_ce(const BlendCeArgs& a, hipStream_t st);
 struct AdamArgs {
@@ -370,6 +376,7 @@ struct AdamArgs {
   // parameter whose grad is None; the gradient buffer is still cleared), and the bias corrections come from the
   // DEVICE step counter (dev_step[0] = steps taken so far; this one is step dev_step[0] + 1) instead of bc1 / bc2
   const float* active; const int* dev_step; int* dev_step_out = nullptr;
+  float* g_inactive = nullptr;         // gated: a group that is not stepped has no gradient -- its buffer is cleared whatever gz says
 };
 int launch_adam(const AdamArgs& a, hipStream_t st);
 int launch_softmax_top2(const float* logits, int B, int classes, float* probs, long long* top_idx, float* top_score,

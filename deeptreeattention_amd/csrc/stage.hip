@@ -80,7 +80,7 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(BnFinK a) {
     float sc = a.gamma[g][c] * rstd;
     coef[c * 4 + 0] = sc; coef[c * 4 + 1] = a.beta[g][c] - (float)mean * sc;
     coef[c * 4 + 2] = (float)mean; coef[c * 4 + 3] = rstd;
-    if (a.rmean[g]) {
+    if (a.rmean[g] && (!a.gate || a.gate[g] > 0.f)) {      // (a year the step skips keeps its statistics, year.py:27)
       double unb = n > 1 ? m2 / (n - 1) : var;
       a.rmean[g][c] = (1.f - a.momentum) * a.rmean[g][c] + a.momentum * (float)mean;
       a.rvar[g][c] = (1.f - a.momentum) * a.rvar[g][c] + a.momentum * (float)unb;
@@ -97,7 +97,7 @@ BnFinK bn_finalize_kargs(const BnFinalizeArgs& b) {
   for (int g = 0; g < MAXG; ++g) {
     a.gamma[g] = b.gamma[g]; a.beta[g] = b.beta[g]; a.rmean[g] = b.rmean[g]; a.rvar[g] = b.rvar[g]; a.nbt[g] = b.nbt[g];
   }
-  a.coef = b.coef; a.training = b.training; a.momentum = b.momentum; a.eps = b.eps;
+  a.coef = b.coef; a.training = b.training; a.momentum = b.momentum; a.eps = b.eps; a.gate = b.gate;
   return a;
 }
 

@@ -595,11 +595,18 @@ class EnsembleTrainer:
         self._shape = None
         self._ws = None
         self._ws_key = None
+        # per-year optimizer step counts on the device, two banks used alternately (the gated launches read one, write the
+        # other); single process: only the device-decided steps (present=None) use them, see _counters_to
+        self.dev_steps = torch.zeros(2, Y, dtype=torch.int32, device=dev)
+        self._bank = 0
+        self._counters_on = "device" if self.world > 1 else "host"
+        # this rank's 0/1 year flags (dta_year_flags): two banks used alternately, each call clears the other one
+        self._flag_banks = torch.zeros(2, Y, dtype=torch.float32, device=dev)
+        self._flag_bank = 0
+        self.local_flags = self._flag_banks[0]
+        self.kept_dev = torch.zeros(2, dtype=torch.float32, device=dev)        # {years kept, 1 / years kept} of the last forward
         if self.world > 1:
             self.sync.broadcast([self.flat[0]] + list(model.buffers()), 0)
-            # per-year optimizer step counts, two banks used alternately (the gated launches read one, write the other)
-            self.dev_steps = torch.zeros(2, Y, dtype=torch.int32, device=dev)
-            self._bank = 0
             # the 2^Y possible flag vectors, resident on the device: setting the flags is a device-to-device copy
             self._flag_table = torch.tensor([[(mask >> i) & 1 for i in range(Y)] for mask in range(1 << Y)],
                                             dtype=torch.float32, device=dev)
@@ -615,9 +622,22 @@ class EnsembleTrainer:
 
     def step_counts(self):
         """Optimizer steps taken per year (data-parallel: read back from the device counters, one host sync)."""
-        if self.world > 1:
+        if self._counters_on == "device":
             return [int(v) for v in self.dev_steps[self._bank].tolist()]
         return [t.step_count for t in self.years]
+
+    def _counters_to(self, where):
+        """Single process: steps with `present=` count on the host (one optimizer launch per kept year), device-decided
+        steps (present=None) on the device.  Mixing the two moves the counts across once per switch (one small transfer,
+        device -> host being a synchronisation); a loop that sticks to one form never pays it."""
+        if self.world > 1 or where == self._counters_on:
+            return
+        if where == "device":
+            self.dev_steps[self._bank].copy_(torch.tensor([t.step_count for t in self.years], dtype=torch.int32))
+        else:
+            for t, n in zip(self.years, self.dev_steps[self._bank].tolist()):
+                t.step_count = int(n)
+        self._counters_on = where
 
     def grad_of(self, param):
         for t in self.years:
@@ -628,10 +648,7 @@ class EnsembleTrainer:
     def _kept(self, images, present):
         if len(images) != len(self.years):
             raise ValueError("expected one image tensor per year ({}), got {}".format(len(self.years), len(images)))
-        if present is None:
-            # reference year.py:27 (`x.sum() == 0`), all years in one host transfer
-            present = (torch.stack([x.sum() for x in images]) != 0).tolist()
-        local = [bool(k) for k in present]
+        local = [bool(k) for k in present]      # (present=None never comes here: that decision is taken on the device)
         if not any(local) and self.world == 1:
             raise RuntimeError("every year of the batch is all-zero: the reference has nothing to average (year.py:33)")
         return local
@@ -674,6 +691,45 @@ class EnsembleTrainer:
         self._live = xs     # inputs stay referenced until the step's launches are enqueued
         return kept
 
+    def _forward_gated(self, images):
+        """All years as the groups of one set of launches, the missing-year decision (reference year.py:27) taken ON THE
+        DEVICE: dta_year_flags -> self.local_flags, dta_ensemble_forward_gated (a flagged-off year is left out of the mean
+        and keeps its BatchNorm statistics), 1 / kept years left in self.kept_dev[1] for the loss launch.  No host
+        synchronisation.  Returns the list of all year indices (what the backward launches)."""
+        L = _lib.lib()
+        Y = len(self.years)
+        if len(images) != Y:
+            raise ValueError("expected one image tensor per year ({}), got {}".format(Y, len(images)))
+        if Y > _lib.MAX_YEARS:
+            raise RuntimeError("at most {} years per grouped launch".format(_lib.MAX_YEARS))
+        xs = [H._check_input(x) for x in images]
+        if any(x.shape != xs[0].shape for x in xs):
+            raise ValueError("all years of a batch must have the same shape")
+        keys = [t._describe(x) for t, x in zip(self.years, xs)]
+        B, classes = xs[0].shape[0], self.model.year_models[0]._classes
+        self._buffers(B, classes)
+        self._nets = (_lib.SubnetParams * Y)(*[t.nets[0] for t in self.years])
+        self._grads = (_lib.SubnetGrads * Y)(*[t.grads[0] for t in self.years])
+        self._xptr = (C.c_void_p * Y)(*[x.data_ptr() for x in xs])
+        self._desc = self.years[0].desc
+        ws_key = (Y,) + keys[0]
+        if ws_key != self._ws_key:
+            nbytes = L.dta_ensemble_workspace_bytes(C.byref(self._desc), Y)
+            if nbytes == 0:
+                raise RuntimeError("dta_ensemble_workspace_bytes: " + L.dta_last_error().decode())
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_key = ws_key
+        st = _lib.current_stream_ptr()
+        self._flag_bank ^= 1
+        self.local_flags = self._flag_banks[self._flag_bank]
+        _lib.check(L.dta_year_flags(self._xptr, Y, xs[0].numel(), _lib.ptr(self.local_flags),
+                                    _lib.ptr(self._flag_banks[self._flag_bank ^ 1]), st), "dta_year_flags")
+        _lib.check(L.dta_ensemble_forward_gated(C.byref(self._desc), Y, self._nets, self._xptr, _lib.ptr(self.local_flags),
+                                                _lib.ptr(self._ws), _lib.ptr(self.scores), _lib.ptr(self.kept_dev), st),
+                   "dta_ensemble_forward_gated")
+        self._live = xs
+        return list(range(Y))
+
     def _backward(self, kept, phases=3):
         L = _lib.lib()
         if phases & 1:
@@ -686,60 +742,90 @@ class EnsembleTrainer:
             self.years[i]._grads_clear = False
 
     def _ce(self, y, want_grad, kept_years=1):
-        """Loss of the mean scores and, in the same launch, d(loss)/d(one year's scores) = d(loss)/d(mean) / kept years."""
+        """Loss of the mean scores and, in the same launch, d(loss)/d(one year's scores) = d(loss)/d(mean) / kept years
+        (kept_years=None: the count the device decided, read from self.kept_dev by the launch)."""
         L = _lib.lib()
         self.loss = torch.empty((), dtype=torch.float32, device=self.device)      # fresh per step (see FusedTrainer._loss)
+        if kept_years is None:
+            _lib.check(L.dta_weighted_ce_scaled_dev(_lib.ptr(self.scores), _lib.ptr(y), _lib.ptr(self.loss_weight),
+                                                    self.scores.shape[0], self.scores.shape[1],
+                                                    C.c_void_p(self.kept_dev.data_ptr() + 4), _lib.ptr(self.loss),
+                                                    _lib.ptr(self.dscores) if want_grad else None, _lib.ptr(self.ce_scratch),
+                                                    _lib.current_stream_ptr()), "dta_weighted_ce_scaled_dev")
+            return
         _lib.check(L.dta_weighted_ce_scaled(_lib.ptr(self.scores), _lib.ptr(y), _lib.ptr(self.loss_weight),
                                             self.scores.shape[0], self.scores.shape[1], 1.0 / kept_years, _lib.ptr(self.loss),
                                             _lib.ptr(self.dscores) if want_grad else None, _lib.ptr(self.ce_scratch),
                                             _lib.current_stream_ptr()), "dta_weighted_ce_scaled")
 
-    def _adam_gated(self):
-        """One gated optimizer pass per year and bucket, driven by the reduced flags / device step counters."""
+    def _adam_gated(self, flags=None):
+        """One gated optimizer pass per year and segment, driven by `flags` (data-parallel: the reduced year flags in the
+        gradient buffer; single process: this rank's dta_year_flags) and the device step counters."""
         L = _lib.lib()
         st = _lib.current_stream_ptr()
+        flags = self.flags if flags is None else flags
         Y = len(self.years)
         cur, nxt = self._bank, 1 - self._bank
         for i, t in enumerate(self.years):
-            active = C.c_void_p(self.flags.data_ptr() + 4 * i)
+            active = C.c_void_p(flags.data_ptr() + 4 * i)
             step = C.c_void_p(self.dev_steps.data_ptr() + 4 * (cur * Y + i))
             step_next = C.c_void_p(self.dev_steps.data_ptr() + 4 * (nxt * Y + i))
-            for k, (p, g, m, v, n) in enumerate(((t.p_head, t.g_head, t.m_head, t.v_head, t.split),
-                                                 (t.p_tail, t.g_tail, t.m_tail, t.v_tail, t.n_first))):
+            if all(h.data_ptr() + 4 * t.split == tl.data_ptr() for h, tl in
+                   ((t.p_head, t.p_tail), (t.g_head, t.g_tail), (t.m_head, t.m_tail), (t.v_head, t.v_tail))):
+                segs = ((t.p_head, t.g_head, t.m_head, t.v_head, t.n),)       # adjacent segments (single process): one pass
+            else:
+                segs = ((t.p_head, t.g_head, t.m_head, t.v_head, t.split), (t.p_tail, t.g_tail, t.m_tail, t.v_tail, t.n_first))
+            for k, (p, g, m, v, n) in enumerate(segs):
                 _lib.check(L.dta_adam_step_gated(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, active, step,
-                                                 step_next if k == 0 else None, t.lr, self.betas[0], self.betas[1], self.eps, self.sync.grad_scale,
-                                                 0 if self.keep_grads else 1, st), "dta_adam_step_gated")
+                                                 step_next if k == 0 else None, t.lr, self.betas[0], self.betas[1], self.eps,
+                                                 self.sync.grad_scale, 0 if self.keep_grads else 1, st), "dta_adam_step_gated")
             t._grads_clear = not self.keep_grads
         self._bank = nxt
 
     def train_step(self, images, y, present=None):
         """images: list of (B, bands, H, W) float32 device tensors, one per year; y: int64 labels.  Returns the loss
-        as a fresh 0-d device tensor."""
-        local = self._kept(images, present)
+        as a fresh 0-d device tensor.
+        present=None: which years are missing (reference year.py:27: the whole tensor sums to zero) is decided ON THE
+        DEVICE -- all years are launched, a missing one is left out of the mean, keeps its BatchNorm statistics and is
+        not stepped -- and the call returns without any host synchronisation.  (No year present: the loss is NaN; the
+        reference raises.)  present=[...]: the caller knows (the reference's loader zero-fills missing years on the host):
+        only the kept years are launched at all."""
         y = self.years[0]._labels(y)
-        kept = self._forward(images, local)
-        self._ce(y, True, len(kept))
-        if self.world == 1:
-            self._backward(kept)
-            for i, t in enumerate(self.years):
-                if local[i]:
-                    t._adam()
-            return self.loss
+        if present is None:
+            self._counters_to("device")
+            kept = self._forward_gated(images)
+            self._ce(y, True, None)
+            if self.world == 1:
+                self._backward(kept)
+                self._adam_gated(self.local_flags)
+                return self.loss
+            local_flags = self.local_flags
+        else:
+            local = self._kept(images, present)
+            kept = self._forward(images, local)
+            self._ce(y, True, len(kept))
+            if self.world == 1:
+                self._counters_to("host")
+                self._backward(kept)
+                for i, t in enumerate(self.years):
+                    if local[i]:
+                        t._adam()
+                return self.loss
+            local_flags = self._flag_table[sum(1 << i for i, k in enumerate(local) if k)]
         # data-parallel: every rank issues the same collectives whatever it kept; skipped years send their zeros
-        mask = sum(1 << i for i, k in enumerate(local) if k)
         if self.ex is not None:
             self._backward(kept, 3)
-            self.flags.copy_(self._flag_table[mask])
+            self.flags.copy_(local_flags)
             self.ex.allreduce()                 # gradients and year flags summed over the ranks in one launch
         elif self.overlap:
             self._backward(kept, 1)
-            self.flags.copy_(self._flag_table[mask])
+            self.flags.copy_(local_flags)
             self.sync.reduce_early(self.g_head)
             self._backward(kept, 2)
             self.sync.reduce_late(self.g_tail)
         else:
             self._backward(kept, 3)
-            self.flags.copy_(self._flag_table[mask])
+            self.flags.copy_(local_flags)
             self.sync.reduce_all(self.flat[1])
         self.sync.finish()
         self._adam_gated()
@@ -761,8 +847,10 @@ class EnsembleTrainer:
 
     def forward_loss(self, images, y, present=None):
         """validation_step of the level (multi_stage.py:290-304): ensemble scores + weighted CE, no update."""
-        local = self._kept(images, present)
-        self._forward(images, local)
+        if present is None:
+            self._forward_gated(images)
+        else:
+            self._forward(images, self._kept(images, present))
         self._ce(self.years[0]._labels(y), False)
         return self.scores.clone(), self.loss
 
@@ -973,9 +1061,20 @@ class Predictor:
         """Eval-mode scores (B, classes) of the batch; the returned tensor is reused by the next call."""
         L = _lib.lib()
         st = _lib.current_stream_ptr()
+        if self.ensemble and present is None:
+            # missing years decided on the device (dta_year_flags), all years launched, no host round trip
+            xs = [H._check_input(x) for x in images]
+            kept = list(range(len(xs)))
+            self._prepare(xs[0].shape, kept)
+            if getattr(self, "_flags", None) is None or self._flags.numel() != len(xs):
+                self._flags = torch.zeros(len(xs), dtype=torch.float32, device=self.device)
+            xptr = (C.c_void_p * len(kept))(*[x.data_ptr() for x in xs])
+            _lib.check(L.dta_year_flags(xptr, len(xs), xs[0].numel(), _lib.ptr(self._flags), None, st), "dta_year_flags")
+            _lib.check(L.dta_ensemble_forward_gated(C.byref(self.desc), len(kept), self.nets, xptr, _lib.ptr(self._flags),
+                                                    _lib.ptr(self.ws), _lib.ptr(self.logits), None, st),
+                       "dta_ensemble_forward_gated")
+            return self.logits
         if self.ensemble:
-            if present is None:
-                present = (torch.stack([x.sum() for x in images]) != 0).tolist()
             kept = [i for i, k in enumerate(present) if k]
             if not kept:
                 raise RuntimeError("every year of the batch is all-zero: nothing to average (reference year.py:33)")

@@ -141,6 +141,21 @@ int dta_net_loss(const dta_net_desc* d, const double* alpha, void* workspace, co
 size_t dta_ensemble_workspace_bytes(const dta_net_desc* d, int years);
 int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
                          void* workspace, float* mean_scores, void* stream);
+/* The reference's missing-year test on the device (year.py:27 `x.sum() == 0`): flags[y] = 1 when year y's tensor has a
+ * non-zero element (NaN counts), else 0.  For the non-negative crops the reference's loader produces (min-max scaled to
+ * [0, 1], missing years zero-filled, src/data.py:295-296) that is the same decision -- a sum of non-negative floats is
+ * zero exactly when all of them are; tensors with negative entries that cancel to an exact zero sum would be skipped by
+ * the reference and are kept here.  x: HOST array of `years` device pointers (16-byte aligned), n_per_year floats each.
+ * clear_next (device, float[years], may be NULL): a second flag bank this call zeroes, so that a caller alternating two
+ * banks never needs a clearing launch; with NULL the call clears `flags` itself first (one more tiny launch). */
+int dta_year_flags(const float* const* x, int years, size_t n_per_year, float* flags, float* clear_next, void* stream);
+/* dta_ensemble_forward over ALL years with the skip decided on the device: gate (device, float[years], e.g. from
+ * dta_year_flags) <= 0 leaves that year out of the mean and leaves its BatchNorm running statistics / counter untouched,
+ * exactly as a year the reference skips -- no host round trip.  (The skipped year's launches still run; their results are
+ * never used.)  kept (device, float[2], may be NULL) receives {years kept, 1 / years kept}: the second word is the
+ * gradient scale dta_weighted_ce_scaled_dev takes.  No year kept: mean_scores are NaN (the reference raises there). */
+int dta_ensemble_forward_gated(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
+                               const float* gate, void* workspace, float* mean_scores, float* kept, void* stream);
 /* Backward of the above.  dscore: d(loss)/d(one year's scores) = d(loss)/d(mean_scores) / years, float32
  * [batch][classes], shared by all years.  grads: `years` entries, every non-null buffer ZERO-FILLED on entry;
  * classifier1/2 gradients are not produced (those heads never reach the loss). */
@@ -189,6 +204,9 @@ int dta_weighted_ce(const float* logits, const long long* labels, const float* w
  * scratch: batch + 2 floats whose LAST 32-bit word is zero on entry (block counter; left zero). */
 int dta_weighted_ce_scaled(const float* logits, const long long* labels, const float* weight, int batch, int classes,
                            float grad_scale, float* loss, float* dlogits, float* scratch, void* stream);
+/* Same with the factor read from the device (grad_scale_dev[0]): 1 / kept years as dta_ensemble_forward_gated left it. */
+int dta_weighted_ce_scaled_dev(const float* logits, const long long* labels, const float* weight, int batch, int classes,
+                               const float* grad_scale_dev, float* loss, float* dlogits, float* scratch, void* stream);
 
 /* Inference epilogue: replaces F.softmax(pred, dim=1) (src/models/multi_stage.py:302,315; src/main.py:190) and the
  * top-1/top-2 label+score extraction of src/main.py:192-205.  probs [batch][classes] may be null.
@@ -217,8 +235,9 @@ int dta_adam_step_dp(float* p, float* g, float* m, float* v, size_t n, double* a
 /* optimizer.step() + zero_grad() gated ON THE DEVICE (year ensembles under data parallelism, where whether a year is
  * stepped -- "some rank kept it", src/models/year.py:27 -- is only known on the device after the gradient exchange):
  * active[0] > 0: Adam step number dev_step[0] + 1 (dev_step[0] = steps this parameter group has taken so far, a device
- * counter); otherwise nothing but the gradient clear (zero_grad != 0) happens (no moment decay, as torch's Adam passes
- * over parameters whose grad is None).  dev_step_next (may be NULL; must not alias dev_step): receives the count after
+ * counter); otherwise only the gradient buffer is cleared -- always: a group that is not stepped has no gradient (torch
+ * leaves grad None), whatever zero_grad says -- and nothing else happens (no moment decay, as torch's Adam passes over
+ * parameters whose grad is None).  dev_step_next (may be NULL; must not alias dev_step): receives the count after
  * this step, dev_step[0] + (active ? 1 : 0) -- callers ping-pong two counter words, so the count advances without any
  * launch of their own; pass it in ONE of the launches that share a counter.  No float64 alpha here. */
 int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const float* active, const int* dev_step,

@@ -245,7 +245,7 @@ def test_ensemble_trainer_steps_vs_reference_golden(golden, use_present):
             tol = 2e-3 if k.endswith("running_mean") else TIGHT
             assert rel_l2(b.cpu().numpy(), g[f"step{step}/buf/{k}"]) < tol, (step, k)
     # the skipped years' optimizer step counts did not advance (torch's Adam passes over grad-None parameters)
-    assert [t.step_count for t in tr.years] == [3, 4, 3]
+    assert tr.step_counts() == [3, 4, 3]
     out = driver.validation_step(batch[0], 0, 0, present)
     assert out["yhat"].shape == (B, classes) and abs(float(out["yhat"].sum()) - B) < 1e-4
     ids, yhats = driver.predict_step((batch[0][0], batch[0][1]))          # multi_stage.py:306-318
