@@ -53,18 +53,18 @@ inline void prof_end(int site, hipStream_t st) {
 }
 
 // Developer switches (same-box A/B runs): the environment is read once per process, not per call.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; };
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; };
 inline Switches read_switches() {
   // these change launch plans (and, for DTA_FP32_ACT, roundings): never meant for a training job's environment, so say
   // so once, loudly, when one is set
   static const char* names[] = {"DTA_NO_FUSED_INPUT", "DTA_NO_TAIL_MERGE", "DTA_BN_INKERNEL", "DTA_FP32_ACT", "DTA_NO_LEAN",
-                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2"};
+                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER"};
   for (const char* n : names)
     if (getenv(n)) fprintf(stderr, "[libdta_hip] developer switch %s is set: kernel plans (and possibly roundings) differ from the default build\n", n);
   return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr,
           getenv("DTA_FP32_ACT") != nullptr, getenv("DTA_NO_LEAN") != nullptr,
           getenv("DTA_LEAN_MASK") ? atoi(getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, getenv("DTA_HALO_TILES") != nullptr,
-          getenv("DTA_NO_WGRAD_NSPLIT") == nullptr};
+          getenv("DTA_NO_WGRAD_NSPLIT") == nullptr, (getenv("DTA_PIXEL_ORDER") ? 1 : 0) | (getenv("DTA_NO_STAGGER") ? 2 : 0)};
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -340,6 +340,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     // conv
     ConvArgs ca;
     memset(&ca, 0, sizeof(ca));
+    ca.pixel_order = switches().conv_order;
     if (L == 0) {
       ca.x_tl = x_tiles ? x_tiles : at<char>(ws, p.x_tl); ca.x_gs = p.x_tl_gs / p.esz; ca.x_compact = p.x_compact;
       if (!x_tiles && fused_input(p)) {
@@ -640,6 +641,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
         if (launch_pack_conv_w<T>(pw, at<char>(ws, p.wd[L]), st)) return 1;
       ConvArgs ca;
       memset(&ca, 0, sizeof(ca));
+      ca.pixel_order = switches().conv_order;
       ca.x_tl = ap.dy_tl; ca.x_gs = ap.dy_gs; ca.wp = at<char>(ws, p.wd[L]); ca.x_compact = p.tl_compact;
       ca.y = at<float>(ws, p.da[L]); ca.y_gs = (size_t)B * p.HWc[L] * CH[L - 1]; ca.y_rs = CH[L - 1];
       ca.y_fmt = (lean_lvl[L - 1] && g16) ? FMT_BF16 : FMT_F32;      // read by stage L-1's backward

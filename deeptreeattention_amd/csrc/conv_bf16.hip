@@ -63,6 +63,79 @@ extern "C" int dta_debug_cticks(long long* out) { return (int)hipMemcpyFromSymbo
 #else
 #define CTICK(i)
 #endif
+// Row tables of a conv workgroup: which pixel each of its MWG tile rows computes (rowtab: global output row or -1;
+// plq: (patch << 16) | haloed-grid row of the window's top-left tap).
+//
+// The A fragments are ds_read_b128 reads of 16 haloed-grid rows per lane group, RB = 48 bytes apart: a lane group is
+// conflict-free exactly when its 16 rows differ mod 16 (48 B = 12 banks, 12 i mod 64 is a bijection of i mod 16 onto the
+// sixteen 16-byte slots of the bank row).  Consecutive pixels do NOT have that property -- every image-row end skips two
+// halo rows -- and the hardware's lane groups are not contiguous ({0-3,12-15,20-27}, {4-11,16-19,28-31}, same +32): in pixel
+// order the A reads cost 2.25 LDS cycles per group instead of 1 (SQ_LDS_BANK_CONFLICT was 43 % of SQ_LDS_IDX_ACTIVE in
+// the first conv).  So pixels are dealt to lane groups by residue: the k-th pixel (in pixel order) whose row is = c mod 16
+// goes to lane group k, slot c.  Any assignment of pixels to tile rows is valid -- outputs and statistics go through
+// rowtab -- and unused slots point at row `slot` (same residue class), so every group reads 16 distinct slots.
+// If some residue class has more pixels than there are groups (possible for split maps), pixel order is kept.
+template <int MWG, int NTHR>
+__device__ __forceinline__ void conv_row_tables(const ConvArgs& a, int* rowtab, int* plq, int* hist, int* flag, int b0, int npatch, int split) {
+  constexpr int PASSES = (MWG + NTHR - 1) / NTHR, NWAVE = NTHR / 64, NGROUP = MWG / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HW = a.HW, W2 = a.W + 2, Q = a.Q;
+  int orow[PASSES], pq[PASSES], res[PASSES], rank[PASSES];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int lr = tid + p * NTHR;
+    int pl, pix;
+    bool valid;
+    if (a.spp == 1) { pl = lr / HW; pix = lr - pl * HW; valid = lr < MWG && pl < npatch; }
+    else { pl = 0; pix = split * MWG + lr; valid = lr < MWG && pix < HW; }
+    const int h = valid ? pix / a.W : 0, w = valid ? pix - h * a.W : 0;
+    orow[p] = valid ? (b0 + pl) * HW + pix : -1;
+    pq[p] = valid ? ((pl << 16) | (h * W2 + w)) : 0;
+    res[p] = valid ? (pl * Q + h * W2 + w) & 15 : -1;
+    int mine = 0, cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const unsigned long long m = __ballot(res[p] == c);
+      if (res[p] == c) mine = __popcll(m & lt);
+      if (lane == c) cnt = __popcll(m);
+    }
+    rank[p] = mine;
+    if (lane < 16) hist[(p * NWAVE + wave) * 16 + lane] = cnt;
+    // unused slots: no output row, and a window row of the slot's own residue class
+    if (lr < MWG) {
+      const int li = lr & 31;
+      const int slot = li < 4 ? li : li < 12 ? li - 4 : li < 16 ? li - 8 : li < 20 ? li - 8 : li < 28 ? li - 12 : li - 16;
+      rowtab[lr] = -1;
+      plq[lr] = (Q * a.ppw > 17 + 2 * W2) ? slot : 0;
+    }
+  }
+  if (tid == 0) *flag = a.pixel_order & 1;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    if (res[p] >= 0) {
+      for (int j = 0; j < p * NWAVE + wave; ++j) rank[p] += hist[j * 16 + res[p]];
+      if (rank[p] >= NGROUP) *flag = 1;
+    }
+  }
+  __syncthreads();
+  const int over = *flag;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int lr = tid + p * NTHR;
+    if (over) {
+      if (lr < MWG) { rowtab[lr] = orow[p]; plq[lr] = pq[p]; }
+    } else if (res[p] >= 0) {
+      const int k = rank[p], c = res[p];
+      const int li = (k & 1) ? (c < 8 ? c + 4 : c < 12 ? c + 8 : c + 16) : (c < 4 ? c : c < 8 ? c + 8 : c + 12);
+      const int dst = (k >> 1) * 32 + li;
+      rowtab[dst] = orow[p];
+      plq[dst] = pq[p];
+    }
+  }
+}
+
 template <int MT, int NT, bool XN, int NWV = 8>
 __global__ __launch_bounds__(NWV * 64, 1) void k_conv3x3_bf16(ConvArgs a) {
   WGSTAMP(XN ? 0 : (a.stats ? (a.N == 64 ? 1 : 2) : -1));      // first conv, second conv, third conv (forward launches)
@@ -94,15 +167,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void k_conv3x3_bf16(ConvArgs a) {
   // (cycle stamps of a two-chunk workgroup: tables 4.0 k cycles, then 2.3 k waiting for the first chunk)
 #define DTA_TABLES \
   { \
-    for (int lr = tid; lr < MWG; lr += NTHR) { \
-      int pl, pix; \
-      bool valid; \
-      if (a.spp == 1) { pl = lr / HW; pix = lr - pl * HW; valid = pl < npatch; } \
-      else { pl = 0; pix = split * MWG + lr; valid = pix < HW; } \
-      int h = valid ? pix / a.W : 0, w = valid ? pix - h * a.W : 0; \
-      rowtab[lr] = valid ? (b0 + pl) * HW + pix : -1; \
-      plq[lr] = valid ? ((pl << 16) | (h * W2 + w)) : 0; \
-    } \
+    conv_row_tables<MWG, NTHR>(a, rowtab, plq, reinterpret_cast<int*>(red), reinterpret_cast<int*>(cmean), b0, npatch, split); \
     if (xc || XN) {   /* (the fused-input kernel writes interior pixels only, whatever the HBM tile format) */ \
       u32x4* z = reinterpret_cast<u32x4*>(sbuf); \
       const u32x4 zero = {0u, 0u, 0u, 0u}; \
@@ -263,27 +328,34 @@ _Pragma("unroll") \
     __syncthreads();
     unsigned char* s0 = sbuf;
     unsigned char* s1 = sbuf + stage;
+    // The two waves of a SIMD (w and w + NW/2) take the two halves of a chunk interval in opposite order: the first stages
+    // the next chunk (waits for its loads, converts, writes LDS) and then multiplies, the second multiplies first and
+    // stages afterwards -- nobody reads the stage being written before the barrier, so the order inside the interval is
+    // free, and the matrix pipe has one wave's MFMAs to run while the other wave's staging waits on memory.
+    const bool late = !(a.pixel_order & 2) && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
     for (int chunk = 0; chunk < a.NC; chunk += 2) {
       // even chunk in stage 0; chunk+1 (set rf) goes to stage 1, then rf refills with chunk+3
       DTA_TILE_OUT(s0, chunk)
+      if (late) { DTA_COMPUTE(s0, s0 + xbytes) }
       if (chunk + 1 < a.NC) {
         DTA_STORE_XF(rf, s1)
         DTA_STORE_W(s1 + xbytes)
         DTA_FETCH_W(chunk + 2)
         DTA_FETCH_XF(rf, chunk + 3)
       }
-      DTA_COMPUTE(s0, s0 + xbytes)
+      if (!late) { DTA_COMPUTE(s0, s0 + xbytes) }
       __syncthreads();
       if (chunk + 1 >= a.NC) break;
       // odd chunk in stage 1; chunk+2 (set rg) goes to stage 0, then rg refills with chunk+4
       DTA_TILE_OUT(s1, chunk + 1)
+      if (late) { DTA_COMPUTE(s1, s1 + xbytes) }
       if (chunk + 2 < a.NC) {
         DTA_STORE_XF(rg, s0)
         DTA_STORE_W(s0 + xbytes)
         DTA_FETCH_W(chunk + 3)
         DTA_FETCH_XF(rg, chunk + 4)
       }
-      DTA_COMPUTE(s1, s1 + xbytes)
+      if (!late) { DTA_COMPUTE(s1, s1 + xbytes) }
       __syncthreads();
     }
 #undef DTA_TILE_OUT
@@ -299,6 +371,8 @@ _Pragma("unroll") \
   if (a.NC > 1) DTA_FETCH(1)
   __syncthreads();
   CTICK(2);
+  // (two LDS stages: the two waves of a SIMD take staging and multiplying in opposite order, as in the fused-input loop)
+  const bool late2 = dbuf && !(a.pixel_order & 2) && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
   for (int chunk = 0; chunk < a.NC; ++chunk) {
     unsigned char* cx = sbuf + ((dbuf && (chunk & 1)) ? stage : 0);
     unsigned char* nx = sbuf + ((dbuf && !(chunk & 1)) ? stage : 0);
@@ -309,11 +383,12 @@ _Pragma("unroll") \
         if (tid + u * NTHR < nxv)
           *reinterpret_cast<u32x4*>(xo + xsrc[u] + (size_t)chunk * xchunk) = *reinterpret_cast<const u32x4*>(cx + xdst[u]);
     }
+    if (late2) { DTA_COMPUTE(cx, cx + xbytes) }
     if (dbuf && more) {
       DTA_STORE(nx, nx + xbytes, chunk + 1)
       if (chunk + 2 < a.NC) DTA_FETCH(chunk + 2)
     }
-    DTA_COMPUTE(cx, cx + xbytes)
+    if (!late2) { DTA_COMPUTE(cx, cx + xbytes) }
     __syncthreads();
     if (!dbuf && more) {
       DTA_STORE(nx, nx + xbytes, chunk + 1)

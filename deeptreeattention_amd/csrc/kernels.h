@@ -26,6 +26,7 @@ struct ConvArgs {
   // bf16 first conv fed straight from the caller's tensor: x_nchw[g] = float32 [B][Cx][H][W]; the kernel converts while
   // staging and (x_tl_out != null) writes the halo-free bf16 tiles it built as a by-product for the weight gradient
   const float* x_nchw[MAXG]; int Cx; void* x_tl_out;
+  int pixel_order;                    // bf16 developer switches: bit 0 = tile rows in pixel order (conv_row_tables), bit 1 = all waves stage before they multiply
 };
 struct WgradArgs {
   const void* x_tl; size_t x_gs; int NCx;
