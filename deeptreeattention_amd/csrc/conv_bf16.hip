@@ -312,19 +312,21 @@ _Pragma("unroll") \
     _Pragma("unroll") for (int u = 0; u < WV; ++u)                                                    \
         if (tid + u * NTHR < wvec) *reinterpret_cast<u32x4*>((sw_) + wdst[u]) = rw[u];
 #define DTA_TILE_OUT(cx_, chunk_)                                                                     \
-    if (xo) {   /* the chunk image just completed: its rows leave as the halo-free bf16 tile of (patch, chunk) */ \
+    if (xo) {   /* the chunk image just completed: its rows leave as the halo-free bf16 tile of (patch, chunk); plain */ \
+                /* stores: nontemporal ones made this kernel 3.5 us slower (same-box A/B), the reader is far either way */ \
       _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                  \
         if (tid + u * NTHR < nxv)                                                                     \
-          __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>((cx_) + xdst[u]),               \
-                                      reinterpret_cast<u32x4*>(xo + xsrc[u] + (size_t)(chunk_) * xchunk)); \
+          *reinterpret_cast<u32x4*>(xo + xsrc[u] + (size_t)(chunk_) * xchunk) = *reinterpret_cast<const u32x4*>((cx_) + xdst[u]); \
     }
     DTA_FETCH_XF(rf, 0)
     DTA_FETCH_W(0)
     DTA_STORE_XF(rf, sbuf)
     DTA_STORE_W(sbuf + xbytes)
-    DTA_FETCH_XF(rf, 1)
-    DTA_FETCH_W(1)
-    DTA_FETCH_XF(rg, 2)
+    if (a.NC > 1) {
+      DTA_FETCH_XF(rf, 1)
+      DTA_FETCH_W(1)
+    }
+    if (a.NC > 2) DTA_FETCH_XF(rg, 2)
     __syncthreads();
     unsigned char* s0 = sbuf;
     unsigned char* s1 = sbuf + stage;
@@ -340,8 +342,8 @@ _Pragma("unroll") \
       if (chunk + 1 < a.NC) {
         DTA_STORE_XF(rf, s1)
         DTA_STORE_W(s1 + xbytes)
-        DTA_FETCH_W(chunk + 2)
-        DTA_FETCH_XF(rf, chunk + 3)
+        if (chunk + 2 < a.NC) DTA_FETCH_W(chunk + 2)
+        if (chunk + 3 < a.NC) DTA_FETCH_XF(rf, chunk + 3)
       }
       if (!late) { DTA_COMPUTE(s0, s0 + xbytes) }
       __syncthreads();
@@ -352,8 +354,8 @@ _Pragma("unroll") \
       if (chunk + 2 < a.NC) {
         DTA_STORE_XF(rg, s0)
         DTA_STORE_W(s0 + xbytes)
-        DTA_FETCH_W(chunk + 3)
-        DTA_FETCH_XF(rg, chunk + 4)
+        if (chunk + 3 < a.NC) DTA_FETCH_W(chunk + 3)
+        if (chunk + 4 < a.NC) DTA_FETCH_XF(rg, chunk + 4)
       }
       if (!late) { DTA_COMPUTE(s1, s1 + xbytes) }
       __syncthreads();
