@@ -244,13 +244,73 @@ def main():
     torch.manual_seed(1234)                      # same initial weights on every rank (then broadcast anyway)
     model = H.Hang2020(BANDS, CLASSES, precision=a.precision).to(dev)
     model.train()
-    trainer = FusedTrainer(model, lr=1e-4, loss_weight=torch.ones(CLASSES), overlap_comm=not a.no_overlap,
-                           exchange=None if a.exchange == "auto" else a.exchange)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)                   # each rank owns a different shard of the global batch
     nb = 2
     xs = [torch.rand(a.batch, BANDS, HW, HW, device=dev, generator=g) for _ in range(nb)]
     ys = [torch.randint(0, CLASSES, (a.batch,), device=dev, generator=g) for _ in range(nb)]
+
+    def build_trainer(exchange):
+        return FusedTrainer(model, lr=1e-4, loss_weight=torch.ones(CLASSES), overlap_comm=not a.no_overlap,
+                            exchange=exchange, exchange_opts={"timeout_s": 30.0} if exchange in (None, "peer") else None)
+
+    # Data-parallel: the exchange is tried for a few steps before anything is timed.  "auto" walks peer -> rccl -> torch:
+    # the trainer's own choice first (its crash-isolated probe decides whether the peer exchange is usable at all), and
+    # if ANY rank fails to build it or sees a step fail, every rank drops it and takes the next one -- a multi-GPU node
+    # this code never ran on must still produce a measured line.  An explicit --exchange is taken as given.
+    chain = [None, "rccl", "torch"] if a.exchange == "auto" else [a.exchange]
+    if not dist_on:
+        chain = chain[:1]
+    trainer, fallbacks = None, []
+    def agreed_failure(err):
+        bad = torch.tensor([1.0 if err else 0.0], device=dev)
+        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+        return bad.item() != 0.0
+
+    for k, choice in enumerate(chain):
+        err = ""
+        try:
+            trainer = build_trainer(choice)
+            hook = os.environ.get("DTA_BENCH_FAIL_EXCHANGE", "").split(",")      # (test hook: tests/test_bench_contract.py)
+            if str(choice) in hook or f"{choice}@{rank}" in hook:
+                raise RuntimeError("DTA_BENCH_FAIL_EXCHANGE")
+        except Exception as e:      # noqa: BLE001 -- whatever went wrong, the ranks must agree on what happens next
+            err = f"{type(e).__name__}: {e}"
+        if not dist_on:
+            if err:
+                raise RuntimeError(err)
+            break
+        failed = agreed_failure(err)         # (a rank whose constructor failed cannot take part in the trial steps)
+        if not failed:
+            try:
+                for i in range(4):
+                    trainer.train_step(xs[i % nb], ys[i % nb])
+                torch.cuda.synchronize()
+                trainer.check_exchange()
+            except Exception as e:      # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+            failed = agreed_failure(err)
+        if not failed:
+            break
+        fallbacks.append({"exchange": (trainer.exchange if trainer is not None else str(choice)), "error": err[:200]})
+        if k + 1 == len(chain):
+            raise RuntimeError(f"no gradient exchange works on this node: {fallbacks}")
+        # teardown without the trainer's own collective close(): a rank whose constructor failed has nothing to close
+        torch.cuda.synchronize()
+        ex = getattr(trainer, "ex", None) if trainer is not None else None
+        if ex is not None and ex._h is not None:
+            trainer.flat_g = trainer.g_head = trainer.g_tail = None
+            trainer._gview = {}
+            ex.grad = None
+        torch.distributed.barrier()                  # nobody unmaps while a peer may still read
+        if ex is not None and ex._h is not None:
+            ex._L.dta_xchg_destroy(ex._h)
+            ex._h = None
+            trainer.ex = None
+        trainer = None
+        torch.manual_seed(1234)
+        model = H.Hang2020(BANDS, CLASSES, precision=a.precision).to(dev)      # the trial steps moved the weights
+        model.train()
 
     L = _lib.lib()
     SITE = {"fwd0": _lib.SITE_CONV_FWD, "wgrad0": _lib.SITE_CONV_WGRAD}
@@ -433,7 +493,7 @@ def main():
             "config": {"workload": "Hang2020 spectral+spatial attention train step (fwd + weighted CE + bwd + Adam"
                                    + (" + RCCL grad all-reduce" if world > 1 else "") + "), bands=369 11x11 classes=200",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "exchange": trainer.exchange,
+                       "parallelism": f"dp{world}", "exchange": trainer.exchange, "exchange_fallbacks": fallbacks,
                        "overlap_comm": bool(trainer.overlap),
                        "collectives_per_step": (0 if trainer.exchange in (None, "peer") else (2 if trainer.overlap else 1)),
                        "exchange_launches_per_step": (1 if trainer.exchange == "peer" else 0)},

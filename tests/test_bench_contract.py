@@ -78,3 +78,26 @@ def test_bench_two_ranks_print_one_json_line():
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
         assert d["config"]["collectives_per_step"] == ncoll and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_fall_back_when_an_exchange_fails():
+    """bench.py tries the gradient exchange for a few untimed steps and, if ANY rank fails, every rank drops it and takes
+    the next of peer -> rccl -> torch.  Here rank 1 alone fails the first choice and both ranks fail the second (test
+    hook DTA_BENCH_FAIL_EXCHANGE): the run must still end with one JSON line, on the torch exchange, saying what it
+    gave up."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, DTA_BENCH_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo", MASTER_ADDR="127.0.0.1",
+               DTA_BENCH_FAIL_EXCHANGE="None@1,rccl")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--steady-steps", "0"],
+                         capture_output=True, text=True, timeout=420, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["exchange"] == "torch"
+    fb = d["config"]["exchange_fallbacks"]
+    assert len(fb) == 2 and fb[1]["exchange"] == "rccl"
