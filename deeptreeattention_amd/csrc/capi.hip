@@ -53,18 +53,18 @@ inline void prof_end(int site, hipStream_t st) {
 }
 
 // Developer switches (same-box A/B runs): the environment is read once per process, not per call.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; };
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; bool no_wgrad_pair; };
 inline Switches read_switches() {
   // these change launch plans (and, for DTA_FP32_ACT, roundings): never meant for a training job's environment, so say
   // so once, loudly, when one is set
   static const char* names[] = {"DTA_NO_FUSED_INPUT", "DTA_NO_TAIL_MERGE", "DTA_BN_INKERNEL", "DTA_FP32_ACT", "DTA_NO_LEAN",
-                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER"};
+                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER", "DTA_NO_WGRAD_PAIR"};
   for (const char* n : names)
     if (getenv(n)) fprintf(stderr, "[libdta_hip] developer switch %s is set: kernel plans (and possibly roundings) differ from the default build\n", n);
   return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr,
           getenv("DTA_FP32_ACT") != nullptr, getenv("DTA_NO_LEAN") != nullptr,
           getenv("DTA_LEAN_MASK") ? atoi(getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, getenv("DTA_HALO_TILES") != nullptr,
-          getenv("DTA_NO_WGRAD_NSPLIT") == nullptr, (getenv("DTA_PIXEL_ORDER") ? 1 : 0) | (getenv("DTA_NO_STAGGER") ? 2 : 0)};
+          getenv("DTA_NO_WGRAD_NSPLIT") == nullptr, (getenv("DTA_PIXEL_ORDER") ? 1 : 0) | (getenv("DTA_NO_STAGGER") ? 2 : 0), getenv("DTA_NO_WGRAD_PAIR") != nullptr};
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -90,6 +90,7 @@ struct Plan {
   int F[MAXG][3], Fmax[3], vec_ld[3];
   int nwg[3], MWG[3];
   int S[3], cgroups[3], ngroups[3], CpadW[3];
+  int wgrad_pair;       // bf16: the second and third conv's weight gradients share one launch (their S are sized for it)
   size_t x_tl, wp[3], wd[3], y[3], stats[3], coef[3], a_tl[3], feat[3], attpk[MAXG][3], scores[MAXG][3];
   size_t dfeat[3], dv[3], bnpart[3], bcoef[3], dy_tl[3], da[3], vec[3], wpart[3];
   size_t attsave[3]; int attsave_ld[3];
@@ -180,6 +181,29 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
     const bool net11 = p->H == 11 && p->W == 11;
     p->tl_compact = p->x_compact && net11 && !switches().no_lean && (switches().lean_mask & 1) && !switches().halo_tiles;
     for (int L = 0; L < 3; ++L) p->Rin[L] = p->tl_compact ? p->HWc[L] : p->Qin[L];
+  }
+  // bf16: the weight gradients of the second and third conv run side by side in one launch (conv_bf16.hip,
+  // k_conv_wgrad_bf16_pair): 96 + 160 of the 256 CUs (the third conv's stacked 5x5 windows carry more work per slab),
+  // batch splits in whole multiples of 8 workgroups so that a split's workgroups stay on one XCD
+  p->wgrad_pair = 0;
+  auto pair_ok = [&]() {
+    WgradArgs w[2];
+    memset(w, 0, sizeof(w));
+    for (int k = 0; k < 2; ++k) {
+      const int L = k + 1;
+      w[k].H = p->Hc[L]; w[k].W = p->Wc[L]; w[k].Q = p->Qin[L]; w[k].N = CH[L]; w[k].Cpad = p->CpadW[L]; w[k].ngroups = p->ngroups[L];
+      w[k].x_compact = w[k].y_compact = p->tl_compact; w[k].S = 1; w[k].B = B;
+    }
+    return wgrad_pair_plan_ok_bf16(w[0], w[1]);
+  };
+  if (d->dtype == DTA_BF16 && !switches().no_wgrad_pair && pair_ok()) {
+    auto split = [&](int L, int budget) {
+      int S = budget / (p->cgroups[L] * p->ngroups[L] * G);
+      while (S > 0 && (S * G) % 8 != 0) --S;
+      return S > B ? 0 : S;
+    };
+    const int S2 = split(1, 96), S3 = split(2, 160);      // (measured: 96/160 0.5266 ms, 88/160 0.5298, 128/128 0.5318, 64/192 0.5395)
+    if (S2 > 0 && S3 > 0) { p->S[1] = S2; p->S[2] = S3; p->wgrad_pair = 1; }
   }
   Carver c;
   const size_t e = p->esz;
@@ -424,7 +448,8 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
 
 template <typename T>
 int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grads* grads, void* ws, int L,
-                     WgradReduceGroup& reduces, hipStream_t st, const void* x_tiles = nullptr) {
+                     WgradReduceGroup& reduces, hipStream_t st, const void* x_tiles = nullptr,
+                     WgradArgs* defer = nullptr, const WgradArgs* partner = nullptr) {
   const int G = p.G, B = p.B, C = CH[L];
   const bool cat = L == 0 && p.shared_x;
   const int Nconv = cat ? 32 * G : C;
@@ -443,9 +468,12 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
   wa.NCy = Nconv / 16; wa.ych0 = 0; wa.ngroups = p.ngroups[L];
   wa.partial = at<float>(ws, p.wpart[L]);
   wa.B = B; wa.H = p.Hc[L]; wa.W = p.Wc[L]; wa.Q = p.Qin[L]; wa.N = Nconv; wa.Cpad = p.CpadW[L]; wa.S = p.S[L];
-  prof_begin(DTA_SITE_CONV_WGRAD + L, st);
-  if (launch_conv_wgrad<T>(wa, launchG, st)) return 1;
-  prof_end(DTA_SITE_CONV_WGRAD + L, st);
+  if (defer) *defer = wa;      // (third conv of a paired plan: launched together with the second conv's)
+  else {
+    prof_begin(DTA_SITE_CONV_WGRAD + L, st);
+    if (partner ? launch_conv_wgrad_pair_bf16(wa, *partner, launchG, st) : launch_conv_wgrad<T>(wa, launchG, st)) return 1;
+    prof_end(DTA_SITE_CONV_WGRAD + L, st);
+  }
   WgradReduceArgs wr;
   memset(&wr, 0, sizeof(wr));
   wr.partial = wa.partial; wr.G = launchG; wr.S = p.S[L]; wr.N = Nconv; wr.C = p.Cin[L]; wr.Cpad = p.CpadW[L];
@@ -468,6 +496,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
   }
   const float* dsc[MAXG][3] = {};
   BlendBwdArgs blend_fin = {}; bool blend_fin_pending = false;
+  WgradArgs pair_conv3; bool pair_pending = false;      // third conv's weight gradient waiting for the second's (paired plan)
   int dsc_mode[MAXG] = {};   // Hang2020: scale mode of the last-head score gradient of each branch
   if (dscores)
     for (int g = 0; g < G; ++g)
@@ -629,8 +658,16 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       prof_end(DTA_SITE_GEMM + 2, st);
       deferred.n = 0;
     }
-    if (L > 0 || (phases & 2))
-      if (conv_wgrad_layer<T>(p, d, grads, ws, L, reduces, st, x_tiles)) return 1;
+    if (L > 0 || (phases & 2)) {
+      bool want1 = false;
+      for (int g = 0; g < G; ++g) want1 |= grads[g].conv_w[1] != nullptr;
+      if (L == 2 && p.wgrad_pair && want1) {
+        if (conv_wgrad_layer<T>(p, d, grads, ws, L, reduces, st, x_tiles, &pair_conv3)) return 1;
+        bool want3 = false;
+        for (int g = 0; g < G; ++g) want3 |= grads[g].conv_w[2] != nullptr;
+        pair_pending = want3;
+      } else if (conv_wgrad_layer<T>(p, d, grads, ws, L, reduces, st, x_tiles, nullptr, (L == 1 && pair_pending) ? &pair_conv3 : nullptr)) return 1;
+    }
     // ---- conv input gradient (feeds the previous stage's gated map) ----
     if (L > 0) {
       PackWArgs pw;

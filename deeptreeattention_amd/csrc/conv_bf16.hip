@@ -648,10 +648,10 @@ extern "C" int dta_debug_wticks(long long* out) { return (int)hipMemcpyFromSymbo
 #define WTICK(i)
 #define WTICK_DUMP
 #endif
+// The workgroup program; bx = index of this workgroup among the job's workgroups (a launch may carry two jobs: below).
 template <int CT, int NTT, bool BIGW, bool STACK = false, bool D2 = false>
-__global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
+__device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx, unsigned char* smem) {
   WGSTAMP(CT == 2 ? 3 : -1);      // first conv's weight gradient
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NTHR = 512;
   // CT 32-channel input tiles x NTT 32-column tiles per workgroup = PAIRS wave tiles; the 8 waves are PAIRS tiles x
   // KS k-slices (KS = 2 for the usual 4 tiles; 4 when the layer has only 32 input channels: CT = 1, NTT = 2)
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   const int ngr = a.ngroups > 0 ? a.ngroups : 1;      // column groups: this workgroup's N columns start at ng * N
   const int total = a.cgroups * ngr * a.S * a.G;
   const int per_xcd = (total + 7) / 8;
-  const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const int logical = (bx % 8) * per_xcd + bx / 8;
   if (logical >= total) return;
   const int cg = logical % a.cgroups, ng = (logical / a.cgroups) % ngr, s = (logical / (a.cgroups * ngr)) % a.S,
             g = logical / (a.cgroups * ngr * a.S);
@@ -902,22 +902,67 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
   }
 }
 
+template <int CT, int NTT, bool BIGW, bool STACK = false, bool D2 = false>
+__global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  wgrad_bf16_body<CT, NTT, BIGW, STACK, D2>(a, blockIdx.x, smem);
+}
+
+// The weight gradients of the SECOND and THIRD conv in one launch (both are <1,2> programs: plain windows for the 11x11
+// maps, stacked patches for the 5x5 maps).  Alone, each is dominated by what a workgroup pays once -- LDS clear, first
+// window, the k-slice hand-over and the slab epilogue, ~15 us of a 24 / 30 us launch -- and each needs the whole GPU
+// to itself (one 512-thread workgroup of 254 registers per CU).  Side by side, each job gets a share of the CUs, its
+// workgroups walk proportionally more patches, and the fixed part is paid once for both: measured model
+// 15.3 + 8.7 (256 / n2) and 14.7 + 15.2 (256 / n3) us -> ~40 us together against 54 one after the other; the slabs
+// (one per batch split) shrink with the workgroup counts.  Blocks [0, na) run job a, the rest job b; na is a multiple
+// of 8, so both keep the XCD-aware placement of their batch splits.
+__global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16_pair(WgradArgs a, WgradArgs b, int na) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((int)blockIdx.x < na) wgrad_bf16_body<1, 2, false, false, false>(a, blockIdx.x, smem);
+  else wgrad_bf16_body<1, 2, false, true, false>(b, blockIdx.x - na, smem);
+}
+
+// kernel variant a launch resolves to
+enum { WV_PLAIN = 0, WV_BIGW = 1, WV_STACK = 2, WV_D2 = 3 };
+
+template <int CT, int NTT>
+static int resolve_wgrad_bf16(const WgradArgs& a, int G, int cgroups, WgradArgs& a2, size_t& lds, int& variant, int& total);
+
 template <int CT, int NTT>
 static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream_t st) {
-  WgradArgs a2 = a;
+  WgradArgs a2;
+  size_t lds;
+  int variant, total;
+  if (resolve_wgrad_bf16<CT, NTT>(a, G, cgroups, a2, lds, variant, total)) return 1;
+  static DevOnce attr_once;      // (function attributes are per device)
+  if (attr_once.first()) {
+    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (CT == 1) hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (CT == 2 && NTT == 2) hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  const dim3 grid(8 * ((total + 7) / 8));
+  if (variant == WV_STACK) {
+    if constexpr (CT == 1) hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false, true>), grid, dim3(512), lds, st, a2);
+  } else if (variant == WV_D2) {
+    if constexpr (CT == 2 && NTT == 2) hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false, false, true>), grid, dim3(512), lds, st, a2);
+  } else if (variant == WV_PLAIN) hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false>), grid, dim3(512), lds, st, a2);
+  else hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, true>), grid, dim3(512), lds, st, a2);
+  DTA_CHECK_LAUNCH("k_conv_wgrad_bf16");
+  return 0;
+}
+
+template <int CT, int NTT>
+static int resolve_wgrad_bf16(const WgradArgs& a, int G, int cgroups, WgradArgs& a2, size_t& lds, int& variant, int& total) {
+  a2 = a;
   // band plan: window rows WR = bl + 2*(W+3), WR == 4 (mod 8) (bank-disjoint chunk tiles), WR <= 252 (staging plan)
   wgrad_band_plan(a.Q, a.W, 252, &a2.bl, &a2.wr, &a2.nbands);
   if (a2.bl < 16 || a2.wr > 256) { dta_set_error("conv_wgrad(bf16): %dx%d patch is too wide for the band plan", a.H, a.W); return 1; }
   size_t stage = (size_t)(CT * 2 + NTT * 2) * a2.wr * RW;
   a2.dbuf = 2 * stage <= 160 * 1024;
-  size_t lds = (a2.dbuf ? 2 : 1) * stage;
+  lds = (a2.dbuf ? 2 : 1) * stage;
   if (lds < 48 * 1024) lds = 48 * 1024;   // the final reduction passes up to 6 x 2 tiles (8 KiB each) through LDS
   if (lds > 160 * 1024) { dta_set_error("conv_wgrad(bf16): LDS need %zu B exceeds 160 KiB", lds); return 1; }
-  static DevOnce attr_once;      // (function attributes are per device)
-  if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
   a2.ppi = 1;
   static const bool no_stack = getenv("DTA_NO_WGRAD_STACK") != nullptr;      // development A/B switches, read once
   static const bool no_d2 = getenv("DTA_NO_WGRAD_D2") != nullptr;
@@ -940,28 +985,13 @@ static int launch_wgrad_bf16_t(const WgradArgs& a, int G, int cgroups, hipStream
   if (lds < 48 * 1024) lds = 48 * 1024;
   a2.cgroups = cgroups; a2.G = G;
   a2.ngroups = a.N / (NTT * 32);
-  const int total = cgroups * a2.ngroups * a.S * G;
-  if (a2.ppi > 1) {
-    if constexpr (CT == 1) {      // (the layers with small maps: 64 -> 128 channels)
-      static bool attr2 = false;
-      if (!attr2) { hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
-      hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false, true>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
-    }
-  }
-  else if (a2.wr <= 192 && a2.dbuf && CT == 2 && NTT == 2 && !no_d2) {
-    // two windows in flight in registers: the first conv's <2,2> (cycle stamps: loop 119.9 k -> 116.7 k cycles; the
-    // second conv's <1,2> measured slower with it, 23.8 -> 24.9 us, and stays on one set)
-    if constexpr (CT == 2 && NTT == 2) {
-      static bool attr3 = false;
-      if (!attr3) { hipFuncSetAttribute((const void*)k_conv_wgrad_bf16<CT, NTT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
-      hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false, false, true>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
-    } else {
-      hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
-    }
-  }
-  else if (a2.wr <= 192) hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, false>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
-  else hipLaunchKernelGGL((k_conv_wgrad_bf16<CT, NTT, true>), dim3(8 * ((total + 7) / 8)), dim3(512), lds, st, a2);
-  DTA_CHECK_LAUNCH("k_conv_wgrad_bf16");
+  total = cgroups * a2.ngroups * a.S * G;
+  // two windows in flight in registers: the first conv's <2,2> (cycle stamps: loop 119.9 k -> 116.7 k cycles; the
+  // second conv's <1,2> measured slower with it, 23.8 -> 24.9 us, and stays on one set)
+  if (a2.ppi > 1) variant = WV_STACK;      // (CT == 1 only: the layers with small maps, 64 -> 128 channels)
+  else if (a2.wr <= 192 && a2.dbuf && CT == 2 && NTT == 2 && !no_d2) variant = WV_D2;
+  else if (a2.wr <= 192) variant = WV_PLAIN;
+  else variant = WV_BIGW;
   return 0;
 }
 
@@ -982,6 +1012,40 @@ int launch_conv_wgrad<bf16_t>(const WgradArgs& a, int G, hipStream_t st) {
   }
   dta_set_error("conv_wgrad: unsupported width %d", a.N);
   return 1;
+}
+
+// Second and third conv in one launch when both resolve to the pair kernel's programs; otherwise one after the other.
+int launch_conv_wgrad_pair_bf16(const WgradArgs& conv2, const WgradArgs& conv3, int G, hipStream_t st) {
+  const bool shapes = conv2.N == 64 && conv2.Cpad <= 32 && conv3.N == 128 && conv3.ngroups == 2;
+  if (shapes) {
+    WgradArgs a2, b2;
+    size_t la, lb;
+    int va, vb, ta, tb;
+    if ((conv2.Cpad + wgrad_cpw(conv2.N) - 1) / wgrad_cpw(conv2.N) != 1) return launch_conv_wgrad<bf16_t>(conv3, G, st) || launch_conv_wgrad<bf16_t>(conv2, G, st);
+    if (resolve_wgrad_bf16<1, 2>(conv2, G, 1, a2, la, va, ta)) return 1;
+    if (resolve_wgrad_bf16<1, 2>(conv3, G, (conv3.Cpad + 31) / 32, b2, lb, vb, tb)) return 1;
+    const int na = 8 * ((ta + 7) / 8), nb = 8 * ((tb + 7) / 8);
+    if (va == WV_PLAIN && vb == WV_STACK && na + nb <= 256) {
+      static DevOnce attr_once;
+      if (attr_once.first()) hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(k_conv_wgrad_bf16_pair, dim3(na + nb), dim3(512), la > lb ? la : lb, st, a2, b2, na);
+      DTA_CHECK_LAUNCH("k_conv_wgrad_bf16_pair");
+      return 0;
+    }
+  }
+  if (launch_conv_wgrad<bf16_t>(conv3, G, st)) return 1;
+  return launch_conv_wgrad<bf16_t>(conv2, G, st);
+}
+// plan-time test: would the two layers' launches resolve to the pair kernel's programs (plain windows / stacked patches)?
+bool wgrad_pair_plan_ok_bf16(const WgradArgs& conv2, const WgradArgs& conv3) {
+  if (!(conv2.N == 64 && conv2.Cpad <= 32 && conv3.N == 128 && conv3.ngroups == 2)) return false;
+  if ((conv2.Cpad + wgrad_cpw(conv2.N) - 1) / wgrad_cpw(conv2.N) != 1) return false;
+  WgradArgs a2, b2;
+  size_t la, lb;
+  int va, vb, ta, tb;
+  if (resolve_wgrad_bf16<1, 2>(conv2, 1, 1, a2, la, va, ta)) return false;
+  if (resolve_wgrad_bf16<1, 2>(conv3, 1, (conv3.Cpad + 31) / 32, b2, lb, vb, tb)) return false;
+  return va == WV_PLAIN && vb == WV_STACK;
 }
 
 }  // namespace dta
