@@ -194,15 +194,18 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
       w[k].H = p->Hc[L]; w[k].W = p->Wc[L]; w[k].Q = p->Qin[L]; w[k].N = CH[L]; w[k].Cpad = p->CpadW[L]; w[k].ngroups = p->ngroups[L];
       w[k].x_compact = w[k].y_compact = p->tl_compact; w[k].S = 1; w[k].B = B;
     }
-    return wgrad_pair_plan_ok_bf16(w[0], w[1]);
+    return wgrad_pair_plan_bf16(w[0], w[1]);
   };
-  if (d->dtype == DTA_BF16 && !switches().no_wgrad_pair && pair_ok()) {
+  const int pair_kind = (d->dtype == DTA_BF16 && !switches().no_wgrad_pair) ? pair_ok() : 0;
+  if (pair_kind) {
     auto split = [&](int L, int budget) {
       int S = budget / (p->cgroups[L] * p->ngroups[L] * G);
-      while (S > 0 && (S * G) % 8 != 0) --S;
+      // (whole XCDs per batch split where the group count allows it; three years do not divide 8: any S then)
+      if (pair_kind == 1) while (S > 0 && (S * G) % 8 != 0) --S;
       return S > B ? 0 : S;
     };
-    const int S2 = split(1, 96), S3 = split(2, 160);      // (measured: 96/160 0.5266 ms, 88/160 0.5298, 128/128 0.5318, 64/192 0.5395)
+    // wide windows (24x24 crops): a launch is 21.7 us fixed + 18.7 us of work at 240 workgroups: equal shares
+    const int S2 = split(1, pair_kind == 1 ? 96 : 128), S3 = split(2, pair_kind == 1 ? 160 : 128);      // (measured: 96/160 0.5266 ms, 88/160 0.5298, 128/128 0.5318, 64/192 0.5395)
     if (S2 > 0 && S3 > 0) { p->S[1] = S2; p->S[2] = S3; p->wgrad_pair = 1; }
   }
   Carver c;

@@ -916,10 +916,13 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16(WgradArgs a) {
 // 15.3 + 8.7 (256 / n2) and 14.7 + 15.2 (256 / n3) us -> ~40 us together against 54 one after the other; the slabs
 // (one per batch split) shrink with the workgroup counts.  Blocks [0, na) run job a, the rest job b; na is a multiple
 // of 8, so both keep the XCD-aware placement of their batch splits.
+// (BIG = false: plain windows + stacked patches, the 11x11 networks; BIG = true: both multi-band / wide windows, the
+// 24x24 crops of the year models)
+template <bool BIG>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16_pair(WgradArgs a, WgradArgs b, int na) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if ((int)blockIdx.x < na) wgrad_bf16_body<1, 2, false, false, false>(a, blockIdx.x, smem);
-  else wgrad_bf16_body<1, 2, false, true, false>(b, blockIdx.x - na, smem);
+  if ((int)blockIdx.x < na) wgrad_bf16_body<1, 2, BIG, false, false>(a, blockIdx.x, smem);
+  else wgrad_bf16_body<1, 2, BIG, !BIG, false>(b, blockIdx.x - na, smem);
 }
 
 // kernel variant a launch resolves to
@@ -1025,10 +1028,18 @@ int launch_conv_wgrad_pair_bf16(const WgradArgs& conv2, const WgradArgs& conv3, 
     if (resolve_wgrad_bf16<1, 2>(conv2, G, 1, a2, la, va, ta)) return 1;
     if (resolve_wgrad_bf16<1, 2>(conv3, G, (conv3.Cpad + 31) / 32, b2, lb, vb, tb)) return 1;
     const int na = 8 * ((ta + 7) / 8), nb = 8 * ((tb + 7) / 8);
+    static DevOnce attr_once;
+    if (attr_once.first()) {
+      hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_pair<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_pair<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     if (va == WV_PLAIN && vb == WV_STACK && na + nb <= 256) {
-      static DevOnce attr_once;
-      if (attr_once.first()) hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(k_conv_wgrad_bf16_pair, dim3(na + nb), dim3(512), la > lb ? la : lb, st, a2, b2, na);
+      hipLaunchKernelGGL(k_conv_wgrad_bf16_pair<false>, dim3(na + nb), dim3(512), la > lb ? la : lb, st, a2, b2, na);
+      DTA_CHECK_LAUNCH("k_conv_wgrad_bf16_pair");
+      return 0;
+    }
+    if (va == WV_BIGW && vb == WV_BIGW && na + nb <= 256) {
+      hipLaunchKernelGGL(k_conv_wgrad_bf16_pair<true>, dim3(na + nb), dim3(512), la > lb ? la : lb, st, a2, b2, na);
       DTA_CHECK_LAUNCH("k_conv_wgrad_bf16_pair");
       return 0;
     }
@@ -1037,15 +1048,15 @@ int launch_conv_wgrad_pair_bf16(const WgradArgs& conv2, const WgradArgs& conv3, 
   return launch_conv_wgrad<bf16_t>(conv2, G, st);
 }
 // plan-time test: would the two layers' launches resolve to the pair kernel's programs (plain windows / stacked patches)?
-bool wgrad_pair_plan_ok_bf16(const WgradArgs& conv2, const WgradArgs& conv3) {
-  if (!(conv2.N == 64 && conv2.Cpad <= 32 && conv3.N == 128 && conv3.ngroups == 2)) return false;
-  if ((conv2.Cpad + wgrad_cpw(conv2.N) - 1) / wgrad_cpw(conv2.N) != 1) return false;
+int wgrad_pair_plan_bf16(const WgradArgs& conv2, const WgradArgs& conv3) {
+  if (!(conv2.N == 64 && conv2.Cpad <= 32 && conv3.N == 128 && conv3.ngroups == 2)) return 0;
+  if ((conv2.Cpad + wgrad_cpw(conv2.N) - 1) / wgrad_cpw(conv2.N) != 1) return 0;
   WgradArgs a2, b2;
   size_t la, lb;
   int va, vb, ta, tb;
-  if (resolve_wgrad_bf16<1, 2>(conv2, 1, 1, a2, la, va, ta)) return false;
-  if (resolve_wgrad_bf16<1, 2>(conv3, 1, (conv3.Cpad + 31) / 32, b2, lb, vb, tb)) return false;
-  return va == WV_PLAIN && vb == WV_STACK;
+  if (resolve_wgrad_bf16<1, 2>(conv2, 1, 1, a2, la, va, ta)) return 0;
+  if (resolve_wgrad_bf16<1, 2>(conv3, 1, (conv3.Cpad + 31) / 32, b2, lb, vb, tb)) return 0;
+  return (va == WV_PLAIN && vb == WV_STACK) ? 1 : (va == WV_BIGW && vb == WV_BIGW) ? 2 : 0;
 }
 
 }  // namespace dta

@@ -61,7 +61,9 @@ int wgrad_reduce_nblocks(const WgradReduceArgs& a);
 // bf16: the weight gradients of the second and third conv in ONE launch when both resolve to the pair kernel's programs
 // (conv_bf16.hip); otherwise third then second, each in its own launch
 int launch_conv_wgrad_pair_bf16(const WgradArgs& conv2, const WgradArgs& conv3, int G, hipStream_t st);
-bool wgrad_pair_plan_ok_bf16(const WgradArgs& conv2, const WgradArgs& conv3);   // geometry fields only (H, W, Q, N, Cpad, ngroups, x/y_compact)
+// plan-time test (geometry fields only: H, W, Q, N, Cpad, ngroups, x/y_compact): 0 = no pairing, 1 = plain + stacked
+// windows (11x11 networks), 2 = both wide / multi-band windows (24x24 crops)
+int wgrad_pair_plan_bf16(const WgradArgs& conv2, const WgradArgs& conv3);
 #if defined(__HIPCC__)
 // out_g[n][c][tap] (torch layout) = sum_s partial[g][tap][c][s][n]
 __device__ __forceinline__ void wgrad_reduce_blocks(const WgradReduceArgs& a, int bx, int nblocks) {
