@@ -1617,7 +1617,8 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int C = CFG::C, NO = CFG::NO, NP = CFG::NP, TPP = CFG::TPP, IPT = CFG::IPT, PPW = CFG::PPW, WZ = CFG::WZ;
   constexpr int K = CFG::K, R = CFG::R, WP = CFG::WP, NPAD = CFG::NPAD;
-  const int g = blockIdx.y, t = threadIdx.x, slot = t / TPP, lt = t % TPP;
+  // (groups dispatched last-first, as in the backward kernel below: the heavier spatial branch goes first)
+  const int g = gridDim.y - 1 - blockIdx.y, t = threadIdx.x, slot = t / TPP, lt = t % TPP;
   const int b = blockIdx.x * PPW + slot;
   const bool live = b < a.B;
   const int kind = a.kind[g];
@@ -1847,7 +1848,11 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
   constexpr int SLOT = LeanBwd<CFG>::SLOT, NPOS = CFG::POOL ? 4 : 1;
   // storage of the gradient maps follows the conv outputs': bf16 next to half outputs, fp32 next to fp32 (launcher checks)
   constexpr int GF = CFG::YF == FMT_F16 ? FMT_BF16 : FMT_F32;
-  const int g = blockIdx.y, t = threadIdx.x, slot0 = t / TPP, lt0 = t % TPP;
+  // groups are dispatched last-first: Hang2020's spatial branch (group 1) is the heavier program, and of the two
+  // workgroups that share a CU the one dispatched first wins the issue arbitration -- with the spectral branch first its
+  // workgroups finished at ~21 us and left the spatial ones alone on half-empty CUs until 32 us (same-box alternation:
+  // step 0.5211 -> 0.5182 ms; with the forward kernel 0.5128 -> 0.5111)
+  const int g = gridDim.y - 1 - blockIdx.y, t = threadIdx.x, slot0 = t / TPP, lt0 = t % TPP;
   const int kind = a.kind[g];
   float* coefL = sm;                                   // [C][4] scale, shift, mean, rstd
   float* sm0 = sm + 4 * C;
