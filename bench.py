@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--tile-steps", type=int, default=100,
                     help="extra steps fed with pre-tiled bf16 input (reported under tile_input; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side workloads (fp32 step, BASELINE configs[4] ensemble24, module-level plugin path) that the "
+                         "default one-GPU line carries as sub-objects, 20 steps each after the contract's timed region")
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-overlap", action="store_true")
@@ -114,13 +117,15 @@ def cpu_baseline(batch, seconds):
         if best is None or rate > best[0]:
             best = (rate, thr, b, n, el)
     rate, thr, b, n, el = best
-    return {"value": round(rate, 1), "unit": "patches/s", "cores": ncpu, "threads": thr, "kind": "port",
+    # `cores` (the contract's key) = the threads actually used; `hw_threads` = what os.cpu_count() reports for the box
+    # (hardware threads, not physical cores)
+    return {"value": round(rate, 1), "unit": "patches/s", "cores": thr, "threads": thr, "hw_threads": ncpu, "kind": "port",
             "sample": f"best of {len(settings)} settings ({', '.join(tried)} patches/s); reported: {n} train steps of "
                       f"batch {b}, fp32, torch {torch.__version__} eager on host CPU, {thr} of the box's {ncpu} "
                       f"hardware threads (oneDNN does not scale this small model further), {el:.1f} s"}
 
 
-def main_ensemble24(a):
+def main_ensemble24(a, emit=True):
     """BASELINE configs[4]: train step of the year ensemble (3 x spectral_network(369, 200) over 24x24 crops, mean of the
     last heads, weighted CE, backward, one Adam per year), bf16 convs / fp32 BN + loss, per-GPU batch 256 unless --batch
     says otherwise.  Single process (the data-parallel form of this step is covered by tests/test_ddp_gpu.py)."""
@@ -184,10 +189,15 @@ def main_ensemble24(a):
         if a.site == "fwd0" and a.precision == "bf16":
             # the bf16 first conv reads the fp32 crops itself and leaves the (haloed) bf16 tiles behind for the weight
             # gradient: per crop-year 369*576*4 B in, 384*676*2 B of tiles + 32*576*2 B of half output out -> HBM-bound
-            nbytes = B * YEARS * (BANDS * px * 4 + 384 * (CROP + 2) * (CROP + 2) * 2 + 32 * px * 2)
+            # `frac` prices the COMPULSORY bytes only (the fp32 crop in, the half conv output out); the
+            # bf16 tile by-product the kernel also writes (for its own weight gradient) is reported beside it
+            withby = B * YEARS * (BANDS * px * 4 + 384 * (CROP + 2) * (CROP + 2) * 2 + 32 * px * 2)
+            nbytes = B * YEARS * (BANDS * px * 4 + 32 * px * 2)
             gbs = nbytes / (avg * 1e-3) / 1e9
             roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes, "mfma_tflops": round(ach, 2),
+                         "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
+                         "frac_with_byproduct": round(withby / (avg * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                         "bytes_per_launch_with_byproduct": withby, "mfma_tflops": round(ach, 2),
                          "kernel": "k_conv3x3_bf16<3,1,XN,6> (conv1 forward of the three years, one grouped launch; converts "
                                    "the fp32 crops and emits the bf16 tiles)"})
     out = {"metric": "crops/sec (train step) year-ensemble 3 x spectral_network 369-band 24x24", "value": round(value, 1),
@@ -202,7 +212,113 @@ def main_ensemble24(a):
                              "algorithmic_flop_per_crop_year": step_flop,
                              "hbm_gbs_algorithmic": round(value * YEARS * bytes_step / 1e9, 1),
                              "hbm_frac_algorithmic": round(value * YEARS * bytes_step / 1e9 / PEAK_HBM_GBS, 4)}}
-    print(json.dumps(out), flush=True)
+    del tr, m, imgs
+    torch.cuda.empty_cache()
+    if emit:
+        print(json.dumps(out), flush=True)
+    return out
+
+
+def side_fp32(a, dev, steps=20):
+    """The reference's own precision: the same Hang2020 step with exact-fp32 MFMA contractions (precision='fp32')."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    torch.manual_seed(1234)
+    m = H.Hang2020(BANDS, CLASSES, precision="fp32").to(dev).train()
+    tr = FusedTrainer(m, lr=1e-4, loss_weight=torch.ones(CLASSES))
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    x = torch.rand(a.batch, BANDS, HW, HW, device=dev, generator=g)
+    y = torch.randint(0, CLASSES, (a.batch,), device=dev, generator=g)
+    for _ in range(5):
+        tr.train_step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.train_step(x, y)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    out = {"dtype": "fp32", "steps": steps, "per_gpu_batch": a.batch, "ms_per_step": round(ms, 4),
+           "patches_per_s": round(a.batch / ms * 1e3, 1),
+           "mfma_frac_fp32_peak": round(a.batch / ms * 1e3 * FLOP_PER_PATCH_STEP / 1e12 / PEAK_TFLOPS["fp32"], 4),
+           "final_loss": round(float(loss), 5),
+           "note": "FusedTrainer, Hang2020(369, 200) precision='fp32' (v_mfma_f32_32x32x2_f32: exact fp32 products), wall clock "
+                   "around the steps after 5 warm-up steps"}
+    del tr, m, x
+    torch.cuda.empty_cache()
+    return out
+
+
+def side_module_path(a, dev, fused_ms, steps=20):
+    """The UNCHANGED reference step (TreeModel.training_step: forward, F.cross_entropy, loss.backward(), optimizer.step(),
+    src/main.py:71-80,135-149) on the plugin modules, with the two one-line swaps INTEGRATION.md section 1 names:
+    optim.DtaAdam for optim.Adam and optim.cross_entropy for F.cross_entropy -- and with stock torch for both."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    from deeptreeattention_amd.year import learned_ensemble
+    import deeptreeattention_amd
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    x = torch.rand(a.batch, BANDS, HW, HW, device=dev, generator=g)
+    y = torch.randint(0, CLASSES, (a.batch,), device=dev, generator=g)
+    w = torch.ones(CLASSES, device=dev)
+
+    def timed(step, n):
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    out = {"steps": steps, "per_gpu_batch": a.batch, "dtype": a.precision}
+    torch.manual_seed(1234)
+    m = H.Hang2020(BANDS, CLASSES, precision=a.precision).to(dev).train()
+    opt = DtaAdam(m.parameters(), lr=1e-4)
+
+    def step_dta():
+        opt.zero_grad()
+        loss = cross_entropy(m(x), y, weight=w)
+        loss.backward()
+        opt.step()
+    ms = timed(step_dta, steps)
+    out["hang2020_dta_adam_ms_per_step"] = round(ms, 4)
+    out["hang2020_vs_fused_trainer"] = round(ms / fused_ms, 3) if fused_ms else None
+    opt.close()
+    del opt, m
+    torch.manual_seed(1234)
+    m = H.Hang2020(BANDS, CLASSES, precision=a.precision).to(dev).train()
+    topt = torch.optim.Adam(m.parameters(), lr=1e-4)
+
+    def step_torch():
+        topt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(m(x), y, weight=w)
+        loss.backward()
+        topt.step()
+    out["hang2020_torch_adam_ms_per_step"] = round(timed(step_torch, steps), 4)
+    del topt, m
+    # the year ensemble the reference actually trains (multi_stage.py:277-288), 3 years of 11x11 patches, device-decided
+    # missing years: module forward + optim.cross_entropy + DtaAdam's gated per-year steps
+    deeptreeattention_amd.set_default_precision(a.precision)
+    ens = learned_ensemble(3, CLASSES, {"pretrain_state_dict": None, "bands": BANDS}).to(dev).train()
+    eopt = DtaAdam(ens.parameters(), lr=1e-4)
+    imgs = [x, x.flip(0), x.flip(1)]
+
+    def step_ens():
+        eopt.zero_grad()
+        loss = cross_entropy(ens(imgs), y, weight=w)
+        loss.backward()
+        eopt.step()
+    out["ensemble3_11x11_dta_adam_ms_per_step"] = round(timed(step_ens, steps), 4)
+    eopt.close()
+    del eopt, ens, imgs, x
+    deeptreeattention_amd.set_default_precision("fp32")
+    torch.cuda.empty_cache()
+    out["note"] = ("module-level plugin path (autograd.Function per network, gradients written in place into DtaAdam's flat "
+                   "buffer); wall clock around the steps after 5 warm-up steps")
+    return out
 
 
 def main():
@@ -211,12 +327,26 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
         return main_ensemble24(a)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher the contract names -- one process per GPU
+        # under torch.distributed.run on 127.0.0.1 -- and hand its exit code on (rank 0 prints the one JSON line)
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU (plain `python bench.py "
+                         f"--gpus N` does that itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     if os.environ.get("DTA_BENCH_BACKEND", "nccl") != "nccl":
@@ -250,9 +380,16 @@ def main():
     xs = [torch.rand(a.batch, BANDS, HW, HW, device=dev, generator=g) for _ in range(nb)]
     ys = [torch.randint(0, CLASSES, (a.batch,), device=dev, generator=g) for _ in range(nb)]
 
+    shared_gpu = dist_on and os.environ.get("DTA_BENCH_BACKEND", "nccl") != "nccl"
+
     def build_trainer(exchange):
+        opts = None
+        if exchange in (None, "peer"):
+            opts = {"timeout_s": 30.0}
+            if shared_gpu:          # development: ranks share one GPU and wait for each other in-kernel -> stay co-resident
+                opts["max_workgroups"] = 32
         return FusedTrainer(model, lr=1e-4, loss_weight=torch.ones(CLASSES), overlap_comm=not a.no_overlap,
-                            exchange=exchange, exchange_opts={"timeout_s": 30.0} if exchange in (None, "peer") else None)
+                            exchange=exchange, exchange_opts=opts)
 
     # Data-parallel: the exchange is tried for a few steps before anything is timed.  "auto" walks peer -> rccl -> torch:
     # the trainer's own choice first (its crash-isolated probe decides whether the peer exchange is usable at all), and
@@ -304,7 +441,7 @@ def main():
             ex.grad = None
         torch.distributed.barrier()                  # nobody unmaps while a peer may still read
         if ex is not None and ex._h is not None:
-            ex._L.dta_xchg_destroy(ex._h)
+            ex._owner.destroy()
             ex._h = None
             trainer.ex = None
         trainer = None
@@ -314,6 +451,11 @@ def main():
 
     L = _lib.lib()
     SITE = {"fwd0": _lib.SITE_CONV_FWD, "wgrad0": _lib.SITE_CONV_WGRAD}
+    ranks_seen = 1
+    if dist_on:      # proof in the record that the process group really spans `world` ranks: an all-reduce of ones
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)
+        ranks_seen = int(one.item())
 
     def barrier():
         if dist_on:
@@ -472,13 +614,16 @@ def main():
                 # = 287,012 B.  That makes it HBM-bound (its MFMA floor is ~21 us, its HBM floor ~37 us at 8 TB/s).
                 # Against the strictly compulsory bytes (input in + output out, the tiles being a by-product) the
                 # fraction is lower:
-                nbytes = a.batch * (BANDS * HW * HW * 4 + 384 * HW * HW * 2 + 64 * HW * HW * 2)
-                compulsory = a.batch * (BANDS * HW * HW * 4 + 64 * HW * HW * 2)
+                # `achieved` / `frac` price SURVEY.md 8(d)'s COMPULSORY bytes only (input in + conv output out); the
+                # bf16 tiles are a by-product for the kernel's own weight gradient and are reported beside it
+                withby = a.batch * (BANDS * HW * HW * 4 + 384 * HW * HW * 2 + 64 * HW * HW * 2)
+                nbytes = a.batch * (BANDS * HW * HW * 4 + 64 * HW * HW * 2)
                 gbs = nbytes / (avg_ms * 1e-3) / 1e9
                 r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
-                          "frac_compulsory_bytes_only": round(compulsory / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                          "mfma_tflops": round(ach, 2),
+                          "frac_with_byproduct": round(withby / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                          "bytes_per_launch_with_byproduct": withby,
+                          "mfma_tflops": round(ach, 2), "mfma_frac": round(ach / PEAK_TFLOPS[a.precision], 4),
                           "kernel": "k_conv3x3_bf16<2,2,XN> (conv1 forward, both branches; converts the fp32 input and "
                                     "emits the bf16 tiles)"})
             roofs["fwd0"] = r
@@ -494,7 +639,7 @@ def main():
                                    + (" + RCCL grad all-reduce" if world > 1 else "") + "), bands=369 11x11 classes=200",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "exchange": trainer.exchange, "exchange_fallbacks": fallbacks,
-                       "overlap_comm": bool(trainer.overlap),
+                       "overlap_comm": bool(trainer.overlap), "ranks_seen": ranks_seen,
                        "collectives_per_step": (0 if trainer.exchange in (None, "peer") else (2 if trainer.overlap else 1)),
                        "exchange_launches_per_step": (1 if trainer.exchange == "peer" else 0)},
             "library_build_id": build_id, "priming_steps_before_warmup": primed,
@@ -516,11 +661,27 @@ def main():
             "steady_state": steady,
             "tile_input": tile_in,
         }
+        if world == 1 and not dist_on and not a.no_side:
+            # side workloads, driver-timed in the same run AFTER the contract's region (20 steps each): the reference's own
+            # precision, BASELINE configs[4], and the unchanged-reference-step plugin path
+            fused_ms = steady["median_ms_per_step"] if steady else el / a.steps * 1e3
+            trainer.close()
+            del trainer, xs, ys
+            torch.cuda.empty_cache()
+            for name, fn in (("fp32", lambda: side_fp32(a, dev)),
+                             ("ensemble24", lambda: main_ensemble24(argparse.Namespace(**dict(vars(a), steps=20, warmup=5, prime_seconds=0.0, batch=1024, site="fwd0")), emit=False)),
+                             ("module_path", lambda: side_module_path(a, dev, fused_ms))):
+                try:
+                    out[name] = fn()
+                except Exception as e:      # noqa: BLE001 -- a side number must never cost the headline line
+                    out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            trainer = None
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist_on:
-        trainer.close()
+        if trainer is not None:
+            trainer.close()
         torch.distributed.destroy_process_group()
 
 

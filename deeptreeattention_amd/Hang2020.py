@@ -171,6 +171,94 @@ def _check_input(x):
     return x.contiguous()
 
 
+# ----------------------------------------------------------------------------------------------------
+# module-level (plugin) path: cached pointer tables and in-place gradient sinks
+# ----------------------------------------------------------------------------------------------------
+# optim.DtaAdam registers itself here for every parameter it owns (id(param) -> weakref of the optimizer): a backward
+# whose parameters all belong to ONE such optimizer writes its gradients straight into the optimizer's flat gradient
+# buffer (the parameters' .grad are views of it) instead of returning 59 fresh tensors for autograd to copy one by one.
+_GRAD_SINKS = {}
+# year.learned_ensemble registers (weakref of the ensemble, year index) for every parameter of its year models, so that
+# the optimizer can step each year's parameters under that year's device-side "kept" flag (reference year.py:27-28: a
+# skipped year's parameters have grad None and torch's Adam passes over them)
+_PARAM_GATE = {}
+_TABLES = None      # module -> {key: cached ctypes tables}; weakly keyed, nothing is stored on the module itself
+
+
+def _sink_for(plist):
+    """The optimizer (optim.DtaAdam) that owns ALL of `plist` and can take a backward's gradients in place, or None."""
+    if not plist:
+        return None
+    ref = _GRAD_SINKS.get(id(plist[0]))
+    if ref is None:
+        return None
+    for p in plist:
+        if _GRAD_SINKS.get(id(p)) is not ref:
+            return None
+    return ref()
+
+
+def _table_cache(module):
+    global _TABLES
+    if _TABLES is None:
+        import weakref
+        _TABLES = weakref.WeakKeyDictionary()
+    c = _TABLES.get(module)
+    if c is None:
+        c = _TABLES[module] = {}
+    return c
+
+
+def _bn_buffers(owner, cache):
+    """[running_mean, running_var, num_batches_tracked] x 3 layers x sub-networks, re-collected after a load_state_dict."""
+    epoch = owner.__dict__.get("_dta_epoch", 0)
+    hit = cache.get("bufs")
+    if hit is None or hit[0] != epoch:
+        lst = []
+        for kind, mod, names in owner._subnets():
+            for Lv in (1, 2, 3):
+                bn = _get(mod, f"conv{Lv}.bn1")
+                lst += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
+        hit = cache["bufs"] = (epoch, lst)
+    return hit[1]
+
+
+def _param_tables(owner, params, shape, heads_mask):
+    """(desc, nets, workspace bytes) for this call, cached per module and (shape, precision, mode, heads); the raw
+    pointers inside are revalidated against the tensors' current addresses on every call (~10 us)."""
+    L = _lib.lib()
+    cache = _table_cache(owner)
+    bufs = _bn_buffers(owner, cache)
+    fp = tuple(t.data_ptr() for t in params) + tuple(t.data_ptr() for t in bufs)
+    key = (tuple(shape), owner.precision, owner.training, heads_mask)
+    hit = cache.get(key)
+    if hit is None or hit[0] != fp:
+        subnets = owner._subnets()
+        B, bands, H, W = shape
+        desc = _lib.NetDesc(B, bands, H, W, owner._classes, owner._net_code, _lib.dtype_code(owner.precision),
+                            1 if owner.training else 0, heads_mask, BN_MOMENTUM, BN_EPS)
+        nbytes = L.dta_net_workspace_bytes(C.byref(desc))
+        if nbytes == 0:
+            raise RuntimeError("dta_net_workspace_bytes: " + L.dta_last_error().decode())
+        nets = (_lib.SubnetParams * len(subnets))()
+        pos = 1 if owner._net_code == _lib.NET_HANG2020 else 0
+        b = 0
+        for i, (kind, mod, names) in enumerate(subnets):
+            tensors = {n: params[pos + j] for j, n in enumerate(names)}
+            pos += len(names)
+            for Lv in (1, 2, 3):
+                tensors[f"conv{Lv}.bn1.running_mean"] = bufs[b]
+                tensors[f"conv{Lv}.bn1.running_var"] = bufs[b + 1]
+                tensors[f"conv{Lv}.bn1.num_batches_tracked"] = bufs[b + 2]
+                b += 3
+            _fill_struct(nets[i], kind, tensors, False)
+        if len(cache) > 8:
+            for k in [k for k in cache if k != "bufs"][:4]:
+                cache.pop(k)
+        hit = cache[key] = (fp, desc, nets, nbytes)
+    return hit[1], hit[2], hit[3]
+
+
 class _NetFn(torch.autograd.Function):
     """One autograd node for a whole network: forward/backward are single C-ABI calls."""
 
@@ -181,26 +269,10 @@ class _NetFn(torch.autograd.Function):
             raise RuntimeError("deeptreeattention_amd networks do not produce a gradient for their input patches "
                                "(the reference's step never asks for one): pass x.detach()")
         ctx.set_materialize_grads(False)               # unused heads arrive as None, not as zero-filled tensors
-        subnets = owner._subnets()                     # [(kind, module, [relative names])]
-        B, bands, H, W = x.shape
-        desc = _lib.NetDesc(B, bands, H, W, owner._classes, owner._net_code, _lib.dtype_code(owner.precision),
-                            1 if owner.training else 0, heads_mask, BN_MOMENTUM, BN_EPS)
-        nbytes = L.dta_net_workspace_bytes(C.byref(desc))
-        if nbytes == 0:
-            raise RuntimeError("dta_net_workspace_bytes: " + L.dta_last_error().decode())
+        B = x.shape[0]
+        desc, nets, nbytes = _param_tables(owner, params, x.shape, heads_mask)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        nets = (_lib.SubnetParams * len(subnets))()
-        pos = 1 if owner._net_code == _lib.NET_HANG2020 else 0
-        alpha = params[0] if pos else None
-        for i, (kind, mod, names) in enumerate(subnets):
-            tensors = {n: params[pos + j] for j, n in enumerate(names)}
-            pos += len(names)
-            for Lv in (1, 2, 3):
-                bn = _get(mod, f"conv{Lv}.bn1")
-                tensors[f"conv{Lv}.bn1.running_mean"] = bn.running_mean
-                tensors[f"conv{Lv}.bn1.running_var"] = bn.running_var
-                tensors[f"conv{Lv}.bn1.num_batches_tracked"] = bn.num_batches_tracked
-            _fill_struct(nets[i], kind, tensors, False)
+        alpha = params[0] if owner._net_code == _lib.NET_HANG2020 else None
         joint = None
         outs = []
         table = _lib.ScoreTable()
@@ -214,7 +286,7 @@ class _NetFn(torch.autograd.Function):
                     outs.append(t)
         _lib.check(L.dta_net_forward(C.byref(desc), nets, _lib.ptr(alpha), _lib.ptr(x), _lib.ptr(ws), C.byref(table),
                                      _lib.ptr(joint), _lib.current_stream_ptr()), "dta_net_forward")
-        ctx.owner, ctx.desc, ctx.heads_mask = owner, desc, heads_mask
+        ctx.owner, ctx.desc, ctx.nets, ctx.heads_mask = owner, desc, nets, heads_mask
         ctx.save_for_backward(ws, *params)
         if joint is not None:
             return joint
@@ -223,21 +295,16 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         L = _lib.lib()
-        owner, desc = ctx.owner, ctx.desc
+        owner, desc, nets = ctx.owner, ctx.desc, ctx.nets      # (the tables of the forward: same tensors, same addresses)
         ws, *params = ctx.saved_tensors
         subnets = owner._subnets()
-        nets = (_lib.SubnetParams * len(subnets))()
-        gstructs = (_lib.SubnetGrads * len(subnets))()
         hang = owner._net_code == _lib.NET_HANG2020
         pos = 1 if hang else 0
         alpha = params[0] if hang else None
-        grads = [None] * len(params)
-        dalpha = torch.zeros((), dtype=torch.float64, device=ws.device) if hang else None
-        if hang:
-            grads[0] = dalpha
         table = _lib.ScoreTable()
         djoint = None
         used_heads = 0
+        keep = []
         if owner._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA):
             if gouts[0] is None:
                 return (None, None, None) + (None,) * len(params)
@@ -245,7 +312,6 @@ class _NetFn(torch.autograd.Function):
             used_heads = 4
         else:
             k = 0
-            keep = []
             for Lv in range(3):
                 if ctx.heads_mask & (1 << Lv):
                     g = gouts[k]
@@ -255,7 +321,6 @@ class _NetFn(torch.autograd.Function):
                         keep.append(g)
                         table[0][Lv] = g.data_ptr()
                         used_heads |= 1 << Lv
-        # one zero-filled flat buffer for all gradients (the C ABI accumulates split-K partials into them)
         wanted = []
         q = pos
         for kind, mod, names in subnets:
@@ -264,22 +329,43 @@ class _NetFn(torch.autograd.Function):
                 if head is None or (used_heads & (1 << head)):
                     wanted.append(q + j)          # heads unused by the loss keep grad None (as in torch)
             q += len(names)
+        # gradient destinations: the owning optimizer's flat buffer in place (optim.DtaAdam: the parameters' .grad are
+        # views of it and arrive cleared), else one zero-filled flat buffer returned to autograd
+        plist = owner._param_list()
+        sink = _sink_for(plist)
+        cache = _table_cache(owner)
+        if sink is not None and sink.take_inplace([plist[i] for i in wanted] + ([plist[0]] if hang else [])):
+            gkey = ("grads", used_heads, id(sink), sink.layout_epoch)
+            gstructs = cache.get(gkey)
+            if gstructs is None:
+                gstructs = (_lib.SubnetGrads * len(subnets))()
+                wset = set(wanted)
+                for i, (kind, mod, names) in enumerate(subnets):
+                    gt = {n: plist[pos + j].grad for j, n in enumerate(names) if (pos + j) in wset}
+                    pos += len(names)
+                    _fill_struct(gstructs[i], kind, gt, True)
+                for k in [k for k in cache if isinstance(k, tuple) and k and k[0] == "grads"]:
+                    cache.pop(k)
+                cache[gkey] = gstructs
+            dalpha = plist[0].grad if hang else None
+            _lib.check(L.dta_net_backward(C.byref(desc), nets, _lib.ptr(alpha), _lib.ptr(ws), C.byref(table),
+                                          _lib.ptr(djoint), gstructs, _lib.ptr(dalpha), 3, _lib.current_stream_ptr()),
+                       "dta_net_backward")
+            return (None, None, None) + (None,) * len(params)
+        grads = [None] * len(params)
+        dalpha = torch.zeros((), dtype=torch.float64, device=ws.device) if hang else None
+        if hang:
+            grads[0] = dalpha
         flat = torch.zeros(sum(params[i].numel() for i in wanted), dtype=torch.float32, device=ws.device)
         off = 0
         for i in wanted:
             k = params[i].numel()
             grads[i] = flat[off:off + k].view(params[i].shape)
             off += k
+        gstructs = (_lib.SubnetGrads * len(subnets))()
         for i, (kind, mod, names) in enumerate(subnets):
-            tensors = {n: params[pos + j] for j, n in enumerate(names)}
             gt = {n: grads[pos + j] for j, n in enumerate(names) if grads[pos + j] is not None}
             pos += len(names)
-            for Lv in (1, 2, 3):
-                bn = _get(mod, f"conv{Lv}.bn1")
-                tensors[f"conv{Lv}.bn1.running_mean"] = bn.running_mean
-                tensors[f"conv{Lv}.bn1.running_var"] = bn.running_var
-                tensors[f"conv{Lv}.bn1.num_batches_tracked"] = bn.num_batches_tracked
-            _fill_struct(nets[i], kind, tensors, False)
             _fill_struct(gstructs[i], kind, gt, True)
         _lib.check(L.dta_net_backward(C.byref(desc), nets, _lib.ptr(alpha), _lib.ptr(ws), C.byref(table),
                                       _lib.ptr(djoint), gstructs, _lib.ptr(dalpha), 3, _lib.current_stream_ptr()),

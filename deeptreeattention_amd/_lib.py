@@ -147,6 +147,9 @@ def lib():
         L.dta_ensemble_backward_phased.restype = C.c_int
         L.dta_ensemble_backward_phased.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams), C.c_void_p,
                                                    C.c_void_p, C.POINTER(SubnetGrads), C.c_int, C.c_void_p]
+        L.dta_ensemble_backward_gated.restype = C.c_int
+        L.dta_ensemble_backward_gated.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams), C.c_void_p,
+                                                  C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p, C.c_int, C.c_void_p]
         vp = C.c_void_p
         L.dta_conv_module_workspace_bytes.restype = C.c_size_t
         L.dta_conv_module_workspace_bytes.argtypes = [C.POINTER(ConvModuleDesc)]
@@ -197,6 +200,8 @@ def lib():
         L.dta_xchg_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.dta_xchg_selftest_fill.restype = C.c_int
+        L.dta_xchg_selftest_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.dta_xchg_status.restype = C.c_int
         L.dta_xchg_status.argtypes = [C.c_void_p]
         L.dta_xchg_last_timing.restype = C.c_int

@@ -489,7 +489,10 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
 template <typename T>
 int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, void* ws,
                const float* const (*dscores)[3], const float* djoint, const dta_subnet_grads* grads, double* dalpha,
-               int phases, hipStream_t st, const void* x_tiles = nullptr, float* dalpha32 = nullptr) {
+               int phases, hipStream_t st, const void* x_tiles = nullptr, float* dalpha32 = nullptr,
+               const float* gate = nullptr) {
+  // gate (device, per group; year ensembles): gate[g] <= 0 -> group g's score gradient is taken as zero, so every
+  // gradient of that group comes out as an exact zero (its launches still run)
   const int G = p.G, B = p.B;
   if (!(phases & 1)) {
     // phase 2 only: the first layer's weight gradient from tensors phase 1 left in the workspace
@@ -560,6 +563,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       ga.Bm = nets[g].fc_w[L]; ga.sb_k = F; ga.sb_n = 1;
       ga.C = at<float>(ws, p.dfeat[L]) + (size_t)g * fgs; ga.sc_m = F; ga.sc_n = 1;
       ga.M = B; ga.N = F; ga.K = p.classes; ga.ksplit = 1;   // plain stores: dfeat needs no clearing
+      ga.gate = gate ? gate + g : nullptr;
       if (L == 2 && dsc_mode[g]) { ga.sig_alpha = alpha; ga.sig_mode = dsc_mode[g]; }
       dfeat_grp.add(ga);
       if (grads[g].fc_w[L]) {
@@ -570,6 +574,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
         ga.M = p.classes; ga.N = F; ga.K = B;
         ga.ksplit = gemm_auto_ksplit(p.classes, F, B);
         ga.rowsum_out = grads[g].fc_b[L];      // db[n] = sum_b dscore[b][n]
+        ga.gate = gate ? gate + g : nullptr;
         if (L == 2 && dsc_mode[g]) { ga.sig_alpha = alpha; ga.sig_mode = dsc_mode[g]; }
         if (!deferred.add(ga)) { if (launch_gemm_group(deferred, st)) return 1; deferred.n = 0; deferred.add(ga); }
       }
@@ -855,14 +860,20 @@ int dta_ensemble_backward(const dta_net_desc* d, int years, const dta_subnet_par
 
 int dta_ensemble_backward_phased(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
                                  const float* dscore, const dta_subnet_grads* grads, int phases, void* stream) {
+  return dta_ensemble_backward_gated(d, years, nets, workspace, dscore, grads, nullptr, phases, stream);
+}
+
+int dta_ensemble_backward_gated(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
+                                const float* dscore, const dta_subnet_grads* grads, const float* gate, int phases,
+                                void* stream) {
   Plan p; dta_net_desc dd;
   if (!nets || !workspace || !dscore || !grads || !(phases & 3)) { dta_set_error("dta_ensemble_backward: null argument"); return 1; }
   if (ensemble_desc(d, years, &dd, &p, "dta_ensemble_backward")) return 1;
   const float* dsc[MAXG][3] = {};
   for (int g = 0; g < years; ++g) dsc[g][2] = dscore;   // d(mean)/d(year score) is the same 1/years for every year
   hipStream_t st = (hipStream_t)stream;
-  if (dd.dtype == DTA_BF16) return backward_t<bf16_t>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, phases, st);
-  if (dd.dtype == DTA_F32) return backward_t<float>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, phases, st);
+  if (dd.dtype == DTA_BF16) return backward_t<bf16_t>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, phases, st, nullptr, nullptr, gate);
+  if (dd.dtype == DTA_F32) return backward_t<float>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, phases, st, nullptr, nullptr, gate);
   dta_set_error("unknown dtype %d", dd.dtype);
   return 1;
 }

@@ -140,7 +140,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, in
     const double wd = 1.0 / (1.0 + exp(-a.sig_alpha[0]));
     osc = a.sig_mode == 1 ? (float)wd : (float)(1.0 - wd);
   }
-  if (a.rowsum_out && by == 0 && t < 64 && m0 + t < a.M) atomicAdd(a.rowsum_out + m0 + t, rsum * osc);
+  const bool off = a.gate && !(a.gate[0] > 0.f);
+  if (a.rowsum_out && by == 0 && t < 64 && m0 + t < a.M) atomicAdd(a.rowsum_out + m0 + t, off ? 0.f : rsum * osc);
   const int n = n0 + wn + (lane & 31);
   if (n >= a.N) return;
   const float bias = (a.bias && bz == 0) ? a.bias[n] : 0.f;
@@ -149,7 +150,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, in
     int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (m >= a.M) continue;
     float* c = a.C + (size_t)m * a.sc_m + (size_t)n * a.sc_n;
-    float v = acc[r] * osc + bias;
+    float v = off ? 0.f : acc[r] * osc + bias;
     if (a.ksplit > 1) atomicAdd(c, v);
     else if (a.accumulate) *c += v;
     else *c = v;
@@ -261,6 +262,7 @@ __device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by,
     const double wd = 1.0 / (1.0 + exp(-a.sig_alpha[0]));
     osc = a.sig_mode == 1 ? (float)wd : (float)(1.0 - wd);
   }
+  const bool off = a.gate && !(a.gate[0] > 0.f);
   // partial tiles -> LDS ([wave][32][33]), then all 256 threads sum the four and store rows of 32 consecutive columns
   float* P = smem + wave * WT_REGION;
 #pragma unroll
@@ -271,7 +273,7 @@ __device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by,
     float rs = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) rs += smem[w * WT_REGION + 32 * 33 + t];
-    atomicAdd(a.rowsum_out + m0 + t, rs * osc);
+    atomicAdd(a.rowsum_out + m0 + t, off ? 0.f : rs * osc);
   }
   const int n = n0 + (t & 31);
 #pragma unroll
@@ -281,7 +283,7 @@ __device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by,
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += smem[w * WT_REGION + ml * 33 + (t & 31)];
-    v = v * osc + ((a.bias && bz == 0) ? a.bias[n] : 0.f);
+    v = off ? 0.f : v * osc + ((a.bias && bz == 0) ? a.bias[n] : 0.f);
     float* c = a.C + (size_t)m * a.sc_m + (size_t)n * a.sc_n;
     if (ks > 1) atomicAdd(c, v);
     else if (a.accumulate) *c += v;
@@ -640,11 +642,15 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
       const float old = __hip_atomic_exchange(a.rowtmp + row, ok ? wy * (lse + mx - zval((int)y)) : poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("" ::"v"(old));
     }
-    const float sc2 = (den > 0.f ? wy / den : 0.f) * (a.gscale_dev ? a.gscale_dev[0] : a.gscale) + poison;
+    // device-decided factor (1 / kept years): an infinite one says this rank kept NO year -- its scores are NaN (an empty
+    // mean, as the reference raises there) and it must contribute nothing to a data-parallel gradient sum: exact zeros
+    const float gs = a.gscale_dev ? a.gscale_dev[0] : a.gscale;
+    const bool none_kept = a.gscale_dev && !(gs < 3.0e38f);
+    const float sc2 = (den > 0.f ? wy / den : 0.f) * gs + poison;
     for (int n = lane, k = 0; n < a.classes; n += 64, ++k) {
       const float z = zget(n, k);
       if (jo && jo != zs) jo[n] = z;
-      if (a.dlogits) a.dlogits[(size_t)row * a.classes + n] = sc2 * (__expf(z - mx - lse) - ((ok && n == (int)y) ? 1.f : 0.f));
+      if (a.dlogits) a.dlogits[(size_t)row * a.classes + n] = none_kept ? 0.f : sc2 * (__expf(z - mx - lse) - ((ok && n == (int)y) ? 1.f : 0.f));
     }
   }
   // the last block to arrive sums the row terms (fixed order) into the loss.  No fence: a device-scope release would

@@ -242,6 +242,9 @@ struct GemmArgs {
   // Hang2020 blend folded into the GEMM: results (and row sums) are multiplied by sigmoid(alpha) (mode 1) or
   // 1 - sigmoid(alpha) (mode 2) -- d(joint)/d(branch score) -- so the branch gradients are never materialised
   const double* sig_alpha; int sig_mode;
+  // year ensembles with the missing-year decision on the device: gate[0] <= 0 -> every output of this GEMM (and its row
+  // sums) is an exact zero, whatever the operands hold (selected, not multiplied: a skipped year's operands may be NaN)
+  const float* gate;
 };
 constexpr int GEMM_GROUP_MAX = 12;
 struct GemmGroup {

@@ -19,8 +19,11 @@
 //      full optimizer state, as under DDP); the gradient elements are cleared (or replaced by the sum: keep_grads).
 //      done[s][j] also says that rank s has finished reading this rank's gradients of that slice, so clearing is safe.
 // Only flags are ever written remotely, and only into uncached memory; bulk data is pulled with system-scope loads
-// (remote lines are never served from a stale local L2 line).  Every wait is bounded (wall clock): a missing peer ends
-// the kernel with a status word in pinned host memory instead of hanging the GPU.
+// (remote lines are never served from a stale local L2 line).  Every wait is bounded (wall clock, default 30 min like a
+// collective library's watchdog): a missing peer ends the kernel with a status word in pinned host memory instead of
+// hanging the GPU, and the abort is STICKY -- every later launch of this exchange returns at once without touching
+// parameters, moments or gradients, so a replica never trains on past a failed exchange; the trainers read the status
+// word (a pinned host word, no synchronisation) at the start of every step and raise.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,7 +40,8 @@ constexpr int XCHG_THREADS = 256;
 
 struct XchgSig {
   unsigned ready[16];                               // ready[s]: rank s's gradients of this epoch are complete
-  unsigned pad[48];
+  unsigned aborted;                                 // sticky: a wait of an earlier launch of THIS rank timed out -- later launches return at once
+  unsigned pad[47];
   unsigned done[XCHG_MAX_WORLD][XCHG_MAX_WGS];      // done[s][j]: workgroup j of rank s has published its sums
 };
 static_assert(sizeof(XchgSig) <= XCHG_SIG_BYTES, "signal page overflow");
@@ -93,7 +97,9 @@ __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
   __shared__ int s_abort;
   const int t = threadIdx.x, j = blockIdx.x;
   XchgSig* mine = (XchgSig*)a.sig[a.rank];
-  if (t == 0) s_abort = 0;
+  if (t == 0) s_abort = (a.world > 1 && ld_sys32(&mine->aborted) != 0) ? 1 : 0;     // (one rank: nothing ever waits)
+  __syncthreads();
+  if (s_abort) return;                       // an earlier step of this rank timed out: nothing may be applied any more
   const long long tk0 = wall_clock64();
   // alpha's float64 gradient enters the exchange as one float32 slot of the gradient buffer: converted here, once, from
   // the (order-independently accumulated) double, so the slot does not depend on the order of any float atomics
@@ -107,6 +113,7 @@ __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
   if (t < a.world && !wait_flag(&mine->ready[t], a.epoch, a.timeout_ticks)) {
     s_abort = 1;
     a.status[0] = (1 << 8) | t;
+    st_sys32(&mine->aborted, 1u);
   }
   __syncthreads();
   if (s_abort) return;
@@ -147,6 +154,7 @@ __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
   if (a.world > 1 && t < a.world && !wait_flag(&mine->done[t][j], a.epoch, a.timeout_ticks)) {
     s_abort = 1;
     a.status[0] = (2 << 8) | t;
+    st_sys32(&mine->aborted, 1u);
   }
   __syncthreads();
   if (s_abort) return;
@@ -202,6 +210,14 @@ __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
   if (j == 0 && t == 0) { a.status[2] = (int)(tk1 - tk0); a.status[3] = (int)(wall_clock64() - tk1); }
 }
 
+// probe pattern (peer_probe.py computes the same numbers with numpy): exact in float32
+__global__ void k_xchg_selftest_fill(float* g, size_t n, int rank, int step) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const long long v = ((long long)i * 2654435761ll + (long long)rank * 40503ll + (long long)step * 9973ll) % 2001ll - 1000ll;
+    g[i] = (float)v / 1024.0f;
+  }
+}
+
 }  // namespace dta
 
 using namespace dta;
@@ -235,7 +251,7 @@ int dta_xchg_create(int rank, int world, size_t n_floats, dta_xchg** out) {
   x->n_pad = (n_floats + 3) & ~(size_t)3;
   x->shard = (((x->n_pad + world - 1) / world) + 3) & ~(size_t)3;
   x->sig_bytes = XCHG_SIG_BYTES + x->shard * sizeof(float);
-  x->timeout_s = 5.0;
+  x->timeout_s = 1800.0;    // like a collective library's watchdog: rank skew of seconds (validation or a checkpoint on one rank) is routine
   x->max_wgs = 256;
   const char* why = nullptr;
   hipError_t e = hipGetDevice(&x->device);
@@ -312,6 +328,13 @@ static int xchg_launch(dta_xchg* x, XchgArgs& a, void* stream) {
   if (wgs < 1) wgs = 1;
   hipLaunchKernelGGL(k_xchg_step, dim3((unsigned)wgs), dim3(XCHG_THREADS), 0, (hipStream_t)stream, a);
   DTA_CHECK_LAUNCH("k_xchg_step");
+  return 0;
+}
+
+int dta_xchg_selftest_fill(dta_xchg* x, int step, void* stream) {
+  if (!x) { dta_set_error("dta_xchg_selftest_fill: null exchange"); return 1; }
+  hipLaunchKernelGGL(k_xchg_selftest_fill, dim3(64), dim3(256), 0, (hipStream_t)stream, x->grads, x->n_pad, x->rank, step);
+  DTA_CHECK_LAUNCH("k_xchg_selftest_fill");
   return 0;
 }
 

@@ -41,11 +41,14 @@ class GradSync:
     (dta_net_backward_dp / dta_adam_step_dp), so nothing runs around the collective; callers without those kernels pass
     (alpha_grad, alpha_slot) and get the two copies done here."""
 
-    def __init__(self, world, group=None, side_stream=None, rccl=None):
+    def __init__(self, world, group=None, side_stream=None, rccl=None, skip_allreduce=False):
         """rccl: a RcclDirect -> every reduction is one ncclAllReduce enqueued on the compute stream itself (nothing to
-        wait for afterwards); None -> torch.distributed work objects on the backend's stream."""
+        wait for afterwards); None -> torch.distributed work objects on the backend's stream.
+        skip_allreduce: development measurement switch (the phase split without the collectives: replicas DIVERGE); an
+        explicit constructor argument of the trainers (`_dev_skip_allreduce=True`), never read from the environment."""
         self.world, self.group = int(world), group
         self.rccl = rccl
+        self.skip_allreduce = bool(skip_allreduce)
         self.grad_scale = 1.0 / self.world
         self.collectives = 0          # all-reduces issued so far (tests: <= 2 per step)
         self._pending, self._post = [], []
@@ -53,11 +56,11 @@ class GradSync:
     _warned_skip = False
 
     def _ar(self, t):
-        if os.environ.get("DTA_SKIP_ALLREDUCE") == "1":      # development: the phase split without the collectives
+        if self.skip_allreduce:      # development: the phase split without the collectives
             if not GradSync._warned_skip:
                 import warnings
-                warnings.warn("DTA_SKIP_ALLREDUCE=1: gradient all-reduces are being DROPPED (replicas diverge); "
-                              "development measurement switch, never set it in a training job")
+                warnings.warn("skip_allreduce=True: gradient all-reduces are being DROPPED (replicas diverge); "
+                              "development measurement switch, never use it in a training job")
                 GradSync._warned_skip = True
             return
         if self.rccl is not None:
@@ -95,11 +98,32 @@ class GradSync:
             dist.broadcast(t, src, group=self.group)
 
 
+class _XchgHandle:
+    """Owner of one dta_xchg object: destroyed (peer mappings closed, device / uncached / pinned memory freed) when the
+    last reference goes -- PeerExchange.close() after its barrier, or garbage collection of a trainer that was dropped
+    without close() (local teardown only, no collective: the peers' own mappings of this rank's memory stay valid until
+    they close them, HIP IPC memory is reference-counted by the driver)."""
+
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    def destroy(self):
+        if self.h is not None:
+            self.L.dta_xchg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 class _DeviceBlock:
     """A device allocation owned by the library, shown to torch through __cuda_array_interface__ (zero copy)."""
 
     def __init__(self, ptr, n, owner):
-        self._owner = owner            # keeps the exchange object alive as long as a tensor view exists
+        self._owner = owner            # the _XchgHandle: the allocation lives as long as a tensor view of it exists
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
 
 
@@ -127,6 +151,7 @@ class PeerExchange:
         h = C.c_void_p()
         _lib.check(L.dta_xchg_create(self.rank, self.world, int(n_floats), C.byref(h)), "dta_xchg_create")
         self._h = h
+        self._owner = _XchgHandle(L, h)      # (no reference back to this object: dropping the trainer frees everything)
         if timeout_s:
             L.dta_xchg_set_timeout(h, float(timeout_s))
         if max_workgroups:
@@ -140,7 +165,7 @@ class PeerExchange:
             blob = C.create_string_buffer(b"".join(gathered), _lib.XCHG_HANDLE_BYTES * self.world)
             _lib.check(L.dta_xchg_connect(h, blob), "dta_xchg_connect")
             dist.barrier(group=group)            # every rank has mapped every peer before the first step
-        self.grad = torch.as_tensor(_DeviceBlock(L.dta_xchg_grad_buffer(h), self.capacity, self), device="cuda")
+        self.grad = torch.as_tensor(_DeviceBlock(L.dta_xchg_grad_buffer(h), self.capacity, self._owner), device="cuda")
         assert self.grad.data_ptr() == L.dta_xchg_grad_buffer(h), "torch copied the exchange buffer instead of wrapping it"
         self.grad_scale = 1.0 / self.world
         self.steps = 0
@@ -162,18 +187,23 @@ class PeerExchange:
         self.steps += 1
 
     def check(self):
-        """Raise if a step timed out waiting for a peer (call after a stream synchronisation)."""
-        if self._L.dta_xchg_status(self._h) != 0:
+        """Raise if an exchange launch timed out waiting for a peer.  A read of a pinned host word (no synchronisation):
+        a launch that timed out has written it when it ends, and from then on every launch of this exchange returns at
+        once without applying anything (sticky abort, csrc/xchg.hip) -- the trainers call this at the start of every
+        step, so a replica stops within the steps that were already enqueued instead of training on alone."""
+        if self._h is not None and self._L.dta_xchg_status(self._h) != 0:
             raise RuntimeError(self._L.dta_last_error().decode())
 
     def close(self):
-        """Collective: every rank stops using its peers' memory before anybody frees it."""
+        """Collective, MANDATORY for an orderly shutdown: every rank stops using its peers' memory (barrier) before
+        anybody frees it.  Every rank must call it (the barrier deadlocks otherwise).  A trainer that is simply dropped
+        still frees its own allocations and mappings when it is collected (_XchgHandle), without the barrier."""
         if self._h is not None:
             torch.cuda.synchronize()
             if self.world > 1 and dist.is_initialized():
                 dist.barrier(group=self.group)
             self.grad = None
-            self._L.dta_xchg_destroy(self._h)
+            self._owner.destroy()
             self._h = None
 
 

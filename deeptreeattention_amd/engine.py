@@ -44,7 +44,8 @@ class FusedTrainer:
 
     def __init__(self, model, lr, loss_weight=None, betas=(0.9, 0.999), eps=1e-8, process_group=None,
                  overlap_comm=True, keep_grads=False, last_head_only=False, three_head_loss=False,
-                 extra_grad_slots=0, storage=None, exchange=None, exchange_opts=None, broadcast_buffers=False):
+                 extra_grad_slots=0, storage=None, exchange=None, exchange_opts=None, broadcast_buffers=False,
+                 _dev_skip_allreduce=False):
         """three_head_loss: train on the SUM of the class-weighted cross-entropies of every classifier head (the Hang
         et al. recipe BASELINE.json's north_star words as "three-head weighted cross-entropy"): three heads for a
         spectral / spatial network, all six for Hang2020 (whose sigmoid(alpha) blend is then not on the graph, so
@@ -166,7 +167,8 @@ class FusedTrainer:
         self._desc_cache, self._ws_cache = {}, {}      # the last two (shape, mode) keys: descriptors / device buffers
         self.broadcast_buffers = bool(broadcast_buffers)
         self._reduced = False          # peer exchange: the gradient buffer already holds the sum (reduce_now)
-        self.sync = GradSync(self.world, self.pg, rccl=RcclDirect(self.pg) if self.exchange == "rccl" else None)
+        self.sync = GradSync(self.world, self.pg, rccl=RcclDirect(self.pg) if self.exchange == "rccl" else None,
+                             skip_allreduce=_dev_skip_allreduce)
         if self.comm and storage is None:
             self.broadcast_parameters()
 
@@ -208,7 +210,9 @@ class FusedTrainer:
         self._reduced = True
 
     def check_exchange(self):
-        """Raise if a peer-exchange step timed out (call after synchronising the stream; free otherwise)."""
+        """Raise if a peer-exchange launch timed out waiting for a rank (a pinned host word: no synchronisation; train_step
+        calls it first thing, so a failed exchange is fatal within the steps already enqueued -- the launches after the
+        failure return without applying anything)."""
         if self.ex is not None:
             self.ex.check()
 
@@ -486,6 +490,8 @@ class FusedTrainer:
             raise RuntimeError("train_step supports Hang2020 / vanilla_CNN (single score), any network with "
                                "three_head_loss=True, or a spectral/spatial network with last_head_only=True; a year "
                                "ensemble of spectral networks trains through EnsembleTrainer")
+        if self.ex is not None:
+            self.ex.check()                # a timed-out exchange is fatal (its later launches apply nothing)
         y = self._labels(y)
         if self.broadcast_buffers and self.world > 1:
             self.sync_buffers()            # DDP's per-forward buffer broadcast from rank 0
@@ -730,14 +736,17 @@ class EnsembleTrainer:
         self._live = xs
         return list(range(Y))
 
-    def _backward(self, kept, phases=3):
+    def _backward(self, kept, phases=3, gate=None):
+        """gate (device, float[len(kept)]): this rank's year flags of a device-decided step -- a year whose flag is 0 gets
+        EXACT-ZERO gradients (reference year.py:27-28: a skipped year has no gradient), so a data-parallel rank whose
+        batch lacks a year that another rank kept contributes nothing to that year's gradient sum."""
         L = _lib.lib()
         if phases & 1:
             for i in kept:
                 self.years[i]._zero_grads()      # C-ABI contract: gradient buffers arrive zero-filled
-        _lib.check(L.dta_ensemble_backward_phased(C.byref(self._desc), len(kept), self._nets, _lib.ptr(self._ws),
-                                                  _lib.ptr(self.dscores), self._grads, phases,
-                                                  _lib.current_stream_ptr()), "dta_ensemble_backward")
+        _lib.check(L.dta_ensemble_backward_gated(C.byref(self._desc), len(kept), self._nets, _lib.ptr(self._ws),
+                                                 _lib.ptr(self.dscores), self._grads, _lib.ptr(gate), phases,
+                                                 _lib.current_stream_ptr()), "dta_ensemble_backward")
         for i in kept:
             self.years[i]._grads_clear = False
 
@@ -790,7 +799,9 @@ class EnsembleTrainer:
         not stepped -- and the call returns without any host synchronisation.  (No year present: the loss is NaN; the
         reference raises.)  present=[...]: the caller knows (the reference's loader zero-fills missing years on the host):
         only the kept years are launched at all."""
+        self.check_exchange()
         y = self.years[0]._labels(y)
+        gate = None
         if present is None:
             self._counters_to("device")
             kept = self._forward_gated(images)
@@ -799,7 +810,7 @@ class EnsembleTrainer:
                 self._backward(kept)
                 self._adam_gated(self.local_flags)
                 return self.loss
-            local_flags = self.local_flags
+            local_flags = gate = self.local_flags      # all years are launched: the flags zero the missing ones' gradients
         else:
             local = self._kept(images, present)
             kept = self._forward(images, local)
@@ -814,22 +825,27 @@ class EnsembleTrainer:
             local_flags = self._flag_table[sum(1 << i for i, k in enumerate(local) if k)]
         # data-parallel: every rank issues the same collectives whatever it kept; skipped years send their zeros
         if self.ex is not None:
-            self._backward(kept, 3)
+            self._backward(kept, 3, gate)
             self.flags.copy_(local_flags)
             self.ex.allreduce()                 # gradients and year flags summed over the ranks in one launch
         elif self.overlap:
-            self._backward(kept, 1)
+            self._backward(kept, 1, gate)
             self.flags.copy_(local_flags)
             self.sync.reduce_early(self.g_head)
-            self._backward(kept, 2)
+            self._backward(kept, 2, gate)
             self.sync.reduce_late(self.g_tail)
         else:
-            self._backward(kept, 3)
+            self._backward(kept, 3, gate)
             self.flags.copy_(local_flags)
             self.sync.reduce_all(self.flat[1])
         self.sync.finish()
         self._adam_gated()
         return self.loss
+
+    def check_exchange(self):
+        """Raise if a peer-exchange launch timed out waiting for a rank (see FusedTrainer.check_exchange)."""
+        if self.ex is not None:
+            self.ex.check()
 
     def close(self):
         """Collective: release the peer exchange / RCCL communicator (every rank calls it)."""

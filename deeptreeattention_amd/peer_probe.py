@@ -4,8 +4,9 @@ trainer trusts the exchange on an unknown node:
     python deeptreeattention_amd/peer_probe.py <rendezvous dir> <rank> <world> <device ordinal>
 
 The ranks' probes find each other through files in the rendezvous directory (IPC handles, two barriers), map each
-other's buffers, run three all-reduces over 256 Ki floats with known contents and compare the result bit for bit with
-the sum in rank order.  Exit code 0 = the exchange works between these devices.  A GPU memory fault, a missing peer
+other's buffers, run three all-reduces over 256 Ki floats with known contents (written by a kernel on the exchange's own
+stream immediately before it, as a train step's gradients are) and compare the result bit for bit with the sum in rank
+order.  Exit code 0 = the exchange works between these devices.  A GPU memory fault, a missing peer
 mapping or a wrong sum ends only the probe process; the parent (dist.probe_peer_exchange) then falls back to RCCL.
 No torch import here: ctypes on libdta_hip.so and libamdhip64.so only, so a probe starts in well under a second."""
 import ctypes as C
@@ -63,11 +64,11 @@ def main(d, rank, world, device, budget_s=60.0):
     out = np.empty(N, np.float32)
     ok = True
     for step in range(3):
-        src = _pattern(rank, step, N)
-        if hip.hipMemcpy(g, src.ctypes.data, 4 * N, 1) != 0:
-            raise RuntimeError("hipMemcpy H2D failed")
-        hip.hipDeviceSynchronize()
-        _lib.check(L.dta_xchg_allreduce(h, None), "dta_xchg_allreduce")
+        # the buffer is written BY A KERNEL on the exchange's own stream and the exchange follows it with no host
+        # synchronisation in between: exactly the train step's situation (csrc/xchg.hip relies on the kernel-boundary
+        # write-back making the gradients visible to the peers' system-scope loads)
+        _lib.check(L.dta_xchg_selftest_fill(h, step, None), "dta_xchg_selftest_fill")
+        _lib.check(L.dta_xchg_allreduce(h, None, -1, None), "dta_xchg_allreduce")
         if hip.hipDeviceSynchronize() != 0:
             raise RuntimeError("exchange kernel failed")
         if L.dta_xchg_status(h) != 0:

@@ -76,6 +76,77 @@ class _EnsembleFn(torch.autograd.Function):
         return (None, None) + (None,) * n + tuple(grads)
 
 
+class _EnsembleGatedFn(torch.autograd.Function):
+    """All years as the groups of one set of launches with the missing-year decision (reference year.py:27) taken ON THE
+    DEVICE: dta_year_flags -> dta_ensemble_forward_gated -> (backward) dta_ensemble_backward_gated.  No host round trip.
+    A flagged-off year is left out of the mean, keeps its BatchNorm statistics and gets exact-zero gradients; the owning
+    optim.DtaAdam steps each year under the same flag (a skipped year's parameters are passed over, as torch's Adam
+    passes over grad None)."""
+
+    @staticmethod
+    def forward(ctx, owner, flags, clear_next, *args):
+        L = _lib.lib()
+        n = len(owner.year_models)
+        xs, params = args[:n], args[n:]
+        if any(x.requires_grad for x in xs):
+            raise RuntimeError("the year ensemble does not produce a gradient for its input crops: pass detached tensors")
+        ctx.set_materialize_grads(False)
+        B = xs[0].shape[0]
+        desc, nets, nbytes = owner._tables(xs[0].shape, params)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xs[0].device)
+        xptr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        out = torch.empty(B, owner.year_models[0]._classes, dtype=torch.float32, device=xs[0].device)
+        kept = torch.empty(2, dtype=torch.float32, device=xs[0].device)      # {years kept, 1 / years kept}
+        st = _lib.current_stream_ptr()
+        _lib.check(L.dta_year_flags(xptr, n, xs[0].numel(), _lib.ptr(flags), _lib.ptr(clear_next), st), "dta_year_flags")
+        _lib.check(L.dta_ensemble_forward_gated(C.byref(desc), n, nets, xptr, _lib.ptr(flags), _lib.ptr(ws), _lib.ptr(out),
+                                                _lib.ptr(kept), st), "dta_ensemble_forward_gated")
+        ctx.owner, ctx.desc, ctx.nets, ctx.n, ctx.flags, ctx.kept = owner, desc, nets, n, flags, kept
+        ctx.save_for_backward(ws, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        ws, *params = ctx.saved_tensors
+        owner, n = ctx.owner, ctx.n
+        if gout is None:
+            return (None, None, None) + (None,) * n + (None,) * len(params)
+        names = Hang2020._subnet_param_names("spectral")
+        dscore = gout.contiguous().float() * ctx.kept[1]        # d(mean over kept years)/d(one year's scores), on the device
+        wanted = [i for i in range(len(params)) if "classifier1" not in names[i % len(names)]
+                  and "classifier2" not in names[i % len(names)]]  # heads 1-2 never reach the loss: grad None
+        plist = [p for m in owner.year_models for p in m._param_list()]
+        sink = Hang2020._sink_for(plist)
+        if sink is not None and sink.take_inplace([plist[i] for i in wanted]):
+            cache = Hang2020._table_cache(owner)
+            gkey = ("grads", id(sink), sink.layout_epoch)
+            gstructs = cache.get(gkey)
+            if gstructs is None:
+                gstructs = (_lib.SubnetGrads * n)()
+                wset = set(wanted)
+                for k in range(n):
+                    gt = {nm: plist[k * len(names) + j].grad for j, nm in enumerate(names) if (k * len(names) + j) in wset}
+                    Hang2020._fill_struct(gstructs[k], "spectral", gt, True)
+                cache[gkey] = gstructs
+            _lib.check(L.dta_ensemble_backward_gated(C.byref(ctx.desc), n, ctx.nets, _lib.ptr(ws), _lib.ptr(dscore), gstructs,
+                                                     _lib.ptr(ctx.flags), 3, _lib.current_stream_ptr()), "dta_ensemble_backward")
+            return (None, None, None) + (None,) * n + (None,) * len(params)
+        flat = torch.zeros(sum(params[i].numel() for i in wanted), dtype=torch.float32, device=ws.device)
+        grads, off = [None] * len(params), 0
+        for i in wanted:
+            k = params[i].numel()
+            grads[i] = flat[off:off + k].view(params[i].shape)
+            off += k
+        gstructs = (_lib.SubnetGrads * n)()
+        for k in range(n):
+            gt = {nm: grads[k * len(names) + j] for j, nm in enumerate(names) if grads[k * len(names) + j] is not None}
+            Hang2020._fill_struct(gstructs[k], "spectral", gt, True)
+        _lib.check(L.dta_ensemble_backward_gated(C.byref(ctx.desc), n, ctx.nets, _lib.ptr(ws), _lib.ptr(dscore), gstructs,
+                                                 _lib.ptr(ctx.flags), 3, _lib.current_stream_ptr()), "dta_ensemble_backward")
+        return (None, None, None) + (None,) * n + tuple(grads)
+
+
 class learned_ensemble(nn.Module):
     def __init__(self, years, classes, config):
         super().__init__()
@@ -88,10 +159,79 @@ class learned_ensemble(nn.Module):
             else:
                 base_model = Hang2020.spectral_network(bands=config["bands"], classes=classes)
             self.year_models.append(base_model)
+        # an optimizer built from .parameters() (optim.DtaAdam) finds each year's parameters through this registry and
+        # steps them under that year's device-side "kept" flag
+        import weakref
+        me = weakref.ref(self)
+        for y, m in enumerate(self.year_models):
+            for p in m.parameters():
+                Hang2020._PARAM_GATE[id(p)] = (me, y)
+        self.__dict__["local_flags"] = None      # (Y,) float32 on the device: years kept by the last TRAINING forward
+        self.__dict__["_flag_state"] = None
+
+    def _tables(self, shape, params):
+        """Cached (descriptor, parameter pointer tables, workspace bytes) of the grouped launch over ALL years."""
+        L = _lib.lib()
+        mods = list(self.year_models)
+        cache = Hang2020._table_cache(self)
+        bufs = [b for m in mods for b in Hang2020._bn_buffers(m, Hang2020._table_cache(m))]
+        fp = tuple(t.data_ptr() for t in params) + tuple(t.data_ptr() for t in bufs)
+        m0 = mods[0]
+        key = (tuple(shape), m0.precision, m0.training)
+        hit = cache.get(key)
+        if hit is None or hit[0] != fp:
+            n = len(mods)
+            names = Hang2020._subnet_param_names("spectral")
+            B, bands, H, W = shape
+            desc = _lib.NetDesc(B, bands, H, W, m0._classes, _lib.NET_SPECTRAL, _lib.dtype_code(m0.precision),
+                                1 if m0.training else 0, 4, Hang2020.BN_MOMENTUM, Hang2020.BN_EPS)
+            nbytes = L.dta_ensemble_workspace_bytes(C.byref(desc), n)
+            if nbytes == 0:
+                raise RuntimeError("dta_ensemble_workspace_bytes: " + L.dta_last_error().decode())
+            nets = (_lib.SubnetParams * n)()
+            for k in range(n):
+                tensors = {nm: params[k * len(names) + j] for j, nm in enumerate(names)}
+                for Lv in (1, 2, 3):
+                    tensors[f"conv{Lv}.bn1.running_mean"] = bufs[9 * k + 3 * (Lv - 1)]
+                    tensors[f"conv{Lv}.bn1.running_var"] = bufs[9 * k + 3 * (Lv - 1) + 1]
+                    tensors[f"conv{Lv}.bn1.num_batches_tracked"] = bufs[9 * k + 3 * (Lv - 1) + 2]
+                Hang2020._fill_struct(nets[k], "spectral", tensors, False)
+            if len(cache) > 8:
+                for k in [k for k in cache if k != "bufs"][:4]:
+                    cache.pop(k)
+            hit = cache[key] = (fp, desc, nets, nbytes)
+        return hit[1], hit[2], hit[3]
+
+    def _next_flags(self, dev, publish):
+        """Two flag banks used alternately (each dta_year_flags call clears the other one: no clearing launch).  A
+        training forward publishes its bank as self.local_flags -- what the optimizer gates this step's updates by."""
+        fs = self.__dict__["_flag_state"]
+        Y = len(self.year_models)
+        if fs is None or fs[0].device != dev:
+            fs = self.__dict__["_flag_state"] = [torch.zeros(2, Y, dtype=torch.float32, device=dev), 0]
+        fs[1] ^= 1
+        flags, other = fs[0][fs[1]], fs[0][fs[1] ^ 1]
+        if publish:
+            self.__dict__["local_flags"] = flags
+        return flags, other
 
     def forward(self, images):
-        # same test as the reference (year.py:27: a year is skipped iff its whole batch tensor sums to zero), but all
-        # years' sums travel to the host in ONE transfer instead of one blocking comparison per year
+        if len(images) != len(self.year_models):
+            raise ValueError("expected one image tensor per year ({}), got {}".format(len(self.year_models), len(images)))
+        params = [p for m in self.year_models for p in m._param_list()]
+        train_graph = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        gated = len(self.year_models) <= _lib.MAX_YEARS and (not train_graph or Hang2020._sink_for(params) is not None)
+        if gated:
+            # missing years decided on the device (no host round trip): inference / validation always; training when
+            # the parameters belong to an optim.DtaAdam, which steps each year under the same device-side flag
+            xs = [Hang2020._check_input(x) for x in images]
+            if any(x.shape != xs[0].shape for x in xs):
+                raise ValueError("all years of a batch must have the same shape")
+            flags, other = self._next_flags(xs[0].device, publish=train_graph and self.training)
+            return _EnsembleGatedFn.apply(self, flags, other, *xs, *params)
+        # stock torch optimizers: same test as the reference (year.py:27: a year is skipped iff its whole batch tensor
+        # sums to zero) with all years' sums travelling to the host in ONE transfer, so that a skipped year's parameters
+        # really have grad None (torch's Adam passes over them)
         keep = (torch.stack([x.sum() for x in images]) != 0).tolist()
         kept = [i for i, k in enumerate(keep) if k]
         if not kept:

@@ -165,6 +165,13 @@ int dta_ensemble_backward(const dta_net_desc* d, int years, const dta_subnet_par
  * bit 1: those), so that a data-parallel caller can overlap the first gradient exchange with them. */
 int dta_ensemble_backward_phased(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
                                  const float* dscore, const dta_subnet_grads* grads, int phases, void* stream);
+/* Backward of dta_ensemble_forward_gated: gate (device, float[years], the flags the forward was gated by; NULL = all on)
+ * <= 0 makes that year's gradients EXACT ZEROS (its score gradient is taken as zero whatever dscore holds; its launches
+ * still run), as a year the reference skips has grad None (year.py:27-28).  A data-parallel rank whose batch lacks a year
+ * that another rank kept thus contributes zeros to that year's gradient sum. */
+int dta_ensemble_backward_gated(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
+                                const float* dscore, const dta_subnet_grads* grads, const float* gate, int phases,
+                                void* stream);
 
 /* ---- Crop preprocessing on the device: replaces load_image / preprocess_image (src/utils.py:36-79: drop the first and
  * last `clip` bands when there are more than 3, float32, per-pixel min-max over the bands as
@@ -264,7 +271,10 @@ float* dta_xchg_grad_buffer(dta_xchg* x);          /* device pointer, dta_xchg_g
 size_t dta_xchg_grad_capacity(dta_xchg* x);        /* n_floats rounded up to a multiple of 4 */
 int dta_xchg_export(dta_xchg* x, void* handles);
 int dta_xchg_connect(dta_xchg* x, const void* all_handles);
-void dta_xchg_set_timeout(dta_xchg* x, double seconds);   /* bound of every in-kernel wait (default 5 s) */
+/* Bound of every in-kernel wait (default 1800 s, a collective library's watchdog scale: rank skew of seconds is routine).
+ * A wait that expires is FATAL for the exchange: the launch writes the status word and returns without applying anything,
+ * and every later launch of this exchange returns at once (sticky), so a replica cannot train on past a failed exchange. */
+void dta_xchg_set_timeout(dta_xchg* x, double seconds);
 /* Grid bound of the exchange launch (default 256, one workgroup per CU); only before the first step.  Ranks that share
  * one GPU (tests) must keep world x workgroups co-resident: every rank's launch waits in-kernel for the others. */
 void dta_xchg_set_max_workgroups(dta_xchg* x, int workgroups);
@@ -279,8 +289,13 @@ int dta_xchg_allreduce(dta_xchg* x, const double* alpha_g, long long alpha_slot,
 int dta_xchg_adam_step(dta_xchg* x, float* p, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,
                        long long alpha_slot, double* alpha_m, double* alpha_v, int step, float lr, float beta1, float beta2,
                        float eps, float grad_scale, int zero_grad, void* stream);
+/* Self-test aid (peer_probe.py): fill the gradient buffer with a known pattern of (rank, step) BY A KERNEL on `stream`, so
+ * that an exchange enqueued right behind it tests exactly what a train step relies on -- gradients written by the kernel
+ * before the exchange on the same stream are visible to the peers' system-scope loads (kernel-boundary write-back). */
+int dta_xchg_selftest_fill(dta_xchg* x, int step, void* stream);
 /* 0 = every step so far completed; otherwise (phase << 8 | rank waited for) of the first timed-out wait (host-side read of
- * a pinned word: meaningful once the stream has been synchronised). */
+ * a pinned word, no synchronisation: a launch that timed out has written it by the time it ends; trainers poll it at the
+ * start of every step). */
 int dta_xchg_status(dta_xchg* x);
 /* Development aid: how long workgroup 0 of the LAST exchange launch waited for the ranks to arrive and how long the
  * exchange proper took afterwards, in microseconds (pinned host words: synchronise the stream first). */

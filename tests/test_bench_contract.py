@@ -43,7 +43,7 @@ def test_committed_bench_artifact_has_the_contract_schema(name):
 @pytest.mark.gpu
 def test_bench_prints_one_conforming_json_line():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "2", "--site-stride", "2",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=240, cwd=REPO)
+                          "--no-cpu-baseline", "--no-side"], capture_output=True, text=True, timeout=240, cwd=REPO)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1
@@ -70,7 +70,8 @@ def test_bench_two_ranks_print_one_json_line():
     for flags, ncoll in (([], 2), (["--no-overlap"], 1)):
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
-                              "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--steady-steps", "0"]
+                              "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--steady-steps", "0",
+                              "--exchange", "torch"]
                              + flags, capture_output=True, text=True, timeout=420, cwd=REPO, env=env)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
@@ -78,6 +79,44 @@ def test_bench_two_ranks_print_one_json_line():
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
         assert d["config"]["collectives_per_step"] == ncoll and "cpu_baseline" not in d
+        assert d["config"]["ranks_seen"] == 2
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` started WITHOUT a launcher (no RANK in the environment) must spawn its ranks itself and
+    still print exactly one JSON line: the first 8-GPU run of the driver must not fail on how it was started.  Both ranks
+    share the test box's one GPU (DTA_BENCH_BACKEND=gloo, development only); the default exchange is the peer exchange
+    (its crash-isolated probe passes between two processes of one device), overlapped with the backward."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(DTA_BENCH_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--batch", "64", "--steady-steps", "0"], capture_output=True, text=True, timeout=420, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["exchange"] == "peer" and d["config"]["exchange_fallbacks"] == []
+
+
+@pytest.mark.gpu
+def test_default_bench_line_carries_the_side_workloads():
+    """The one-GPU driver line times, after the contract's region, the reference's own precision (fp32), BASELINE
+    configs[4] (ensemble24) and the unchanged-reference-step plugin path (module_path), 20 steps each."""
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "2", "--steady-steps", "20",
+                          "--tile-steps", "0", "--no-cpu-baseline", "--prime-seconds", "0.2"], capture_output=True, text=True,
+                         timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
+    for k in ("fp32", "ensemble24", "module_path"):
+        assert k in d and "error" not in d[k], d.get(k)
+    assert d["fp32"]["dtype"] == "fp32" and d["fp32"]["ms_per_step"] > d["ms_per_step"]
+    assert d["ensemble24"]["config"]["crop"] == 24 and d["ensemble24"]["roofline"]["frac"] < d["ensemble24"]["roofline"]["frac_with_byproduct"]
+    mp = d["module_path"]
+    assert mp["hang2020_dta_adam_ms_per_step"] < mp["hang2020_torch_adam_ms_per_step"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["frac"] < r["frac_with_byproduct"]
 
 
 @pytest.mark.gpu

@@ -166,6 +166,17 @@ def _lonely_worker(rank, world, port, out):
             out[0] = "no error"
         except RuntimeError as e:
             out[0] = str(e)
+        # the abort is STICKY: a later fused-Adam launch of the same exchange returns at once and applies nothing
+        # (a replica must not train on past a failed exchange)
+        n = ex.capacity
+        ex.grad.fill_(1.0)
+        p = torch.ones(n, device="cuda")
+        m = torch.zeros(n, device="cuda")
+        v = torch.zeros(n, device="cuda")
+        t1 = time.time()
+        ex.adam_step(p, m, v, None, None, -1, None, None, 1, 1e-3, (0.9, 0.999), 1e-8, zero_grad=True)
+        torch.cuda.synchronize()
+        out["sticky"] = (time.time() - t1, float(p.min()), float(m.abs().max()), float(ex.grad.min()))
     dist.barrier()
     ex.close()
     dist.destroy_process_group()
@@ -178,3 +189,5 @@ def test_missing_peer_times_out_instead_of_hanging():
     mp.spawn(_lonely_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert "timed out" in out[0] and "rank 1" in out[0], out[0]
     assert time.time() - t0 < 60
+    dt, pmin, mmax, gmin = out["sticky"]
+    assert dt < 0.2 and pmin == 1.0 and mmax == 0.0 and gmin == 1.0, out["sticky"]      # nothing waited, nothing applied

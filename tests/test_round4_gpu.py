@@ -1,0 +1,310 @@
+"""Round 4: the drop-in module path (optim.DtaAdam + optim.cross_entropy around the UNCHANGED reference step,
+src/main.py:71-80,135-149; multi_stage.py:258-288), the data-parallel year ensemble with a year missing on ONE rank only,
+and the peer-exchange probe."""
+import copy
+import datetime
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import rel_l2
+from oracle import hang2020_np as O
+from oracle import prng
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TIGHT = 2e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def load(model, p):
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in p.items()})
+    return model.to(dev())
+
+
+def test_cross_entropy_matches_torch():
+    from deeptreeattention_amd.optim import cross_entropy
+    torch.manual_seed(0)
+    for B, classes in ((7, 5), (130, 200)):
+        z = torch.randn(B, classes, device=dev(), requires_grad=True)
+        z2 = z.detach().clone().requires_grad_(True)
+        y = torch.randint(0, classes, (B,), device=dev())
+        y[0] = -100                                       # torch's ignore_index
+        w = torch.rand(classes, device=dev()) + 0.1
+        for weight in (None, w):
+            z.grad = z2.grad = None
+            a = cross_entropy(z, y, weight=weight)
+            b = torch.nn.functional.cross_entropy(z2, y, weight=weight)
+            (a * 3.0).backward()
+            (b * 3.0).backward()
+            assert abs(float(a) - float(b)) < 1e-5 * abs(float(b))
+            assert rel_l2(z.grad.cpu().numpy(), z2.grad.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_module_path_with_dta_adam_equals_the_fused_trainer(precision):
+    """TreeModel.training_step unchanged (forward, cross-entropy, loss.backward(), optimizer.step()) with DtaAdam and
+    optim.cross_entropy: gradients land in the optimizer's flat buffer in place, three steps give the FusedTrainer's
+    parameters (same kernels, same order) and the oracle's Adam loop."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    bands, classes, B, lr = 20, 7, 6, 1e-3
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=41)
+    w = torch.from_numpy((0.1 + (np.arange(classes) % 7)).astype(np.float32)).to(dev())
+    m1 = load(H.Hang2020(bands, classes, precision=precision), p).train()
+    m2 = load(H.Hang2020(bands, classes, precision=precision), p).train()
+    tr = FusedTrainer(m1, lr=lr, loss_weight=w)
+    opt = DtaAdam(m2.parameters(), lr=lr)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.75, patience=8)      # attaches like to torch's Adam
+    state, pp = {}, {k: np.array(v) for k, v in p.items()}
+    for step in range(3):
+        x = prng.uniform01(300 + step, 1, (B, bands, 11, 11))
+        y = prng.randint(300 + step, 2, (B,), classes)
+        xt, yt = torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev())
+        l1 = tr.train_step(xt, yt)
+        opt.zero_grad()
+        l2 = cross_entropy(m2(xt), yt, weight=w)
+        l2.backward()
+        if step == 0:
+            g = m2.spectral_network.conv1.conv_layer.weight.grad
+            assert g is not None and g.data_ptr() == opt._gview[id(m2.spectral_network.conv1.conv_layer.weight)].data_ptr()
+            assert float(g.abs().sum()) > 0 and float(m2.alpha.grad.abs()) > 0
+            assert float(m2.spectral_network.classifier1.fc1.weight.grad.abs().sum()) == 0.0      # heads 1-2: no gradient
+        opt.step()
+        assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l1)), step
+        if precision == "fp32":
+            logits, cache, upd = O.hang2020_fwd(pp, x, True, np.float64)
+            _, dl = O.weighted_cross_entropy(logits, y, w.cpu().numpy())
+            pp.update(upd)
+            pp = O.adam_step(pp, O.hang2020_bwd(pp, cache, dl, np.float64), state, lr=lr)
+    sched.step(1.0)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        a, b = sd1[k].double().cpu().numpy(), sd2[k].double().cpu().numpy()
+        assert rel_l2(b, a) < 1e-6, k                     # module path == fused path
+        if precision == "fp32" and not (O.is_buffer(k) or k.endswith("conv_layer.bias")):
+            assert rel_l2(b, pp[k]) < 2e-3, k             # == the oracle's Adam loop
+    assert opt.step_counts() == [3]
+    osd = opt.state_dict()
+    assert len(osd["state"]) == len(list(m2.parameters())) and float(osd["state"][0]["step"]) == 3.0
+
+
+def test_second_backward_before_step_accumulates_like_torch():
+    """Gradient accumulation: the second backward before step() does not overwrite the in-place gradients -- it goes
+    through autograd's accumulation into the same views."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    torch.manual_seed(2)
+    m = H.spectral_network(12, 5).to(dev()).train()
+    opt = DtaAdam(m.parameters(), lr=1e-3, fuse_zero_grad=False)
+    x = torch.rand(4, 12, 11, 11, device=dev())
+    y = torch.randint(0, 5, (4,), device=dev())
+    opt.zero_grad()
+    cross_entropy(m(x)[-1], y).backward()
+    g1 = m.conv2.conv_layer.weight.grad.clone()
+    m.conv2.bn1.reset_running_stats()
+    cross_entropy(m(x)[-1], y).backward()
+    assert rel_l2(m.conv2.conv_layer.weight.grad.cpu().numpy(), (2 * g1).cpu().numpy()) < 1e-5
+    opt.step()
+    assert float(m.conv2.conv_layer.weight.grad.abs().sum()) > 0        # fuse_zero_grad=False: still readable
+    opt.zero_grad()
+    assert float(m.conv2.conv_layer.weight.grad.abs().sum()) == 0.0
+
+
+def _ensemble_step_inputs(step, years, B, bands, classes):
+    imgs = [prng.uniform01(82 + step, yy, (B, bands, 11, 11)) for yy in range(years)]
+    if step == 1:
+        imgs[2] = np.zeros_like(imgs[2])
+    if step == 2:
+        imgs[0] = np.zeros_like(imgs[0])
+    return imgs, prng.randint(82 + step, 7, (B,), classes)
+
+
+def test_module_path_ensemble_steps_vs_reference_golden(golden):
+    """The reference's MultiStage step on one level (multi_stage.py:277-288: forward, F.cross_entropy, backward, Adam)
+    through the plugin modules with DtaAdam: four steps, two with an all-zero year, decided on the device (no host
+    round trip in learned_ensemble.forward), against the reference's own learned_ensemble + torch Adam golden."""
+    from deeptreeattention_amd.year import learned_ensemble
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    g = golden("ensemble_steps.npz")
+    years, bands, classes, B, lr = 3, 16, 7, 6, 1e-3
+    p = O.init_params(O.learned_ensemble_spec(years, bands, classes), seed=81)
+    m = load(learned_ensemble(years=years, classes=classes, config={"pretrain_state_dict": None, "bands": bands}), p)
+    m.train()
+    w = torch.from_numpy((0.1 + (np.arange(classes) % 7)).astype(np.float32)).to(dev())
+    opt = DtaAdam(m.parameters(), lr=lr)
+    for step in range(4):
+        imgs, y = _ensemble_step_inputs(step, years, B, bands, classes)
+        xs = [torch.from_numpy(a).to(dev()) for a in imgs]
+        opt.zero_grad()
+        scores = m(xs)
+        loss = cross_entropy(scores, torch.from_numpy(y).to(dev()), weight=w)
+        loss.backward()
+        opt.step()
+        assert rel_l2(scores.detach().cpu().numpy(), g[f"step{step}/score"]) < TIGHT, step
+        ref = float(g[f"step{step}/loss"])
+        assert abs(float(loss) - ref) < TIGHT * abs(ref), step
+        for k, prm in m.named_parameters():
+            if k.endswith("conv_layer.bias"):
+                continue
+            a = prm.detach().cpu().numpy()
+            ref = float(g[f"step{step}/pnorm/{k}"])
+            assert abs(np.sqrt((a.astype(np.float64) ** 2).sum()) - ref) <= 1e-3 * ref, (step, k)
+            if f"step{step}/pfull/{k}" in g:
+                assert rel_l2(a, g[f"step{step}/pfull/{k}"]) < 2e-3, (step, k)
+        for k, b in m.named_buffers():
+            tol = 2e-3 if k.endswith("running_mean") else TIGHT
+            assert rel_l2(b.cpu().numpy(), g[f"step{step}/buf/{k}"]) < tol, (step, k)
+    assert opt.step_counts() == [3, 4, 3]                 # skipped years: passed over, as torch's Adam passes over grad None
+    m.eval()
+    with torch.no_grad():
+        s = m(xs)                                         # validation forward: gated on the device too, flags not republished
+    assert torch.isfinite(s).all()
+
+
+def test_ensemble_without_dta_adam_keeps_grad_none_for_skipped_years():
+    from deeptreeattention_amd.year import learned_ensemble
+    torch.manual_seed(1)
+    m = learned_ensemble(3, 5, {"pretrain_state_dict": None, "bands": 12}).to(dev()).train()
+    xs = [torch.rand(4, 12, 11, 11, device=dev()) for _ in range(3)]
+    xs[1].zero_()
+    torch.nn.functional.cross_entropy(m(xs), torch.randint(0, 5, (4,), device=dev())).backward()
+    assert m.year_models[1].conv1.conv_layer.weight.grad is None
+    assert m.year_models[0].conv1.conv_layer.weight.grad is not None
+
+
+# ---- data-parallel year ensemble: a year missing on ONE rank only -------------------------------------
+BANDS, CLASSES, B = 20, 7, 6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ens_worker(rank, world, port, mode, exchange, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    from deeptreeattention_amd.engine import EnsembleTrainer
+    from deeptreeattention_amd.year import learned_ensemble
+    d = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    torch.manual_seed(5)
+    m = learned_ensemble(3, CLASSES, {"pretrain_state_dict": None, "bands": BANDS}).to(d).train()
+    tr = EnsembleTrainer(m, lr=1e-3, exchange=exchange, keep_grads=True,
+                         exchange_opts={"max_workgroups": 32, "timeout_s": 20.0} if exchange == "peer" else None)
+    losses = []
+    for step in range(2):
+        imgs = [torch.from_numpy(prng.uniform01(200 + 10 * step + rank, yy, (B, BANDS, 11, 11))).to(d) for yy in range(3)]
+        if rank == 0:
+            imgs[1].zero_()                           # year 1 is missing on rank 0 ONLY
+        if step == 1 and rank == 1:
+            imgs[0].zero_(); imgs[1].zero_(); imgs[2].zero_()          # rank 1 has NO year at all in step 2
+        y = torch.from_numpy(prng.randint(200 + rank, 2, (B,), CLASSES)).to(d)
+        present = None if mode == "device" else [bool(x.any()) for x in imgs]
+        if mode == "present" and not any(present):
+            present = None                            # (a rank without any year cannot use the host-flag form)
+        losses.append(float(tr.train_step(imgs, y, present)))
+    torch.cuda.synchronize()
+    tr.check_exchange()
+    g1 = tr.grad_of(m.year_models[1].classifier3.fc1.bias).detach().cpu().numpy().copy()
+    out[(mode, rank)] = ({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, losses, tr.step_counts(), g1)
+    tr.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["torch", "peer"])
+def test_dp_ensemble_year_missing_on_one_rank_contributes_zeros(exchange):
+    """A rank whose batch lacks a year that the other rank kept must send ZEROS for that year (the reference's skipped year
+    has grad None): the device-decided step (all years launched, gradients gated by the rank's own flags) must equal the
+    `present=[...]` step (only the kept years launched), which the reference's golden pins.  Second step: rank 1 has no
+    year at all -- NaN loss there, nothing contributed, rank 0's years still stepped on both ranks."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    for mode in ("device", "present"):
+        for attempt in range(2):
+            try:
+                mp.spawn(_ens_worker, args=(world, _free_port(), mode, exchange, out), nprocs=world, join=True)
+                break
+            except Exception:
+                if attempt == 1:
+                    raise
+    for rank in range(world):
+        sd_d, l_d, steps_d, g_d = out[("device", rank)]
+        sd_p, l_p, steps_p, g_p = out[("present", rank)]
+        assert steps_d == steps_p == [2, 1, 2], (steps_d, steps_p)
+        assert np.isfinite(l_d[0]) and abs(l_d[0] - l_p[0]) < 1e-5 * abs(l_p[0])
+        if rank == 1:
+            assert np.isnan(l_d[1])                   # no year on this rank: an empty mean (the reference raises)
+        for k in sd_d:
+            if "num_batches_tracked" in k:
+                assert int(sd_d[k]) == int(sd_p[k]), (rank, k)
+            elif k.endswith("conv_layer.bias"):
+                continue
+            else:
+                assert rel_l2(sd_d[k], sd_p[k]) < 2e-5, (rank, k)
+    # replicas identical; year 1's summed gradient after step 2 is zero (nobody kept it)
+    for k in out[("device", 0)][0]:
+        if "running_" in k or "num_batches_tracked" in k:
+            continue
+        assert rel_l2(out[("device", 0)][0][k], out[("device", 1)][0][k]) < 1e-6, k
+    assert np.all(out[("device", 0)][3] == 0.0)
+
+
+# ---- peer-exchange probe (the probe always failed on a ctypes argument-count error) -----------------
+def test_peer_probe_runs_single_rank():
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([sys.executable, os.path.join(REPO, "deeptreeattention_amd", "peer_probe.py"), d, "0", "1", "0"],
+                           capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_peer_probe_two_ranks_sharing_the_gpu():
+    with tempfile.TemporaryDirectory() as d:
+        procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "deeptreeattention_amd", "peer_probe.py"), d, str(r), "2", "0"],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=180) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+
+
+def _probe_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    torch.cuda.set_device(0)
+    from deeptreeattention_amd.dist import choose_exchange, probe_peer_exchange
+    ok, why = probe_peer_exchange(None)
+    out[rank] = (ok, why, choose_exchange(None))
+    dist.destroy_process_group()
+
+
+def test_choose_exchange_selects_peer_when_the_probe_passes():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_probe_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in range(2):
+        ok, why, choice = out[rank]
+        assert ok, why
+        assert choice == "peer"
