@@ -185,6 +185,48 @@ _PARAM_GATE = {}
 _TABLES = None      # module -> {key: cached ctypes tables}; weakly keyed, nothing is stored on the module itself
 
 
+_SINK_EPOCH = [0]      # bumped whenever an optimizer registers / unregisters parameters in _GRAD_SINKS
+
+
+def _cached_plist(owner):
+    """owner._param_list() (a walk over ~70 dotted names), cached per module until a load_state_dict may have replaced
+    Parameter objects (_dta_epoch)."""
+    cache = _table_cache(owner)
+    epoch = owner.__dict__.get("_dta_epoch", 0)
+    hit = cache.get("plist")
+    if hit is None or hit[0] != epoch:
+        hit = cache["plist"] = (epoch, owner._param_list())
+    return hit[1]
+
+
+def _cached_sink(owner, plist):
+    cache = _table_cache(owner)
+    hit = cache.get("sink")
+    if hit is None or hit[0] != _SINK_EPOCH[0] or hit[1] is not plist:
+        s = _sink_for(plist)
+        import weakref
+        hit = cache["sink"] = (_SINK_EPOCH[0], plist, None if s is None else weakref.ref(s))
+    return None if hit[2] is None else hit[2]()
+
+
+def _wanted(owner, used_heads):
+    """Indices (into the parameter list) of the tensors a backward with these heads produces gradients for: heads unused by
+    the loss keep grad None, as in torch."""
+    cache = _table_cache(owner)
+    key = ("wanted", used_heads)
+    hit = cache.get(key)
+    if hit is None:
+        hit, q = [], (1 if owner._net_code == _lib.NET_HANG2020 else 0)
+        for kind, mod, names in owner._subnets():
+            for j, n in enumerate(names):
+                head = int(n.split("classifier")[1][0]) - 1 if "classifier" in n else None
+                if head is None or (used_heads & (1 << head)):
+                    hit.append(q + j)
+            q += len(names)
+        cache[key] = hit
+    return hit
+
+
 def _sink_for(plist):
     """The optimizer (optim.DtaAdam) that owns ALL of `plist` and can take a backward's gradients in place, or None."""
     if not plist:
@@ -237,9 +279,6 @@ def _param_tables(owner, params, shape, heads_mask):
         B, bands, H, W = shape
         desc = _lib.NetDesc(B, bands, H, W, owner._classes, owner._net_code, _lib.dtype_code(owner.precision),
                             1 if owner.training else 0, heads_mask, BN_MOMENTUM, BN_EPS)
-        nbytes = L.dta_net_workspace_bytes(C.byref(desc))
-        if nbytes == 0:
-            raise RuntimeError("dta_net_workspace_bytes: " + L.dta_last_error().decode())
         nets = (_lib.SubnetParams * len(subnets))()
         pos = 1 if owner._net_code == _lib.NET_HANG2020 else 0
         b = 0
@@ -255,8 +294,12 @@ def _param_tables(owner, params, shape, heads_mask):
         if len(cache) > 8:
             for k in [k for k in cache if k != "bufs"][:4]:
                 cache.pop(k)
-        hit = cache[key] = (fp, desc, nets, nbytes)
-    return hit[1], hit[2], hit[3]
+        hit = cache[key] = (fp, desc, nets)
+    # (the workspace size is asked for on every call: it belongs to the library's launch plan, not to this cache)
+    nbytes = L.dta_net_workspace_bytes(C.byref(hit[1]))
+    if nbytes == 0:
+        raise RuntimeError("dta_net_workspace_bytes: " + L.dta_last_error().decode())
+    return hit[1], hit[2], nbytes
 
 
 class _NetFn(torch.autograd.Function):
@@ -270,6 +313,12 @@ class _NetFn(torch.autograd.Function):
                                "(the reference's step never asks for one): pass x.detach()")
         ctx.set_materialize_grads(False)               # unused heads arrive as None, not as zero-filled tensors
         B = x.shape[0]
+        # anchor mode (_Net._run): the parameters belong to an optim.DtaAdam that takes the gradients in place, so only ONE
+        # of them is an autograd input (the graph node needs an input that requires grad; 70 inputs cost ~100 us of host
+        # time per step in argument handling and saved-tensor bookkeeping)
+        ctx.anchor = len(params) == 1
+        if ctx.anchor:
+            params = _cached_plist(owner)
         desc, nets, nbytes = _param_tables(owner, params, x.shape, heads_mask)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         alpha = params[0] if owner._net_code == _lib.NET_HANG2020 else None
@@ -287,7 +336,10 @@ class _NetFn(torch.autograd.Function):
         _lib.check(L.dta_net_forward(C.byref(desc), nets, _lib.ptr(alpha), _lib.ptr(x), _lib.ptr(ws), C.byref(table),
                                      _lib.ptr(joint), _lib.current_stream_ptr()), "dta_net_forward")
         ctx.owner, ctx.desc, ctx.nets, ctx.heads_mask = owner, desc, nets, heads_mask
-        ctx.save_for_backward(ws, *params)
+        if ctx.anchor:
+            ctx.save_for_backward(ws)
+        else:
+            ctx.save_for_backward(ws, *params)
         if joint is not None:
             return joint
         return tuple(outs)
@@ -297,6 +349,10 @@ class _NetFn(torch.autograd.Function):
         L = _lib.lib()
         owner, desc, nets = ctx.owner, ctx.desc, ctx.nets      # (the tables of the forward: same tensors, same addresses)
         ws, *params = ctx.saved_tensors
+        plist = _cached_plist(owner)
+        if ctx.anchor:
+            params = plist
+        nret = 1 if ctx.anchor else len(params)
         subnets = owner._subnets()
         hang = owner._net_code == _lib.NET_HANG2020
         pos = 1 if hang else 0
@@ -307,7 +363,7 @@ class _NetFn(torch.autograd.Function):
         keep = []
         if owner._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA):
             if gouts[0] is None:
-                return (None, None, None) + (None,) * len(params)
+                return (None, None, None) + (None,) * nret
             djoint = gouts[0].contiguous().float()
             used_heads = 4
         else:
@@ -321,20 +377,13 @@ class _NetFn(torch.autograd.Function):
                         keep.append(g)
                         table[0][Lv] = g.data_ptr()
                         used_heads |= 1 << Lv
-        wanted = []
-        q = pos
-        for kind, mod, names in subnets:
-            for j, n in enumerate(names):
-                head = int(n.split("classifier")[1][0]) - 1 if "classifier" in n else None
-                if head is None or (used_heads & (1 << head)):
-                    wanted.append(q + j)          # heads unused by the loss keep grad None (as in torch)
-            q += len(names)
+        wanted = _wanted(owner, used_heads)
         # gradient destinations: the owning optimizer's flat buffer in place (optim.DtaAdam: the parameters' .grad are
         # views of it and arrive cleared), else one zero-filled flat buffer returned to autograd
-        plist = owner._param_list()
-        sink = _sink_for(plist)
+        sink = _cached_sink(owner, plist)
         cache = _table_cache(owner)
-        if sink is not None and sink.take_inplace([plist[i] for i in wanted] + ([plist[0]] if hang else [])):
+        if sink is not None and sink.take_inplace((id(owner), used_heads),
+                                                  lambda: [plist[i] for i in wanted] + ([plist[0]] if hang else [])):
             gkey = ("grads", used_heads, id(sink), sink.layout_epoch)
             gstructs = cache.get(gkey)
             if gstructs is None:
@@ -351,7 +400,7 @@ class _NetFn(torch.autograd.Function):
             _lib.check(L.dta_net_backward(C.byref(desc), nets, _lib.ptr(alpha), _lib.ptr(ws), C.byref(table),
                                           _lib.ptr(djoint), gstructs, _lib.ptr(dalpha), 3, _lib.current_stream_ptr()),
                        "dta_net_backward")
-            return (None, None, None) + (None,) * len(params)
+            return (None, None, None) + (None,) * nret
         grads = [None] * len(params)
         dalpha = torch.zeros((), dtype=torch.float64, device=ws.device) if hang else None
         if hang:
@@ -370,6 +419,19 @@ class _NetFn(torch.autograd.Function):
         _lib.check(L.dta_net_backward(C.byref(desc), nets, _lib.ptr(alpha), _lib.ptr(ws), C.byref(table),
                                       _lib.ptr(djoint), gstructs, _lib.ptr(dalpha), 3, _lib.current_stream_ptr()),
                    "dta_net_backward")
+        if ctx.anchor:
+            # the optimizer could not take this backward in place (a second backward before step(): gradient accumulation):
+            # add into the parameters' gradients here, as autograd's accumulation would
+            with torch.no_grad():
+                for i, g in enumerate(grads):
+                    if g is None:
+                        continue
+                    p = plist[i]
+                    if p.grad is None:
+                        p.grad = g.clone()
+                    else:
+                        p.grad.add_(g)
+            return (None, None, None, None)
         return (None, None, None, *grads)
 
 
@@ -402,7 +464,12 @@ class _Net(nn.Module):
 
     def _run(self, x, heads_mask):
         x = _check_input(x)
-        return _NetFn.apply(self, x, heads_mask, *self._param_list())
+        plist = _cached_plist(self)
+        if torch.is_grad_enabled() and _cached_sink(self, plist) is not None:
+            anchor = next((p for p in plist if p.requires_grad), None)
+            if anchor is not None:
+                return _NetFn.apply(self, x, heads_mask, anchor)      # anchor mode: see _NetFn.forward
+        return _NetFn.apply(self, x, heads_mask, *plist)
 
 
 def _build_subnet(self, kind, bands, classes):

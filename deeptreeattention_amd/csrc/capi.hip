@@ -53,18 +53,19 @@ inline void prof_end(int site, hipStream_t st) {
 }
 
 // Developer switches (same-box A/B runs): the environment is read once per process, not per call.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; bool no_wgrad_pair; };
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; bool no_wgrad_pair; int no_fanin; };
 inline Switches read_switches() {
   // these change launch plans (and, for DTA_FP32_ACT, roundings): never meant for a training job's environment, so say
   // so once, loudly, when one is set
   static const char* names[] = {"DTA_NO_FUSED_INPUT", "DTA_NO_TAIL_MERGE", "DTA_BN_INKERNEL", "DTA_FP32_ACT", "DTA_NO_LEAN",
-                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER", "DTA_NO_WGRAD_PAIR"};
+                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER", "DTA_NO_WGRAD_PAIR", "DTA_NO_FANIN"};
   for (const char* n : names)
     if (getenv(n)) fprintf(stderr, "[libdta_hip] developer switch %s is set: kernel plans (and possibly roundings) differ from the default build\n", n);
   return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr,
           getenv("DTA_FP32_ACT") != nullptr, getenv("DTA_NO_LEAN") != nullptr,
           getenv("DTA_LEAN_MASK") ? atoi(getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, getenv("DTA_HALO_TILES") != nullptr,
-          getenv("DTA_NO_WGRAD_NSPLIT") == nullptr, (getenv("DTA_PIXEL_ORDER") ? 1 : 0) | (getenv("DTA_NO_STAGGER") ? 2 : 0), getenv("DTA_NO_WGRAD_PAIR") != nullptr};
+          getenv("DTA_NO_WGRAD_NSPLIT") == nullptr, (getenv("DTA_PIXEL_ORDER") ? 1 : 0) | (getenv("DTA_NO_STAGGER") ? 2 : 0), getenv("DTA_NO_WGRAD_PAIR") != nullptr,
+          getenv("DTA_NO_FANIN") ? atoi(getenv("DTA_NO_FANIN")) : 0};      // bit 0: forward finalize launches stay, bit 1: backward ones
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -99,6 +100,9 @@ struct Plan {
   int tl_compact;  // bf16 11x11 networks on the lean stage kernels: gated-map and output-gradient tiles are halo-free too
   int Rin[3];      // tile rows per chunk of layer L's conv INPUT tiles and of its output-gradient tiles (Qin or HWc)
   size_t scores_all, scores_bytes, dfeat_all, dfeat_bytes;
+  // BatchNorm statistics / batch sums folded inside the producing launches (kernels.h, FanIn): arrival counters (zeroed by
+  // the forward's prep launch, self re-arming), per layer FAN_R rows of forward sums and of backward sums
+  size_t fan_cnt, fan_cnt_bytes, fan_fwd[3], fan_bwd[3];
   size_t total;
 };
 
@@ -226,6 +230,14 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
     p->feat[L] = c.take((size_t)G * B * (p->Fmax[L] > 0 ? p->Fmax[L] : 1) * 4);
     for (int g = 0; g < G; ++g) p->attpk[g][L] = c.take((size_t)4 * CH[L] * CH[L] * 4);
   }
+  for (int L = 0; L < 3; ++L) {
+    int Nconv = (L == 0 && p->shared_x) ? 32 * G : CH[L];
+    int gw = (L == 0 && p->shared_x) ? 1 : G;
+    p->fan_fwd[L] = c.take((size_t)gw * FAN_R * Nconv * 3 * 8);
+    p->fan_bwd[L] = c.take((size_t)G * FAN_R * CH[L] * 2 * 8);
+  }
+  p->fan_cnt = c.take((size_t)2 * 3 * MAXG * FAN_R * 4);       // directly in front of the scores: one clearing job for both
+  p->fan_cnt_bytes = c.off - p->fan_cnt;
   p->scores_all = c.off;
   for (int g = 0; g < G; ++g)
     for (int L = 0; L < 3; ++L) p->scores[g][L] = c.take((size_t)B * p->classes * 4);
@@ -356,7 +368,8 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
     pa.x_compact = p.x_compact;
     pa.packs = packs; pa.spacks = spacks;
-    if (d->heads_mask) { pa.zero = at<float>(ws, p.scores_all); pa.zero_n4 = (p.scores_bytes + 15) / 16; }   // split-K GEMM targets
+    // the fan-in arrival counters (always) and, directly behind them, the split-K GEMM targets
+    pa.zero = at<float>(ws, p.fan_cnt); pa.zero_n4 = (p.fan_cnt_bytes + (d->heads_mask ? p.scores_bytes : 0) + 15) / 16;
     if (launch_forward_prep<T>(pa, st)) return 1;
   }
   for (int L = 0; L < 3; ++L) {
@@ -382,6 +395,10 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     ca.y = at<float>(ws, p.y[L]); ca.y_fmt = p.y_fmt; ca.mwg = p.MWG[L];
     if (cat) { ca.y_gs = 0; ca.y_rs = Nconv; } else { ca.y_gs = (size_t)B * p.HWc[L] * C; ca.y_rs = C; }
     ca.stats = d->training ? at<float>(ws, p.stats[L]) : nullptr;
+    // training: the conv launch folds its BatchNorm partials itself (FAN_R rows of raw sums), the stage workgroups add
+    // those up in their prologue -- no finalize launch (DTA_NO_FANIN=1 keeps it, for A/B runs)
+    const bool fan_fwd = d->training && !(switches().no_fanin & 1);
+    if (fan_fwd) { ca.fan_count = at<unsigned>(ws, p.fan_cnt) + (size_t)L * MAXG * FAN_R; ca.fan_sums = at<double>(ws, p.fan_fwd[L]); }
     ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
     prof_begin(DTA_SITE_CONV_FWD + L, st);
     if (launch_conv3x3<T>(ca, launchG, st)) return 1;
@@ -404,7 +421,8 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     // combining the conv partials redundantly in every stage workgroup was measured SLOWER than the launch (each of
     // 2048 workgroups pulls 64-128 KB through its XCD's L2: +5 / +14 / +13 us on the three layers against a 4-5 us
     // launch), so it stays a separate wide-and-shallow launch; DTA_BN_INKERNEL=1 re-enables it for experiments
-    if ((!d->training || switches().bn_inkernel) && p.nwg[L] <= BN_INKERNEL_MAX_NWG) { sa.bn_inkernel = 1; sa.bnfin = bn_finalize_kargs(bf); }
+    if (fan_fwd) { bf.fsum = ca.fan_sums; sa.bn_inkernel = 1; sa.bnfin = bn_finalize_kargs(bf); }
+    else if ((!d->training || switches().bn_inkernel) && p.nwg[L] <= BN_INKERNEL_MAX_NWG) { sa.bn_inkernel = 1; sa.bnfin = bn_finalize_kargs(bf); }
     else if (launch_bn_finalize(bf, G, st)) return 1;
     if (d->heads_mask & DTA_FORWARD_ONLY) sa.attsave = nullptr;   // attention state is kept for the backward only
     prof_begin(DTA_SITE_STAGE_FWD + L, st);
@@ -599,6 +617,14 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     sb.da_fmt = (L < 2 && lean_lvl[L] && g16) ? FMT_BF16 : FMT_F32;
     sb.dv_fmt = g16 ? FMT_BF16 : FMT_F32;      // (the generic stage kernels store it in bf16 too)
     sb.bnpart = at<float>(ws, p.bnpart[L]); sb.bnpart_gs = (size_t)B * C * 2;
+    // lean kernels: the batch sums of BatchNorm's backward are folded inside the stage launch (FAN_R rows) and the apply
+    // launch derives its coefficients from them -- no finalize launch (DTA_NO_FANIN=2 keeps it)
+    const bool fan_bwd = lean_lvl[L] && !(switches().no_fanin & 2);
+    if (fan_bwd) {
+      sb.bn_fan_rows = sb.bnpart;      // (the per-patch partials' buffer: a workgroup row needs no more than a patch row)
+      sb.bn_fan_sums = at<double>(ws, p.fan_bwd[L]);
+      sb.bn_fan_count = at<unsigned>(ws, p.fan_cnt) + (size_t)(3 + L) * MAXG * FAN_R;
+    }
     sb.vec = at<float>(ws, p.vec[L]); sb.vec_gs = (size_t)B * p.vec_ld[L]; sb.vec_ld = p.vec_ld[L];
     prof_begin(DTA_SITE_STAGE_BWD + L, st);
     if (launch_stage_bwd(sb, G, st)) return 1;
@@ -644,7 +670,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       bf.dconvbias[g] = grads[g].conv_b[L];
     }
     bf.bcoef = at<float>(ws, p.bcoef[L]); bf.bcoef_gs = C * 4; bf.training = d->training;
-    if (launch_bn_bwd_finalize_colsum(bf, G, cs_jobs, ncs_jobs, st)) return 1;
+    if (!fan_bwd && launch_bn_bwd_finalize_colsum(bf, G, cs_jobs, ncs_jobs, st)) return 1;
     BnBwdApplyArgs ap;
     memset(&ap, 0, sizeof(ap));
     ap.dv = sb.dv; ap.dv_gs = sb.dv_gs; ap.y = sa.y; ap.y_gs = sa.y_gs; ap.y_rs = sa.y_rs; ap.y_fmt = sa.y_fmt;
@@ -655,7 +681,12 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     if (L == 0 && p.shared_x) { ap.dy_gs = (size_t)2 * p.Rin[0] * 16; ap.dy_nc = 2 * G; ap.dy_ch0 = 0; }   // group g -> chunks [2g, 2g+2)
     else { ap.dy_gs = (size_t)B * (C / 16) * p.Rin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
     ap.dy_compact = p.tl_compact;
-    if (launch_bn_bwd_apply<T>(ap, G, st)) return 1;
+    if (fan_bwd) {
+      ap.fan = sb.bn_fan_sums; ap.training = d->training;
+      for (int g = 0; g < G; ++g) { ap.gamma[g] = bf.gamma[g]; ap.dgamma[g] = bf.dgamma[g]; ap.dbeta[g] = bf.dbeta[g]; ap.dconvbias[g] = bf.dconvbias[g]; }
+      // (the spatial-attention column sums that rode in the finalize launch ride in this one)
+      if (launch_bn_bwd_apply<T>(ap, G, st, cs_jobs, ncs_jobs)) return 1;
+    } else if (launch_bn_bwd_apply<T>(ap, G, st)) return 1;
     // ---- conv weight gradient ----
     // the deferred parameter-gradient GEMMs always ride in the launch of the split-K reductions that ends this call
     // (phase 1 of a data-parallel step: the reductions of layers 3 and 2, so the first gradient bucket is complete

@@ -419,9 +419,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   if (tid < N) {
     float m2 = red[tid] + red[N + tid] + red[2 * N + tid] + red[3 * N + tid];
     float* o = a.stats + (((size_t)g * gridDim.x + blockIdx.x) * N + tid) * 2;
-    o[0] = cmean[tid];
-    o[1] = m2;
+    if (a.fan_count) fan_store2(o, cmean[tid], m2);
+    else { o[0] = cmean[tid]; o[1] = m2; }
   }
+  if (a.fan_count) conv_stats_fanin<256>(a, g, N, HW, MWG, reinterpret_cast<double*>(sx), reinterpret_cast<int*>(cmean));
 }
 
 void conv_geometry(int HW, int MWG, int B, int* ppw, int* spp, int* nwg) {

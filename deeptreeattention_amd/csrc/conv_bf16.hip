@@ -525,10 +525,12 @@ _Pragma("unroll") \
 #pragma unroll
     for (int w = 0; w < NW; ++w) m2 += red[w * N + tid];
     float* o = a.stats + (((size_t)g * gridDim.x + blockIdx.x) * N + tid) * 2;
-    o[0] = cmean[tid];
-    o[1] = m2;
+    if (a.fan_count) fan_store2(o, cmean[tid], m2);
+    else { o[0] = cmean[tid]; o[1] = m2; }
   }
   CTICK(5);
+  // no finalize launch: the last workgroup of each logical group folds the group's rows (kernels.h); the staging area is free
+  if (a.fan_count) conv_stats_fanin<NTHR>(a, g, N, HW, MWG, reinterpret_cast<double*>(sbuf), reinterpret_cast<int*>(cmean));
 }
 
 template <int MT, int NT, int NW = 8>

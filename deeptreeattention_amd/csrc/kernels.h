@@ -27,7 +27,19 @@ struct ConvArgs {
   // staging and (x_tl_out != null) writes the halo-free bf16 tiles it built as a by-product for the weight gradient
   const float* x_nchw[MAXG]; int Cx; void* x_tl_out;
   int pixel_order;                    // bf16 developer switches: bit 0 = tile rows in pixel order (conv_row_tables), bit 1 = all waves stage before they multiply
+  // BatchNorm statistics without a finalize launch (see FanIn below): the last workgroup to arrive in each of FAN_R
+  // logical groups folds that group's (mean, M2) rows into one row of raw sums; the stage kernels add the FAN_R rows up
+  unsigned* fan_count;                // [gridDim.y][FAN_R] arrival counters (zero on entry, left zero) or null
+  double* fan_sums;                   // [gridDim.y][FAN_R][N][3] = sum n m, sum n m^2, sum M2 per column
 };
+// ---- fan-in of per-workgroup partial rows inside one launch ---------------------------------------------------------
+// Workgroups whose linear block id has the same residue mod FAN_R form a LOGICAL group (on this GPU they also share an
+// XCD -- block b runs on XCD b % 8 -- which only makes the hand-off faster; nothing depends on the placement).  Every
+// workgroup publishes its row with 8-byte agent-scope stores, drains them and bumps the group's counter; the one that
+// sees the count complete (the last to arrive) reads the group's rows back with 8-byte agent-scope loads ("8-B agent
+// atomics both sides", the cross-XCD-safe hand-off), folds them in a fixed order and leaves ONE row per group for the
+// NEXT launch, which then adds FAN_R rows instead of waiting for a finalize launch over hundreds.
+constexpr int FAN_R = 8;
 struct WgradArgs {
   const void* x_tl; size_t x_gs; int NCx;
   const void* dy_tl; size_t dy_gs; int NCy, ych0;
@@ -123,6 +135,69 @@ __device__ __forceinline__ void wgrad_reduce_blocks(const WgradReduceArgs& a, in
 }
 
 #endif
+#if defined(__HIPCC__)
+__device__ __forceinline__ int fan_group() { return (int)((blockIdx.x + blockIdx.y * gridDim.x) & (FAN_R - 1)); }
+// first block x of row blockIdx.y whose linear id has residue q, and how many there are
+__device__ __forceinline__ int fan_first(int q) { return (q - (int)((blockIdx.y * gridDim.x) & (FAN_R - 1))) & (FAN_R - 1); }
+__device__ __forceinline__ int fan_members(int q) { const int x0 = fan_first(q); return (int)gridDim.x > x0 ? ((int)gridDim.x - x0 + FAN_R - 1) / FAN_R : 0; }
+__device__ __forceinline__ void fan_store2(float* p, float a, float b) {      // one 8-byte agent-scope store
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 fan_load2(const float* p) {                  // one 8-byte agent-scope load
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+}
+// Call with the whole workgroup after its row stores were ISSUED: drains them, arrives, and returns true in every thread of
+// the group's last arriver (which also re-arms the counter for the next launch).  flag: one int of LDS.
+__device__ __forceinline__ bool fan_arrive(unsigned* count, int* flag) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): this wave's row stores are performed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int q = fan_group();
+    unsigned* c = count + blockIdx.y * FAN_R + q;
+    const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old + 1u == (unsigned)fan_members(q);
+    if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+// output rows a conv workgroup owns (its weight in the combination of the (mean, M2) partials)
+__device__ __forceinline__ int conv_wg_count(int wg, int HW, int MWG, int B) {
+  if (HW <= MWG) { int ppw = MWG / HW; return min(ppw, B - wg * ppw) * HW; }
+  int spp = (HW + MWG - 1) / MWG;
+  return min(MWG, HW - (wg % spp) * MWG);
+}
+// Tail of a conv kernel's BatchNorm-statistics epilogue when ConvArgs::fan_count is set.  Every workgroup has just
+// published its (mean, M2) row with fan_store2; the last arriver of each logical group folds the group's rows into raw
+// sums in double -- sum n m, sum n m^2, sum M2, the single-pass form k_bn_finalize uses -- in a fixed order (slices of rows,
+// then slices in order), so the result does not depend on which workgroup arrived last.  dred: NTHR * 3 doubles of LDS.
+template <int NTHR>
+__device__ __forceinline__ void conv_stats_fanin(const ConvArgs& a, int g, int N, int HW, int MWG, double* dred, int* flag) {
+  if (!fan_arrive(a.fan_count, flag)) return;
+  const int tid = threadIdx.x, q = fan_group(), x0 = fan_first(q), nrows = fan_members(q);
+  const int col = tid % N, sl = tid / N, T = NTHR / N;
+  const float* st = a.stats + (size_t)g * gridDim.x * N * 2;
+  double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll 4
+  for (int r = sl; r < nrows; r += T) {
+    const int wg = x0 + r * FAN_R;
+    const float2 v = fan_load2(st + ((size_t)wg * N + col) * 2);
+    const double nb = conv_wg_count(wg, HW, MWG, a.B), m = (double)v.x;
+    s0 += nb * m; s1 += nb * m * m; s2 += (double)v.y;
+  }
+  dred[tid] = s0; dred[NTHR + tid] = s1; dred[2 * NTHR + tid] = s2;
+  __syncthreads();
+  if (tid < N) {
+    double t0 = 0, t1 = 0, t2 = 0;
+    for (int j = 0; j < T; ++j) { t0 += dred[j * N + tid]; t1 += dred[NTHR + j * N + tid]; t2 += dred[2 * NTHR + j * N + tid]; }
+    double* o = a.fan_sums + (((size_t)blockIdx.y * FAN_R + q) * N + tid) * 3;
+    o[0] = t0; o[1] = t1; o[2] = t2;
+  }
+}
+#endif
 void conv_geometry(int HW, int MWG, int B, int* ppw, int* spp, int* nwg);
 int conv_mwg(int N);
 // bf16 kernels: output rows per workgroup for an HW-pixel map -- 576 (six waves x three 32-row tiles) when that wastes
@@ -131,8 +206,10 @@ int conv_mwg_bf16(int N, int HW);
 int wgrad_cpw(int N);
 int wgrad_ngroups(int N, int bf16);     // column groups of the bf16 weight-gradient kernel (the slab count divides by it)
 
+struct ColsumArgs;
 // ---- stage.hip (BatchNorm + ReLU + pool + attention, forward and backward) ------------------------
 struct BnFinalizeArgs {
+  const double* fsum = nullptr;                        // FAN_R rows of raw sums per conv launch row (instead of `stats`)
   const float* stats; int nwg, N, HW, MWG, B;          // partials of one conv launch (per group)
   const float* gamma[MAXG]; const float* beta[MAXG];   // per group (bias_mode 1: concatenated columns)
   float* rmean[MAXG]; float* rvar[MAXG]; long long* nbt[MAXG];
@@ -144,6 +221,9 @@ struct BnFinalizeArgs {
 int launch_bn_finalize(const BnFinalizeArgs& a, int G, hipStream_t st);
 // kernel-side form of the above (group offsets resolved)
 struct BnFinK {
+  // fsum != null: the conv launch already folded its partials into FAN_R rows of raw sums (ConvArgs::fan_sums):
+  // fsum[(q * fsum_ld + c) * 3 + k] for group g at fsum + g * fsum_goff
+  const double* fsum; size_t fsum_goff; int fsum_ld;
   const float* stats; size_t stats_goff; int stats_ld;
   int nwg, C, HW, MWG, B;
   const float* gamma[MAXG]; const float* beta[MAXG];
@@ -202,6 +282,10 @@ struct StageBwdArgs {
   // storage formats (FMT_F32 / FMT_BF16) of the incoming gradient map `da` and of `dv`; 16-bit only with the lean kernels
   // (stage_bwd_is_lean): per-patch strides stay the same element counts, the compact position bytes follow the values
   int da_fmt, dv_fmt;
+  // lean kernels, no finalize launch: every workgroup folds the BatchNorm partial sums of ITS patches into one row,
+  // the last arriver of each logical group (FanIn) folds the group's rows: bn_fan_rows [G][grid x][C][2] floats (hand-off
+  // scratch), bn_fan_sums [G][FAN_R][C][2] doubles (sum dv, sum dv xhat) for the apply launch, bn_fan_count [G][FAN_R]
+  float* bn_fan_rows; double* bn_fan_sums; unsigned* bn_fan_count;
 };
 int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st);
 bool stage_bwd_is_lean(const StageBwdArgs& a, int G);
@@ -226,9 +310,14 @@ struct BnBwdApplyArgs {
   int dy_compact;                      // halo-free output tiles [patch][chunk][pixel][16] (LDS-image kernel, bf16)
   int dv_compact, Hz, Wz;              // see StageBwdArgs::dv_compact
   int cslice;                          // channels per workgroup (filled by the launcher)
+  // fan != null: no finalize launch ran -- every workgroup derives the apply coefficients of its channels from the FAN_R
+  // rows of batch sums the stage-backward launch left (StageBwdArgs::bn_fan_sums), and workgroup (0, g, *) also writes
+  // d(gamma), d(beta), d(conv bias)
+  const double* fan; const float* gamma[MAXG]; float* dgamma[MAXG]; float* dbeta[MAXG]; float* dconvbias[MAXG]; int training;
 };
 bool bn_bwd_apply_uses_lds(int C, int H, int W, size_t elem_bytes);
-template <typename T> int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st);
+// cs / ncs: up to two batch column-sum jobs riding as extra workgroups of the launch (LDS-image kernel)
+template <typename T> int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st, const ColsumArgs* cs = nullptr, int ncs = 0);
 
 // ---- heads.hip -----------------------------------------------------------------------------------
 // C[m][n] (+)= sum_k A(m,k) * B(k,n) + bias[n]; arbitrary element strides; fp32 MFMA 32x32x2.
@@ -269,15 +358,16 @@ struct ColsumArgs {
 // then three shuffles fold the 8 slices of a wave and 16 wave partials meet in LDS.
 // colsum8<NV>: column j (< ncols <= 8) of A (row pitch lda floats, NV consecutive floats per item); on return threads
 // t < 8 * NV hold the sums in double (item t / NV, component t % NV).  sc: 16 x 16 floats.
-template <int NV>
+template <int NV, int NTHR = 1024>
 __device__ __forceinline__ double colsum8(const float* A, size_t lda, int rows, int ncols, float (*sc)[16]) {
+  constexpr int NSL = NTHR / 8, NWV = NTHR / 64;       // row slices, waves
   const int t = threadIdx.x, cl = t & 7, sl = t >> 3, lane = t & 63, wave = t >> 6;
   float acc[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) acc[k] = 0.f;
   if (cl < ncols) {
 #pragma unroll 8
-    for (int r = sl; r < rows; r += 128) {
+    for (int r = sl; r < rows; r += NSL) {
       const float* p = A + (size_t)r * lda + cl * NV;
       if (NV == 2) { const float2 v = *reinterpret_cast<const float2*>(p); acc[0] += v.x; acc[NV - 1] += v.y; }
       else acc[0] += p[0];
@@ -293,14 +383,15 @@ __device__ __forceinline__ double colsum8(const float* A, size_t lda, int rows, 
   double out = 0;
   if (t < 8 * NV) {
 #pragma unroll
-    for (int w = 0; w < 16; ++w) out += (double)sc[w][t];
+    for (int w = 0; w < NWV; ++w) out += (double)sc[w][t];
   }
   __syncthreads();
   return out;
 }
+template <int NTHR = 1024>
 __device__ __forceinline__ void colsum_scatter_block(const ColsumArgs& a, int bx, float (*sc)[16]) {
   const int j0 = bx * 8, t = threadIdx.x;
-  const double v = colsum8<1>(a.A + j0, (size_t)a.lda, a.rows, min(8, a.cols - j0), sc);
+  const double v = colsum8<1, NTHR>(a.A + j0, (size_t)a.lda, a.rows, min(8, a.cols - j0), sc);
   const int j = j0 + t;
   if (t < 8 && j < a.cols)
     for (int s = 0; s < a.nseg; ++s)
@@ -315,6 +406,9 @@ int launch_colsum_scatter(const ColsumArgs& a, hipStream_t st);
 // BatchNorm-backward finalize and up to two batch column-sum jobs (spatial-attention parameter gradients) in one
 // launch: both are [batch] reductions over per-patch partials that the same stage-backward kernel produced.
 int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const ColsumArgs* cs, int ncs, hipStream_t st);
+// up to two batch column-sum jobs riding as extra workgroups of another launch (the BatchNorm-backward apply launch
+// when no finalize launch exists)
+struct ColsumPair { ColsumArgs cs[2]; int nblk[2]; };
 int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, float* packed, hipStream_t st);
 struct SpecPackGroup { const float* w1[3 * MAXG]; const float* w2[3 * MAXG]; float* packed[3 * MAXG]; int C[3 * MAXG], K[3 * MAXG]; int n = 0; };
 int launch_pack_spectral_att_group(const SpecPackGroup& gr, hipStream_t st);

@@ -27,11 +27,6 @@ struct WgStamp {
 // ------------------------------------------------------------------------------------------------
 // BatchNorm statistics: combine the conv workgroups' (mean, M2) partials (Chan et al.) in double.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int conv_wg_count(int wg, int HW, int MWG, int B) {
-  if (HW <= MWG) { int ppw = MWG / HW; return min(ppw, B - wg * ppw) * HW; }
-  int spp = (HW + MWG - 1) / MWG;
-  return min(MWG, HW - (wg % spp) * MWG);
-}
 
 __global__ __launch_bounds__(1024) void k_bn_finalize(BnFinK a) {
   // block = 8 channels x 128 slices of the conv workgroups' partials (grid = (C/8, G)): at most nwg/128 independent
@@ -92,8 +87,9 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(BnFinK a) {
 BnFinK bn_finalize_kargs(const BnFinalizeArgs& b) {
   BnFinK a;
   a.stats = b.stats; a.nwg = b.nwg; a.HW = b.HW; a.MWG = b.MWG; a.B = b.B;
-  if (b.cat_mode) { a.C = b.nsplit; a.stats_goff = (size_t)b.nsplit * 2; a.stats_ld = b.N; }
-  else { a.C = b.N; a.stats_goff = (size_t)b.nwg * b.N * 2; a.stats_ld = b.N; }
+  a.fsum = b.fsum; a.fsum_ld = b.N;
+  if (b.cat_mode) { a.C = b.nsplit; a.stats_goff = (size_t)b.nsplit * 2; a.stats_ld = b.N; a.fsum_goff = (size_t)b.nsplit * 3; }
+  else { a.C = b.N; a.stats_goff = (size_t)b.nwg * b.N * 2; a.stats_ld = b.N; a.fsum_goff = (size_t)FAN_R * b.N * 3; }
   for (int g = 0; g < MAXG; ++g) {
     a.gamma[g] = b.gamma[g]; a.beta[g] = b.beta[g]; a.rmean[g] = b.rmean[g]; a.rvar[g] = b.rvar[g]; a.nbt[g] = b.nbt[g];
   }
@@ -127,13 +123,23 @@ __device__ __forceinline__ void bn_coef_block(const BnFinK& a, int g, float* lc,
       lc[t * 4 + 2] = a.rmean[g][t]; lc[t * 4 + 3] = rstd;
     }
   } else {
-    const float* st = a.stats + (size_t)g * a.stats_goff;
     double s1 = 0, s2 = 0, s3 = 0;
+    if (a.fsum) {
+      // the conv launch folded its partials into FAN_R rows of raw sums already: slice sl adds rows sl, sl + T, ...
+      // (fixed order: every workgroup computes bit-identical coefficients)
+      const double* fs = a.fsum + (size_t)g * a.fsum_goff;
+      for (int q = sl; q < FAN_R; q += T) {
+        const double* r = fs + ((size_t)q * a.fsum_ld + c) * 3;
+        s1 += r[0]; s2 += r[1]; s3 += r[2];
+      }
+    } else {
+      const float* st = a.stats + (size_t)g * a.stats_goff;
 #pragma unroll 8
-    for (int wg = sl; wg < a.nwg; wg += T) {       // unrolled: independent L2 loads in flight
-      const float2 v = *reinterpret_cast<const float2*>(st + ((size_t)wg * a.stats_ld + c) * 2);
-      const double nb = conv_wg_count(wg, a.HW, a.MWG, a.B), m = (double)v.x;
-      s1 += nb * m; s2 += nb * m * m; s3 += (double)v.y;
+      for (int wg = sl; wg < a.nwg; wg += T) {       // unrolled: independent L2 loads in flight
+        const float2 v = *reinterpret_cast<const float2*>(st + ((size_t)wg * a.stats_ld + c) * 2);
+        const double nb = conv_wg_count(wg, a.HW, a.MWG, a.B), m = (double)v.x;
+        s1 += nb * m; s2 += nb * m * m; s3 += (double)v.y;
+      }
     }
     double tot[3];
     const double part[3] = {s1, s2, s3};
@@ -155,7 +161,7 @@ __device__ __forceinline__ void bn_coef_block(const BnFinK& a, int g, float* lc,
       const float rstd = (float)(1.0 / sqrt(var + (double)a.eps)), sc = a.gamma[g][t] * rstd;
       lc[t * 4 + 0] = sc; lc[t * 4 + 1] = a.beta[g][t] - (float)mean * sc;
       lc[t * 4 + 2] = (float)mean; lc[t * 4 + 3] = rstd;
-      if (writer && a.rmean[g]) {
+      if (writer && a.rmean[g] && (!a.gate || a.gate[g] > 0.f)) {      // (a year the step skips keeps its statistics, year.py:27)
         const double unb = n > 1 ? m2 / (n - 1) : var;
         a.rmean[g][t] = (1.f - a.momentum) * a.rmean[g][t] + a.momentum * (float)mean;
         a.rvar[g][t] = (1.f - a.momentum) * a.rvar[g][t] + a.momentum * (float)unb;
@@ -1064,7 +1070,6 @@ int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, int G, hipStream_t st) {
 }
 
 // blocks [0, nbn): BatchNorm finalize (block -> (channel tile, group)); then the column-sum jobs
-struct ColsumPair { ColsumArgs cs[2]; int nblk[2]; };
 __global__ __launch_bounds__(1024) void k_bn_bwd_finalize_colsum(BnBwdFinalizeArgs a, int nbx, int nbn, ColsumPair cp) {
   __shared__ float sc[16][16];
   int bx = blockIdx.x;
@@ -1086,6 +1091,25 @@ int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const Colsu
   return 0;
 }
 
+// Apply coefficients of channel cc of group g when no finalize launch ran: the FAN_R rows of batch sums the stage-backward
+// launch left are added in a fixed order (every workgroup gets the same bits); `writer` also stores the parameter gradients.
+__device__ __forceinline__ void bn_bwd_fan_coef(const BnBwdApplyArgs& a, int g, int cc, bool writer, float& A, float& Bc, float& Cc) {
+  const double* f = a.fan + ((size_t)g * FAN_R * a.C + cc) * 2;
+  double d1 = 0, d2 = 0;
+#pragma unroll
+  for (int q = 0; q < FAN_R; ++q) { d1 += f[(size_t)q * a.C * 2]; d2 += f[(size_t)q * a.C * 2 + 1]; }
+  const double n = (double)a.B * a.H * a.W;
+  A = a.gamma[g][cc] * a.coef[(size_t)g * a.coef_gs + cc * 4 + 3];
+  Bc = a.training ? (float)(d1 / n) : 0.f;
+  Cc = a.training ? (float)(d2 / n) : 0.f;
+  if (writer) {
+    if (a.dbeta[g]) a.dbeta[g][cc] = (float)d1;
+    if (a.dgamma[g]) a.dgamma[g][cc] = (float)d2;
+    // conv bias feeds BN directly: with batch statistics its gradient is exactly zero
+    if (a.dconvbias[g]) a.dconvbias[g][cc] = a.training ? 0.f : A * (float)d1;
+  }
+}
+
 template <typename T, int YF, int DVF>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
   // per channel: dy = k0 * dv + k1 * y + k2  (folded from A*(dv - Bc - ((y-mean)*rstd)*Cc)), coefficients in LDS
@@ -1097,7 +1121,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
   const float* coef = a.coef + (size_t)g * a.coef_gs;
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
   for (int c = t; c < C; c += 256) {
-    float A = bc[c * 4 + 0], Bc = bc[c * 4 + 1], Cc = bc[c * 4 + 2], mean = coef[c * 4 + 2], rstd = coef[c * 4 + 3];
+    float A, Bc, Cc;
+    const float mean = coef[c * 4 + 2], rstd = coef[c * 4 + 3];
+    if (a.fan) bn_bwd_fan_coef(a, g, c, b == 0, A, Bc, Cc);
+    else { A = bc[c * 4 + 0]; Bc = bc[c * 4 + 1]; Cc = bc[c * 4 + 2]; }
     sk[0][c] = A;
     sk[1][c] = -A * Cc * rstd;
     sk[2][c] = A * (Cc * rstd * mean - Bc);
@@ -1141,9 +1168,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
 // Same transform, patch image assembled in LDS: pixel-major float4 reads of dv / y (fully coalesced), the tile-layout
 // image of the patch (halo included) built in LDS, then one linear 16-byte-per-lane copy to HBM.
 template <typename T, int YF, int DVF>
-__global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a, ColsumPair cp) {
   WGSTAMP(3);      // (the last launch of a step is the first stage's)
   extern __shared__ __attribute__((aligned(16))) char smem_apply[];
+  if ((int)blockIdx.x >= a.B) {
+    // extra workgroups (group row 0, slice 0 only): the batch column sums of the spatial-attention parameter gradients,
+    // which used to ride in the finalize launch
+    if (blockIdx.y != 0 || blockIdx.z != 0) return;
+    int bx = blockIdx.x - a.B;
+    float (*sc)[16] = reinterpret_cast<float (*)[16]>(smem_apply);
+    if (bx < cp.nblk[0]) colsum_scatter_block<256>(cp.cs[0], bx, sc);
+    else colsum_scatter_block<256>(cp.cs[1], bx - cp.nblk[0], sc);
+    return;
+  }
   // a workgroup = one patch x one slice of CS channels (blockIdx.z): small LDS images keep 8 workgroups on a CU
   const int b = blockIdx.x, g = blockIdx.y, t = threadIdx.x, C = a.C, CS = a.cslice, c0 = blockIdx.z * CS;
   const int W2 = a.W + 2, Q = (a.H + 2) * W2, HW = a.H * a.W, nch = CS / 16, C4 = CS / 4;
@@ -1159,7 +1196,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
   for (int c = t; c < CS; c += 256) {
     const int cc = c0 + c;
-    float A = bc[cc * 4 + 0], Bc = bc[cc * 4 + 1], Cc = bc[cc * 4 + 2], mean = coef[cc * 4 + 2], rstd = coef[cc * 4 + 3];
+    float A, Bc, Cc;
+    const float mean = coef[cc * 4 + 2], rstd = coef[cc * 4 + 3];
+    if (a.fan) bn_bwd_fan_coef(a, g, cc, b == 0, A, Bc, Cc);
+    else { A = bc[cc * 4 + 0]; Bc = bc[cc * 4 + 1]; Cc = bc[cc * 4 + 2]; }
     sk[c] = A;
     sk[CS + c] = -A * Cc * rstd;
     sk[2 * CS + c] = A * (Cc * rstd * mean - Bc);
@@ -1303,8 +1343,11 @@ bool bn_bwd_apply_uses_lds(int C, int H, int W, size_t esz) {
 }
 
 template <typename T>
-int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st) {
+int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st, const ColsumArgs* cs, int ncs) {
   BnBwdApplyArgs a = a_in;
+  ColsumPair cp = {};
+  int extra = 0;
+  for (int i = 0; i < ncs && i < 2; ++i) { cp.cs[i] = cs[i]; cp.nblk[i] = colsum_nblocks(cs[i]); extra += cp.nblk[i]; }
   a.cslice = bn_bwd_apply_cslice(a.C, a.H, a.W, sizeof(T));
   const size_t lds = bn_bwd_apply_lds_bytes(a.cslice, a.H, a.W, sizeof(T));
   if ((a.dv_compact || a.dy_compact) && lds > 48 * 1024) { dta_set_error("bn_bwd_apply: compact dv / dy need the LDS-image kernel"); return 1; }
@@ -1314,21 +1357,23 @@ int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st) {
   const bool h = a.y_fmt == FMT_F16, d16 = a.dv_fmt == FMT_BF16;
   if (d16 && !h) { dta_set_error("bn_bwd_apply: bf16 gradient maps come with half conv outputs (bf16 mode)"); return 1; }
   if (lds <= 48 * 1024) {
-    const dim3 grid(a.B, G, a.C / a.cslice);
-    if (d16) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16, FMT_BF16>), grid, dim3(256), lds, st, a);
-    else if (h) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16, FMT_F32>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F32, FMT_F32>), grid, dim3(256), lds, st, a);
+    const dim3 grid(a.B + extra, G, a.C / a.cslice);
+    if (d16) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16, FMT_BF16>), grid, dim3(256), lds, st, a, cp);
+    else if (h) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16, FMT_F32>), grid, dim3(256), lds, st, a, cp);
+    else hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F32, FMT_F32>), grid, dim3(256), lds, st, a, cp);
     DTA_CHECK_LAUNCH("k_bn_bwd_apply_lds");
     return 0;
   }
+  for (int i = 0; i < ncs; ++i)      // (the plain kernel carries no extra workgroups)
+    if (launch_colsum_scatter(cs[i], st)) return 1;
   if (d16) hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F16, FMT_BF16>), dim3(a.B, G), dim3(256), 0, st, a);
   else if (h) hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F16, FMT_F32>), dim3(a.B, G), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F32, FMT_F32>), dim3(a.B, G), dim3(256), 0, st, a);
   DTA_CHECK_LAUNCH("k_bn_bwd_apply");
   return 0;
 }
-template int launch_bn_bwd_apply<float>(const BnBwdApplyArgs&, int, hipStream_t);
-template int launch_bn_bwd_apply<bf16_t>(const BnBwdApplyArgs&, int, hipStream_t);
+template int launch_bn_bwd_apply<float>(const BnBwdApplyArgs&, int, hipStream_t, const ColsumArgs*, int);
+template int launch_bn_bwd_apply<bf16_t>(const BnBwdApplyArgs&, int, hipStream_t, const ColsumArgs*, int);
 
 // ================================================================================================
 // Lean forms of the three 11x11-network stages.
@@ -1920,6 +1965,12 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
     }
   };
   const int nb = (a.B + PPW - 1) / PPW;
+  // no finalize launch (StageBwdArgs::bn_fan_count): the BatchNorm partial sums of all the patches this workgroup walks,
+  // per channel (thread lt of a slot owns channels lt, lt + TPP, ...)
+  constexpr int NCH = (C + TPP - 1) / TPP;
+  float wgsum[NCH][2];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) { wgsum[k][0] = 0.f; wgsum[k][1] = 0.f; }
   // the 128-wide stage has no registers to spare (a loop costs it spills): one batch per workgroup, fetched at the top
   constexpr bool PF = CFG::PERSIST;
   if (PF && (int)blockIdx.x < nb) fetch(blockIdx.x);
@@ -2190,7 +2241,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
       }
     }
   }
-  if (ba.bnpart) {
+  if (ba.bnpart || ba.bn_fan_count) {
     // sum dv, sum dv xhat per channel (dv is zero for threads without an item and for dead patches)
     float bp[2][8];
 #pragma unroll
@@ -2203,11 +2254,56 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
     float* s1L = red + S1 + slot * 2 * C;
     float* const outs[2] = {red + S1, red + S1 + C};
     lean_colsum_reg<CFG, 2>(bp, red, outs, 2 * C, 1.f);
-    if (bnp)
+    if (ba.bn_fan_count) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int c = lt + k * TPP;
+        if (c < C) { wgsum[k][0] += s1L[c]; wgsum[k][1] += s1L[C + c]; }
+      }
+    } else if (bnp)
       for (int c = lt; c < C; c += TPP) *reinterpret_cast<f32x2*>(bnp + c * 2) = f32x2{s1L[c], s1L[C + c]};
   }
   if (!PF) break;       // (compile-time single trip: straight-line code)
   __syncthreads();      // the next batch reuses the vectors and the scratch
+  }
+  if (ba.bn_fan_count) {
+    // ---- this workgroup's row of batch sums -> the logical group's fan-in (kernels.h) ----
+    const int lt = t % TPP, slot = t / TPP;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = lt + k * TPP;
+      if (c < C) { red[(slot * C + c) * 2] = wgsum[k][0]; red[(slot * C + c) * 2 + 1] = wgsum[k][1]; }
+    }
+    __syncthreads();
+    if (t < C) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < PPW; ++sl) { s0 += red[(sl * C + t) * 2]; s1 += red[(sl * C + t) * 2 + 1]; }
+      fan_store2(ba.bn_fan_rows + (((size_t)g * gridDim.x + blockIdx.x) * C + t) * 2, s0, s1);
+    }
+    int* flag = reinterpret_cast<int*>(red + 2 * PPW * C);
+    if (!fan_arrive(ba.bn_fan_count, flag)) return;
+    // last arriver of its logical group: fold the group's rows in double, fixed order (row slices, then slices in order)
+    const int q = fan_group(), x0 = fan_first(q), nrows = fan_members(q);
+    constexpr int T = CFG::NT / C;
+    const int col = t % C, sl = t / C;
+    const float* rows = ba.bn_fan_rows + (size_t)g * gridDim.x * C * 2;
+    double d0 = 0, d1 = 0;
+#pragma unroll 4
+    for (int r = sl; r < nrows; r += T) {
+      const float2 v = fan_load2(rows + ((size_t)(x0 + r * FAN_R) * C + col) * 2);
+      d0 += (double)v.x; d1 += (double)v.y;
+    }
+    double* dred = reinterpret_cast<double*>(sm);          // the whole LDS plan is free now (>= 2 NT doubles, checked by the launcher)
+    dred[t] = d0; dred[CFG::NT + t] = d1;
+    __syncthreads();
+    if (t < C) {
+      double t0 = 0, t1 = 0;
+      for (int j = 0; j < T; ++j) { t0 += dred[j * C + t]; t1 += dred[CFG::NT + j * C + t]; }
+      double* o = ba.bn_fan_sums + (((size_t)g * FAN_R + q) * C + t) * 2;
+      o[0] = t0; o[1] = t1;
+    }
   }
 }
 
@@ -2230,6 +2326,7 @@ template <typename CFG>
 static int launch_stage_bwd_lean_c(const StageBwdArgs& a, int G, hipStream_t st) {
   const size_t lds = (size_t)LeanBwd<CFG>::LDS * 4;
   static_assert(LeanBwd<CFG>::LDS * 4 <= 64 * 1024, "lean stage backward: LDS plan exceeds the default 64 KiB limit");
+  static_assert(LeanBwd<CFG>::LDS * 4 >= 2 * CFG::NT * 8, "lean stage backward: the fan-in fold needs 2 NT doubles of LDS");
   constexpr int GF = CFG::YF == FMT_F16 ? FMT_BF16 : FMT_F32;
   if ((a.da && a.da_fmt != GF) || a.dv_fmt != GF) {     // gradient maps are stored like the conv outputs
     dta_set_error("k_stage_bwd_lean: gradient-map storage format does not follow the conv outputs'");

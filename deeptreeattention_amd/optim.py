@@ -155,6 +155,8 @@ class DtaAdam(torch.optim.Optimizer):
             self.state[a] = {"step": torch.zeros((), dtype=torch.float32), "exp_avg": self._alpha_m, "exp_avg_sq": self._alpha_v}
         self._flat_params = flat
         self._written = set()           # ids of parameters whose gradient was written in place since the last clear
+        self._sets = {}                 # take_inplace: caller key -> (parameters, ids, views)
+        self._loose = None
         self._clean = True              # the whole gradient buffer holds zeros
         self.layout_epoch = 0
         self._steps = 0
@@ -162,36 +164,57 @@ class DtaAdam(torch.optim.Optimizer):
         self._bank = 0
         self._zero_flags = torch.zeros(max(1, n_gated), dtype=torch.float32, device=dev)
         self._attach()
+        H._SINK_EPOCH[0] += 1
         if self.world > 1:
             for t in [self.flat_p] + ([self._alpha.data] if self._alpha is not None else []):
                 torch.distributed.broadcast(t, 0, group=process_group)      # DDP start-up: rank 0's parameters
 
     # ---- gradient views ------------------------------------------------------------------------------------
-    def _attach(self):
-        for p in self._flat_params + ([self._alpha] if self._alpha is not None else []):
+    def _attach(self, everything=True):
+        """(Re-)install the .grad views.  Parameters whose gradients arrive through a network's in-place backward are
+        re-attached lazily by take_inplace; the others (small torch modules sharing the optimizer, e.g. the site MLP of the
+        metadata model: autograd accumulates INTO a .grad that exists, but would install its own tensor over a None)
+        are checked on every zero_grad."""
+        if everything or self._loose is None or self._loose[0] != len(self._sets):
+            taken = set()
+            for params, ids, views in self._sets.values():
+                taken.update(ids)
+            allp = self._flat_params + ([self._alpha] if self._alpha is not None else [])
+            self._loose = (len(self._sets), [p for p in allp if id(p) not in taken])
+            todo = allp if everything else self._loose[1]
+        else:
+            todo = self._loose[1]
+        for p in todo:
             if p.grad is not self._gview[id(p)]:
                 p.grad = self._gview[id(p)]
 
-    def take_inplace(self, params):
-        """Called by a network's backward: may it write these parameters' gradients straight into their .grad views?
+    def take_inplace(self, key, build):
+        """Called by a network's backward: may it write its parameters' gradients straight into their .grad views?
+        key: identifies the caller's parameter set (cached here); build(): the list of those Parameters.
         Yes when each still IS this optimizer's view and none has been written since the buffer was cleared (a second
-        backward before step() -- gradient accumulation -- goes through autograd's accumulation instead)."""
-        ids = [id(p) for p in params]
-        if any(i in self._written for i in ids):
+        backward before step() -- gradient accumulation -- goes through accumulation instead)."""
+        hit = self._sets.get(key)
+        if hit is None:
+            params = build()
+            hit = self._sets[key] = (params, [id(p) for p in params], [self._gview.get(id(p)) for p in params])
+        params, ids, views = hit
+        written = self._written
+        if written and not written.isdisjoint(ids):
             return False
-        for p in params:
-            if p.grad is not self._gview.get(id(p)):
-                if p.grad is not None:
+        for p, v in zip(params, views):
+            g = p.grad
+            if g is not v:
+                if g is not None or v is None:
                     return False            # somebody installed their own gradient tensor: leave it to autograd
-                p.grad = self._gview[id(p)]          # set to None by a module.zero_grad(): same as cleared
-        self._written.update(ids)
+                p.grad = v                  # set to None by a module.zero_grad(): same as cleared
+        written.update(ids)
         self._clean = False
         return True
 
     def zero_grad(self, set_to_none=False):
         """Clears the flat gradient buffer (free when step() already did: fuse_zero_grad) and keeps the .grad views in
         place whatever `set_to_none` says -- they are what lets a backward write gradients without copies."""
-        self._attach()
+        self._attach(everything=False)
         touched = self._written or not self._clean
         if touched and not (self.fuse_zero_grad and self._cleared_by_step):
             self.flat_g.zero_()
@@ -333,9 +356,13 @@ class DtaAdam(torch.optim.Optimizer):
 
     def close(self):
         """Collective (data-parallel): release the peer exchange / RCCL communicator; every rank calls it."""
-        for p in self._flat_params:
+        for p in self._flat_params + ([self._alpha] if self._alpha is not None else []):
             if p.grad is self._gview.get(id(p)):
                 p.grad = None
+            if H._GRAD_SINKS.get(id(p)) is self._me:
+                del H._GRAD_SINKS[id(p)]
+        H._SINK_EPOCH[0] += 1
+        self._sets = {}
         if self.ex is not None:
             self._gview = {}
             self.flat_g = None

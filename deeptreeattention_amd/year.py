@@ -92,6 +92,9 @@ class _EnsembleGatedFn(torch.autograd.Function):
             raise RuntimeError("the year ensemble does not produce a gradient for its input crops: pass detached tensors")
         ctx.set_materialize_grads(False)
         B = xs[0].shape[0]
+        ctx.anchor = len(params) == 1          # anchor mode: one autograd input stands for all parameters (Hang2020._NetFn)
+        if ctx.anchor:
+            params = owner._plist()
         desc, nets, nbytes = owner._tables(xs[0].shape, params)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xs[0].device)
         xptr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
@@ -102,7 +105,10 @@ class _EnsembleGatedFn(torch.autograd.Function):
         _lib.check(L.dta_ensemble_forward_gated(C.byref(desc), n, nets, xptr, _lib.ptr(flags), _lib.ptr(ws), _lib.ptr(out),
                                                 _lib.ptr(kept), st), "dta_ensemble_forward_gated")
         ctx.owner, ctx.desc, ctx.nets, ctx.n, ctx.flags, ctx.kept = owner, desc, nets, n, flags, kept
-        ctx.save_for_backward(ws, *params)
+        if ctx.anchor:
+            ctx.save_for_backward(ws)
+        else:
+            ctx.save_for_backward(ws, *params)
         return out
 
     @staticmethod
@@ -110,15 +116,18 @@ class _EnsembleGatedFn(torch.autograd.Function):
         L = _lib.lib()
         ws, *params = ctx.saved_tensors
         owner, n = ctx.owner, ctx.n
+        if ctx.anchor:
+            params = owner._plist()
+        nret = 1 if ctx.anchor else len(params)
         if gout is None:
-            return (None, None, None) + (None,) * n + (None,) * len(params)
+            return (None, None, None) + (None,) * n + (None,) * nret
         names = Hang2020._subnet_param_names("spectral")
         dscore = gout.contiguous().float() * ctx.kept[1]        # d(mean over kept years)/d(one year's scores), on the device
         wanted = [i for i in range(len(params)) if "classifier1" not in names[i % len(names)]
                   and "classifier2" not in names[i % len(names)]]  # heads 1-2 never reach the loss: grad None
-        plist = [p for m in owner.year_models for p in m._param_list()]
-        sink = Hang2020._sink_for(plist)
-        if sink is not None and sink.take_inplace([plist[i] for i in wanted]):
+        plist = owner._plist()
+        sink = Hang2020._cached_sink(owner, plist)
+        if sink is not None and sink.take_inplace((id(owner), 4), lambda: [plist[i] for i in wanted]):
             cache = Hang2020._table_cache(owner)
             gkey = ("grads", id(sink), sink.layout_epoch)
             gstructs = cache.get(gkey)
@@ -131,7 +140,7 @@ class _EnsembleGatedFn(torch.autograd.Function):
                 cache[gkey] = gstructs
             _lib.check(L.dta_ensemble_backward_gated(C.byref(ctx.desc), n, ctx.nets, _lib.ptr(ws), _lib.ptr(dscore), gstructs,
                                                      _lib.ptr(ctx.flags), 3, _lib.current_stream_ptr()), "dta_ensemble_backward")
-            return (None, None, None) + (None,) * n + (None,) * len(params)
+            return (None, None, None) + (None,) * n + (None,) * nret
         flat = torch.zeros(sum(params[i].numel() for i in wanted), dtype=torch.float32, device=ws.device)
         grads, off = [None] * len(params), 0
         for i in wanted:
@@ -144,6 +153,16 @@ class _EnsembleGatedFn(torch.autograd.Function):
             Hang2020._fill_struct(gstructs[k], "spectral", gt, True)
         _lib.check(L.dta_ensemble_backward_gated(C.byref(ctx.desc), n, ctx.nets, _lib.ptr(ws), _lib.ptr(dscore), gstructs,
                                                  _lib.ptr(ctx.flags), 3, _lib.current_stream_ptr()), "dta_ensemble_backward")
+        if ctx.anchor:      # a second backward before step(): accumulate here, as autograd would
+            with torch.no_grad():
+                for p, g in zip(plist, grads):
+                    if g is None:
+                        continue
+                    if p.grad is None:
+                        p.grad = g.clone()
+                    else:
+                        p.grad.add_(g)
+            return (None, None, None) + (None,) * n + (None,)
         return (None, None, None) + (None,) * n + tuple(grads)
 
 
@@ -185,9 +204,6 @@ class learned_ensemble(nn.Module):
             B, bands, H, W = shape
             desc = _lib.NetDesc(B, bands, H, W, m0._classes, _lib.NET_SPECTRAL, _lib.dtype_code(m0.precision),
                                 1 if m0.training else 0, 4, Hang2020.BN_MOMENTUM, Hang2020.BN_EPS)
-            nbytes = L.dta_ensemble_workspace_bytes(C.byref(desc), n)
-            if nbytes == 0:
-                raise RuntimeError("dta_ensemble_workspace_bytes: " + L.dta_last_error().decode())
             nets = (_lib.SubnetParams * n)()
             for k in range(n):
                 tensors = {nm: params[k * len(names) + j] for j, nm in enumerate(names)}
@@ -199,8 +215,20 @@ class learned_ensemble(nn.Module):
             if len(cache) > 8:
                 for k in [k for k in cache if k != "bufs"][:4]:
                     cache.pop(k)
-            hit = cache[key] = (fp, desc, nets, nbytes)
-        return hit[1], hit[2], hit[3]
+            hit = cache[key] = (fp, desc, nets)
+        nbytes = L.dta_ensemble_workspace_bytes(C.byref(hit[1]), len(mods))
+        if nbytes == 0:
+            raise RuntimeError("dta_ensemble_workspace_bytes: " + L.dta_last_error().decode())
+        return hit[1], hit[2], nbytes
+
+    def _plist(self):
+        """All years' parameters in struct order (cached until a load_state_dict may have replaced Parameter objects)."""
+        cache = Hang2020._table_cache(self)
+        epoch = tuple(m.__dict__.get("_dta_epoch", 0) for m in self.year_models)
+        hit = cache.get("plist")
+        if hit is None or hit[0] != epoch:
+            hit = cache["plist"] = (epoch, [p for m in self.year_models for p in m._param_list()])
+        return hit[1]
 
     def _next_flags(self, dev, publish):
         """Two flag banks used alternately (each dta_year_flags call clears the other one: no clearing launch).  A
@@ -218,9 +246,9 @@ class learned_ensemble(nn.Module):
     def forward(self, images):
         if len(images) != len(self.year_models):
             raise ValueError("expected one image tensor per year ({}), got {}".format(len(self.year_models), len(images)))
-        params = [p for m in self.year_models for p in m._param_list()]
+        params = self._plist()
         train_graph = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        gated = len(self.year_models) <= _lib.MAX_YEARS and (not train_graph or Hang2020._sink_for(params) is not None)
+        gated = len(self.year_models) <= _lib.MAX_YEARS and (not train_graph or Hang2020._cached_sink(self, params) is not None)
         if gated:
             # missing years decided on the device (no host round trip): inference / validation always; training when
             # the parameters belong to an optim.DtaAdam, which steps each year under the same device-side flag
@@ -228,6 +256,9 @@ class learned_ensemble(nn.Module):
             if any(x.shape != xs[0].shape for x in xs):
                 raise ValueError("all years of a batch must have the same shape")
             flags, other = self._next_flags(xs[0].device, publish=train_graph and self.training)
+            if train_graph:      # (the parameters belong to a DtaAdam: one anchor input instead of 123 parameter inputs)
+                anchor = next(p for p in params if p.requires_grad)
+                return _EnsembleGatedFn.apply(self, flags, other, *xs, anchor)
             return _EnsembleGatedFn.apply(self, flags, other, *xs, *params)
         # stock torch optimizers: same test as the reference (year.py:27: a year is skipped iff its whole batch tensor
         # sums to zero) with all years' sums travelling to the host in ONE transfer, so that a skipped year's parameters
