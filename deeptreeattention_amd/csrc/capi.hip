@@ -53,19 +53,19 @@ inline void prof_end(int site, hipStream_t st) {
 }
 
 // Developer switches (same-box A/B runs): the environment is read once per process, not per call.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; bool no_wgrad_pair; int no_fanin; };
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; bool no_wgrad_pair; int fanin; };
 inline Switches read_switches() {
   // these change launch plans (and, for DTA_FP32_ACT, roundings): never meant for a training job's environment, so say
   // so once, loudly, when one is set
   static const char* names[] = {"DTA_NO_FUSED_INPUT", "DTA_NO_TAIL_MERGE", "DTA_BN_INKERNEL", "DTA_FP32_ACT", "DTA_NO_LEAN",
-                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER", "DTA_NO_WGRAD_PAIR", "DTA_NO_FANIN"};
+                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER", "DTA_NO_WGRAD_PAIR", "DTA_FANIN"};
   for (const char* n : names)
     if (getenv(n)) fprintf(stderr, "[libdta_hip] developer switch %s is set: kernel plans (and possibly roundings) differ from the default build\n", n);
   return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr,
           getenv("DTA_FP32_ACT") != nullptr, getenv("DTA_NO_LEAN") != nullptr,
           getenv("DTA_LEAN_MASK") ? atoi(getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, getenv("DTA_HALO_TILES") != nullptr,
           getenv("DTA_NO_WGRAD_NSPLIT") == nullptr, (getenv("DTA_PIXEL_ORDER") ? 1 : 0) | (getenv("DTA_NO_STAGGER") ? 2 : 0), getenv("DTA_NO_WGRAD_PAIR") != nullptr,
-          getenv("DTA_NO_FANIN") ? atoi(getenv("DTA_NO_FANIN")) : 0};      // bit 0: forward finalize launches stay, bit 1: backward ones
+          getenv("DTA_FANIN") ? atoi(getenv("DTA_FANIN")) : 0};      // bit 0: forward BatchNorm statistics folded in-launch, bit 1: backward batch sums
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -102,7 +102,7 @@ struct Plan {
   size_t scores_all, scores_bytes, dfeat_all, dfeat_bytes;
   // BatchNorm statistics / batch sums folded inside the producing launches (kernels.h, FanIn): arrival counters (zeroed by
   // the forward's prep launch, self re-arming), per layer FAN_R rows of forward sums and of backward sums
-  size_t fan_cnt, fan_cnt_bytes, fan_fwd[3], fan_bwd[3];
+  size_t fan_cnt, fan_cnt_bytes, fan_ctr, fan_fwd[3], fan_bwd[3];      // fan_cnt..: the cleared range (rows, then the counters at fan_ctr)
   size_t total;
 };
 
@@ -236,8 +236,12 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
     p->fan_fwd[L] = c.take((size_t)gw * FAN_R * Nconv * 3 * 8);
     p->fan_bwd[L] = c.take((size_t)G * FAN_R * CH[L] * 2 * 8);
   }
-  p->fan_cnt = c.take((size_t)2 * 3 * MAXG * FAN_R * 4);       // directly in front of the scores: one clearing job for both
+  c.take((size_t)2 * 3 * MAXG * FAN_R * 4);                    // the counters
+  // (rows + counters sit directly in front of the scores: one clearing job for all -- a logical group without
+  //  workgroups, e.g. a launch of fewer than FAN_R workgroups, leaves its row untouched, and a zero row adds nothing)
+  p->fan_cnt = p->fan_fwd[0];
   p->fan_cnt_bytes = c.off - p->fan_cnt;
+  p->fan_ctr = c.off - (((size_t)2 * 3 * MAXG * FAN_R * 4 + 255) & ~(size_t)255);
   p->scores_all = c.off;
   for (int g = 0; g < G; ++g)
     for (int L = 0; L < 3; ++L) p->scores[g][L] = c.take((size_t)B * p->classes * 4);
@@ -368,8 +372,9 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
     pa.x_compact = p.x_compact;
     pa.packs = packs; pa.spacks = spacks;
-    // the fan-in arrival counters (always) and, directly behind them, the split-K GEMM targets
-    pa.zero = at<float>(ws, p.fan_cnt); pa.zero_n4 = (p.fan_cnt_bytes + (d->heads_mask ? p.scores_bytes : 0) + 15) / 16;
+    // the split-K GEMM targets (and, for the DTA_FANIN experiment, the fan-in rows and counters directly in front of them)
+    if (switches().fanin) { pa.zero = at<float>(ws, p.fan_cnt); pa.zero_n4 = (p.fan_cnt_bytes + (d->heads_mask ? p.scores_bytes : 0) + 15) / 16; }
+    else if (d->heads_mask) { pa.zero = at<float>(ws, p.scores_all); pa.zero_n4 = (p.scores_bytes + 15) / 16; }
     if (launch_forward_prep<T>(pa, st)) return 1;
   }
   for (int L = 0; L < 3; ++L) {
@@ -395,10 +400,10 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     ca.y = at<float>(ws, p.y[L]); ca.y_fmt = p.y_fmt; ca.mwg = p.MWG[L];
     if (cat) { ca.y_gs = 0; ca.y_rs = Nconv; } else { ca.y_gs = (size_t)B * p.HWc[L] * C; ca.y_rs = C; }
     ca.stats = d->training ? at<float>(ws, p.stats[L]) : nullptr;
-    // training: the conv launch folds its BatchNorm partials itself (FAN_R rows of raw sums), the stage workgroups add
-    // those up in their prologue -- no finalize launch (DTA_NO_FANIN=1 keeps it, for A/B runs)
-    const bool fan_fwd = d->training && !(switches().no_fanin & 1);
-    if (fan_fwd) { ca.fan_count = at<unsigned>(ws, p.fan_cnt) + (size_t)L * MAXG * FAN_R; ca.fan_sums = at<double>(ws, p.fan_fwd[L]); }
+    // DTA_FANIN=1 (experiment, measured SLOWER than the finalize launch it removes: profiles/README.md, round 4): the conv
+    // launch folds its BatchNorm partials itself (FAN_R rows of raw sums), the stage workgroups add those up in their prologue
+    const bool fan_fwd = d->training && (switches().fanin & 1);
+    if (fan_fwd) { ca.fan_count = at<unsigned>(ws, p.fan_ctr) + (size_t)L * MAXG * FAN_R; ca.fan_sums = at<double>(ws, p.fan_fwd[L]); }
     ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
     prof_begin(DTA_SITE_CONV_FWD + L, st);
     if (launch_conv3x3<T>(ca, launchG, st)) return 1;
@@ -617,13 +622,13 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     sb.da_fmt = (L < 2 && lean_lvl[L] && g16) ? FMT_BF16 : FMT_F32;
     sb.dv_fmt = g16 ? FMT_BF16 : FMT_F32;      // (the generic stage kernels store it in bf16 too)
     sb.bnpart = at<float>(ws, p.bnpart[L]); sb.bnpart_gs = (size_t)B * C * 2;
-    // lean kernels: the batch sums of BatchNorm's backward are folded inside the stage launch (FAN_R rows) and the apply
-    // launch derives its coefficients from them -- no finalize launch (DTA_NO_FANIN=2 keeps it)
-    const bool fan_bwd = lean_lvl[L] && !(switches().no_fanin & 2);
+    // DTA_FANIN=2 (experiment, measured no faster than the finalize launch): the batch sums of BatchNorm's backward are
+    // folded inside the lean stage launch (FAN_R rows) and the apply launch derives its coefficients from them
+    const bool fan_bwd = lean_lvl[L] && (switches().fanin & 2);
     if (fan_bwd) {
       sb.bn_fan_rows = sb.bnpart;      // (the per-patch partials' buffer: a workgroup row needs no more than a patch row)
       sb.bn_fan_sums = at<double>(ws, p.fan_bwd[L]);
-      sb.bn_fan_count = at<unsigned>(ws, p.fan_cnt) + (size_t)(3 + L) * MAXG * FAN_R;
+      sb.bn_fan_count = at<unsigned>(ws, p.fan_ctr) + (size_t)(3 + L) * MAXG * FAN_R;
     }
     sb.vec = at<float>(ws, p.vec[L]); sb.vec_gs = (size_t)B * p.vec_ld[L]; sb.vec_ld = p.vec_ld[L];
     prof_begin(DTA_SITE_STAGE_BWD + L, st);

@@ -359,7 +359,7 @@ int dta_profile_set_stride(int stride);
 int dta_profile_collect(float* ms, int max);
 int dta_profile_collect_site(int site, float* ms, int max);
 /* Development aid: the library reads its developer environment switches (DTA_NO_FUSED_INPUT, DTA_NO_TAIL_MERGE,
- * DTA_BN_INKERNEL: same-box A/B runs of alternative launch plans) once at load time; this re-reads them. */
+ * DTA_BN_INKERNEL, DTA_FANIN: same-box A/B runs of alternative launch plans) once at load time; this re-reads them. */
 int dta_dev_reload_switches(void);
 
 #ifdef __cplusplus

@@ -113,3 +113,66 @@ def test_patch_size_limit_of_the_stage_kernels_is_an_error():
     with pytest.raises(RuntimeError, match="LDS|too|exceeds"):
         out = m(torch.rand(2, 16, 40, 40, device=dev()))
         torch.nn.functional.cross_entropy(out[-1], torch.zeros(2, dtype=torch.int64, device=dev())).backward()
+
+
+def test_ensemble_trainer_full_size_two_steps_vs_bf16_oracle():
+    """The step `bench.py --workload ensemble24` times -- EnsembleTrainer at 3 x 369 x 24x24 bf16: gated forward with the
+    missing-year decision on the device, dta_weighted_ce_scaled_dev, gated per-year Adam with device step counters; at
+    B = 130 the plan takes the fused fp32-input first conv (390 first-conv workgroups), the lean 24x24 stage kernels and
+    the paired wide-window weight gradients -- two steps, year 1 missing in the second, against the bf16-mode oracle with
+    one Adam state per year (reference year.py:24-33, multi_stage.py:277-288): loss, scores, every parameter, every
+    BatchNorm buffer and the per-year step counts."""
+    from deeptreeattention_amd.engine import EnsembleTrainer
+    from deeptreeattention_amd.year import learned_ensemble
+    Bt, lr = 130, 1e-3
+    p = O.init_params(O.learned_ensemble_spec(YEARS, BANDS, CLASSES), seed=23)
+    m = learned_ensemble(YEARS, CLASSES, {"pretrain_state_dict": None, "bands": BANDS})
+    for net in m.year_models:
+        net.precision = "bf16"
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in p.items()})
+    m = m.to(dev()).train()
+    w = (0.1 + (np.arange(CLASSES) % 5)).astype(np.float32)
+    tr = EnsembleTrainer(m, lr=lr, loss_weight=torch.from_numpy(w))
+    states = [dict() for _ in range(YEARS)]
+    y = prng.randint(77, 3, (Bt,), CLASSES)
+    yt = torch.from_numpy(y).to(dev())
+    for step in range(2):
+        imgs = [prng.uniform01(500 + step, yy, (Bt, BANDS, HW, HW)) for yy in range(YEARS)]
+        if step == 1:
+            imgs[1] = np.zeros_like(imgs[1])
+        loss = float(tr.train_step([torch.from_numpy(a).to(dev()) for a in imgs], yt))      # present=None: decided on the device
+        scores = tr.scores.cpu().numpy()
+        O.bf16_mode(True)
+        try:
+            q_scores, cache, upd = O.learned_ensemble_fwd(p, imgs, True, np.float64)
+            q_loss, dl = O.weighted_cross_entropy(q_scores, y, w)
+            g = O.learned_ensemble_bwd(p, cache, dl.astype(np.float64), np.float64)
+        finally:
+            O.bf16_mode(False)
+        assert abs(loss - q_loss) / q_loss < 2e-3, (step, loss, q_loss)
+        assert rel_l2(scores, q_scores) < (1e-3 if step == 0 else 6e-3), step
+        for yy in range(YEARS):
+            gy = {k: v for k, v in g.items() if k.startswith(f"year_models.{yy}.")}
+            if gy:
+                p = O.adam_step(p, gy, states[yy], lr=lr)      # a skipped year: no gradient, no moment decay, no step
+        p.update(upd)
+        del cache, g
+    sd = m.state_dict()
+    for yy in range(YEARS):
+        num = den = 0.0
+        for k, v in p.items():
+            if not k.startswith(f"year_models.{yy}."):
+                continue
+            if k.endswith("num_batches_tracked"):
+                assert int(sd[k]) == (1 if yy == 1 else 2), k
+                continue
+            if k.endswith("conv_layer.bias"):
+                continue   # zero gradient analytically: Adam's sign(noise) updates are not comparable
+            a, b = sd[k].double().cpu().numpy(), np.asarray(v, np.float64)
+            if O.is_buffer(k):
+                assert rel_l2(a, b) < 2e-3, k
+                continue
+            num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum())
+        print(f"config 5 trainer, year {yy}: parameters after 2 bf16 steps vs per-year oracle Adam: rel-L2 {np.sqrt(num / den):.2e}")
+        assert np.sqrt(num / den) < 3e-3, yy
+    assert tr.step_counts() == [2, 1, 2]

@@ -106,3 +106,42 @@ def test_lean_stage_kernels_for_24x24_crops_match_generic_kernels(B, monkeypatch
     for k in keep:
         if g2[k].numel() >= 1000:
             assert abs(float(g1[k].norm()) - float(g2[k].norm())) <= 1e-2 * float(g2[k].norm()), k
+
+
+@pytest.mark.parametrize("precision,B", [("fp32", 3), ("fp32", 64), ("bf16", 70), ("bf16", 530)])
+def test_in_launch_fanin_of_batchnorm_sums_matches_the_finalize_launches(precision, B, monkeypatch):
+    """DTA_FANIN=3 (a measured experiment, off by default: profiles/README.md round 4) folds BatchNorm's batch statistics
+    and backward batch sums inside the conv / stage launches (logical fan-in groups, kernels.h) instead of the finalize
+    launches.  Same sums in another order: loss, scores, gradients and BatchNorm buffers must agree -- including launches
+    of fewer workgroups than fan-in groups (B = 3)."""
+    from deeptreeattention_amd import Hang2020 as H, _lib
+    torch.manual_seed(B)
+    bands, classes = 24, 11
+    m = H.Hang2020(bands, classes, precision=precision).cuda().train()
+    x = torch.rand(B, bands, 11, 11, device="cuda")
+    y = torch.randint(0, classes, (B,), device="cuda")
+    L = _lib.lib()
+    monkeypatch.delenv("DTA_FANIN", raising=False)
+    L.dta_dev_reload_switches()
+    l1, o1, g1 = _step(m, x, y)
+    b1 = {k: v.clone() for k, v in m.named_buffers()}
+    monkeypatch.setenv("DTA_FANIN", "3")
+    L.dta_dev_reload_switches()
+    try:
+        l2, o2, g2 = _step(m, x, y)
+        b2 = {k: v.clone() for k, v in m.named_buffers()}
+    finally:
+        monkeypatch.delenv("DTA_FANIN", raising=False)
+        L.dta_dev_reload_switches()
+    tol = 1e-5 if precision == "fp32" else 2e-3
+    assert abs(l1 - l2) < tol * max(1.0, abs(l1)) and rel_l2(o2.cpu().numpy(), o1.cpu().numpy()) < tol
+    assert g1.keys() == g2.keys()
+    num = den = 0.0
+    for k in g1:
+        if k.endswith("conv_layer.bias"):
+            continue
+        a, b = g2[k].double().cpu().numpy(), g1[k].double().cpu().numpy()
+        num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum())
+    assert (num / den) ** 0.5 < (2e-5 if precision == "fp32" else 5e-3)
+    for k in b1:
+        assert rel_l2(b2[k].double().cpu().numpy(), b1[k].double().cpu().numpy()) < 1e-5, k
