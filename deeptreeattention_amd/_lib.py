@@ -200,6 +200,12 @@ def lib():
         L.dta_xchg_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.dta_xchg_set_split.restype = C.c_int
+        L.dta_xchg_set_split.argtypes = [C.c_void_p, C.c_size_t]
+        L.dta_net_backward_xchg.restype = C.c_int
+        L.dta_net_backward_xchg.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(ScoreTable), C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p, C.c_void_p,
+                                            C.c_longlong, C.c_void_p]
         L.dta_xchg_selftest_fill.restype = C.c_int
         L.dta_xchg_selftest_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.dta_xchg_status.restype = C.c_int

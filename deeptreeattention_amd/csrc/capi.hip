@@ -8,8 +8,13 @@
 
 #include "../../include/dta_hip.h"
 #include "kernels.h"
+#include "xchg_dev.h"
 
 using namespace dta;
+
+// xchg.hip (internal): arguments of the head segment's overlapped reduce-scatter for the exchange's NEXT launch / undo
+int dta_xchg_side_args(dta_xchg* x, const double* alpha_g, long long alpha_slot, dta::XchgArgs* out);
+void dta_xchg_side_cancel(dta_xchg* x);
 
 static thread_local char g_err[512] = "";
 void dta_set_error(const char* fmt, ...) {
@@ -475,7 +480,8 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
 template <typename T>
 int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grads* grads, void* ws, int L,
                      WgradReduceGroup& reduces, hipStream_t st, const void* x_tiles = nullptr,
-                     WgradArgs* defer = nullptr, const WgradArgs* partner = nullptr) {
+                     WgradArgs* defer = nullptr, const WgradArgs* partner = nullptr, dta_xchg* xchg = nullptr,
+                     const double* dalpha = nullptr, long long alpha_slot = -1) {
   const int G = p.G, B = p.B, C = CH[L];
   const bool cat = L == 0 && p.shared_x;
   const int Nconv = cat ? 32 * G : C;
@@ -497,7 +503,18 @@ int conv_wgrad_layer(const Plan& p, const dta_net_desc* d, const dta_subnet_grad
   if (defer) *defer = wa;      // (third conv of a paired plan: launched together with the second conv's)
   else {
     prof_begin(DTA_SITE_CONV_WGRAD + L, st);
-    if (partner ? launch_conv_wgrad_pair_bf16(wa, *partner, launchG, st) : launch_conv_wgrad<T>(wa, launchG, st)) return 1;
+    bool done = false;
+    if (xchg && L == 0 && !partner && sizeof(T) == 2) {
+      // data-parallel peer exchange: the head bucket's reduce-scatter rides in this launch as side workgroups
+      XchgArgs side;
+      if (dta_xchg_side_args(xchg, dalpha, alpha_slot, &side) == 0) {
+        const int rc = launch_conv_wgrad_bf16_xchg(wa, launchG, side, st);
+        if (rc == 1) return 1;
+        if (rc == 0) done = true;
+        else dta_xchg_side_cancel(xchg);      // (this plan has no combined kernel: the exchange sums the head itself)
+      }
+    }
+    if (!done && (partner ? launch_conv_wgrad_pair_bf16(wa, *partner, launchG, st) : launch_conv_wgrad<T>(wa, launchG, st))) return 1;
     prof_end(DTA_SITE_CONV_WGRAD + L, st);
   }
   WgradReduceArgs wr;
@@ -513,7 +530,7 @@ template <typename T>
 int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, void* ws,
                const float* const (*dscores)[3], const float* djoint, const dta_subnet_grads* grads, double* dalpha,
                int phases, hipStream_t st, const void* x_tiles = nullptr, float* dalpha32 = nullptr,
-               const float* gate = nullptr) {
+               const float* gate = nullptr, dta_xchg* xchg = nullptr, long long alpha_slot = -1) {
   // gate (device, per group; year ensembles): gate[g] <= 0 -> group g's score gradient is taken as zero, so every
   // gradient of that group comes out as an exact zero (its launches still run)
   const int G = p.G, B = p.B;
@@ -710,7 +727,16 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
         bool want3 = false;
         for (int g = 0; g < G; ++g) want3 |= grads[g].conv_w[2] != nullptr;
         pair_pending = want3;
-      } else if (conv_wgrad_layer<T>(p, d, grads, ws, L, reduces, st, x_tiles, nullptr, (L == 1 && pair_pending) ? &pair_conv3 : nullptr)) return 1;
+      } else {
+        if (L == 0 && xchg) {
+          // the exchange's head bucket (everything but the first conv's weights) must be COMPLETE before the launch whose
+          // side workgroups sum it over the ranks: the parameter-gradient GEMMs and the other layers' slab reductions go now
+          if (deferred.n > 0 ? launch_gemm_group_with_reduce(deferred, reduces, st) : launch_wgrad_reduce_group(reduces, st)) return 1;
+          deferred.n = 0; reduces.n = 0;
+        }
+        if (conv_wgrad_layer<T>(p, d, grads, ws, L, reduces, st, x_tiles, nullptr, (L == 1 && pair_pending) ? &pair_conv3 : nullptr,
+                                L == 0 ? xchg : nullptr, dalpha, alpha_slot)) return 1;
+      }
     }
     // ---- conv input gradient (feeds the previous stage's gated map) ----
     if (L > 0) {
@@ -937,6 +963,20 @@ int dta_net_backward_dp(const dta_net_desc* d, const dta_subnet_params* nets, co
   if (x_tiles && d->dtype != DTA_BF16) { dta_set_error("dta_net_backward_dp: tile input is bf16 mode only"); return 1; }
   if (d->dtype == DTA_BF16) return backward_t<bf16_t>(p, d, nets, alpha, workspace, dscores, djoint, grads, dalpha, phases, st, x_tiles, dalpha_f32);
   if (d->dtype == DTA_F32) return backward_t<float>(p, d, nets, alpha, workspace, dscores, djoint, grads, dalpha, phases, st, nullptr, dalpha_f32);
+  dta_set_error("unknown dtype %d", d->dtype);
+  return 1;
+}
+
+int dta_net_backward_xchg(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,
+                          void* workspace, const float* const dscores[2][3], const float* djoint,
+                          const dta_subnet_grads* grads, double* dalpha, dta_xchg* xchg, long long alpha_slot, void* stream) {
+  Plan p;
+  if (!d || !nets || !workspace || !grads || !xchg) { dta_set_error("dta_net_backward_xchg: null argument"); return 1; }
+  if (build_plan(d, &p)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (x_tiles && d->dtype != DTA_BF16) { dta_set_error("dta_net_backward_xchg: tile input is bf16 mode only"); return 1; }
+  if (d->dtype == DTA_BF16) return backward_t<bf16_t>(p, d, nets, alpha, workspace, dscores, djoint, grads, dalpha, 3, st, x_tiles, nullptr, nullptr, xchg, alpha_slot);
+  if (d->dtype == DTA_F32) return backward_t<float>(p, d, nets, alpha, workspace, dscores, djoint, grads, dalpha, 3, st, nullptr, nullptr, nullptr, xchg, alpha_slot);
   dta_set_error("unknown dtype %d", d->dtype);
   return 1;
 }

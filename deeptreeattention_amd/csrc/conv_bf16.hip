@@ -5,6 +5,7 @@
 //   k_conv_wgrad_bf16<NTT>  weight gradient (same contract as k_conv_wgrad in conv.hip)
 #include <type_traits>
 #include "kernels.h"
+#include "xchg_dev.h"
 
 namespace dta {
 
@@ -927,6 +928,17 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16_pair(WgradArgs a, Wg
   else wgrad_bf16_body<1, 2, BIG, !BIG, false>(b, blockIdx.x - na, smem);
 }
 
+// The first conv's weight gradient with the data-parallel exchange's head segment riding along: blocks [0, nmain) are the
+// weight gradient (one 512-thread workgroup per CU, 240 of the 256 CUs for Hang2020), the XCHG_SIDE_WGS blocks behind
+// them pull and sum this rank's shard of every rank's head bucket -- 76 % of the gradient bytes, complete before this
+// launch -- through peer memory while the matrix cores work (xchg_dev.h; reference train.py:89-98: DDP overlaps the
+// gradient all-reduce with the backward).  The main workgroups never wait for the side ones.
+__global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16_xchg(WgradArgs a, XchgArgs side, int nmain) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((int)blockIdx.x < nmain) { wgrad_bf16_body<2, 2, false, false, true>(a, blockIdx.x, smem); return; }
+  xchg_side_job(side, (int)blockIdx.x - nmain, reinterpret_cast<int*>(smem));
+}
+
 // kernel variant a launch resolves to
 enum { WV_PLAIN = 0, WV_BIGW = 1, WV_STACK = 2, WV_D2 = 3 };
 
@@ -997,6 +1009,25 @@ static int resolve_wgrad_bf16(const WgradArgs& a, int G, int cgroups, WgradArgs&
   else if (a2.wr <= 192 && a2.dbuf && CT == 2 && NTT == 2 && !no_d2) variant = WV_D2;
   else if (a2.wr <= 192) variant = WV_PLAIN;
   else variant = WV_BIGW;
+  return 0;
+}
+
+// Weight gradient of the first conv + the exchange's side job in one launch.  Returns 0 = launched, 2 = this plan does not
+// resolve to the program the combined kernel is built from (the caller launches the plain weight gradient and lets the
+// exchange sum its head segment itself), 1 = error.
+int launch_conv_wgrad_bf16_xchg(const WgradArgs& a, int G, const XchgArgs& side, hipStream_t st) {
+  if (a.N != 64 || (a.Cpad <= 32)) return 2;
+  const int cpw = wgrad_cpw(a.N), cgroups = (a.Cpad + cpw - 1) / cpw;
+  WgradArgs a2;
+  size_t lds;
+  int variant, total;
+  if (resolve_wgrad_bf16<2, 2>(a, G, cgroups, a2, lds, variant, total)) return 1;
+  if (variant != WV_D2) return 2;
+  static DevOnce attr_once;
+  if (attr_once.first()) hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_xchg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int nmain = 8 * ((total + 7) / 8);
+  hipLaunchKernelGGL(k_conv_wgrad_bf16_xchg, dim3(nmain + XCHG_SIDE_WGS), dim3(512), lds, st, a2, side, nmain);
+  DTA_CHECK_LAUNCH("k_conv_wgrad_bf16_xchg");
   return 0;
 }
 

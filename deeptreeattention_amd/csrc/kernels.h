@@ -73,6 +73,10 @@ int wgrad_reduce_nblocks(const WgradReduceArgs& a);
 // bf16: the weight gradients of the second and third conv in ONE launch when both resolve to the pair kernel's programs
 // (conv_bf16.hip); otherwise third then second, each in its own launch
 int launch_conv_wgrad_pair_bf16(const WgradArgs& conv2, const WgradArgs& conv3, int G, hipStream_t st);
+// the first conv's weight gradient with the peer exchange's head-segment reduce-scatter as side workgroups (conv_bf16.hip,
+// xchg_dev.h): 0 launched, 2 not applicable to this plan, 1 error
+struct XchgArgs;
+int launch_conv_wgrad_bf16_xchg(const WgradArgs& a, int G, const XchgArgs& side, hipStream_t st);
 // plan-time test (geometry fields only: H, W, Q, N, Cpad, ngroups, x/y_compact): 0 = no pairing, 1 = plain + stacked
 // windows (11x11 networks), 2 = both wide / multi-band windows (24x24 crops)
 int wgrad_pair_plan_bf16(const WgradArgs& conv2, const WgradArgs& conv3);

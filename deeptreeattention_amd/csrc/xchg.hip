@@ -18,6 +18,11 @@
 //      N-1 links of the mesh at the same time) and applies Adam to the local parameters / moments (all ranks hold the
 //      full optimizer state, as under DDP); the gradient elements are cleared (or replaced by the sum: keep_grads).
 //      done[s][j] also says that rank s has finished reading this rank's gradients of that slice, so clearing is safe.
+// Overlap with the backward (dta_net_backward_xchg): the buffer is cut into a HEAD segment (everything but the first conv's
+// weights, 76 % of the bytes, complete before that layer's weight gradient starts) and a TAIL segment, each with its own
+// shards.  The head's phase A runs as 16 side workgroups of the weight-gradient launch itself (xchg_dev.h: own ready /
+// done flags), i.e. on the CUs that launch leaves idle and for the ~70 us it takes; this launch then finds the head
+// summed, sums only the tail and runs phase B over both.  Without that (one segment, fp32 mode) it does everything.
 // Only flags are ever written remotely, and only into uncached memory; bulk data is pulled with system-scope loads
 // (remote lines are never served from a stale local L2 line).  Every wait is bounded (wall clock, default 30 min like a
 // collective library's watchdog): a missing peer ends the kernel with a status word in pinned host memory instead of
@@ -29,146 +34,28 @@
 #include <string.h>
 
 #include "../../include/dta_hip.h"
-#include "common.h"
+#include "xchg_dev.h"
 
 namespace dta {
 
-constexpr int XCHG_MAX_WORLD = 8;
-constexpr int XCHG_MAX_WGS = 256;
-constexpr int XCHG_SIG_BYTES = 16384;    // signal page (XchgSig), then the staging area
-constexpr int XCHG_THREADS = 256;
-
-struct XchgSig {
-  unsigned ready[16];                               // ready[s]: rank s's gradients of this epoch are complete
-  unsigned aborted;                                 // sticky: a wait of an earlier launch of THIS rank timed out -- later launches return at once
-  unsigned pad[47];
-  unsigned done[XCHG_MAX_WORLD][XCHG_MAX_WGS];      // done[s][j]: workgroup j of rank s has published its sums
-};
-static_assert(sizeof(XchgSig) <= XCHG_SIG_BYTES, "signal page overflow");
-
-struct XchgArgs {
-  const float* grads[XCHG_MAX_WORLD];    // every rank's gradient buffer (own entry: the local one)
-  char* sig[XCHG_MAX_WORLD];             // every rank's signal page + staging area
-  int rank, world;
-  unsigned epoch;
-  size_t n, shard;                       // floats; shard is a multiple of 4
-  long long timeout_ticks;               // wall_clock64 ticks (100 MHz)
-  int* status;                           // pinned host word: 0 ok, else (phase << 8) | peer
-  int mode;                              // 0: all-reduce only (g := sum), 1: fused Adam
-  int zero_grad;
-  float* p; float* g; float* m; float* v;
-  double* alpha_p; double* alpha_m; double* alpha_v; double* alpha_g;
-  long long alpha_slot;                  // index into g of alpha's fp32 exchange slot, or -1
-  float lr, beta1, beta2, eps, bc1, bc2, grad_scale;
-};
-
-__device__ __forceinline__ unsigned ld_sys32(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ void st_sys32(unsigned* p, unsigned v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// 16-byte system-scope accesses (sc0 sc1: never served from / parked in a non-coherent cache line) as raw buffer
-// operations: the compiler tracks their completion like any other load (hand-written global_load asm is not tracked, and
-// a register copy the compiler places before a hand-placed s_waitcnt reads the destination too early).
-typedef __amdgpu_buffer_rsrc_t xrsrc_t;
-__device__ __forceinline__ xrsrc_t xchg_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
-}
-constexpr int XCHG_SYS = 1 | 16;      // cache policy bits: sc0 | sc1 = system scope
-__device__ __forceinline__ f32x4 ld_sys128(xrsrc_t r, size_t float_index) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(float_index * 4), 0, XCHG_SYS));
-}
-__device__ __forceinline__ void st_sys128(xrsrc_t r, size_t float_index, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (unsigned)(float_index * 4), 0, XCHG_SYS);
-}
-
-// spin on a flag of the local page until it reaches `epoch` (wrap-safe) or the budget runs out
-__device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned epoch, long long budget) {
-  const long long t0 = wall_clock64();
-  while ((int)(ld_sys32(flag) - epoch) < 0) {
-    if (wall_clock64() - t0 > budget) return false;
-    __builtin_amdgcn_s_sleep(2);
-  }
-  return true;
-}
-
-__global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
-  __shared__ int s_abort;
-  const int t = threadIdx.x, j = blockIdx.x;
-  XchgSig* mine = (XchgSig*)a.sig[a.rank];
-  if (t == 0) s_abort = (a.world > 1 && ld_sys32(&mine->aborted) != 0) ? 1 : 0;     // (one rank: nothing ever waits)
-  __syncthreads();
-  if (s_abort) return;                       // an earlier step of this rank timed out: nothing may be applied any more
-  const long long tk0 = wall_clock64();
-  // alpha's float64 gradient enters the exchange as one float32 slot of the gradient buffer: converted here, once, from
-  // the (order-independently accumulated) double, so the slot does not depend on the order of any float atomics
-  if (j == 0 && t == 0 && a.alpha_slot >= 0 && a.alpha_g) {
-    st_sys32((unsigned*)(a.g + a.alpha_slot), __float_as_uint((float)a.alpha_g[0]));
-    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
-  }
-  __syncthreads();
-  // 0. announce (one workgroup), 1. wait for every rank's gradients
-  if (j == 0 && t < a.world) st_sys32(&((XchgSig*)a.sig[t])->ready[a.rank], a.epoch);
-  if (t < a.world && !wait_flag(&mine->ready[t], a.epoch, a.timeout_ticks)) {
-    s_abort = 1;
-    a.status[0] = (1 << 8) | t;
-    st_sys32(&mine->aborted, 1u);
-  }
-  __syncthreads();
-  if (s_abort) return;
-  if (t < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // drop what this CU / L2 still holds of the peers' buffers
-  __syncthreads();
-  const long long tk1 = wall_clock64();
-
-  // Workgroup j owns the same relative slice {j*256 + t + k*G*256} (in 16-byte quads) of EVERY shard, in both phases:
-  // its phase-B reads of rank s's sums depend only on workgroup j of rank s, so the "sums published" flags are per
-  // (rank, workgroup) and no rank-wide counter or last-workgroup election sits on the critical path.
-  const size_t nq = a.n / 4, shard_q = a.shard / 4, stride = (size_t)gridDim.x * XCHG_THREADS;
-  auto len_q = [&](int s) -> size_t {
-    const size_t lo = (size_t)s * shard_q;
-    return lo >= nq ? 0 : (nq - lo < shard_q ? nq - lo : shard_q);
-  };
-  // A. my shard: sum over ranks in rank order -> staging (one 16-byte load per rank in flight per thread).
-  //    A single rank has nothing to sum or publish: phase B reads its gradient buffer directly.
-  if (a.world > 1) {
-    const size_t lo = (size_t)a.rank * a.shard, mylen = len_q(a.rank);
-    const xrsrc_t stage = xchg_rsrc(a.sig[a.rank] + XCHG_SIG_BYTES);
-    for (size_t q = (size_t)j * XCHG_THREADS + t; q < mylen; q += stride) {
-      f32x4 part[XCHG_MAX_WORLD];
-#pragma unroll
-      for (int s = 0; s < XCHG_MAX_WORLD; ++s)
-        if (s < a.world) part[s] = ld_sys128(xchg_rsrc(a.grads[s]), lo + 4 * q);
-      f32x4 acc = part[0];
-#pragma unroll
-      for (int s = 1; s < XCHG_MAX_WORLD; ++s)
-        if (s < a.world) acc += part[s];
-      st_sys128(stage, 4 * q, acc);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's staging stores have reached memory
-    __syncthreads();
-    if (t < a.world) st_sys32(&((XchgSig*)a.sig[t])->done[a.rank][j], a.epoch);
-  }
-  // B. every rank's workgroup j has published its sums (which also says: it has finished reading this rank's gradients
-  //    of that slice, so the slice may be cleared)
-  if (a.world > 1 && t < a.world && !wait_flag(&mine->done[t][j], a.epoch, a.timeout_ticks)) {
-    s_abort = 1;
-    a.status[0] = (2 << 8) | t;
-    st_sys32(&mine->aborted, 1u);
-  }
-  __syncthreads();
-  if (s_abort) return;
+// Phase B for one segment: pull every rank's summed shard (one load per rank in flight, starting at rank r+1 so that the N
+// ranks use the N-1 links of the mesh at the same time) and apply Adam to the local parameters / moments; the gradient
+// elements are cleared (or replaced by the sum: keep_grads).  A single rank reads its own gradient buffer.
+__device__ __forceinline__ void xchg_gather_adam(const XchgArgs& a, size_t seg_lo, size_t seg_len, size_t shard, size_t stage_off,
+                                                 int j, int nj) {
+  const size_t seg_q = seg_len / 4, shard_q = shard / 4, stride = (size_t)nj * XCHG_THREADS;
   const float ss = a.lr / a.bc1, rbc2 = rsqrtf(a.bc2);
-  for (size_t q = (size_t)j * XCHG_THREADS + t; q < shard_q; q += stride) {
-    // one load per shard in flight; rank r starts with shard r+1, so the N ranks pull over N different links at a time
+  for (size_t q = (size_t)j * XCHG_THREADS + threadIdx.x; q < shard_q; q += stride) {
     f32x4 gs[XCHG_MAX_WORLD];
 #pragma unroll
     for (int u = 0; u < XCHG_MAX_WORLD; ++u) {
       if (u < a.world) {
         int s = a.rank + 1 + u;
         if (s >= a.world) s -= a.world;
-        if (q < len_q(s))
-          gs[u] = ld_sys128(xchg_rsrc(a.world > 1 ? (const void*)(a.sig[s] + XCHG_SIG_BYTES) : (const void*)a.grads[0]), 4 * q);
+        if (q < xchg_len_q(seg_q, shard_q, s)) {
+          if (a.world > 1) gs[u] = ld_sys128(xchg_rsrc(a.sig[s] + XCHG_SIG_BYTES), stage_off + 4 * q);
+          else gs[u] = ld_sys128(xchg_rsrc(a.grads[0]), seg_lo + 4 * q);
+        }
       }
     }
 #pragma unroll
@@ -176,8 +63,8 @@ __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
       if (u >= a.world) continue;
       int s = a.rank + 1 + u;
       if (s >= a.world) s -= a.world;
-      if (q >= len_q(s)) continue;
-      const size_t i = (size_t)s * a.shard + 4 * q;
+      if (q >= xchg_len_q(seg_q, shard_q, s)) continue;
+      const size_t i = seg_lo + (size_t)s * shard + 4 * q;
       if (a.mode == 1) {
         const f32x4 mo = __builtin_nontemporal_load((const f32x4*)(a.m + i));
         const f32x4 vo = __builtin_nontemporal_load((const f32x4*)(a.v + i));
@@ -206,6 +93,70 @@ __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
       *(f32x4*)(a.g + i) = (a.mode == 1 && a.zero_grad) ? z : gs[u];
     }
   }
+}
+
+__global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
+  __shared__ int s_abort;
+  const int t = threadIdx.x, j = blockIdx.x, nj = gridDim.x;
+  XchgSig* mine = (XchgSig*)a.sig[a.rank];
+  if (t == 0) s_abort = (a.world > 1 && ld_sys32(&mine->aborted) != 0) ? 1 : 0;     // (one rank: nothing ever waits)
+  __syncthreads();
+  if (s_abort) return;                       // an earlier step of this rank timed out: nothing may be applied any more
+  const long long tk0 = wall_clock64();
+  // alpha's float64 gradient enters the exchange as one float32 slot of the gradient buffer: converted here, once, from
+  // the (order-independently accumulated) double, so the slot does not depend on the order of any float atomics
+  // (a head segment that was summed ahead of this launch carried it already: xchg_side_job)
+  if (j == 0 && t == 0 && a.alpha_slot >= 0 && a.alpha_g && !a.head_presummed) {
+    st_sys32((unsigned*)(a.g + a.alpha_slot), __float_as_uint((float)a.alpha_g[0]));
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+  }
+  __syncthreads();
+  // 0. announce (one workgroup), 1. wait for every rank's gradients
+  if (j == 0 && t < a.world) st_sys32(&((XchgSig*)a.sig[t])->ready[a.rank], a.epoch);
+  if (t < a.world && !wait_flag(&mine->ready[t], a.epoch, a.timeout_ticks)) {
+    s_abort = 1;
+    a.status[0] = (1 << 8) | t;
+    st_sys32(&mine->aborted, 1u);
+  }
+  __syncthreads();
+  if (s_abort) return;
+  if (t < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // drop what this CU / L2 still holds of the peers' buffers
+  __syncthreads();
+  const long long tk1 = wall_clock64();
+
+  // Workgroup j owns the same relative slice {j*256 + t + k*G*256} (in 16-byte quads) of EVERY shard, in both phases:
+  // its phase-B reads of rank s's sums depend only on workgroup j of rank s, so the "sums published" flags are per
+  // (rank, workgroup) and no rank-wide counter or last-workgroup election sits on the critical path.  (A head segment
+  // summed ahead by the side workgroups of the weight-gradient launch has its own flags: done_head[s][*].)
+  // A. my shards: sum over ranks in rank order -> staging.  A single rank has nothing to sum or publish.
+  if (a.world > 1) {
+    if (a.split > 0 && !a.head_presummed) xchg_reduce_scatter(a, 0, a.split, a.shard_h, 0, j, nj);
+    xchg_reduce_scatter(a, a.split, a.n - a.split, a.shard_t, a.shard_h, j, nj);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's staging stores have reached memory
+    __syncthreads();
+    if (t < a.world) st_sys32(&((XchgSig*)a.sig[t])->done[a.rank][j], a.epoch);
+  }
+  // B. every rank's workgroup j has published its sums (which also says: it has finished reading this rank's gradients
+  //    of that slice, so the slice may be cleared); a head summed ahead: all of every rank's side workgroups have
+  if (a.world > 1) {
+    if (t < a.world && !wait_flag(&mine->done[t][j], a.epoch, a.timeout_ticks)) {
+      s_abort = 1;
+      a.status[0] = (2 << 8) | t;
+      st_sys32(&mine->aborted, 1u);
+    }
+    if (a.head_presummed && t >= 64 && t < 64 + a.world * XCHG_SIDE_WGS) {
+      const int s = (t - 64) / XCHG_SIDE_WGS, k = (t - 64) % XCHG_SIDE_WGS;
+      if (!wait_flag(&mine->done_head[s][k], a.epoch, a.timeout_ticks)) {
+        s_abort = 1;
+        a.status[0] = (4 << 8) | s;
+        st_sys32(&mine->aborted, 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (s_abort) return;
+  if (a.split > 0) xchg_gather_adam(a, 0, a.split, a.shard_h, 0, j, nj);
+  xchg_gather_adam(a, a.split, a.n - a.split, a.shard_t, a.shard_h, j, nj);
   // workgroup 0's view of the launch, in 10 ns ticks: [2] waiting for the ranks to arrive, [3] the exchange proper
   if (j == 0 && t == 0) { a.status[2] = (int)(tk1 - tk0); a.status[3] = (int)(wall_clock64() - tk1); }
 }
@@ -225,6 +176,8 @@ using namespace dta;
 struct dta_xchg {
   int rank, world, device;
   size_t n, n_pad, shard;
+  size_t split, shard_h, shard_t;      // segments (dta_xchg_set_split): head [0, split), tail [split, n_pad)
+  unsigned side_epoch;                 // epoch whose head segment the side workgroups of a weight-gradient launch summed
   float* grads;
   char* sig;
   size_t sig_bytes;
@@ -250,7 +203,8 @@ int dta_xchg_create(int rank, int world, size_t n_floats, dta_xchg** out) {
   x->rank = rank; x->world = world; x->n = n_floats;
   x->n_pad = (n_floats + 3) & ~(size_t)3;
   x->shard = (((x->n_pad + world - 1) / world) + 3) & ~(size_t)3;
-  x->sig_bytes = XCHG_SIG_BYTES + x->shard * sizeof(float);
+  x->sig_bytes = XCHG_SIG_BYTES + (x->shard + 16) * sizeof(float);      // (+16: two segments round their shards up separately)
+  x->split = 0; x->shard_h = 0; x->shard_t = x->shard;
   x->timeout_s = 1800.0;    // like a collective library's watchdog: rank skew of seconds (validation or a checkpoint on one rank) is routine
   x->max_wgs = 256;
   const char* why = nullptr;
@@ -311,18 +265,35 @@ int dta_xchg_connect(dta_xchg* x, const void* all_handles) {
 }
 
 void dta_xchg_set_timeout(dta_xchg* x, double seconds) { if (x && seconds > 0) x->timeout_s = seconds; }
+int dta_xchg_set_split(dta_xchg* x, size_t split_floats) {
+  if (!x || x->epoch != 0 || (split_floats & 3) || split_floats >= x->n_pad) { dta_set_error("dta_xchg_set_split: before the first step, a multiple of 4 floats inside the buffer"); return 1; }
+  x->split = split_floats;
+  if (split_floats == 0) { x->shard_h = 0; x->shard_t = x->shard; return 0; }
+  const size_t w = (size_t)x->world;
+  x->shard_h = (((split_floats + w - 1) / w) + 3) & ~(size_t)3;
+  x->shard_t = ((((x->n_pad - split_floats) + w - 1) / w) + 3) & ~(size_t)3;
+  if (x->shard_h + x->shard_t > x->shard + 16) { dta_set_error("dta_xchg_set_split: staging area too small"); return 1; }
+  return 0;
+}
 void dta_xchg_set_max_workgroups(dta_xchg* x, int wgs) { if (x && wgs > 0 && x->epoch == 0) x->max_wgs = wgs < XCHG_MAX_WGS ? wgs : XCHG_MAX_WGS; }
 
-static int xchg_launch(dta_xchg* x, XchgArgs& a, void* stream) {
-  if (!x->connected) { dta_set_error("dta_xchg: not connected (dta_xchg_connect)"); return 1; }
+static void xchg_fill_common(dta_xchg* x, XchgArgs& a) {
   for (int s = 0; s < x->world; ++s) { a.grads[s] = x->peer_grads[s]; a.sig[s] = x->peer_sig[s]; }
-  a.rank = x->rank; a.world = x->world; a.n = x->n_pad; a.shard = x->shard;
-  a.epoch = ++x->epoch;
+  a.rank = x->rank; a.world = x->world; a.n = x->n_pad;
+  a.split = x->split; a.shard_h = x->shard_h; a.shard_t = x->shard_t;
   a.timeout_ticks = (long long)(x->timeout_s * 1e8);
   a.status = x->status_dev;
   a.g = x->grads;
-  // one workgroup per CU at most, never more than there are element pairs per shard
-  size_t wgs = (x->shard / 4 + XCHG_THREADS - 1) / XCHG_THREADS;
+}
+
+static int xchg_launch(dta_xchg* x, XchgArgs& a, void* stream) {
+  if (!x->connected) { dta_set_error("dta_xchg: not connected (dta_xchg_connect)"); return 1; }
+  xchg_fill_common(x, a);
+  a.epoch = ++x->epoch;
+  a.head_presummed = (x->world > 1 && x->split > 0 && x->side_epoch == a.epoch) ? 1 : 0;
+  // one workgroup per CU at most, never more than there are element quads per shard
+  const size_t big = x->shard_h > x->shard_t ? x->shard_h : x->shard_t;
+  size_t wgs = (big / 4 + XCHG_THREADS - 1) / XCHG_THREADS;
   if (wgs > (size_t)x->max_wgs) wgs = x->max_wgs;
   if (wgs > XCHG_MAX_WGS) wgs = XCHG_MAX_WGS;
   if (wgs < 1) wgs = 1;
@@ -330,6 +301,22 @@ static int xchg_launch(dta_xchg* x, XchgArgs& a, void* stream) {
   DTA_CHECK_LAUNCH("k_xchg_step");
   return 0;
 }
+
+// internal (capi.hip): arguments of the head segment's overlapped reduce-scatter for THE NEXT exchange launch of `x` (its
+// epoch), to be run by the side workgroups of the first conv's weight-gradient launch.  Returns 1 when the exchange has no
+// head segment to overlap (one rank, or no split set).
+int dta_xchg_side_args(dta_xchg* x, const double* alpha_g, long long alpha_slot, dta::XchgArgs* out) {
+  if (!x || !x->connected || x->world < 2 || x->split == 0) return 1;
+  memset(out, 0, sizeof(*out));
+  xchg_fill_common(x, *out);
+  out->epoch = x->epoch + 1;
+  out->alpha_g = (double*)alpha_g;
+  out->alpha_slot = alpha_g ? alpha_slot : -1;
+  x->side_epoch = out->epoch;
+  return 0;
+}
+
+void dta_xchg_side_cancel(dta_xchg* x) { if (x) x->side_epoch = 0; }
 
 int dta_xchg_selftest_fill(dta_xchg* x, int step, void* stream) {
   if (!x) { dta_set_error("dta_xchg_selftest_fill: null exchange"); return 1; }

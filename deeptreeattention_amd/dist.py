@@ -135,7 +135,7 @@ class PeerExchange:
     trainer points its gradient views into it.  Handles travel once, at start-up, through torch.distributed's object
     collective of `group` (any backend)."""
 
-    def __init__(self, n_floats, group=None, timeout_s=None, max_workgroups=None):
+    def __init__(self, n_floats, group=None, timeout_s=None, max_workgroups=None, split=0):
         """max_workgroups: grid bound of the exchange launch (default 256 = one per CU).  Processes that SHARE a GPU (the
         multi-rank tests on a one-GPU box) must keep world x max_workgroups within what stays co-resident, since every
         rank's launch waits inside the kernel for the others."""
@@ -156,6 +156,11 @@ class PeerExchange:
             L.dta_xchg_set_timeout(h, float(timeout_s))
         if max_workgroups:
             L.dta_xchg_set_max_workgroups(h, int(max_workgroups))
+        # split > 0: the buffer is exchanged as head [0, split) + tail; the head's sum over the ranks can then ride in the
+        # first conv's weight-gradient launch (dta_net_backward_xchg): the exchange overlaps with the backward
+        self.split = int(split)
+        if self.split:
+            _lib.check(L.dta_xchg_set_split(h, self.split), "dta_xchg_set_split")
         self.capacity = int(L.dta_xchg_grad_capacity(h))
         mine = C.create_string_buffer(_lib.XCHG_HANDLE_BYTES)
         _lib.check(L.dta_xchg_export(h, mine), "dta_xchg_export")

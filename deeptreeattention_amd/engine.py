@@ -87,7 +87,7 @@ class FusedTrainer:
         self.exchange = None           # "peer" / "rccl" / "torch" when this trainer exchanges gradients itself
         if self.comm and storage is None:
             self.exchange = choose_exchange(exchange, process_group) if self.world > 1 else (exchange or "torch")
-        self.overlap = overlap_comm and self.comm and self.exchange in (None, "torch")
+        self.overlap = overlap_comm and self.comm and (self.exchange in (None, "torch") or (self.exchange == "peer" and self.world > 1))
         self.hang = model._net_code == _lib.NET_HANG2020
         self.single_score = model._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
         self.three_head = bool(three_head_loss)
@@ -121,8 +121,11 @@ class FusedTrainer:
         if storage is None:
             self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
             if self.exchange == "peer":
-                # the gradient buffer is the exchange's: library-owned device memory every peer has mapped
-                self.ex = PeerExchange(n, process_group, **(exchange_opts or {}))
+                # the gradient buffer is the exchange's: library-owned device memory every peer has mapped; with
+                # overlap_comm its head segment [everything but the first conv's weights] is summed over the ranks by side
+                # workgroups of the first conv's weight-gradient launch (dta_net_backward_xchg)
+                self.ex = PeerExchange(n, process_group, split=(self.split if (overlap_comm and self.world > 1) else 0),
+                                       **(exchange_opts or {}))
                 assert self.ex.capacity == n
                 self.flat_g = self.ex.grad
             else:
@@ -409,7 +412,14 @@ class FusedTrainer:
             _lib.check(L.dta_net_backward_dp(d, self.nets, alpha, tiles, _lib.ptr(self._ws), C.byref(table), djoint,
                                              self.grads, dalpha, slot, phases, st), "dta_net_backward_dp")
         ag, slot_t = None, None        # (GradSync's copy-in / copy-out of alpha is for callers without the slot kernels)
-        if not self.comm or self.ex is not None:
+        if self.ex is not None and self.ex.split:
+            # peer exchange, overlapped: the head bucket's sum over the ranks rides in the first conv's weight-gradient
+            # launch (side workgroups); the optimizer launch that follows sums only the tail
+            tiles = None if self._tiles is None else _lib.ptr(self._tiles)
+            _lib.check(L.dta_net_backward_xchg(d, self.nets, alpha, tiles, _lib.ptr(self._ws), C.byref(table), djoint,
+                                               self.grads, dalpha, self.ex._h, self.alpha_slot_off if self.alpha_on_graph else -1,
+                                               st), "dta_net_backward_xchg")
+        elif not self.comm or self.ex is not None:
             run(3)                     # peer exchange: the sum over ranks happens inside the optimizer launch
         elif self.overlap:
             # phase 1: everything but the first conv's weight gradient; its all-reduce (backend stream) runs while

@@ -120,6 +120,21 @@ int dta_net_backward_dp(const dta_net_desc* d, const dta_subnet_params* nets, co
                         void* workspace, const float* const dscores[2][3], const float* djoint,
                         const dta_subnet_grads* grads, double* dalpha, float* dalpha_f32, int phases, void* stream);
 
+/* dta_net_backward_dp for a caller that exchanges gradients through a peer exchange object (dta_xchg_* below) whose
+ * buffer has a head / tail split (dta_xchg_set_split): the whole backward in one call, ordered so that the exchange's HEAD
+ * segment -- every gradient except the first conv's weights, 76 % of the bytes -- is complete before the first conv's
+ * weight-gradient launch, whose spare workgroups (the 16 CUs that launch leaves idle) then sum this rank's shard of the
+ * head over the ranks through peer memory WHILE the matrix cores compute the last gradient (reference train.py:89-98:
+ * DDP overlaps the gradient all-reduce with the backward).  The dta_xchg_adam_step / dta_xchg_allreduce that follows on
+ * the same stream finds the head summed and only has the tail left.  grads must point into dta_xchg_grad_buffer(xchg);
+ * alpha_slot: index of alpha's float32 exchange slot inside the head (or -1).  When the plan has no combined kernel
+ * (fp32 mode, other shapes) this is exactly dta_net_backward_dp(phases = 3) and the exchange sums both segments itself. */
+struct dta_xchg;
+int dta_net_backward_xchg(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,
+                          void* workspace, const float* const dscores[2][3], const float* djoint,
+                          const dta_subnet_grads* grads, double* dalpha, struct dta_xchg* xchg, long long alpha_slot,
+                          void* stream);
+
 /* Loss head of the network whose forward just ran on `workspace`: the Hang2020 blend (Hang2020.py:260-261; the forward
  * was built with DTA_SKIP_BLEND), F.cross_entropy(scores, labels, weight) (src/main.py:78), d(loss)/d(scores) and the
  * scalar loss in ONE launch (dta_net_forward + dta_weighted_ce take three for the same).
@@ -275,6 +290,10 @@ int dta_xchg_connect(dta_xchg* x, const void* all_handles);
  * A wait that expires is FATAL for the exchange: the launch writes the status word and returns without applying anything,
  * and every later launch of this exchange returns at once (sticky), so a replica cannot train on past a failed exchange. */
 void dta_xchg_set_timeout(dta_xchg* x, double seconds);
+/* Exchange the buffer as two segments, head [0, split_floats) and tail [split_floats, n): the head can then be summed
+ * ahead of the exchange launch by dta_net_backward_xchg.  Only before the first step; every rank sets the same split
+ * (a multiple of 4 floats; 0 = one segment, the default). */
+int dta_xchg_set_split(dta_xchg* x, size_t split_floats);
 /* Grid bound of the exchange launch (default 256, one workgroup per CU); only before the first step.  Ranks that share
  * one GPU (tests) must keep world x workgroups co-resident: every rank's launch waits in-kernel for the others. */
 void dta_xchg_set_max_workgroups(dta_xchg* x, int workgroups);

@@ -50,9 +50,16 @@ def _worker(rank, world, port, B, exchange, out):
     m = H.Hang2020(BANDS, CLASSES, precision="bf16")
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in p.items()})
     m = m.to(dev).train()
+    overlap = exchange != "peer0"          # "peer0": the peer exchange WITHOUT the overlapped head segment (one launch does all)
+    exchange = "peer" if exchange == "peer0" else exchange
     tr = FusedTrainer(m, lr=1e-3, loss_weight=torch.from_numpy(_weights()), keep_grads=True, exchange=exchange,
+                      overlap_comm=overlap,
                       exchange_opts={"max_workgroups": 32, "timeout_s": 30.0} if exchange == "peer" else None)
     assert tr.exchange == exchange and tr.world == world
+    if exchange == "peer" and overlap:      # the head bucket's sum over the ranks rides in the first conv's weight-gradient launch
+        assert tr.overlap and tr.ex.split == tr.split and tr.split % 4 == 0
+    elif exchange == "peer":
+        assert not tr.overlap and tr.ex.split == 0
     x, y = _batch(rank, B)
     loss = tr.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
     torch.cuda.synchronize()
@@ -70,8 +77,8 @@ def _worker(rank, world, port, B, exchange, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,world,B", [("peer", 2, 530), ("peer", 4, 530), ("peer", 2, 1024), ("torch", 2, 530),
-                                              ("torch", 2, 1024)])
+@pytest.mark.parametrize("exchange,world,B", [("peer", 2, 530), ("peer", 4, 530), ("peer", 2, 1024), ("peer0", 2, 530),
+                                              ("torch", 2, 530), ("torch", 2, 1024)])
 def test_dp_step_at_bench_batch_vs_oracle(exchange, world, B):
     from conftest import rel_l2
     from oracle import hang2020_np as O
