@@ -13,8 +13,10 @@
 using namespace dta;
 
 // xchg.hip (internal): arguments of the head segment's overlapped reduce-scatter for the exchange's NEXT launch / undo
+extern "C" {
 int dta_xchg_side_args(dta_xchg* x, const double* alpha_g, long long alpha_slot, dta::XchgArgs* out);
 void dta_xchg_side_cancel(dta_xchg* x);
+}
 
 static thread_local char g_err[512] = "";
 void dta_set_error(const char* fmt, ...) {
