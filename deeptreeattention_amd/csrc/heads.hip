@@ -440,14 +440,17 @@ int launch_blend(const BlendArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 __global__ void k_mean_scores(MeanArgs a) {
   float kept = 0.f;
-  bool use[MAXG];
-  for (int k = 0; k < a.n; ++k) { use[k] = !a.gate || a.gate[k] > 0.f; kept += use[k] ? 1.f : 0.f; }
+  unsigned use = 0u;                                  // bit k: source k takes part (a bit mask: an indexed array would live in scratch)
+#pragma unroll
+  for (int k = 0; k < MAXG; ++k)
+    if (k < a.n && (!a.gate || a.gate[k] > 0.f)) { use |= 1u << k; kept += 1.f; }
   const float inv = 1.f / kept;                       // nothing kept: inf, and 0 * inf = NaN below -- an empty mean
   if (a.kept && blockIdx.x == 0 && threadIdx.x == 0) { a.kept[0] = kept; a.kept[1] = inv; }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.count; i += (size_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
-    for (int k = 0; k < a.n; ++k)
-      if (use[k]) acc += a.src[k][i];                 // (selected, not multiplied: a skipped year's scores may be anything)
+#pragma unroll
+    for (int k = 0; k < MAXG; ++k)
+      if ((use >> k) & 1u) acc += a.src[k][i];         // (selected, not multiplied: a skipped year's scores may be anything)
     a.dst[i] = acc * inv;
   }
 }

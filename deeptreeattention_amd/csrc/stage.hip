@@ -2007,12 +2007,19 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
   __syncthreads();
 
   // ---- recompute BN -> ReLU -> pool; keep z, the window position of the maximum and xhat there ----
-  float z[IPT][8], xh[IPT][8];
+  // RECOMP (several items per thread: the 24x24 crops): only the selected raw conv output of an item stays in registers;
+  // z = relu(BN(y)) and xhat are re-derived from it (two FMAs and one LDS read of the coefficients) at each of their three
+  // uses instead of living in 16 registers per item through the whole kernel -- the 5-item / 3-item configurations
+  // spilled 78 / 44 registers to scratch with them
+  constexpr bool RECOMP = CFG::HC > 11;
+  float z[RECOMP ? 1 : IPT][8], xh[IPT][8];      // RECOMP: xh holds the selected raw output, z is unused
   unsigned first[IPT];
+  unsigned vmask = 0u;                          // RECOMP: bit j = item j exists and its patch is live
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
     const int it = lt + j * TPP, itc = it < CFG::ITEMS ? it : 0, o = itc % NO;
     first[j] = 0u;
+    if (live && it < CFG::ITEMS) vmask |= 1u << j;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const f32x4 q = *reinterpret_cast<const f32x4*>(coefL + (o * 8 + e) * 4);
@@ -2024,10 +2031,27 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
           if (v > m) { m = v; ys = yraw[j][k][e]; first[j] = (first[j] & ~(3u << (2 * e))) | ((unsigned)k << (2 * e)); }
         }
       }
-      z[j][e] = (live && it < CFG::ITEMS) ? relu_nan(m) : 0.f;
-      xh[j][e] = (ys - q[2]) * q[3];
+      if constexpr (RECOMP) xh[j][e] = ys;
+      else {
+        z[j][e] = (live && it < CFG::ITEMS) ? relu_nan(m) : 0.f;
+        xh[j][e] = (ys - q[2]) * q[3];
+      }
     }
   }
+  auto ZV = [&](int j, int e) -> float {
+    if constexpr (RECOMP) {
+      const int it = lt + j * TPP, o = (it < CFG::ITEMS ? it : 0) % NO;
+      const f32x2 q = *reinterpret_cast<const f32x2*>(coefL + (o * 8 + e) * 4);
+      return ((vmask >> j) & 1u) ? relu_nan(xh[j][e] * q[0] + q[1]) : 0.f;
+    } else return z[j][e];
+  };
+  auto XV = [&](int j, int e) -> float {
+    if constexpr (RECOMP) {
+      const int it = lt + j * TPP, o = (it < CFG::ITEMS ? it : 0) % NO;
+      const f32x2 q = *reinterpret_cast<const f32x2*>(coefL + (o * 8 + e) * 4 + 2);
+      return (xh[j][e] - q[0]) * q[1];
+    } else return xh[j][e];
+  };
   // the raw registers are free again: next batch in flight behind everything below
   if (PF && bi + (int)gridDim.x < nb) fetch(bi + gridDim.x);
   float* bnp = (ba.bnpart && live) ? ba.bnpart + (size_t)g * ba.bnpart_gs + (size_t)b * C * 2 : nullptr;
@@ -2049,7 +2073,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           if (df) D[j][e] += df[o * 8 + e] * inv;
-          part[0][e] += D[j][e] * z[j][e];            // z is zero for threads without an item
+          part[0][e] += D[j][e] * ZV(j, e);           // z is zero for threads without an item
         }
       }
       float* const outs[1] = {sm0 + VOFF + 3 * C};
@@ -2077,7 +2101,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float dz = D[j][e] * gL[o * 8 + e] + dpL[o * 8 + e];
-        dv[j][e] = z[j][e] > 0.f ? dz : 0.f;
+        dv[j][e] = ZV(j, e) > 0.f ? dz : 0.f;
       }
     }
   } else if (kind == KIND_SPATIAL) {
@@ -2093,7 +2117,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if (CFG::PS == 1 && df) D[j][e] += df[(o * 8 + e) * NP + p];
-        acc += D[j][e] * z[j][e];
+        acc += D[j][e] * ZV(j, e);
       }
       acc = lean_octet_sum<NO>(acc);
       if (it < CFG::ITEMS && o == 0) { const float sp = sL[p]; d2L[(p / WZ + R) * WP + p % WZ + R] = acc * sp * (1.f - sp); }
@@ -2130,8 +2154,8 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float dz = D[j][e] * sp + dm * wc[o * 8 + e];
-        dv[j][e] = z[j][e] > 0.f ? dz : 0.f;
-        dwp[0][e] += dm * z[j][e];                    // z is zero for threads without an item
+        dv[j][e] = ZV(j, e) > 0.f ? dz : 0.f;
+        dwp[0][e] += dm * ZV(j, e);                   // z is zero for threads without an item
       }
     }
     if (ba.vec) {
@@ -2183,7 +2207,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
       for (int e = 0; e < 8; ++e) {
         float dz = D[j][e];
         if (df) dz += df[(o * 8 + e) * NP + p];
-        dv[j][e] = z[j][e] > 0.f ? dz : 0.f;
+        dv[j][e] = ZV(j, e) > 0.f ? dz : 0.f;
       }
     }
   }
@@ -2248,7 +2272,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
     for (int e = 0; e < 8; ++e) {
       bp[0][e] = 0.f; bp[1][e] = 0.f;
 #pragma unroll
-      for (int j = 0; j < IPT; ++j) { bp[0][e] += dv[j][e]; bp[1][e] += dv[j][e] * xh[j][e]; }
+      for (int j = 0; j < IPT; ++j) { bp[0][e] += dv[j][e]; bp[1][e] += dv[j][e] * XV(j, e); }
     }
     constexpr int S1 = 2 * PPW * (TPP / 64) * C;         // the head of red is the column-sum scratch
     float* s1L = red + S1 + slot * 2 * C;
