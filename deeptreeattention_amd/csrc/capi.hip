@@ -706,10 +706,11 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     else { ap.dy_gs = (size_t)B * (C / 16) * p.Rin[L] * 16; ap.dy_nc = C / 16; ap.dy_ch0 = 0; }
     ap.dy_compact = p.tl_compact;
     if (fan_bwd) {
-      ap.fan = sb.bn_fan_sums; ap.training = d->training;
-      for (int g = 0; g < G; ++g) { ap.gamma[g] = bf.gamma[g]; ap.dgamma[g] = bf.dgamma[g]; ap.dbeta[g] = bf.dbeta[g]; ap.dconvbias[g] = bf.dconvbias[g]; }
+      BnBwdFanArgs fa = {};
+      fa.fan = sb.bn_fan_sums; fa.training = d->training;
+      for (int g = 0; g < G; ++g) { fa.gamma[g] = bf.gamma[g]; fa.dgamma[g] = bf.dgamma[g]; fa.dbeta[g] = bf.dbeta[g]; fa.dconvbias[g] = bf.dconvbias[g]; }
       // (the spatial-attention column sums that rode in the finalize launch ride in this one)
-      if (launch_bn_bwd_apply<T>(ap, G, st, cs_jobs, ncs_jobs)) return 1;
+      if (launch_bn_bwd_apply<T>(ap, G, st, &fa, cs_jobs, ncs_jobs)) return 1;
     } else if (launch_bn_bwd_apply<T>(ap, G, st)) return 1;
     // ---- conv weight gradient ----
     // the deferred parameter-gradient GEMMs always ride in the launch of the split-K reductions that ends this call

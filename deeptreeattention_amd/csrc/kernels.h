@@ -211,6 +211,7 @@ int wgrad_cpw(int N);
 int wgrad_ngroups(int N, int bf16);     // column groups of the bf16 weight-gradient kernel (the slab count divides by it)
 
 struct ColsumArgs;
+struct BnBwdFanArgs;
 // ---- stage.hip (BatchNorm + ReLU + pool + attention, forward and backward) ------------------------
 struct BnFinalizeArgs {
   const double* fsum = nullptr;                        // FAN_R rows of raw sums per conv launch row (instead of `stats`)
@@ -314,14 +315,17 @@ struct BnBwdApplyArgs {
   int dy_compact;                      // halo-free output tiles [patch][chunk][pixel][16] (LDS-image kernel, bf16)
   int dv_compact, Hz, Wz;              // see StageBwdArgs::dv_compact
   int cslice;                          // channels per workgroup (filled by the launcher)
-  // fan != null: no finalize launch ran -- every workgroup derives the apply coefficients of its channels from the FAN_R
-  // rows of batch sums the stage-backward launch left (StageBwdArgs::bn_fan_sums), and workgroup (0, g, *) also writes
-  // d(gamma), d(beta), d(conv bias)
+};
+// DTA_FANIN experiment: no finalize launch ran -- every apply workgroup derives the coefficients of its channels from the
+// FAN_R rows of batch sums the stage-backward launch left (StageBwdArgs::bn_fan_sums), and workgroup (0, g, *) also writes
+// d(gamma), d(beta), d(conv bias)
+struct BnBwdFanArgs {
   const double* fan; const float* gamma[MAXG]; float* dgamma[MAXG]; float* dbeta[MAXG]; float* dconvbias[MAXG]; int training;
 };
 bool bn_bwd_apply_uses_lds(int C, int H, int W, size_t elem_bytes);
 // cs / ncs: up to two batch column-sum jobs riding as extra workgroups of the launch (LDS-image kernel)
-template <typename T> int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st, const ColsumArgs* cs = nullptr, int ncs = 0);
+template <typename T> int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hipStream_t st, const BnBwdFanArgs* fan = nullptr,
+                                              const ColsumArgs* cs = nullptr, int ncs = 0);
 
 // ---- heads.hip -----------------------------------------------------------------------------------
 // C[m][n] (+)= sum_k A(m,k) * B(k,n) + bias[n]; arbitrary element strides; fp32 MFMA 32x32x2.

@@ -1093,20 +1093,21 @@ int launch_bn_bwd_finalize_colsum(const BnBwdFinalizeArgs& a, int G, const Colsu
 
 // Apply coefficients of channel cc of group g when no finalize launch ran: the FAN_R rows of batch sums the stage-backward
 // launch left are added in a fixed order (every workgroup gets the same bits); `writer` also stores the parameter gradients.
-__device__ __forceinline__ void bn_bwd_fan_coef(const BnBwdApplyArgs& a, int g, int cc, bool writer, float& A, float& Bc, float& Cc) {
-  const double* f = a.fan + ((size_t)g * FAN_R * a.C + cc) * 2;
+__device__ __forceinline__ void bn_bwd_fan_coef(const BnBwdApplyArgs& a, const BnBwdFanArgs& fa, int g, int cc, bool writer, float& A, float& Bc,
+                                                float& Cc) {
+  const double* f = fa.fan + ((size_t)g * FAN_R * a.C + cc) * 2;
   double d1 = 0, d2 = 0;
 #pragma unroll
   for (int q = 0; q < FAN_R; ++q) { d1 += f[(size_t)q * a.C * 2]; d2 += f[(size_t)q * a.C * 2 + 1]; }
   const double n = (double)a.B * a.H * a.W;
-  A = a.gamma[g][cc] * a.coef[(size_t)g * a.coef_gs + cc * 4 + 3];
-  Bc = a.training ? (float)(d1 / n) : 0.f;
-  Cc = a.training ? (float)(d2 / n) : 0.f;
+  A = fa.gamma[g][cc] * a.coef[(size_t)g * a.coef_gs + cc * 4 + 3];
+  Bc = fa.training ? (float)(d1 / n) : 0.f;
+  Cc = fa.training ? (float)(d2 / n) : 0.f;
   if (writer) {
-    if (a.dbeta[g]) a.dbeta[g][cc] = (float)d1;
-    if (a.dgamma[g]) a.dgamma[g][cc] = (float)d2;
+    if (fa.dbeta[g]) fa.dbeta[g][cc] = (float)d1;
+    if (fa.dgamma[g]) fa.dgamma[g][cc] = (float)d2;
     // conv bias feeds BN directly: with batch statistics its gradient is exactly zero
-    if (a.dconvbias[g]) a.dconvbias[g][cc] = a.training ? 0.f : A * (float)d1;
+    if (fa.dconvbias[g]) fa.dconvbias[g][cc] = fa.training ? 0.f : A * (float)d1;
   }
 }
 
@@ -1123,8 +1124,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
   for (int c = t; c < C; c += 256) {
     float A, Bc, Cc;
     const float mean = coef[c * 4 + 2], rstd = coef[c * 4 + 3];
-    if (a.fan) bn_bwd_fan_coef(a, g, c, b == 0, A, Bc, Cc);
-    else { A = bc[c * 4 + 0]; Bc = bc[c * 4 + 1]; Cc = bc[c * 4 + 2]; }
+    A = bc[c * 4 + 0]; Bc = bc[c * 4 + 1]; Cc = bc[c * 4 + 2];
     sk[0][c] = A;
     sk[1][c] = -A * Cc * rstd;
     sk[2][c] = A * (Cc * rstd * mean - Bc);
@@ -1167,11 +1167,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdApplyArgs a) {
 
 // Same transform, patch image assembled in LDS: pixel-major float4 reads of dv / y (fully coalesced), the tile-layout
 // image of the patch (halo included) built in LDS, then one linear 16-byte-per-lane copy to HBM.
-template <typename T, int YF, int DVF>
-__global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a, ColsumPair cp) {
+template <typename T, int YF, int DVF, bool FAN>
+__device__ __forceinline__ void bn_bwd_apply_lds_body(const BnBwdApplyArgs& a, const BnBwdFanArgs* fa, const ColsumPair* cpp) {
   WGSTAMP(3);      // (the last launch of a step is the first stage's)
   extern __shared__ __attribute__((aligned(16))) char smem_apply[];
-  if ((int)blockIdx.x >= a.B) {
+  if (FAN && (int)blockIdx.x >= a.B) {
+    const ColsumPair& cp = *cpp;
     // extra workgroups (group row 0, slice 0 only): the batch column sums of the spatial-attention parameter gradients,
     // which used to ride in the finalize launch
     if (blockIdx.y != 0 || blockIdx.z != 0) return;
@@ -1198,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a, Cols
     const int cc = c0 + c;
     float A, Bc, Cc;
     const float mean = coef[cc * 4 + 2], rstd = coef[cc * 4 + 3];
-    if (a.fan) bn_bwd_fan_coef(a, g, cc, b == 0, A, Bc, Cc);
+    if constexpr (FAN) bn_bwd_fan_coef(a, *fa, g, cc, b == 0, A, Bc, Cc);
     else { A = bc[cc * 4 + 0]; Bc = bc[cc * 4 + 1]; Cc = bc[cc * 4 + 2]; }
     sk[c] = A;
     sk[CS + c] = -A * Cc * rstd;
@@ -1330,6 +1331,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a, Cols
   u32x4* dst = (u32x4*)((T*)a.dy_tl + (size_t)g * a.dy_gs + ((size_t)b * a.dy_nc + a.dy_ch0 + c0 / 16) * QI * 16);
   for (int i = t; i < nvec; i += 256) dst[i] = img4[i];
 }
+template <typename T, int YF, int DVF>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_lds(BnBwdApplyArgs a) {
+  bn_bwd_apply_lds_body<T, YF, DVF, false>(a, nullptr, nullptr);
+}
+// DTA_FANIN experiment: coefficients from the stage launch's fan-in rows, column-sum jobs as extra workgroups
+template <typename T, int YF, int DVF>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_lds_fan(BnBwdApplyArgs a, BnBwdFanArgs fa, ColsumPair cp) {
+  bn_bwd_apply_lds_body<T, YF, DVF, true>(a, &fa, &cp);
+}
 
 static size_t bn_bwd_apply_lds_bytes(int CS, int H, int W, size_t esz) {
   return ((3 * CS * 4 + H * W * 4 + 15) & ~15) + (size_t)(CS / 16) * (H + 2) * (W + 2) * 16 * esz;
@@ -1343,7 +1353,7 @@ bool bn_bwd_apply_uses_lds(int C, int H, int W, size_t esz) {
 }
 
 template <typename T>
-int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st, const ColsumArgs* cs, int ncs) {
+int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st, const BnBwdFanArgs* fan, const ColsumArgs* cs, int ncs) {
   BnBwdApplyArgs a = a_in;
   ColsumPair cp = {};
   int extra = 0;
@@ -1356,24 +1366,31 @@ int launch_bn_bwd_apply(const BnBwdApplyArgs& a_in, int G, hipStream_t st, const
   if (a.dv_fmt != FMT_F32 && a.dv_fmt != FMT_BF16) { dta_set_error("bn_bwd_apply: unsupported gradient-map format %d", a.dv_fmt); return 1; }
   const bool h = a.y_fmt == FMT_F16, d16 = a.dv_fmt == FMT_BF16;
   if (d16 && !h) { dta_set_error("bn_bwd_apply: bf16 gradient maps come with half conv outputs (bf16 mode)"); return 1; }
+  if (fan && lds > 48 * 1024) { dta_set_error("bn_bwd_apply: the fan-in form needs the LDS-image kernel"); return 1; }
   if (lds <= 48 * 1024) {
-    const dim3 grid(a.B + extra, G, a.C / a.cslice);
-    if (d16) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16, FMT_BF16>), grid, dim3(256), lds, st, a, cp);
-    else if (h) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16, FMT_F32>), grid, dim3(256), lds, st, a, cp);
-    else hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F32, FMT_F32>), grid, dim3(256), lds, st, a, cp);
+    if (fan) {
+      const dim3 grid(a.B + extra, G, a.C / a.cslice);
+      if (d16) hipLaunchKernelGGL((k_bn_bwd_apply_lds_fan<T, FMT_F16, FMT_BF16>), grid, dim3(256), lds, st, a, *fan, cp);
+      else if (h) hipLaunchKernelGGL((k_bn_bwd_apply_lds_fan<T, FMT_F16, FMT_F32>), grid, dim3(256), lds, st, a, *fan, cp);
+      else hipLaunchKernelGGL((k_bn_bwd_apply_lds_fan<T, FMT_F32, FMT_F32>), grid, dim3(256), lds, st, a, *fan, cp);
+      DTA_CHECK_LAUNCH("k_bn_bwd_apply_lds_fan");
+      return 0;
+    }
+    const dim3 grid(a.B, G, a.C / a.cslice);
+    if (d16) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16, FMT_BF16>), grid, dim3(256), lds, st, a);
+    else if (h) hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F16, FMT_F32>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_bn_bwd_apply_lds<T, FMT_F32, FMT_F32>), grid, dim3(256), lds, st, a);
     DTA_CHECK_LAUNCH("k_bn_bwd_apply_lds");
     return 0;
   }
-  for (int i = 0; i < ncs; ++i)      // (the plain kernel carries no extra workgroups)
-    if (launch_colsum_scatter(cs[i], st)) return 1;
   if (d16) hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F16, FMT_BF16>), dim3(a.B, G), dim3(256), 0, st, a);
   else if (h) hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F16, FMT_F32>), dim3(a.B, G), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((k_bn_bwd_apply<T, FMT_F32, FMT_F32>), dim3(a.B, G), dim3(256), 0, st, a);
   DTA_CHECK_LAUNCH("k_bn_bwd_apply");
   return 0;
 }
-template int launch_bn_bwd_apply<float>(const BnBwdApplyArgs&, int, hipStream_t, const ColsumArgs*, int);
-template int launch_bn_bwd_apply<bf16_t>(const BnBwdApplyArgs&, int, hipStream_t, const ColsumArgs*, int);
+template int launch_bn_bwd_apply<float>(const BnBwdApplyArgs&, int, hipStream_t, const BnBwdFanArgs*, const ColsumArgs*, int);
+template int launch_bn_bwd_apply<bf16_t>(const BnBwdApplyArgs&, int, hipStream_t, const BnBwdFanArgs*, const ColsumArgs*, int);
 
 // ================================================================================================
 // Lean forms of the three 11x11-network stages.
@@ -2011,7 +2028,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::MINW) void k_stage_bwd_lean(StageBwdA
   // z = relu(BN(y)) and xhat are re-derived from it (two FMAs and one LDS read of the coefficients) at each of their three
   // uses instead of living in 16 registers per item through the whole kernel -- the 5-item / 3-item configurations
   // spilled 78 / 44 registers to scratch with them
-  constexpr bool RECOMP = CFG::HC > 11;
+  constexpr bool RECOMP = CFG::HC > 12;      // (the 12x12 x 128 stage fits its registers; measured 38 -> 49 us with the recomputation)
   float z[RECOMP ? 1 : IPT][8], xh[IPT][8];      // RECOMP: xh holds the selected raw output, z is unused
   unsigned first[IPT];
   unsigned vmask = 0u;                          // RECOMP: bit j = item j exists and its patch is live
