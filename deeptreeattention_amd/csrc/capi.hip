@@ -169,7 +169,11 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
     }
     int Nconv = (L == 0 && p->shared_x) ? 32 * G : CH[L];
     p->MWG[L] = d->dtype == DTA_BF16 ? conv_mwg_bf16(Nconv, p->HWc[L]) : conv_mwg(Nconv);
-    if (d->dtype == DTA_BF16 && L > 0 && Nconv == 64) p->MWG[L] = 256;   // second conv: two 256-row workgroups per CU
+    if (d->dtype == DTA_BF16 && L > 0 && Nconv == 64) {
+      // second conv: two 256-row workgroups per CU; a 24x24 map is exactly one 576-row workgroup of six waves (256-row
+      // workgroups cut it into 256 + 256 + 64 rows: a quarter of the tile rows empty and three weight stagings per patch)
+      p->MWG[L] = (p->HWc[L] == 576 && !getenv("DTA_NO_CONV2_576")) ? 576 : 256;
+    }
     int ppw, spp;
     conv_geometry(p->HWc[L], p->MWG[L], B, &ppw, &spp, &p->nwg[L]);
     // weight-gradient split
@@ -411,6 +415,10 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     // launch folds its BatchNorm partials itself (FAN_R rows of raw sums), the stage workgroups add those up in their prologue
     const bool fan_fwd = d->training && (switches().fanin & 1);
     if (fan_fwd) { ca.fan_count = at<unsigned>(ws, p.fan_ctr) + (size_t)L * MAXG * FAN_R; ca.fan_sums = at<double>(ws, p.fan_fwd[L]); }
+    // bf16, 128 output channels (third conv): two 64-column groups per row tile -- the layer is weight staging (36 KiB per
+    // 16-channel chunk against a 6 KiB input tile), and half-width workgroups stage half of it each, twice as many of them
+    static const bool no_nsplit = getenv("DTA_NO_NSPLIT") != nullptr;
+    if (sizeof(T) == 2 && Nconv == 128 && !fan_fwd && !no_nsplit) ca.ncg = 2;
     ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
     prof_begin(DTA_SITE_CONV_FWD + L, st);
     if (launch_conv3x3<T>(ca, launchG, st)) return 1;

@@ -199,7 +199,9 @@ _Pragma("unroll") \
   const int vpp = trows * 2;                  // vectors per patch tile
   const int nxv = npatch * vpp, wvec = 9 * N * 2;
   const bf16_t* xg = (const bf16_t*)a.x_tl + (size_t)g * a.x_gs + ((size_t)b0 * a.NC) * ((size_t)(a.x_compact ? HW : Q) * 16);
-  const bf16_t* wg = (const bf16_t*)a.wp + (size_t)g * a.NC * 9 * N * 16;
+  // column groups (ConvArgs::ncg > 1): this workgroup computes columns [cgi * N, cgi * N + N) of NF = ncg * N
+  const int ncg = a.ncg > 1 ? a.ncg : 1, cgi = ncg > 1 ? (int)blockIdx.z : 0, NF = N * ncg;
+  const bf16_t* wg = (const bf16_t*)a.wp + (size_t)g * a.NC * 9 * NF * 16;
   const size_t xchunk = (size_t)trows * 16;   // elements between consecutive chunks of one patch
   // (offsets are 32-bit and relative to the workgroup's first patch: the 64-bit part is a scalar base, not a register pair per vector)
   unsigned xsrc[XV];
@@ -235,10 +237,12 @@ _Pragma("unroll") \
   }
   float rf[QV][4];
   bf16_t* xo = (XN && a.x_tl_out) ? (bf16_t*)a.x_tl_out + (size_t)g * a.x_gs + ((size_t)b0 * a.NC) * ((size_t)(a.x_compact ? HW : Q) * 16) : nullptr;
+  int wsrc[WV];                       // 16-byte vector index inside a chunk's [9][NF][16] weight slab
 #pragma unroll
   for (int u = 0; u < WV; ++u) {
     int v = min(tid + u * NTHR, wvec - 1);
     wdst[u] = (v >> 1) * RB + (v & 1) * 16;
+    wsrc[u] = ncg > 1 ? (v / (2 * N)) * (2 * NF) + cgi * 2 * N + v % (2 * N) : v;
   }
   u32x4 rx[XV], rw[WV];
   CTICK(1);
@@ -254,8 +258,8 @@ _Pragma("unroll") \
       _Pragma("unroll") for (int u = 0; u < XV; ++u)                                                  \
           rx[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xg + xsrc[u] + (size_t)(chunk_) * xchunk)); /* next reader is far (weight gradient) or none */ \
     }                                                                                                 \
-    const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)(chunk_) * 9 * N * 16);           \
-    _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[min(tid + u * NTHR, wvec - 1)];       \
+    const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)(chunk_) * 9 * NF * 16);          \
+    _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[wsrc[u]];                             \
   }
 #define DTA_STORE(sx_, sw_, chunk_)                                                                   \
   {                                                                                                   \
@@ -306,8 +310,8 @@ _Pragma("unroll") \
     }
 #define DTA_FETCH_W(chunk_)                                                                           \
     {                                                                                                 \
-      const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)min((chunk_), a.NC - 1) * 9 * N * 16); \
-      _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[min(tid + u * NTHR, wvec - 1)];     \
+      const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)min((chunk_), a.NC - 1) * 9 * NF * 16); \
+      _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[wsrc[u]];                           \
     }
 #define DTA_STORE_W(sw_)                                                                              \
     _Pragma("unroll") for (int u = 0; u < WV; ++u)                                                    \
@@ -414,14 +418,14 @@ _Pragma("unroll") \
     float bv = 0.f;
     if (a.bias[0]) {
       if (a.bias_mode == 1) bv = n < a.bias_split ? a.bias[0][n] : a.bias[1][n - a.bias_split];
-      else bv = a.bias[g][n];
+      else bv = a.bias[g][cgi * N + n];
     }
     bias[nt] = bv;
   }
   float csum[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) csum[nt] = 0.f;
-  float* yg = a.y + (size_t)g * a.y_gs;
+  float* yg = a.y + (size_t)g * a.y_gs + cgi * N;
   if (a.y_fmt == FMT_F32) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -447,7 +451,7 @@ _Pragma("unroll") \
     // as 16-byte vectors, 8 per thread, contiguous in HBM -- four times fewer, four times wider stores than 4-byte ones
     // scattered from the accumulator layout (cycle stamps: 10.7 k -> the epilogue was 37 % of a few-chunk workgroup).
     // Statistics stay on the fp32 values.
-    unsigned short* y16 = reinterpret_cast<unsigned short*>(a.y) + (size_t)g * a.y_gs;
+    unsigned short* y16 = reinterpret_cast<unsigned short*>(a.y) + (size_t)g * a.y_gs + cgi * N;
     const bool odd = lane & 1;
     const int ncol = (lane & 31) & ~1;
     constexpr int EP = N * 2 + 16;                  // LDS row pitch in bytes (16-byte aligned, rows 4 apart miss banks)
@@ -525,7 +529,7 @@ _Pragma("unroll") \
     float m2 = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) m2 += red[w * N + tid];
-    float* o = a.stats + (((size_t)g * gridDim.x + blockIdx.x) * N + tid) * 2;
+    float* o = a.stats + (((size_t)g * gridDim.x + blockIdx.x) * NF + cgi * N + tid) * 2;
     if (a.fan_count) fan_store2(o, cmean[tid], m2);
     else { o[0] = cmean[tid]; o[1] = m2; }
   }
@@ -559,7 +563,7 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
     if (a.spp != 1) { dta_set_error("conv3x3(bf16): the fused-input first conv needs whole patches per workgroup"); return 1; }
     hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, true, NW>), dim3(nwg, G), dim3(NW * 64), lds, st, a);
   } else {
-    hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, false, NW>), dim3(nwg, G), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, false, NW>), dim3(nwg, G, a.ncg > 1 ? a.ncg : 1), dim3(NW * 64), lds, st, a);
   }
   DTA_CHECK_LAUNCH("k_conv3x3_bf16");
   return 0;
@@ -589,11 +593,15 @@ int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
       // 256-row workgroups need 114 VGPRs against 184: two workgroups share a CU instead of one (the few-chunk layers are
       // all prologue / epilogue, so the overlap of two workgroups is worth more than the larger tile)
       if (a.mwg == 256) return launch_conv_bf16_t<1, 2>(a, G, st);
+      if (a.mwg == 576) return launch_conv_bf16_t<3, 2, 6>(a, G, st);
       return launch_conv_bf16_t<2, 2>(a, G, st);
     }
     case 128:
       // (four-wave, 128-row workgroups for the 5x5 maps were measured: every workgroup stages the full weight set, so
       // halving the rows doubles that traffic -- third conv 18.9 -> 18.0 us, its input-gradient conv 17 -> 24 us; not used)
+      // ncg == 2 (the plan's choice): two 64-column groups per row tile -- twice the workgroups, each staging HALF the
+      // weight slab per chunk (the layer is all weight staging: 36 KiB per chunk against a 6 KiB input tile)
+      if (a.ncg == 2) { ConvArgs h = a; h.N = 64; return h.mwg == 576 ? launch_conv_bf16_t<3, 2, 6>(h, G, st) : launch_conv_bf16_t<1, 2>(h, G, st); }
       return launch_conv_bf16_t<1, 4>(a, G, st);
   }
   dta_set_error("conv3x3: unsupported output width %d", a.N);

@@ -29,6 +29,8 @@ struct ConvArgs {
   int pixel_order;                    // bf16 developer switches: bit 0 = tile rows in pixel order (conv_row_tables), bit 1 = all waves stage before they multiply
   // BatchNorm statistics without a finalize launch (see FanIn below): the last workgroup to arrive in each of FAN_R
   // logical groups folds that group's (mean, M2) rows into one row of raw sums; the stage kernels add the FAN_R rows up
+  int ncg;                            // bf16 kernels: column groups (blockIdx.z) of N / ncg columns each (0 / 1 = one); the
+                                      // weight slab, bias, outputs and statistics rows keep their full-width layouts
   unsigned* fan_count;                // [gridDim.y][FAN_R] arrival counters (zero on entry, left zero) or null
   double* fan_sums;                   // [gridDim.y][FAN_R][N][3] = sum n m, sum n m^2, sum M2 per column
 };
