@@ -415,10 +415,11 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     // launch folds its BatchNorm partials itself (FAN_R rows of raw sums), the stage workgroups add those up in their prologue
     const bool fan_fwd = d->training && (switches().fanin & 1);
     if (fan_fwd) { ca.fan_count = at<unsigned>(ws, p.fan_ctr) + (size_t)L * MAXG * FAN_R; ca.fan_sums = at<double>(ws, p.fan_fwd[L]); }
-    // bf16, 128 output channels (third conv): two 64-column groups per row tile -- the layer is weight staging (36 KiB per
-    // 16-channel chunk against a 6 KiB input tile), and half-width workgroups stage half of it each, twice as many of them
+    // bf16, 128 output channels (third conv) on maps of 12x12 and up: two 64-column groups per row tile -- half-width
+    // workgroups stage half the weight slab each, twice as many of them (same-box alternation, 3 x 369 x 24x24: 1.0215 ->
+    // 1.0148 ms; the 5x5 maps of the 11x11 networks measured 0.5248 -> 0.5260 ms with it and keep the full-width tile)
     static const bool no_nsplit = getenv("DTA_NO_NSPLIT") != nullptr;
-    if (sizeof(T) == 2 && Nconv == 128 && !fan_fwd && !no_nsplit) ca.ncg = 2;
+    if (sizeof(T) == 2 && Nconv == 128 && p.HWc[L] >= 64 && !fan_fwd && !no_nsplit) ca.ncg = 2;
     ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
     prof_begin(DTA_SITE_CONV_FWD + L, st);
     if (launch_conv3x3<T>(ca, launchG, st)) return 1;
