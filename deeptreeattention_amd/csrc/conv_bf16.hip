@@ -137,8 +137,8 @@ __device__ __forceinline__ void conv_row_tables(const ConvArgs& a, int* rowtab, 
   }
 }
 
-template <int MT, int NT, bool XN, int NWV = 8>
-__global__ __launch_bounds__(NWV * 64, 1) void k_conv3x3_bf16(ConvArgs a) {
+template <int MT, int NT, bool XN, int NWV = 8, int MINW = 1>
+__global__ __launch_bounds__(NWV * 64, MINW) void k_conv3x3_bf16(ConvArgs a) {
   WGSTAMP(XN ? 0 : (a.stats ? (a.N == 64 ? 1 : 2) : -1));      // first conv, second conv, third conv (forward launches)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   CTICK(0);
@@ -190,6 +190,21 @@ _Pragma("unroll") \
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  // the epilogue's bias: fetched here, so that its global round trip (~0.7 us) runs under the chunk loop instead of
+  // standing at the head of the epilogue of a few-chunk workgroup
+  float bias[NT];
+  if (!XN) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 32 + (lane & 31);
+      float bv = 0.f;
+      if (a.bias[0]) {
+        if (a.bias_mode == 1) bv = n < a.bias_split ? a.bias[0][n] : a.bias[1][n - a.bias_split];
+        else bv = a.bias[g][(a.ncg > 1 ? (int)blockIdx.z : 0) * N + n];
+      }
+      bias[nt] = bv;
+    }
+  }
 
   // ---- staging plan: 16-byte vectors; thread t owns vectors t, t+512, ... (fixed per thread for all chunks) ----
   constexpr int XV = 4, WV = (9 * N * 2 + NTHR - 1) / NTHR;
@@ -237,13 +252,16 @@ _Pragma("unroll") \
   }
   float rf[QV][4];
   bf16_t* xo = (XN && a.x_tl_out) ? (bf16_t*)a.x_tl_out + (size_t)g * a.x_gs + ((size_t)b0 * a.NC) * ((size_t)(a.x_compact ? HW : Q) * 16) : nullptr;
-  int wsrc[WV];                       // 16-byte vector index inside a chunk's [9][NF][16] weight slab
 #pragma unroll
   for (int u = 0; u < WV; ++u) {
     int v = min(tid + u * NTHR, wvec - 1);
     wdst[u] = (v >> 1) * RB + (v & 1) * 16;
-    wsrc[u] = ncg > 1 ? (v / (2 * N)) * (2 * NF) + cgi * 2 * N + v % (2 * N) : v;
   }
+  // 16-byte vector index inside a chunk's [9][NF][16] weight slab (recomputed at each fetch: shifts and masks, no registers held)
+  auto wsrc = [&](int u) -> int {
+    const int v = min(tid + u * NTHR, wvec - 1);
+    return ncg > 1 ? (v / (2 * N)) * (2 * NF) + cgi * 2 * N + v % (2 * N) : v;
+  };
   u32x4 rx[XV], rw[WV];
   CTICK(1);
 #define DTA_FETCH(chunk_)                                                                             \
@@ -259,7 +277,7 @@ _Pragma("unroll") \
           rx[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xg + xsrc[u] + (size_t)(chunk_) * xchunk)); /* next reader is far (weight gradient) or none */ \
     }                                                                                                 \
     const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)(chunk_) * 9 * NF * 16);          \
-    _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[wsrc[u]];                             \
+    _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[wsrc(u)];                             \
   }
 #define DTA_STORE(sx_, sw_, chunk_)                                                                   \
   {                                                                                                   \
@@ -311,7 +329,7 @@ _Pragma("unroll") \
 #define DTA_FETCH_W(chunk_)                                                                           \
     {                                                                                                 \
       const u32x4* swp_ = reinterpret_cast<const u32x4*>(wg + (size_t)min((chunk_), a.NC - 1) * 9 * NF * 16); \
-      _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[wsrc[u]];                           \
+      _Pragma("unroll") for (int u = 0; u < WV; ++u) rw[u] = swp_[wsrc(u)];                           \
     }
 #define DTA_STORE_W(sw_)                                                                              \
     _Pragma("unroll") for (int u = 0; u < WV; ++u)                                                    \
@@ -411,16 +429,17 @@ _Pragma("unroll") \
 
   CTICK(3);
   // ---- epilogue: bias, store, per-workgroup (mean, M2) per column ----
-  float bias[NT];
+  if (XN) {      // (the fused-input kernel had no register to spare for the bias during its loop)
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    int n = nt * 32 + (lane & 31);
-    float bv = 0.f;
-    if (a.bias[0]) {
-      if (a.bias_mode == 1) bv = n < a.bias_split ? a.bias[0][n] : a.bias[1][n - a.bias_split];
-      else bv = a.bias[g][cgi * N + n];
+    for (int nt = 0; nt < NT; ++nt) {
+      int n = nt * 32 + (lane & 31);
+      float bv = 0.f;
+      if (a.bias[0]) {
+        if (a.bias_mode == 1) bv = n < a.bias_split ? a.bias[0][n] : a.bias[1][n - a.bias_split];
+        else bv = a.bias[g][cgi * N + n];
+      }
+      bias[nt] = bv;
     }
-    bias[nt] = bv;
   }
   float csum[NT];
 #pragma unroll
@@ -538,7 +557,7 @@ _Pragma("unroll") \
   if (a.fan_count) conv_stats_fanin<NTHR>(a, g, N, HW, MWG, reinterpret_cast<double*>(sbuf), reinterpret_cast<int*>(cmean));
 }
 
-template <int MT, int NT, int NW = 8>
+template <int MT, int NT, int NW = 8, int MINW = 1>
 static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   constexpr int MWG = NW * MT * 32, N = NT * 32;
   int nwg;
@@ -556,14 +575,14 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   if (a.ppw * a.Q * 2 > 4 * NW * 64) { dta_set_error("conv3x3(bf16): %dx%d tile exceeds the staging plan", a.H, a.W); return 1; }
   static DevOnce attr_once;      // (function attributes are per device)
   if (attr_once.first()) {
-    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, false, NW, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   if (a.x_nchw[0]) {
     if (a.spp != 1) { dta_set_error("conv3x3(bf16): the fused-input first conv needs whole patches per workgroup"); return 1; }
     hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, true, NW>), dim3(nwg, G), dim3(NW * 64), lds, st, a);
   } else {
-    hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, false, NW>), dim3(nwg, G, a.ncg > 1 ? a.ncg : 1), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, false, NW, MINW>), dim3(nwg, G, a.ncg > 1 ? a.ncg : 1), dim3(NW * 64), lds, st, a);
   }
   DTA_CHECK_LAUNCH("k_conv3x3_bf16");
   return 0;
@@ -592,7 +611,9 @@ int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st) {
       if (a.stats == nullptr && nwg * G <= 128) return launch_conv_bf16_t<1, 2>(a, G, st);
       // 256-row workgroups need 114 VGPRs against 184: two workgroups share a CU instead of one (the few-chunk layers are
       // all prologue / epilogue, so the overlap of two workgroups is worth more than the larger tile)
+      // (three 256-row workgroups per CU -- __launch_bounds__(512, 6), 80 registers -- spill 72 registers: not an option)
       if (a.mwg == 256) return launch_conv_bf16_t<1, 2>(a, G, st);
+      // (a 24x24 map as one 576-row workgroup; two 32-column groups of <3,1> tiles instead were measured slower: 1.046 -> 1.063 ms)
       if (a.mwg == 576) return launch_conv_bf16_t<3, 2, 6>(a, G, st);
       return launch_conv_bf16_t<2, 2>(a, G, st);
     }
