@@ -148,8 +148,8 @@ __global__ __launch_bounds__(NWV * 64, MINW) void k_conv3x3_bf16(ConvArgs a) {
   int* rowtab = (int*)smem;                 // [MWG] global output row or -1
   int* plq = rowtab + MWG;                  // [MWG] (pl << 16) | q_topleft
   float* red = (float*)(plq + MWG);         // [NW][N]
-  float* cmean = red + NW * N;              // [N]
-  unsigned char* sbuf = (unsigned char*)(cmean + N);
+  float* cmean = red + NW * N;              // [N], then a second [NW][N] reduction array (statistics epilogue)
+  unsigned char* sbuf = (unsigned char*)(cmean + N + NW * N);
   const int Q = a.Q, HW = a.HW, W2 = a.W + 2;
   const int xbytes = a.ppw * Q * RB, wbytes = 9 * N * RB, stage = xbytes + wbytes;
   const bool dbuf = a.dbuf != 0;            // two LDS stages: staging of chunk k+1 overlaps the MFMAs of chunk k
@@ -441,9 +441,25 @@ _Pragma("unroll") \
       bias[nt] = bv;
     }
   }
-  float csum[NT];
+  // BatchNorm partials of this workgroup's rows, per column: (mean, M2) from ONE pass over the accumulators -- sums of
+  // d = v - K and d^2 with the shift K = the column's value in the tile's first row (a sample of the distribution: the
+  // cancellation in S2 - S1^2 / n then costs ~eps (1 + (mean - K)^2 / var), a few ulp; a constant column gives d = 0
+  // exactly).  The two-pass form (mean first, then squared deviations: a second sweep over the accumulators behind two
+  // more barriers) was 11 % of a few-chunk workgroup.
+  float s1[NT], s2[NT], shiftK[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) csum[nt] = 0.f;
+  for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; shiftK[nt] = 0.f; }
+  float* red2 = cmean + N;                  // [NW][N]
+  if (a.stats) {
+    if (wave == 0 && lane < 32) {
+      const bool v0 = rowtab[0] >= 0;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) cmean[nt * 32 + lane] = bias[nt] + (v0 ? acc[0][nt][0] : 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) shiftK[nt] = cmean[nt * 32 + (lane & 31)];
+  }
   float* yg = a.y + (size_t)g * a.y_gs + cgi * N;
   if (a.y_fmt == FMT_F32) {
 #pragma unroll
@@ -455,10 +471,10 @@ _Pragma("unroll") \
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           float v = acc[mt][nt][r] + bias[nt];
-          acc[mt][nt][r] = v;
           if (orow >= 0) {
             yg[(size_t)orow * a.y_rs + nt * 32 + (lane & 31)] = v;
-            csum[nt] += v;
+            const float d = v - shiftK[nt];
+            s1[nt] += d; s2[nt] += d * d;
           }
         }
       }
@@ -488,9 +504,9 @@ _Pragma("unroll") \
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const float v0 = acc[mt][nt][r] + bias[nt], v1 = acc[mt][nt][r + 1] + bias[nt];
-          acc[mt][nt][r] = v0; acc[mt][nt][r + 1] = v1;
-          if (orow0 >= 0) csum[nt] += v0;
-          if (orow1 >= 0) csum[nt] += v1;
+          const float d0 = v0 - shiftK[nt], d1 = v1 - shiftK[nt];
+          if (orow0 >= 0) { s1[nt] += d0; s2[nt] += d0 * d0; }
+          if (orow1 >= 0) { s1[nt] += d1; s2[nt] += d1 * d1; }
           const float got = lane_xor1(odd ? v0 : v1);      // even lane <- neighbour's row r, odd lane <- neighbour's row r + 1
           const unsigned pk = odd ? pack2_fmt(got, v1, YFMT) : pack2_fmt(v0, got, YFMT);
           *reinterpret_cast<unsigned*>(E + (lr0 + (odd ? 1 : 0)) * EP + (nt * 32 + ncol) * 2) = pk;
@@ -515,39 +531,19 @@ _Pragma("unroll") \
   const int cnt = (a.spp == 1) ? npatch * HW : min(MWG, HW - split * MWG);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    float v = csum[nt] + __shfl_xor(csum[nt], 32);
-    if (lane < 32) red[wave * N + nt * 32 + lane] = v;
+    const float u1 = s1[nt] + __shfl_xor(s1[nt], 32), u2 = s2[nt] + __shfl_xor(s2[nt], 32);
+    if (lane < 32) { red[wave * N + nt * 32 + lane] = u1; red2[wave * N + nt * 32 + lane] = u2; }
   }
   __syncthreads();
   if (tid < N) {
-    float s = 0.f;
+    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) s += red[w * N + tid];
-    cmean[tid] = s / (float)cnt;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    float mu = cmean[nt * 32 + (lane & 31)];
-    float m2 = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int lr = (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (rowtab[lr] >= 0) { float d = acc[mt][nt][r] - mu; m2 += d * d; }
-      }
-    csum[nt] = m2 + __shfl_xor(m2, 32);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-    if (lane < 32) red[wave * N + nt * 32 + lane] = csum[nt];
-  __syncthreads();
-  if (tid < N) {
-    float m2 = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) m2 += red[w * N + tid];
+    for (int w = 0; w < NW; ++w) { t1 += red[w * N + tid]; t2 += red2[w * N + tid]; }
+    const float dm = t1 / (float)cnt;
+    const float mean = cmean[tid] + dm;
+    float m2 = t2 - t1 * dm;
+    m2 = m2 > 0.f ? m2 : 0.f;
+    cmean[tid] = mean;
     float* o = a.stats + (((size_t)g * gridDim.x + blockIdx.x) * NF + cgi * N + tid) * 2;
     if (a.fan_count) fan_store2(o, cmean[tid], m2);
     else { o[0] = cmean[tid]; o[1] = m2; }
@@ -562,7 +558,7 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   constexpr int MWG = NW * MT * 32, N = NT * 32;
   int nwg;
   conv_geometry(a.HW, MWG, a.B, &a.ppw, &a.spp, &nwg);
-  size_t tab = (size_t)MWG * 8 + (size_t)9 * N * 4, stage = ((size_t)a.ppw * a.Q + (size_t)9 * N) * RB;
+  size_t tab = (size_t)MWG * 8 + (size_t)17 * N * 4, stage = ((size_t)a.ppw * a.Q + (size_t)9 * N) * RB;
   // few chunks (the 32- and 64-channel layers): one LDS stage, so that two or three workgroups share a CU and overlap
   // each other's prologue / epilogue instead of double-buffering a two-iteration loop
   a.dbuf = tab + 2 * stage <= 160 * 1024 && a.NC > 4;   // measured: conv2's input-gradient conv 28 -> 22 us

@@ -1195,6 +1195,41 @@ __device__ __forceinline__ void bn_bwd_apply_lds_body(const BnBwdApplyArgs& a, c
                               (dvbase + (size_t)a.Hz * a.Wz * C) * (DVF == FMT_F32 ? 4 : 2) + c0;   // compact form only
   const float* coef = a.coef + (size_t)g * a.coef_gs;
   const float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
+  // 16-bit everything (the bf16 networks' lean path): a thread item is 8 channels of a pixel -- one 16-byte load of the
+  // half conv output, one of the bf16 gradient, one 16-byte LDS store.  The loads of a thread's FIRST items are issued
+  // here, before the coefficient / table prologue and its barrier, so that the two global round trips overlap (an 11x11
+  // patch is a single round of items: the launch was one dependent chain coef -> barrier -> loads -> image -> store)
+  constexpr bool V8 = sizeof(T) == 2 && YF != FMT_F32 && DVF != FMT_F32;
+  constexpr int UB8 = 2;
+  const int c8sh = c4sh - 1, total8 = HW << c8sh;
+  auto lut_of = [&](int pix) -> int {
+    const int hh = pix / a.W, ww = pix - hh * a.W, hz = hh >> 1, wz = ww >> 1;
+    const int inw = (a.dv_compact && hz < a.Hz && wz < a.Wz) ? 1 : 0;
+    return ((hh + 1) * W2 + ww + 1) | ((inw ? hz * a.Wz + wz : 0) << 10) | ((((hh & 1) << 1) | (ww & 1)) << 20) | (inw << 22);
+  };
+  u32x4 ry[UB8], rd[UB8];
+  u32x2 rfb[UB8];
+  int rl[UB8];
+  auto issue8 = [&](int i0) {
+#pragma unroll
+    for (int u = 0; u < UB8; ++u) {
+      const int i = i0 + u * 256;
+      rl[u] = 0;
+      if (i < total8) {
+        const int pix = i >> c8sh, c8 = (i - (pix << c8sh)) * 8;
+        ry[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.y) + ybase + (size_t)pix * a.y_rs + c8));   // last reader of the conv output
+        const int l = lut_of(pix);
+        rl[u] = l;
+        if (!a.dv_compact) rd[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.dv) + dvbase + (size_t)pix * C + c0 + c8));
+        else if (l >> 22) {
+          const int pz = (l >> 10) & 1023;
+          rd[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.dv) + dvbase + (size_t)pz * C + c0 + c8));
+          rfb[u] = *(const u32x2*)(fpos + (size_t)pz * C + c8);
+        }
+      }
+    }
+  };
+  if constexpr (V8) issue8(t);
   for (int c = t; c < CS; c += 256) {
     const int cc = c0 + c;
     float A, Bc, Cc;
@@ -1205,11 +1240,8 @@ __device__ __forceinline__ void bn_bwd_apply_lds_body(const BnBwdApplyArgs& a, c
     sk[CS + c] = -A * Cc * rstd;
     sk[2 * CS + c] = A * (Cc * rstd * mean - Bc);
   }
-  for (int pix = t; pix < HW; pix += 256) {
-    const int hh = pix / a.W, ww = pix - hh * a.W, hz = hh >> 1, wz = ww >> 1;
-    const int inw = (a.dv_compact && hz < a.Hz && wz < a.Wz) ? 1 : 0;
-    lut[pix] = ((hh + 1) * W2 + ww + 1) | ((inw ? hz * a.Wz + wz : 0) << 10) | ((((hh & 1) << 1) | (ww & 1)) << 20) | (inw << 22);
-  }
+  if constexpr (!V8)
+    for (int pix = t; pix < HW; pix += 256) lut[pix] = lut_of(pix);
   // dy_compact: the image holds the HW pixels only (no halo rows to zero, 28 % fewer bytes out for an 11x11 patch)
   const int QI = a.dy_compact ? HW : Q;
   const int nvec = nch * QI * 16 * (int)sizeof(T) / 16;
@@ -1217,54 +1249,40 @@ __device__ __forceinline__ void bn_bwd_apply_lds_body(const BnBwdApplyArgs& a, c
   if (!a.dy_compact)
     for (int i = t; i < nvec; i += 256) img4[i] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
-  // 16-bit everything (the bf16 networks' lean path): a thread item is 8 channels of a pixel -- one 16-byte load of the
-  // half conv output, one of the bf16 gradient, one 16-byte LDS store -- half the instructions of the 4-channel form
-  constexpr bool V8 = sizeof(T) == 2 && YF != FMT_F32 && DVF != FMT_F32;
   if constexpr (V8) {
-    const int c8sh = c4sh - 1, total8 = HW << c8sh;
-    constexpr int UB8 = 2;
-    auto ld8 = [](float (&v)[8], const void* base, size_t idx, int fmt) {
-      const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(base) + idx));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[2 * e] = unpack_lo(q[e], fmt); v[2 * e + 1] = unpack_hi(q[e], fmt); }
-    };
     for (int i0 = t; i0 < total8; i0 += 256 * UB8) {
-      float yv[UB8][8], dvv[UB8][8];
-      int lq[UB8];
+      if (i0 != t) issue8(i0);              // (later rounds of a larger map: loaded here; the first round is in flight)
 #pragma unroll
       for (int u = 0; u < UB8; ++u) {
         const int i = i0 + u * 256;
         if (i < total8) {
           const int pix = i >> c8sh, c8 = (i - (pix << c8sh)) * 8;
-          ld8(yv[u], a.y, ybase + (size_t)pix * a.y_rs + c8, YF);            // last reader of the conv output
-          const int l = lut[pix];
-          lq[u] = l;
-          if (!a.dv_compact) ld8(dvv[u], a.dv, dvbase + (size_t)pix * C + c0 + c8, DVF);
-          else {
+          const int l = rl[u];
+          float yv[8], dvv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dvv[u][j] = 0.f;
+          for (int e = 0; e < 4; ++e) { yv[2 * e] = unpack_lo(ry[u][e], YF); yv[2 * e + 1] = unpack_hi(ry[u][e], YF); }
+          if (!a.dv_compact) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dvv[2 * e] = unpack_lo(rd[u][e], DVF); dvv[2 * e + 1] = unpack_hi(rd[u][e], DVF); }
+          } else {
+            // expand the pooled stage's compact gradient: the value lands on the window position the forward chose
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dvv[j] = 0.f;
             if (l >> 22) {
-              const int pz = (l >> 10) & 1023, k = (l >> 20) & 3;
-              float dc[8];
-              ld8(dc, a.dv, dvbase + (size_t)pz * C + c0 + c8, DVF);
-              const u32x2 fb = *(const u32x2*)(fpos + (size_t)pz * C + c8);
+              const int k = (l >> 20) & 3;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) dvv[u][j] = (int)((fb[j >> 2] >> (8 * (j & 3))) & 0xFFu) == k ? dc[j] : 0.f;
+              for (int j = 0; j < 8; ++j) {
+                const float dc = (j & 1) ? unpack_hi(rd[u][j >> 1], DVF) : unpack_lo(rd[u][j >> 1], DVF);
+                dvv[j] = (int)((rfb[u][j >> 2] >> (8 * (j & 3))) & 0xFFu) == k ? dc : 0.f;
+              }
             }
           }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UB8; ++u) {
-        const int i = i0 + u * 256;
-        if (i < total8) {
-          const int pix = i >> c8sh, c8 = (i - (pix << c8sh)) * 8;
-          const int q = a.dy_compact ? pix : (lq[u] & 1023);
+          const int q = a.dy_compact ? pix : (l & 1023);
           u32x4 pk;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float v0 = sk[c8 + 2 * j] * dvv[u][2 * j] + sk[CS + c8 + 2 * j] * yv[u][2 * j] + sk[2 * CS + c8 + 2 * j];
-            const float v1 = sk[c8 + 2 * j + 1] * dvv[u][2 * j + 1] + sk[CS + c8 + 2 * j + 1] * yv[u][2 * j + 1] + sk[2 * CS + c8 + 2 * j + 1];
+            const float v0 = sk[c8 + 2 * j] * dvv[2 * j] + sk[CS + c8 + 2 * j] * yv[2 * j] + sk[2 * CS + c8 + 2 * j];
+            const float v1 = sk[c8 + 2 * j + 1] * dvv[2 * j + 1] + sk[CS + c8 + 2 * j + 1] * yv[2 * j + 1] + sk[2 * CS + c8 + 2 * j + 1];
             pk[j] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
           }
           *(u32x4*)(img + ((size_t)(c8 >> 4) * QI + q) * 16 + (c8 & 15)) = pk;
