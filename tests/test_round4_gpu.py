@@ -308,3 +308,63 @@ def test_choose_exchange_selects_peer_when_the_probe_passes():
         ok, why, choice = out[rank]
         assert ok, why
         assert choice == "peer"
+
+
+# ---- DtaAdam data-parallel: the module-level step under DDP semantics, without a DDP wrapper ----------------------------
+def _dta_adam_dp_worker(rank, world, port, kind, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    d = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    p = O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=31)
+    m = H.Hang2020(BANDS, CLASSES)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in p.items()})
+    m = m.to(d).train()
+    w = torch.from_numpy((0.1 + (np.arange(CLASSES) % 7)).astype(np.float32)).to(d)
+    opts = {"max_workgroups": 32, "timeout_s": 20.0}
+    if kind == "fused":
+        tr = FusedTrainer(m, lr=1e-3, loss_weight=w, exchange="torch")
+    else:
+        opt = DtaAdam(m.parameters(), lr=1e-3, exchange=kind, exchange_opts=opts if kind == "peer" else None)
+    for step in range(2):
+        x = torch.from_numpy(prng.uniform01(700 + 10 * step + rank, 1, (B, BANDS, 11, 11))).to(d)
+        y = torch.from_numpy(prng.randint(700 + rank, 2, (B,), CLASSES)).to(d)
+        if kind == "fused":
+            tr.train_step(x, y)
+        else:
+            opt.zero_grad()
+            cross_entropy(m(x), y, weight=w).backward()
+            opt.step()
+    torch.cuda.synchronize()
+    out[(kind, rank)] = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    if kind == "fused":
+        tr.close()
+    else:
+        opt.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["torch", "peer"])
+def test_dta_adam_data_parallel_equals_the_fused_trainer(kind):
+    """DtaAdam(process_group) sums the flat gradient over the ranks inside step() (DDP's mean, per-rank BatchNorm): two
+    ranks, two steps, against the FusedTrainer's data-parallel step (pinned to the oracle in tests/test_ddp_gpu.py)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    for k in ("fused", kind):
+        mp.spawn(_dta_adam_dp_worker, args=(2, _free_port(), k, out), nprocs=2, join=True)
+    for rank in range(2):
+        a, b = out[("fused", rank)], out[(kind, rank)]
+        for k in a:
+            if k.endswith("conv_layer.bias"):
+                continue
+            assert rel_l2(b[k], a[k]) < 2e-5, (rank, k)
+    for k in out[(kind, 0)]:
+        if "running_" in k or "num_batches_tracked" in k:
+            continue
+        assert rel_l2(out[(kind, 0)][k], out[(kind, 1)][k]) < 1e-6, k
