@@ -183,24 +183,22 @@ def test_train_step_from_tiles_equals_train_step_from_the_float_batch(B):
     import copy
     rng = np.random.RandomState(3)
     crops = [rng.randint(0, 9000, size=(43, rng.randint(8, 20), rng.randint(8, 20))).astype(np.int16) for _ in range(B)]
-    y = torch.from_numpy(rng.randint(0, 6, size=B)).to(_dev())
+    # (8 classes: score rows of 32 bytes keep the classifier GEMMs on the no-atomics form, so the two paths give the same bits;
+    #  with 6 the split-K float atomics differ in the last bit from run to run and Adam's sign-like first steps amplify that)
+    y = torch.from_numpy(rng.randint(0, 8, size=B)).to(_dev())
     x32 = PP.preprocess_batch(crops, 11, train=True)
     xt = PP.preprocess_batch(crops, 11, train=True, tiles=True)
     assert np.array_equal(xt.float().cpu().numpy(), _bf16(x32.cpu().numpy()))
     torch.manual_seed(5)
-    m1 = H.Hang2020(23, 6, precision="bf16").to(_dev()).train()
+    m1 = H.Hang2020(23, 8, precision="bf16").to(_dev()).train()
     m2 = copy.deepcopy(m1)
     t1, t2 = FusedTrainer(m1, lr=1e-3), FusedTrainer(m2, lr=1e-3)
     for _ in range(2):
         l1, l2 = t1.train_step(x32, y), t2.train_step(xt, y)
     assert abs(float(l1) - float(l2)) <= 1e-5 * abs(float(l1))
     assert float((t1.logits - t2.logits).abs().max()) <= 1e-4 * float(t1.logits.abs().max())
-    # (with 6 classes the classifier's weight-gradient GEMM takes the split-K form with float atomics -- rows of 6 floats are
-    #  not 16-byte loadable -- so two runs differ in the last bit of a few classifier gradients; Adam's sign-like first steps
-    #  turn such a bit into +-lr on an element now and then, which shows in tensors that START at zero (BatchNorm biases are
-    #  two Adam steps long): 1e-3 of the norm, not 1e-4)
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         if a.dtype.is_floating_point and not k.endswith("conv_layer.bias"):
-            assert float((a.double() - b.double()).norm()) <= 1e-3 * max(float(a.double().norm()), 1e-12), k
+            assert float((a.double() - b.double()).norm()) <= 1e-4 * max(float(a.double().norm()), 1e-12), k
     lg, lv = t2.forward_loss(xt, y)
     assert torch.isfinite(lg).all() and np.isfinite(float(lv))
