@@ -124,14 +124,20 @@ __device__ __forceinline__ void bn_coef_block(const BnFinK& a, int g, float* lc,
     }
   } else {
     double s1 = 0, s2 = 0, s3 = 0;
+    double tot[3];
     if (a.fsum) {
-      // the conv launch folded its partials into FAN_R rows of raw sums already: slice sl adds rows sl, sl + T, ...
-      // (fixed order: every workgroup computes bit-identical coefficients)
-      const double* fs = a.fsum + (size_t)g * a.fsum_goff;
-      for (int q = sl; q < FAN_R; q += T) {
-        const double* r = fs + ((size_t)q * a.fsum_ld + c) * 3;
-        s1 += r[0]; s2 += r[1]; s3 += r[2];
+      // the conv launch folded its partials into FAN_R rows of raw sums already: thread c adds its channel's FAN_R rows
+      // itself (24 independent loads in flight, fixed order: every workgroup computes bit-identical coefficients) -- no
+      // reduction rounds through LDS
+      if (t < C) {
+        const double* fs = a.fsum + (size_t)g * a.fsum_goff + (size_t)t * 3;
+        double r[FAN_R][3];
+#pragma unroll
+        for (int q = 0; q < FAN_R; ++q) { r[q][0] = fs[(size_t)q * a.fsum_ld * 3]; r[q][1] = fs[(size_t)q * a.fsum_ld * 3 + 1]; r[q][2] = fs[(size_t)q * a.fsum_ld * 3 + 2]; }
+#pragma unroll
+        for (int q = 0; q < FAN_R; ++q) { s1 += r[q][0]; s2 += r[q][1]; s3 += r[q][2]; }
       }
+      tot[0] = s1; tot[1] = s2; tot[2] = s3;
     } else {
       const float* st = a.stats + (size_t)g * a.stats_goff;
 #pragma unroll 8
@@ -141,7 +147,7 @@ __device__ __forceinline__ void bn_coef_block(const BnFinK& a, int g, float* lc,
         s1 += nb * m; s2 += nb * m * m; s3 += (double)v.y;
       }
     }
-    double tot[3];
+    if (!a.fsum) {
     const double part[3] = {s1, s2, s3};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {                  // three rounds through the 256-double scratch
@@ -152,6 +158,7 @@ __device__ __forceinline__ void bn_coef_block(const BnFinK& a, int g, float* lc,
       if (t < C)
         for (int j = 0; j < T; ++j) acc += dred[j * C + t];
       tot[k] = acc;
+    }
     }
     if (t < C) {
       const double n = (double)a.B * a.HW, mean = tot[0] / n;

@@ -54,7 +54,7 @@ __device__ __forceinline__ void xchg_gather_adam(const XchgArgs& a, size_t seg_l
         if (s >= a.world) s -= a.world;
         if (q < xchg_len_q(seg_q, shard_q, s)) {
           if (a.world > 1) gs[u] = ld_sys128(xchg_rsrc(a.sig[s] + XCHG_SIG_BYTES), stage_off + 4 * q);
-          else gs[u] = ld_sys128(xchg_rsrc(a.grads[0]), seg_lo + 4 * q);
+          else gs[u] = *(const f32x4*)(a.g + seg_lo + 4 * q);      // (a single rank: its own gradients, written by the launch before: plain loads)
         }
       }
     }
@@ -65,6 +65,14 @@ __device__ __forceinline__ void xchg_gather_adam(const XchgArgs& a, size_t seg_l
       if (s >= a.world) s -= a.world;
       if (q >= xchg_len_q(seg_q, shard_q, s)) continue;
       const size_t i = seg_lo + (size_t)s * shard + 4 * q;
+      if (a.world == 1 && a.alpha_slot >= 0 && a.alpha_g && (size_t)(a.alpha_slot & ~3ll) == i) {
+        // a single rank skips the handshake that orders the slot conversion before the sums: the owner of the slot's
+        // quad takes alpha's float64 gradient (rounded to float32, as it would travel) directly
+        const float ag = (float)a.alpha_g[0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c == (int)(a.alpha_slot & 3)) gs[u][c] = ag;
+      }
       if (a.mode == 1) {
         const f32x4 mo = __builtin_nontemporal_load((const f32x4*)(a.m + i));
         const f32x4 vo = __builtin_nontemporal_load((const f32x4*)(a.v + i));
@@ -106,22 +114,25 @@ __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
   // alpha's float64 gradient enters the exchange as one float32 slot of the gradient buffer: converted here, once, from
   // the (order-independently accumulated) double, so the slot does not depend on the order of any float atomics
   // (a head segment that was summed ahead of this launch carried it already: xchg_side_job)
-  if (j == 0 && t == 0 && a.alpha_slot >= 0 && a.alpha_g && !a.head_presummed) {
+  if (j == 0 && t == 0 && a.alpha_slot >= 0 && a.alpha_g && !a.head_presummed && a.world > 1) {
     st_sys32((unsigned*)(a.g + a.alpha_slot), __float_as_uint((float)a.alpha_g[0]));
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
   }
   __syncthreads();
-  // 0. announce (one workgroup), 1. wait for every rank's gradients
-  if (j == 0 && t < a.world) st_sys32(&((XchgSig*)a.sig[t])->ready[a.rank], a.epoch);
-  if (t < a.world && !wait_flag(&mine->ready[t], a.epoch, a.timeout_ticks)) {
-    s_abort = 1;
-    a.status[0] = (1 << 8) | t;
-    st_sys32(&mine->aborted, 1u);
+  // 0. announce (one workgroup), 1. wait for every rank's gradients  (a single rank has nobody to wait for and nothing
+  //    stale to drop: its launch is the optimizer pass with the slot conversion in front)
+  if (a.world > 1) {
+    if (j == 0 && t < a.world) st_sys32(&((XchgSig*)a.sig[t])->ready[a.rank], a.epoch);
+    if (t < a.world && !wait_flag(&mine->ready[t], a.epoch, a.timeout_ticks)) {
+      s_abort = 1;
+      a.status[0] = (1 << 8) | t;
+      st_sys32(&mine->aborted, 1u);
+    }
+    __syncthreads();
+    if (s_abort) return;
+    if (t < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // drop what this CU / L2 still holds of the peers' buffers
+    __syncthreads();
   }
-  __syncthreads();
-  if (s_abort) return;
-  if (t < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // drop what this CU / L2 still holds of the peers' buffers
-  __syncthreads();
   const long long tk1 = wall_clock64();
 
   // Workgroup j owns the same relative slice {j*256 + t + k*G*256} (in 16-byte quads) of EVERY shard, in both phases:
@@ -294,8 +305,10 @@ static int xchg_launch(dta_xchg* x, XchgArgs& a, void* stream) {
   // one workgroup per CU at most, never more than there are element quads per shard
   const size_t big = x->shard_h > x->shard_t ? x->shard_h : x->shard_t;
   size_t wgs = (big / 4 + XCHG_THREADS - 1) / XCHG_THREADS;
-  if (wgs > (size_t)x->max_wgs) wgs = x->max_wgs;
-  if (wgs > XCHG_MAX_WGS) wgs = XCHG_MAX_WGS;
+  if (x->world > 1) {      // (co-resident workgroups with per-workgroup flags; a single rank is a plain optimizer pass)
+    if (wgs > (size_t)x->max_wgs) wgs = x->max_wgs;
+    if (wgs > XCHG_MAX_WGS) wgs = XCHG_MAX_WGS;
+  } else if (wgs > 2048) wgs = 2048;
   if (wgs < 1) wgs = 1;
   hipLaunchKernelGGL(k_xchg_step, dim3((unsigned)wgs), dim3(XCHG_THREADS), 0, (hipStream_t)stream, a);
   DTA_CHECK_LAUNCH("k_xchg_step");
