@@ -6,9 +6,13 @@ all-reduce when >1 GPU) at bands=369, 11x11, 200 classes (BASELINE.json metric /
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 50 --warmup 10
 
-One process per GPU; per-GPU batch is fixed (weak scaling; 1024 per GPU = 8192 global on 8 GPUs).  Synthetic
-patches (U[0,1), like the reference's min-max-scaled crops) are resident in HBM before the timed region.  Rank 0
-prints ONE JSON line.  Inside the timed loop the two first-conv kernels are timed with HIP events recorded on their own
+One process per GPU; per-GPU batch is fixed (weak scaling; 1024 per GPU = 8192 global on 8 GPUs).  Started WITHOUT a
+launcher (`python bench.py --gpus N`, no RANK in the environment) it spawns its own N ranks under torch.distributed.run.
+Synthetic patches (U[0,1), like the reference's min-max-scaled crops) are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.  `roofline.frac` prices SURVEY.md 8(d)'s COMPULSORY bytes of the conv1 forward (input in +
+output out); the bf16 tile by-product it also writes is in `frac_with_byproduct`.  The one-GPU line also carries, timed
+after the contract's region (20 steps each): `fp32` (the reference's own precision), `ensemble24` (BASELINE configs[4])
+and `module_path` (the unchanged reference step on the plugin modules with optim.DtaAdam / optim.cross_entropy).  Inside the timed loop the two first-conv kernels are timed with HIP events recorded on their own
 stream: `roofline` = the conv1 forward (the step's longest kernel; HBM-bound since it also converts the fp32 input and
 emits the bf16 tiles), `roofline_mfma` = the conv1 weight gradient (the longest MFMA-bound kernel); `step_roofline`
 prices the whole step's algorithmic FLOPs / bytes against the MI355X peaks.  `value` comes from the
