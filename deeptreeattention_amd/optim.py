@@ -354,6 +354,60 @@ class DtaAdam(torch.optim.Optimizer):
             self.state[self._alpha]["step"] = torch.tensor(float(self._steps))
         return super().state_dict()
 
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Resume (Lightning restores optimizer states from its checkpoints; a state_dict of torch.optim.Adam over the same
+        parameter list has the same layout and loads too).  torch's loader replaces the state tensors by copies: their
+        values go back into the flat moment buffers the kernel reads, the views are re-installed, and the step counts
+        return to the host counter (ungated parameters, alpha) and the per-year device counters."""
+        super().load_state_dict(state_dict)
+        steps = []
+        for p in self._flat_params:
+            o, k = self._offs[id(p)], p.numel()
+            st = self.state.get(p)
+            m, v = self.flat_m[o:o + k].view(p.shape), self.flat_v[o:o + k].view(p.shape)
+            if st and "exp_avg" in st:
+                m.copy_(st["exp_avg"].to(m))
+                v.copy_(st["exp_avg_sq"].to(v))
+                steps.append((o, int(float(st.get("step", 0)))))
+            else:       # torch leaves no entry for a parameter that was never stepped (an always-missing year)
+                m.zero_(); v.zero_()
+                steps.append((o, 0))
+                st = self.state[p] = {}
+            st["step"] = torch.tensor(float(steps[-1][1]))
+            st["exp_avg"], st["exp_avg_sq"] = m, v
+        if self._alpha is not None:
+            st = self.state.get(self._alpha) or {}
+            if "exp_avg" in st:
+                self._alpha_m.copy_(st["exp_avg"].to(self._alpha_m))
+                self._alpha_v.copy_(st["exp_avg_sq"].to(self._alpha_v))
+            else:
+                self._alpha_m.zero_(); self._alpha_v.zero_()
+            self.state[self._alpha] = {"step": torch.tensor(float(st.get("step", 0))), "exp_avg": self._alpha_m, "exp_avg_sq": self._alpha_v}
+        # one count per segment (all parameters of a segment were stepped together)
+        seg_steps = []
+        for ens_ref, year, off, n in self._segs:
+            # (a parameter torch never stepped -- grad None every time, e.g. the unused heads -- has count 0 and zero
+            #  moments: stepping it with the segment's count and its all-zero gradient leaves it where it is)
+            c = sorted({s for o, s in steps if off <= o < off + n and s > 0})
+            if len(c) > 1:
+                raise ValueError("DtaAdam.load_state_dict: parameters of one segment carry different step counts")
+            seg_steps.append(c[0] if c else 0)
+        k = 0
+        for (ens_ref, year, off, n), c in zip(self._segs, seg_steps):
+            if ens_ref is None:
+                self._steps = c
+                if self._alpha is not None and not any(off <= o < off + n for o, _ in steps):
+                    self._steps = int(float(self.state[self._alpha]["step"]))
+            else:
+                self.dev_steps[:, k] = c
+                k += 1
+
+    def add_param_group(self, param_group):
+        if getattr(self, "param_groups", None):
+            raise ValueError("DtaAdam keeps one parameter group: build it over all parameters (as the reference's optimizers are)")
+        super().add_param_group(param_group)
+
     def close(self):
         """Collective (data-parallel): release the peer exchange / RCCL communicator; every rank calls it."""
         for p in self._flat_params + ([self._alpha] if self._alpha is not None else []):

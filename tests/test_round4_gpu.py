@@ -123,6 +123,97 @@ def test_second_backward_before_step_accumulates_like_torch():
     assert float(m.conv2.conv_layer.weight.grad.abs().sum()) == 0.0
 
 
+def test_dta_adam_resumes_from_its_own_and_from_torch_adam_state_dict():
+    """Optimizer resume (Lightning restores optimizer_states from its checkpoints): three uninterrupted steps == two steps,
+    state_dict() -> a NEW DtaAdam on a reloaded model -> load_state_dict() -> one step; and the state_dict of a
+    torch.optim.Adam that took the first two steps loads the same way."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    bands, classes, B, lr = 14, 6, 5, 1e-3
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=43)
+    batches = [(torch.from_numpy(prng.uniform01(500 + s, 1, (B, bands, 11, 11))).to(dev()),
+                torch.from_numpy(prng.randint(500 + s, 2, (B,), classes)).to(dev())) for s in range(3)]
+
+    def steps(m, opt, which, ce):
+        for s in which:
+            x, y = batches[s]
+            opt.zero_grad()
+            ce(m(x), y).backward()
+            opt.step()
+
+    full = load(H.Hang2020(bands, classes), p).train()
+    ofull = DtaAdam(full.parameters(), lr=lr)
+    steps(full, ofull, range(3), cross_entropy)
+    want = {k: v.detach().double().cpu().numpy() for k, v in full.state_dict().items()}
+
+    # (a) DtaAdam -> DtaAdam
+    a = load(H.Hang2020(bands, classes), p).train()
+    oa = DtaAdam(a.parameters(), lr=lr)
+    steps(a, oa, range(2), cross_entropy)
+    msd, osd = copy.deepcopy(a.state_dict()), copy.deepcopy(oa.state_dict())
+    oa.close()
+    b = H.Hang2020(bands, classes).to(dev()).train()
+    b.load_state_dict(msd)
+    ob = DtaAdam(b.parameters(), lr=lr * 7)                # (the learning rate comes back from the state dict as well)
+    ob.load_state_dict(osd)
+    assert ob.param_groups[0]["lr"] == lr and ob.step_counts() == [2]
+    w = b.spectral_network.conv1.conv_layer.weight
+    assert ob.state[w]["exp_avg"].data_ptr() == ob.flat_m.data_ptr() + 4 * ob._offs[id(w)]      # still views of the flat moments
+    steps(b, ob, [2], cross_entropy)
+    for k, v in b.state_dict().items():
+        assert rel_l2(v.double().cpu().numpy(), want[k]) < 1e-6, k
+    assert ob.step_counts() == [3]
+
+    # (b) torch.optim.Adam (first two steps, torch's cross-entropy) -> DtaAdam
+    c = load(H.Hang2020(bands, classes), p).train()
+    oc = torch.optim.Adam(c.parameters(), lr=lr)
+    steps(c, oc, range(2), torch.nn.functional.cross_entropy)
+    d = H.Hang2020(bands, classes).to(dev()).train()
+    d.load_state_dict(copy.deepcopy(c.state_dict()))
+    od = DtaAdam(d.parameters(), lr=lr)
+    od.load_state_dict(copy.deepcopy(oc.state_dict()))
+    assert od.step_counts() == [2]
+    steps(d, od, [2], cross_entropy)
+    for k, v in d.state_dict().items():
+        if k.endswith("conv_layer.bias"):
+            continue                                       # (no gradient signal in front of a BatchNorm: Adam noise only)
+        assert rel_l2(v.double().cpu().numpy(), want[k]) < 2e-3, k
+
+
+def test_dta_adam_resume_keeps_per_year_step_counts():
+    from deeptreeattention_amd.year import learned_ensemble
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    years, bands, classes, B, lr = 3, 16, 7, 6, 1e-3
+    p = O.init_params(O.learned_ensemble_spec(years, bands, classes), seed=81)
+    cfg = {"pretrain_state_dict": None, "bands": bands}
+
+    def run(m, opt, which):
+        for step in which:
+            imgs, y = _ensemble_step_inputs(step, years, B, bands, classes)
+            opt.zero_grad()
+            cross_entropy(m([torch.from_numpy(a).to(dev()) for a in imgs]), torch.from_numpy(y).to(dev())).backward()
+            opt.step()
+
+    full = load(learned_ensemble(years=years, classes=classes, config=cfg), p).train()
+    ofull = DtaAdam(full.parameters(), lr=lr)
+    run(full, ofull, range(4))
+    a = load(learned_ensemble(years=years, classes=classes, config=cfg), p).train()
+    oa = DtaAdam(a.parameters(), lr=lr)
+    run(a, oa, range(2))                                   # step 1 skips year 2
+    assert oa.step_counts() == [2, 2, 1]
+    msd, osd = copy.deepcopy(a.state_dict()), copy.deepcopy(oa.state_dict())
+    oa.close()
+    b = learned_ensemble(years=years, classes=classes, config=cfg).to(dev()).train()
+    b.load_state_dict(msd)
+    ob = DtaAdam(b.parameters(), lr=lr)
+    ob.load_state_dict(osd)
+    assert ob.step_counts() == [2, 2, 1]
+    run(b, ob, [2, 3])
+    assert ob.step_counts() == ofull.step_counts() == [3, 4, 3]
+    for (k, v), (_, u) in zip(b.state_dict().items(), full.state_dict().items()):
+        assert rel_l2(v.double().cpu().numpy(), u.double().cpu().numpy()) < 1e-6, k
+
+
 def _ensemble_step_inputs(step, years, B, bands, classes):
     imgs = [prng.uniform01(82 + step, yy, (B, bands, 11, 11)) for yy in range(years)]
     if step == 1:
