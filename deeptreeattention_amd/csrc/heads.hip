@@ -1,6 +1,7 @@
 // Small dense pieces of the Hang2020 hot path on gfx950: classifier heads (nn.Linear forward/backward,
 // reference src/models/Hang2020.py:55-66), batch reductions of attention/bias gradients, the
 // sigmoid(alpha) blend (:260-261), class-weighted cross-entropy (src/main.py:78) and Adam (src/main.py:136).
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace dta {
@@ -217,14 +218,17 @@ __device__ __forceinline__ void wt_fetch(float (&v)[16], const float* S, int row
     for (int j = 0; j < 4; ++j) { f32x4 q = p[j]; v[4 * j] = q[0]; v[4 * j + 1] = q[1]; v[4 * j + 2] = q[2]; v[4 * j + 3] = q[3]; }
   }
 }
-template <int AM, int BM>
+// NWT waves per workgroup split the K range (4: the 256-thread launches; 8 / 16: the step's last launch, whose long-K
+// weight-gradient GEMMs run beside the split-K slab reduction -- under its HBM load a chunk's round trip is ~3 us, so
+// the dependent chunks per wave, not the flops, set that launch's duration)
+template <int AM, int BM, int NWT = 4>
 __device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by, int bz, float* smem) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m0 = bx * 32, n0 = by * 32;
   const int ks = a.ksplit < 1 ? 1 : a.ksplit;
   const int kblk = ((a.K + ks - 1) / ks + GK - 1) / GK * GK;            // this workgroup's K range
   const int kb0 = bz * kblk, kb1 = min(a.K, kb0 + kblk);
-  const int kper = (((kb1 - kb0) + 3) / 4 + GK - 1) / GK * GK;          // this wave's share of it
+  const int kper = (((kb1 - kb0) + NWT - 1) / NWT + GK - 1) / GK * GK;  // this wave's share of it
   const int kbeg = kb0 + wave * kper, kend = min(kb1, kbeg + kper);
   float* As = smem + wave * WT_REGION;
   float* Bs = As + 32 * GP;
@@ -272,17 +276,17 @@ __device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by,
   if (a.rowsum_out && by == 0 && t < 32 && m0 + t < a.M) {
     float rs = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) rs += smem[w * WT_REGION + 32 * 33 + t];
+    for (int w = 0; w < NWT; ++w) rs += smem[w * WT_REGION + 32 * 33 + t];
     atomicAdd(a.rowsum_out + m0 + t, off ? 0.f : rs * osc);
   }
   const int n = n0 + (t & 31);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ml = (t >> 5) + 8 * j, m = m0 + ml;
+  for (int j = 0; j < 16 / NWT; ++j) {
+    const int ml = (t >> 5) + 2 * NWT * j, m = m0 + ml;
     if (m >= a.M || n >= a.N) continue;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += smem[w * WT_REGION + ml * 33 + (t & 31)];
+    for (int w = 0; w < NWT; ++w) v += smem[w * WT_REGION + ml * 33 + (t & 31)];
     v = off ? 0.f : v * osc + ((a.bias && bz == 0) ? a.bias[n] : 0.f);
     float* c = a.C + (size_t)m * a.sc_m + (size_t)n * a.sc_n;
     if (ks > 1) atomicAdd(c, v);
@@ -292,6 +296,7 @@ __device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by,
 }
 
 // Several independent small GEMMs in one launch: block -> (problem, m-tile, n-tile, k-slice).
+template <int NWT = 4>
 __device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, float* smem) {
   int pi = 0;
   while (pi + 1 < gg.n && (int)blockIdx.x >= gg.start[pi + 1]) ++pi;
@@ -303,12 +308,13 @@ __device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, float* sme
     const int bx = local % tm; local /= tm;
     const int by = local % tn;
     const int bz = local / tn;
-    if (am == LD_VEC_K && bm == LD_VEC_K) gemm_block_wt<LD_VEC_K, LD_VEC_K>(a, bx, by, bz, smem);              // x W^T
-    else if (am == LD_VEC_K && bm == LD_VEC_ROW) gemm_block_wt<LD_VEC_K, LD_VEC_ROW>(a, bx, by, bz, smem);     // dy W
-    else if (am == LD_VEC_ROW && bm == LD_VEC_ROW) gemm_block_wt<LD_VEC_ROW, LD_VEC_ROW>(a, bx, by, bz, smem); // dy^T x
-    else gemm_block_wt<LD_VEC_ROW, LD_VEC_K>(a, bx, by, bz, smem);
+    if (am == LD_VEC_K && bm == LD_VEC_K) gemm_block_wt<LD_VEC_K, LD_VEC_K, NWT>(a, bx, by, bz, smem);              // x W^T
+    else if (am == LD_VEC_K && bm == LD_VEC_ROW) gemm_block_wt<LD_VEC_K, LD_VEC_ROW, NWT>(a, bx, by, bz, smem);     // dy W
+    else if (am == LD_VEC_ROW && bm == LD_VEC_ROW) gemm_block_wt<LD_VEC_ROW, LD_VEC_ROW, NWT>(a, bx, by, bz, smem); // dy^T x
+    else gemm_block_wt<LD_VEC_ROW, LD_VEC_K, NWT>(a, bx, by, bz, smem);
     return;
   }
+  if (NWT > 4 && threadIdx.x >= 256) return;     // (the 64x64 form is a 256-thread program; exited waves leave its barriers)
   const int tm = (a.M + 63) / 64, tn = (a.N + 63) / 64;
   const int bx = local % tm; local /= tm;
   const int by = local % tn;
@@ -318,7 +324,7 @@ __device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, float* sme
 constexpr int GEMM_SMEM_FLOATS = 4 * WT_REGION;     // 36 KiB (the 64x64 form needs 2 * 64 * GP of it)
 __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup gg) {
   __shared__ __attribute__((aligned(16))) float smem[GEMM_SMEM_FLOATS];
-  gemm_group_block(gg, smem);
+  gemm_group_block<4>(gg, smem);
 }
 
 int gemm_auto_ksplit(int M, int N, int K) {
@@ -353,13 +359,24 @@ int launch_gemm_group(GemmGroup& gg, hipStream_t st) {
   return 0;
 }
 
-__global__ __launch_bounds__(256) void k_gemm_group_reduce(GemmGroup gg, WgradReduceGroup gr, int ngemm) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM_SMEM_FLOATS];
-  if ((int)blockIdx.x < ngemm) { gemm_group_block(gg, smem); return; }
+template <int NWT>
+__global__ __launch_bounds__(NWT * 64) void k_gemm_group_reduce(GemmGroup gg, WgradReduceGroup gr, int ngemm) {
+  extern __shared__ __attribute__((aligned(16))) float smem_dyn[];      // NWT * WT_REGION floats
+  if ((int)blockIdx.x < ngemm) { gemm_group_block<NWT>(gg, smem_dyn); return; }
   const int bx = blockIdx.x - ngemm;
   int j = 0;
   while (j + 1 < gr.n && bx >= gr.start[j + 1]) ++j;
   wgrad_reduce_blocks(gr.job[j], bx - gr.start[j], gr.start[j + 1] - gr.start[j]);
+}
+template <int NWT>
+static void launch_gemm_group_reduce_t(const GemmGroup& gg, WgradReduceGroup& gr, int ngemm, hipStream_t st) {
+  static DevOnce attr_once;
+  const size_t lds = (size_t)NWT * WT_REGION * sizeof(float);
+  if (attr_once.first()) hipFuncSetAttribute((const void*)k_gemm_group_reduce<NWT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int total = 0;       // (the jobs' block counts are planned for 256 threads)
+  for (int j = 0; j < gr.n; ++j) { gr.start[j] = total; total += (wgrad_reduce_nblocks(gr.job[j]) * 4 + NWT - 1) / NWT; }
+  gr.start[gr.n] = total;
+  hipLaunchKernelGGL(k_gemm_group_reduce<NWT>, dim3(ngemm + total), dim3(NWT * 64), lds, st, gg, gr, ngemm);
 }
 
 int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream_t st) {
@@ -372,10 +389,10 @@ int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream
     ngemm += gemm_nblocks(gg.g[i]);
   }
   gg.start[gg.n] = ngemm;
-  int total = 0;
-  for (int j = 0; j < gr.n; ++j) { gr.start[j] = total; total += wgrad_reduce_nblocks(gr.job[j]); }
-  gr.start[gr.n] = total;
-  hipLaunchKernelGGL(k_gemm_group_reduce, dim3(ngemm + total), dim3(256), 0, st, gg, gr, ngemm);
+  static const int nwt_env = getenv("DTA_TAIL_NWT") ? atoi(getenv("DTA_TAIL_NWT")) : 0;
+  // (measured, same box: 4 waves 25.6 us, 8 waves 27.5, 16 waves 24.0 -- DTA_TAIL_NWT=4 selects the four-wave form)
+  if (nwt_env == 4) launch_gemm_group_reduce_t<4>(gg, gr, ngemm, st);
+  else launch_gemm_group_reduce_t<16>(gg, gr, ngemm, st);
   DTA_CHECK_LAUNCH("k_gemm_group_reduce");
   return 0;
 }
@@ -421,12 +438,21 @@ int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, flo
 // ------------------------------------------------------------------------------------------------
 // Hang2020 blend: joint = spec * sigmoid(alpha) + spat * (1 - sigmoid(alpha)); alpha is float64.
 // ------------------------------------------------------------------------------------------------
+// The Hang2020 blend (reference Hang2020.py:260-261) exactly as torch evaluates it: sigmoid and 1 - sigmoid in double (alpha
+// is a float64 0-dim tensor), each rounded to float when it meets the float32 scores, then two products and a sum with
+// no fused multiply-add.  ONE definition for every kernel that blends, so that the stand-alone blend (module path) and
+// the blend folded into the loss kernel (fused path) produce the same bits.
+__device__ __forceinline__ float blend2(float zs, float zt, float w, float w1) {
+#pragma clang fp contract(off)      // (hipcc contracts a * b + c into an FMA by default, site by site; HIP's __fmul_rn is a plain product)
+  const float ps = zs * w, pt = zt * w1;
+  return ps + pt;
+}
 __global__ void k_blend(BlendArgs a) {
   const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
   const float w = (float)wd, w1 = (float)(1.0 - wd);
   size_t n = (size_t)a.B * a.classes;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    a.joint[i] = a.spec[i] * w + a.spat[i] * w1;
+    a.joint[i] = blend2(a.spec[i], a.spat[i], w, w1);
 }
 int launch_blend(const BlendArgs& a, hipStream_t st) {
   size_t n = (size_t)a.B * a.classes;
@@ -529,7 +555,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd_fin(BlendBwdArgs a) {
 __global__ __launch_bounds__(256) void k_gemm_group_fin(GemmGroup gg, BlendBwdArgs fin, int ngemm) {
   __shared__ __attribute__((aligned(16))) float smem[GEMM_SMEM_FLOATS];
   if ((int)blockIdx.x >= ngemm) { blend_bwd_fin_block(fin, reinterpret_cast<double*>(smem), blockIdx.x - ngemm, gridDim.x - ngemm); return; }
-  gemm_group_block(gg, smem);
+  gemm_group_block<4>(gg, smem);
 }
 int launch_gemm_group_with_blend_fin(GemmGroup& gg, const BlendBwdArgs& fin, hipStream_t st) {
   const int nfin = BLEND_FIN_BLOCKS;
@@ -607,6 +633,20 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
   const int t = threadIdx.x, lane = t & 63, row = blockIdx.x * 4 + (t >> 6);
   // normaliser sum_i w[y_i] (every block needs it for its gradient rows): label loads of four strides in flight at
   // once, then their weight gathers -- two dependent round trips per 1024 labels instead of eight
+  // this wave's row first: its score loads, label and blend weight go out together with the normaliser's label loads
+  // (behind the normaliser's barrier they would be one more dependent round trip of an all-latency launch)
+  const int rowc = row < a.B ? row : a.B - 1;
+  const double alpha0 = a.spat ? a.alpha[0] : 0.0;
+  const float* zs = a.spec + (size_t)rowc * a.classes;
+  const float* zt = a.spat ? a.spat + (size_t)rowc * a.classes : nullptr;
+  float zsr[4], ztr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int n = lane + 64 * k;
+    zsr[k] = n < a.classes ? zs[n] : 0.f;
+    ztr[k] = (zt && n < a.classes) ? zt[n] : 0.f;
+  }
+  const long long y = a.labels[rowc];
   float part = 0.f;
   for (int i0 = t; i0 < a.B; i0 += 1024) {
     long long yy[4];
@@ -616,21 +656,19 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
     for (int k = 0; k < 4; ++k)
       if (yy[k] >= 0 && yy[k] < a.classes) part += a.weight ? a.weight[yy[k]] : 1.f;
   }
+  const bool ok = y >= 0 && y < a.classes;
+  const float wy = ok ? (a.weight ? a.weight[y] : 1.f) : 0.f;
   const float den = block_sum256(part, sc);
   if (row < a.B) {
-    const float w = a.spat ? (float)(1.0 / (1.0 + exp(-a.alpha[0]))) : 1.f;
-    const float* zs = a.spec + (size_t)row * a.classes;
-    const float* zt = a.spat ? a.spat + (size_t)row * a.classes : nullptr;
+    const double wd = 1.0 / (1.0 + exp(-alpha0));
+    const float w = (float)wd, w1 = (float)(1.0 - wd);
     float* jo = a.joint ? a.joint + (size_t)row * a.classes : nullptr;
-    auto zval = [&](int n) { return zt ? zs[n] * w + zt[n] * (1.f - w) : zs[n]; };
+    auto zval = [&](int n) { return zt ? blend2(zs[n], zt[n], w, w1) : zs[n]; };
     // the first 256 classes of the row live in registers (four per lane); wider rows re-read the rest
     float zc[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int n = lane + 64 * k; zc[k] = n < a.classes ? zval(n) : -3.4e38f; }
+    for (int k = 0; k < 4; ++k) { const int n = lane + 64 * k; zc[k] = n < a.classes ? (zt ? blend2(zsr[k], ztr[k], w, w1) : zsr[k]) : -3.4e38f; }
     auto zget = [&](int n, int k) { return k < 4 ? zc[k] : zval(n); };
-    const long long y = a.labels[row];
-    const bool ok = y >= 0 && y < a.classes;
-    const float wy = ok ? (a.weight ? a.weight[y] : 1.f) : 0.f;
     float mx = -3.4e38f;
     for (int n = lane, k = 0; n < a.classes; n += 64, ++k) mx = fmaxf(mx, zget(n, k));
     mx = wave_max(mx);

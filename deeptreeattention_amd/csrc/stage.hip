@@ -47,6 +47,14 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(BnFinK a) {
     return;
   }
   const float* st = a.stats + (size_t)g * a.stats_goff;
+  // the finishing threads' parameter loads go out with the partials (behind the barrier they would be a second
+  // dependent round trip of this all-latency launch)
+  float pgam = 0.f, pbet = 0.f, prm = 0.f, prv = 0.f, pgate = 1.f;
+  if (t < 8 && c < C) {
+    pgam = a.gamma[g][c]; pbet = a.beta[g][c];
+    if (a.rmean[g]) { prm = a.rmean[g][c]; prv = a.rvar[g][c]; }
+    if (a.gate) pgate = a.gate[g];
+  }
   double s[3] = {0, 0, 0};
   if (c < C) {
 #pragma unroll 4
@@ -72,13 +80,13 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(BnFinK a) {
     m2 = m2 > 0 ? m2 : 0;
     double var = m2 / n;
     float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-    float sc = a.gamma[g][c] * rstd;
-    coef[c * 4 + 0] = sc; coef[c * 4 + 1] = a.beta[g][c] - (float)mean * sc;
+    float sc = pgam * rstd;
+    coef[c * 4 + 0] = sc; coef[c * 4 + 1] = pbet - (float)mean * sc;
     coef[c * 4 + 2] = (float)mean; coef[c * 4 + 3] = rstd;
-    if (a.rmean[g] && (!a.gate || a.gate[g] > 0.f)) {      // (a year the step skips keeps its statistics, year.py:27)
+    if (a.rmean[g] && pgate > 0.f) {      // (a year the step skips keeps its statistics, year.py:27)
       double unb = n > 1 ? m2 / (n - 1) : var;
-      a.rmean[g][c] = (1.f - a.momentum) * a.rmean[g][c] + a.momentum * (float)mean;
-      a.rvar[g][c] = (1.f - a.momentum) * a.rvar[g][c] + a.momentum * (float)unb;
+      a.rmean[g][c] = (1.f - a.momentum) * prm + a.momentum * (float)mean;
+      a.rvar[g][c] = (1.f - a.momentum) * prv + a.momentum * (float)unb;
       if (c == 0 && a.nbt[g]) a.nbt[g][0] += 1;
     }
   }
@@ -1044,15 +1052,18 @@ __device__ __forceinline__ void bn_bwd_finalize_block(const BnBwdFinalizeArgs& a
   // block = 8 channels x 128 batch slices (see colsum8)
   const int t = threadIdx.x, C = a.C, c0 = bx * 8;
   const float* part = a.bnpart + (size_t)g * a.bnpart_gs + (size_t)c0 * 2;
+  const int c = c0 + (t >> 1);
+  const float* coef = a.coef + (size_t)g * a.coef_gs;
+  // (the finishing threads' two parameter loads go out with the partials, not behind the reduction's barriers)
+  float pgam = 0.f, prstd = 0.f;
+  if (t < 16 && !(t & 1) && c < C) { pgam = a.gamma[g][c]; prstd = coef[c * 4 + 3]; }
   const double v = colsum8<2>(part, (size_t)C * 2, a.B, min(8, C - c0), sc);
   // thread 2j holds sum(dv) of channel c0 + j, thread 2j + 1 its sum(dv * xhat): the even thread finishes the channel
   const double d2 = __shfl_down(v, 1);
-  const int c = c0 + (t >> 1);
   if (t < 16 && !(t & 1) && c < C) {
     const double d1 = v;
-    const float* coef = a.coef + (size_t)g * a.coef_gs;
     float* bc = a.bcoef + (size_t)g * a.bcoef_gs;
-    float A = a.gamma[g][c] * coef[c * 4 + 3];
+    float A = pgam * prstd;
     double n = (double)a.B * a.HW;
     bc[c * 4 + 0] = A;
     bc[c * 4 + 1] = a.training ? (float)(d1 / n) : 0.f;
