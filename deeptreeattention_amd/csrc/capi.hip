@@ -743,7 +743,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
         if (L == 0 && xchg) {
           // the exchange's head bucket (everything but the first conv's weights) must be COMPLETE before the launch whose
           // side workgroups sum it over the ranks: the parameter-gradient GEMMs and the other layers' slab reductions go now
-          if (deferred.n > 0 ? launch_gemm_group_with_reduce(deferred, reduces, st) : launch_wgrad_reduce_group(reduces, st)) return 1;
+          if (deferred.n > 0 ? launch_gemm_group_with_reduce(deferred, reduces, st, sizeof(T) == 2) : launch_wgrad_reduce_group(reduces, st)) return 1;
           deferred.n = 0; reduces.n = 0;
         }
         if (conv_wgrad_layer<T>(p, d, grads, ws, L, reduces, st, x_tiles, nullptr, (L == 1 && pair_pending) ? &pair_conv3 : nullptr,
@@ -770,7 +770,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       prof_end(DTA_SITE_CONV_DGRAD + L, st);
     }
   }
-  if (deferred.n > 0) return launch_gemm_group_with_reduce(deferred, reduces, st);
+  if (deferred.n > 0) return launch_gemm_group_with_reduce(deferred, reduces, st, sizeof(T) == 2);
   return launch_wgrad_reduce_group(reduces, st);
 }
 

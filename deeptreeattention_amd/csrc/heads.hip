@@ -379,7 +379,7 @@ static void launch_gemm_group_reduce_t(const GemmGroup& gg, WgradReduceGroup& gr
   hipLaunchKernelGGL(k_gemm_group_reduce<NWT>, dim3(ngemm + total), dim3(NWT * 64), lds, st, gg, gr, ngemm);
 }
 
-int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream_t st) {
+int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream_t st, bool wide) {
   if (gg.n == 0) return launch_wgrad_reduce_group(gr, st);
   if (gr.n == 0) return launch_gemm_group(gg, st);
   gemm_group_plan(gg);
@@ -390,8 +390,8 @@ int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream
   }
   gg.start[gg.n] = ngemm;
   static const int nwt_env = getenv("DTA_TAIL_NWT") ? atoi(getenv("DTA_TAIL_NWT")) : 0;
-  // (measured, same box: 4 waves 25.6 us, 8 waves 27.5, 16 waves 24.0 -- DTA_TAIL_NWT=4 selects the four-wave form)
-  if (nwt_env == 4) launch_gemm_group_reduce_t<4>(gg, gr, ngemm, st);
+  // (measured, same box: 4 waves 25.6 us, 8 waves 27.5, 16 waves 24.0 -- DTA_TAIL_NWT=4 / 16 force a form)
+  if (nwt_env == 4 || (!wide && nwt_env != 16)) launch_gemm_group_reduce_t<4>(gg, gr, ngemm, st);
   else launch_gemm_group_reduce_t<16>(gg, gr, ngemm, st);
   DTA_CHECK_LAUNCH("k_gemm_group_reduce");
   return 0;

@@ -356,7 +356,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st);
 int launch_gemm_group(GemmGroup& gg, hipStream_t st);
 // the parameter-gradient GEMMs nothing waits for and the split-K reductions of the conv weight gradients as ONE launch
 // (both are block-range -> job kernels with 256-thread blocks; a dependent launch costs ~11 us on this GPU)
-int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream_t st);
+// wide: the GEMM workgroups are 16 waves (the bf16 step: -1.5 us); false: four waves (the fp32 step measured 0.3 % slower wide)
+int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream_t st, bool wide = false);
 int gemm_auto_ksplit(int M, int N, int K);
 struct ColsumArgs {
   const float* A; int rows, cols; long lda;
