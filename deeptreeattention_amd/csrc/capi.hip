@@ -570,7 +570,7 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
     // (GemmArgs::sig_mode); d(alpha) is reduced by one extra block of the first GEMM launch below
     BlendBwdArgs bb = {};
     bb.spec = at<float>(ws, p.scores[0][2]); bb.spat = at<float>(ws, p.scores[1][2]);
-    bb.alpha = alpha; bb.djoint = djoint; bb.dalpha = dalpha; bb.dalpha32 = dalpha32; bb.B = B; bb.classes = p.classes;
+    bb.alpha = alpha; bb.djoint = djoint; bb.dalpha = dalpha; bb.B = B; bb.classes = p.classes;
     if (dalpha == nullptr) { dta_set_error("Hang2020 backward needs a dalpha destination"); return 1; }
     blend_fin = bb; blend_fin_pending = true;
     dsc[0][2] = djoint; dsc[1][2] = djoint;
@@ -594,6 +594,9 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
   }
   GemmGroup deferred;   // parameter-gradient GEMMs nothing downstream waits for: one grouped launch at the end
   WgradReduceGroup reduces;   // likewise the split-K reductions of the conv weight gradients
+  // data-parallel (torch / RCCL buckets): alpha's finished float64 gradient is rounded ONCE into its fp32 exchange slot
+  // by the launch that ends this call (phase 1 or the whole backward)
+  if (dalpha32 && blend_fin_pending) { reduces.slot_src = dalpha; reduces.slot_dst = dalpha32; }
   for (int L = 2; L >= 0; --L) {
     const int C = CH[L];
     StageArgs sa = stage_args(p, d, nets, ws, L);

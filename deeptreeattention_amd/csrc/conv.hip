@@ -583,7 +583,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradReduceArgs a) { wgrad_reduce_blocks(a, blockIdx.x, gridDim.x); }
+__global__ void k_slot_copy(const double* src, float* dst) { dst[0] = (float)src[0]; }
 __global__ __launch_bounds__(256) void k_wgrad_reduce_group(WgradReduceGroup gr) {
+  if (gr.slot_dst && blockIdx.x == 0 && threadIdx.x == 0) gr.slot_dst[0] = (float)gr.slot_src[0];
   int j = 0;
   while (j + 1 < gr.n && (int)blockIdx.x >= gr.start[j + 1]) ++j;
   wgrad_reduce_blocks(gr.job[j], blockIdx.x - gr.start[j], gr.start[j + 1] - gr.start[j]);
@@ -648,8 +650,11 @@ int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {
   return 0;
 }
 int launch_wgrad_reduce_group(WgradReduceGroup& gr, hipStream_t st) {
-  if (gr.n == 0) return 0;
-  if (gr.n == 1) return launch_wgrad_reduce(gr.job[0], st);
+  if (gr.n == 0) {
+    if (gr.slot_dst) { hipLaunchKernelGGL(k_slot_copy, dim3(1), dim3(1), 0, st, gr.slot_src, gr.slot_dst); DTA_CHECK_LAUNCH("k_slot_copy"); }
+    return 0;
+  }
+  if (gr.n == 1 && !gr.slot_dst) return launch_wgrad_reduce(gr.job[0], st);
   int total = 0;
   for (int j = 0; j < gr.n; ++j) { gr.start[j] = total; total += wgrad_reduce_nblocks(gr.job[j]); }
   gr.start[gr.n] = total;

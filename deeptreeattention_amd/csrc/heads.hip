@@ -362,6 +362,7 @@ int launch_gemm_group(GemmGroup& gg, hipStream_t st) {
 template <int NWT>
 __global__ __launch_bounds__(NWT * 64) void k_gemm_group_reduce(GemmGroup gg, WgradReduceGroup gr, int ngemm) {
   extern __shared__ __attribute__((aligned(16))) float smem_dyn[];      // NWT * WT_REGION floats
+  if (gr.slot_dst && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) gr.slot_dst[0] = (float)gr.slot_src[0];
   if ((int)blockIdx.x < ngemm) { gemm_group_block<NWT>(gg, smem_dyn); return; }
   const int bx = blockIdx.x - ngemm;
   int j = 0;
@@ -381,7 +382,7 @@ static void launch_gemm_group_reduce_t(const GemmGroup& gg, WgradReduceGroup& gr
 
 int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream_t st, bool wide) {
   if (gg.n == 0) return launch_wgrad_reduce_group(gr, st);
-  if (gr.n == 0) return launch_gemm_group(gg, st);
+  if (gr.n == 0) return launch_gemm_group(gg, st) || launch_wgrad_reduce_group(gr, st);      // (the second: the slot rider, if any)
   gemm_group_plan(gg);
   int ngemm = 0;
   for (int i = 0; i < gg.n; ++i) {
@@ -544,7 +545,6 @@ __device__ __forceinline__ void blend_bwd_fin_block(const BlendBwdArgs& a, doubl
     // depend on the order and the whole train step is bit-reproducible (cost: 4e-16 absolute per partial).
     const double pq = rint(sd[0] * wd * (1.0 - wd) * 0x1p50) * 0x1p-50;
     atomicAdd(a.dalpha, pq);
-    if (a.dalpha32) atomicAdd(a.dalpha32, (float)pq);
   }
 }
 __global__ __launch_bounds__(256) void k_blend_bwd_fin(BlendBwdArgs a) {
@@ -821,6 +821,33 @@ __global__ void k_adam(AdamArgs a) {
   // alpha's gradient in an exchange slot of g: the thread that owns that element steps alpha (it reads the slot before
   // the pass clears it)
   const bool slot_mode = a.alpha_p && a.alpha_g32;
+  // 16-byte form (the flat buffers of the trainers / DtaAdam: every segment starts on a 16-byte boundary and is padded to
+  // a multiple of four floats): a quarter of the memory instructions of the scalar loop below, same arithmetic per element
+  const bool vec = (a.n & 3) == 0 && ((((size_t)a.p | (size_t)a.g | (size_t)a.m | (size_t)a.v | (size_t)a.gz) & 15) == 0);
+  if (vec) {
+    const size_t nq = a.n >> 2;
+    for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+      const size_t i = q << 2;
+      const f32x4 gr = *(const f32x4*)(a.g + i);
+      const f32x4 mo = __builtin_nontemporal_load((const f32x4*)(a.m + i));
+      const f32x4 vo = __builtin_nontemporal_load((const f32x4*)(a.v + i));
+      f32x4 po = *(const f32x4*)(a.p + i), mn, vn;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float g = gr[c] * a.grad_scale;
+        mn[c] = a.beta1 * mo[c] + (1.f - a.beta1) * g;
+        vn[c] = a.beta2 * vo[c] + (1.f - a.beta2) * g * g;
+        po[c] -= ss * (mn[c] / (sqrtf(vn[c]) * rbc2 + a.eps));
+      }
+      __builtin_nontemporal_store(mn, (f32x4*)(a.m + i));
+      __builtin_nontemporal_store(vn, (f32x4*)(a.v + i));
+      *(f32x4*)(a.p + i) = po;
+      if (slot_mode && a.alpha_g32 >= a.g + i && a.alpha_g32 < a.g + i + 4) alpha_update((double)gr[(int)(a.alpha_g32 - (a.g + i))]);
+      if (a.gz) { const f32x4 z = {0.f, 0.f, 0.f, 0.f}; *(f32x4*)(a.gz + i) = z; }
+    }
+    if (a.alpha_p && !a.alpha_g32 && blockIdx.x == 0 && threadIdx.x == 0) alpha_update(a.alpha_g[0]);
+    return;
+  }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
     // moments: touched once per step, by this kernel only -> nontemporal both ways (they would only evict useful lines)
     const float graw = a.g[i];
@@ -835,7 +862,10 @@ __global__ void k_adam(AdamArgs a) {
   if (a.alpha_p && !a.alpha_g32 && blockIdx.x == 0 && threadIdx.x == 0) alpha_update(a.alpha_g[0]);
 }
 int launch_adam(const AdamArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_adam, dim3((unsigned)min((size_t)2048, (a.n + 255) / 256)), dim3(256), 0, st, a);
+  // (workgroups for the 16-byte form: a quad per thread)
+  const bool vec = (a.n & 3) == 0 && ((((size_t)a.p | (size_t)a.g | (size_t)a.m | (size_t)a.v | (size_t)a.gz) & 15) == 0);
+  const size_t items = vec ? a.n / 4 : a.n;
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)max((size_t)1, min((size_t)2048, (items + 255) / 256))), dim3(256), 0, st, a);
   DTA_CHECK_LAUNCH("k_adam");
   return 0;
 }

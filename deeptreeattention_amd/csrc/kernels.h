@@ -69,7 +69,13 @@ template <> int launch_conv3x3<bf16_t>(const ConvArgs& a, int G, hipStream_t st)
 template <> int launch_conv_wgrad<bf16_t>(const WgradArgs& a, int G, hipStream_t st);   // conv_bf16.hip
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st);
 // several layers' split-K reductions in one launch (block ranges -> jobs)
-struct WgradReduceGroup { WgradReduceArgs job[3]; int start[4]; int n = 0; };
+struct WgradReduceGroup {
+  WgradReduceArgs job[3]; int start[4]; int n = 0;
+  // optional rider: slot_dst[0] = (float)slot_src[0] -- alpha's float64 gradient (complete since the backward's first
+  // launch, accumulated order-independently) into its fp32 exchange slot of the gradient buffer: ONE rounding of the
+  // finished double instead of fp32 atomics in arrival order, so the data-parallel step is run-to-run reproducible too
+  const double* slot_src = nullptr; float* slot_dst = nullptr;
+};
 int launch_wgrad_reduce_group(WgradReduceGroup& gr, hipStream_t st);
 int wgrad_reduce_nblocks(const WgradReduceArgs& a);
 // bf16: the weight gradients of the second and third conv in ONE launch when both resolve to the pair kernel's programs
@@ -460,8 +466,6 @@ int launch_mean_scores(const MeanArgs& a, hipStream_t st);
 struct BlendBwdArgs {
   const float* spec; const float* spat; const double* alpha; const float* djoint;
   double* dalpha; int B, classes;
-  float* dalpha32;      // optional fp32 copy of d(alpha), accumulated alongside: the slot of the flat gradient buffer in
-                        // which alpha's gradient travels through a data-parallel exchange (no copy kernels around it)
 };
 // the blend's backward lives inside the head GEMMs (GemmArgs::sig_mode); its d(alpha) reduction rides as extra blocks
 // of a grouped GEMM launch

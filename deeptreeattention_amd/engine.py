@@ -403,7 +403,7 @@ class FusedTrainer:
             djoint = None
         self._zero_grads()             # C-ABI contract: gradient buffers (and dalpha) arrive zero-filled
 
-        # data-parallel: alpha's gradient is also accumulated (fp32) into its slot of the first bucket by the kernels
+        # data-parallel: alpha's finished float64 gradient is also rounded (once) into its fp32 slot of the first bucket by the backward's last launch
         # (peer exchange: the exchange launch itself converts the float64 d(alpha) into the slot)
         slot = _lib.ptr(self.alpha_slot) if (self.comm and self.alpha_on_graph and self.ex is None) else None
 

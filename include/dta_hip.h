@@ -112,8 +112,9 @@ int dta_net_backward_tiles(const dta_net_desc* d, const dta_subnet_params* nets,
                            const dta_subnet_grads* grads, double* dalpha, int phases, void* stream);
 
 /* Data-parallel form of dta_net_backward / dta_net_backward_tiles (x_tiles NULL: the workspace's own tiles).  One extra
- * destination: dalpha_f32 (may be NULL), a float32 copy of d(alpha) accumulated next to the float64 one.  A
- * data-parallel caller points it at a (zeroed) slot of its flat float32 gradient buffer, so that alpha's gradient takes
+ * destination: dalpha_f32 (may be NULL) receives d(alpha) rounded to float32 -- ONE rounding of the finished float64 sum,
+ * written by the launch that ends the call (any call with phases & 1), no float atomics: reruns give the same bits.  A
+ * data-parallel caller points it at a slot of its flat float32 gradient buffer, so that alpha's gradient takes
  * part in the buffer's all-reduce without copy kernels around the collective (reference train.py:89-98 lets Lightning's
  * DDP all-reduce every parameter; here that is at most two collectives per step). */
 int dta_net_backward_dp(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,

@@ -87,6 +87,18 @@ def test_one_rank_direct_exchanges_match_plain_step(tmp_path, exch):
             assert torch.allclose(ref[k].float(), got[k].float(), rtol=1e-4, atol=1e-6), k
 
 
+@pytest.mark.parametrize("mode", ["plain", "rccl", "torch", "peer"])
+def test_reruns_in_separate_processes_are_bit_identical(tmp_path, mode):
+    """Three bf16 steps, twice, each in its own process: every tensor of the state dict has the same bits -- no float atomics
+    on any path (alpha's fp32 exchange slot is ONE rounding of the finished float64 sum; the split-K sums meet in a fixed
+    order), no dependence on allocation addresses."""
+    force = mode != "plain"
+    a = _run(tmp_path, mode + "_a", force, mode == "torch", "bf16", "" if mode in ("plain", "torch") else mode)
+    b = _run(tmp_path, mode + "_b", force, mode == "torch", "bf16", "" if mode in ("plain", "torch") else mode)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_bench_runs_on_rccl_backend_with_one_rank():
     env = dict(os.environ, DTA_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", RANK="0",
                LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
