@@ -78,7 +78,10 @@ class DtaAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_zero_grad=True, process_group=None,
                  exchange=None, exchange_opts=None):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # (torch.optim.Adam's remaining group keys ride along with the values this optimizer implements, so that a state
+        #  dict saved here loads into torch.optim.Adam and steps there)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                                      capturable=False, differentiable=False, fused=None))
         if len(self.param_groups) != 1:
             raise ValueError("DtaAdam keeps one parameter group (one learning rate), as the reference's optimizers do")
         plist = [p for p in self.param_groups[0]["params"] if p.requires_grad]
@@ -251,6 +254,8 @@ class DtaAdam(torch.optim.Optimizer):
         L = _lib.lib()
         st = _lib.current_stream_ptr()
         g = self.param_groups[0]
+        if g.get("weight_decay") or g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("DtaAdam implements torch.optim.Adam without weight decay / amsgrad / maximize (the reference's setting)")
         lr, (b1, b2), eps = float(g["lr"]), g["betas"], float(g["eps"])
         self._steps += 1
         zero = 1 if self.fuse_zero_grad else 0

@@ -181,6 +181,43 @@ def test_dta_adam_resumes_from_its_own_and_from_torch_adam_state_dict():
         assert rel_l2(v.double().cpu().numpy(), want[k]) < 2e-3, k
 
 
+def test_torch_adam_resumes_from_a_dta_adam_state_dict():
+    """The other direction: a DtaAdam state dict loads into torch.optim.Adam (same group keys, same state layout) and
+    the third step there lands on the uninterrupted DtaAdam run."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    bands, classes, B, lr = 14, 8, 5, 1e-3
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=44)
+    batches = [(torch.from_numpy(prng.uniform01(600 + s, 1, (B, bands, 11, 11))).to(dev()),
+                torch.from_numpy(prng.randint(600 + s, 2, (B,), classes)).to(dev())) for s in range(3)]
+
+    def steps(m, opt, which, ce):
+        for s in which:
+            x, y = batches[s]
+            opt.zero_grad()
+            ce(m(x), y).backward()
+            opt.step()
+
+    full = load(H.Hang2020(bands, classes), p).train()
+    ofull = DtaAdam(full.parameters(), lr=lr)
+    steps(full, ofull, range(3), cross_entropy)
+    a = load(H.Hang2020(bands, classes), p).train()
+    oa = DtaAdam(a.parameters(), lr=lr)
+    steps(a, oa, range(2), cross_entropy)
+    msd, osd = copy.deepcopy(a.state_dict()), copy.deepcopy(oa.state_dict())
+    oa.close()
+    b = H.Hang2020(bands, classes).to(dev()).train()
+    b.load_state_dict(msd)
+    ob = torch.optim.Adam(b.parameters(), lr=lr * 3)
+    ob.load_state_dict(osd)
+    assert ob.param_groups[0]["lr"] == lr
+    steps(b, ob, [2], torch.nn.functional.cross_entropy)
+    for (k, v), (_, u) in zip(b.state_dict().items(), full.state_dict().items()):
+        if k.endswith("conv_layer.bias") or "classifier1" in k or "classifier2" in k:
+            continue      # no gradient signal (BatchNorm behind the bias) / torch leaves the unused heads' grad None
+        assert rel_l2(v.double().cpu().numpy(), u.double().cpu().numpy()) < 2e-3, k
+
+
 def test_dta_adam_resume_keeps_per_year_step_counts():
     from deeptreeattention_amd.year import learned_ensemble
     from deeptreeattention_amd.optim import DtaAdam, cross_entropy
