@@ -647,8 +647,33 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
     ztr[k] = (zt && n < a.classes) ? zt[n] : 0.f;
   }
   const long long y = a.labels[rowc];
+  // the normaliser's first 1024 labels (usually all of them) are requested here, their weight gathers after the row's
+  // softmax below: the row arithmetic runs under the sweep's two dependent round trips instead of behind its barrier
+  long long yy0[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) yy0[k] = (t + 256 * k < a.B) ? a.labels[t + 256 * k] : -1;
+  const bool ok = y >= 0 && y < a.classes;
+  const double wd = 1.0 / (1.0 + exp(-alpha0));
+  const float w = (float)wd, w1 = (float)(1.0 - wd);
+  auto zval = [&](int n) { return zt ? blend2(zs[n], zt[n], w, w1) : zs[n]; };
+  // the first 256 classes of the row live in registers (four per lane); wider rows re-read the rest
+  float zc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int n = lane + 64 * k; zc[k] = n < a.classes ? (zt ? blend2(zsr[k], ztr[k], w, w1) : zsr[k]) : -3.4e38f; }
+  auto zget = [&](int n, int k) { return k < 4 ? zc[k] : zval(n); };
+  float mx = -3.4e38f;
+  for (int n = lane, k = 0; n < a.classes; n += 64, ++k) mx = fmaxf(mx, zget(n, k));
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int n = lane, k = 0; n < a.classes; n += 64, ++k) se += __expf(zget(n, k) - mx);
+  se = wave_sum(se);
+  const float lse = __logf(se);
+  const float wy = ok ? (a.weight ? a.weight[y] : 1.f) : 0.f;
   float part = 0.f;
-  for (int i0 = t; i0 < a.B; i0 += 1024) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (yy0[k] >= 0 && yy0[k] < a.classes) part += a.weight ? a.weight[yy0[k]] : 1.f;
+  for (int i0 = t + 1024; i0 < a.B; i0 += 1024) {
     long long yy[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) yy[k] = (i0 + 256 * k < a.B) ? a.labels[i0 + 256 * k] : -1;
@@ -656,33 +681,17 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
     for (int k = 0; k < 4; ++k)
       if (yy[k] >= 0 && yy[k] < a.classes) part += a.weight ? a.weight[yy[k]] : 1.f;
   }
-  const bool ok = y >= 0 && y < a.classes;
-  const float wy = ok ? (a.weight ? a.weight[y] : 1.f) : 0.f;
+  const float poison = (ok || y == -100) ? 0.f : __builtin_nanf("");
+  float xold = 0.f;
+  if (row < a.B && lane == 0) {
+    // device-scope exchange: performed at the coherence point (the per-XCD L2s are not coherent for plain stores); issued
+    // before the normaliser's reduction, its return value consumed after it (the wave must not reach the counter below
+    // before the exchange HAS been performed)
+    xold = __hip_atomic_exchange(a.rowtmp + row, ok ? wy * (lse + mx - zval((int)y)) : poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const float den = block_sum256(part, sc);
   if (row < a.B) {
-    const double wd = 1.0 / (1.0 + exp(-alpha0));
-    const float w = (float)wd, w1 = (float)(1.0 - wd);
     float* jo = a.joint ? a.joint + (size_t)row * a.classes : nullptr;
-    auto zval = [&](int n) { return zt ? blend2(zs[n], zt[n], w, w1) : zs[n]; };
-    // the first 256 classes of the row live in registers (four per lane); wider rows re-read the rest
-    float zc[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const int n = lane + 64 * k; zc[k] = n < a.classes ? (zt ? blend2(zsr[k], ztr[k], w, w1) : zsr[k]) : -3.4e38f; }
-    auto zget = [&](int n, int k) { return k < 4 ? zc[k] : zval(n); };
-    float mx = -3.4e38f;
-    for (int n = lane, k = 0; n < a.classes; n += 64, ++k) mx = fmaxf(mx, zget(n, k));
-    mx = wave_max(mx);
-    float se = 0.f;
-    for (int n = lane, k = 0; n < a.classes; n += 64, ++k) se += __expf(zget(n, k) - mx);
-    se = wave_sum(se);
-    const float lse = __logf(se);
-    const float poison = (ok || y == -100) ? 0.f : __builtin_nanf("");
-    if (lane == 0) {
-      // device-scope exchange: performed at the coherence point (the per-XCD L2s are not coherent for plain stores);
-      // consuming its return value makes this wave wait until it HAS been performed before it reaches the barrier
-      const float old = __hip_atomic_exchange(a.rowtmp + row, ok ? wy * (lse + mx - zval((int)y)) : poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("" ::"v"(old));
-    }
     // device-decided factor (1 / kept years): an infinite one says this rank kept NO year -- its scores are NaN (an empty
     // mean, as the reference raises there) and it must contribute nothing to a data-parallel gradient sum: exact zeros
     const float gs = a.gscale_dev ? a.gscale_dev[0] : a.gscale;
@@ -694,6 +703,7 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
       if (a.dlogits) a.dlogits[(size_t)row * a.classes + n] = none_kept ? 0.f : sc2 * (__expf(z - mx - lse) - ((ok && n == (int)y) ? 1.f : 0.f));
     }
   }
+  asm volatile("" ::"v"(xold));
   // the last block to arrive sums the row terms (fixed order) into the loss.  No fence: a device-scope release would
   // write back this XCD's whole L2 (measured: 28 us for this kernel); the row terms and the counter are all device-scope
   // atomics, ordered by the waits above and the barrier

@@ -1,0 +1,17 @@
+#!/bin/bash
+# copy one run_profiles.sh result set (gpurun_out/<tag>) into profiles/ under the round's names: tools/copy_profiles.sh <tag> <rNN>
+S=gpurun_out/$1; R=$2
+cp $S/bench_default.json profiles/${R}_bench_bf16_default.json
+cp $S/bench_wgrad0.json profiles/${R}_bench_bf16_site_wgrad0.json
+cp $S/bench_ensemble24.json profiles/${R}_bench_ensemble24.json
+cp $S/bench_ensemble24_wgrad0.json profiles/${R}_bench_ensemble24_site_wgrad0.json
+cp $S/dp_one_rank.txt profiles/${R}_dp_one_rank.txt
+cp $S/ab_fanin.txt profiles/${R}_ab_fanin.txt
+cp $S/ab_ensemble24.txt profiles/${R}_ab_ensemble24.txt
+cp $S/ensemble24_private_segment.txt profiles/${R}_ensemble24_private_segment.txt
+cp $S/infer.txt profiles/${R}_inference.txt
+cp $S/kernel_trace.txt profiles/${R}_kernel_trace_bf16_B1024.txt
+cp $S/kernel_trace_fanin.txt profiles/${R}_kernel_trace_bf16_B1024_fanin.txt
+cp $S/kernel_trace_ensemble24.txt profiles/${R}_kernel_trace_ensemble24.txt
+cp $S/traffic_step.json profiles/${R}_traffic_step.json
+[ -f $S/gpu_tests.txt ] && cp $S/gpu_tests.txt profiles/${R}_gpu_tests.txt
