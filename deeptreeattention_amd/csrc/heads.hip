@@ -15,7 +15,17 @@ constexpr int GP = 36;   // LDS row pitch (floats): 16-byte aligned rows, confli
 
 // Both operands live in LDS as [row][kperm] (row = m for A, n for B) with kperm(k) = (k & 1) * 16 + (k >> 1): the
 // 16 k values one lane feeds to the 16 MFMAs of a chunk (k = 2j + lane/32) are contiguous -> four ds_read_b128.
-enum { LD_SCALAR = 0, LD_VEC_K = 1, LD_VEC_ROW = 2, LD_RUNTIME = 3 };
+enum { LD_SCALAR = 0, LD_VEC_K = 1, LD_VEC_ROW = 2, LD_RUNTIME = 3,
+       // wave-tile form only: unit stride along k / along the rows but NOT 16-byte loadable (a score matrix whose class count
+       // is not a multiple of four): element-wise loads into the same LDS images as LD_VEC_K / LD_VEC_ROW
+       LD_SC_K = 4, LD_SC_ROW = 5 };
+// wave-tile load mode of one operand, or LD_SCALAR if neither stride is 1
+__host__ __device__ __forceinline__ int gemm_load_mode(const float* p, int rows, int K, long s_row, long s_k);
+__host__ __device__ __forceinline__ int gemm_wt_mode(const float* p, int rows, int K, long s_row, long s_k) {
+  const int m = gemm_load_mode(p, rows, K, s_row, s_k);
+  if (m != LD_SCALAR) return m;
+  return s_k == 1 ? LD_SC_K : (s_row == 1 ? LD_SC_ROW : LD_SCALAR);
+}
 
 __host__ __device__ __forceinline__ int gemm_load_mode(const float* p, int rows, int K, long s_row, long s_k) {
   const bool al = (((size_t)p) & 15) == 0;
@@ -166,9 +176,12 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, in
 // over 200-500 workgroups): 4x as many, 4x shorter dependent chains than the 64x64 form below.
 // ------------------------------------------------------------------------------------------------
 constexpr int WT_REGION = 2 * 32 * GP;     // floats per wave: A chunk + B chunk ([32][GP] k-fast or [32][32] row-fast)
+// (element-wise A with a row-fast vector B: the two GEMMs that read a score-gradient matrix [batch][classes] -- head input
+//  gradient and head weight gradient -- when the class count is not a multiple of four)
 __host__ __device__ __forceinline__ bool gemm_wave_tiles(const GemmArgs& a) {
-  const int am = gemm_load_mode(a.A, a.M, a.K, a.sa_m, a.sa_k), bm = gemm_load_mode(a.Bm, a.N, a.K, a.sb_n, a.sb_k);
-  return am != LD_SCALAR && bm != LD_SCALAR;
+  const int am = gemm_wt_mode(a.A, a.M, a.K, a.sa_m, a.sa_k), bm = gemm_load_mode(a.Bm, a.N, a.K, a.sb_n, a.sb_k);
+  if (bm == LD_SCALAR || am == LD_SCALAR) return false;
+  return am == LD_VEC_K || am == LD_VEC_ROW || bm == LD_VEC_ROW;
 }
 __host__ __device__ __forceinline__ int gemm_nblocks(const GemmArgs& a) {
   const int ks = a.ksplit < 1 ? 1 : a.ksplit;
@@ -178,6 +191,18 @@ __host__ __device__ __forceinline__ int gemm_nblocks(const GemmArgs& a) {
 // one 32 x GK operand chunk -> 16 floats per lane (four 16-byte loads)
 template <int MODE>
 __device__ __forceinline__ void wt_load(f32x4 (&r)[4], const float* p, int rows, int r0, long s_row, long s_k, int k0, int kend, int lane) {
+  if (MODE == LD_SC_K || MODE == LD_SC_ROW) {
+    // element e = lane + 64 j: consecutive lanes read consecutive addresses (k-fast: 32 k of one row; row-fast: 32 rows of one k)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int e = lane + 64 * (4 * u + c);
+        const int row = MODE == LD_SC_K ? e >> 5 : e & 31, k = MODE == LD_SC_K ? e & 31 : e >> 5;
+        r[u][c] = (r0 + row < rows && k0 + k < kend) ? p[(size_t)(r0 + row) * s_row + (size_t)(k0 + k) * s_k] : 0.f;
+      }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int i = lane + u * 64;
@@ -194,6 +219,17 @@ __device__ __forceinline__ void wt_load(f32x4 (&r)[4], const float* p, int rows,
 }
 template <int MODE>
 __device__ __forceinline__ void wt_store(float* S, const f32x4 (&r)[4], int lane) {
+  if (MODE == LD_SC_K || MODE == LD_SC_ROW) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int e = lane + 64 * (4 * u + c);
+        if (MODE == LD_SC_K) S[(e >> 5) * GP + kperm(e & 31)] = r[u][c];      // the LD_VEC_K image
+        else S[(e >> 5) * 32 + (e & 31)] = r[u][c];                           // the LD_VEC_ROW image
+      }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int i = lane + u * 64;
@@ -209,7 +245,7 @@ __device__ __forceinline__ void wt_store(float* S, const f32x4 (&r)[4], int lane
 }
 template <int MODE>
 __device__ __forceinline__ void wt_fetch(float (&v)[16], const float* S, int row, int h) {
-  if (MODE == LD_VEC_ROW) {
+  if (MODE == LD_VEC_ROW || MODE == LD_SC_ROW) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = S[(2 * j + h) * 32 + row];
   } else {
@@ -252,7 +288,7 @@ __device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by,
     __builtin_amdgcn_wave_barrier();
     if (a.rowsum_out && by == 0 && lane < 32) {
 #pragma unroll
-      for (int k = 0; k < GK; ++k) rsum += AM == LD_VEC_ROW ? As[k * 32 + lane] : As[lane * GP + k];
+      for (int k = 0; k < GK; ++k) rsum += (AM == LD_VEC_ROW || AM == LD_SC_ROW) ? As[k * 32 + lane] : As[lane * GP + k];
     }
     float av[16], bv[16];
     wt_fetch<AM>(av, As, lane & 31, lane >> 5);
@@ -302,8 +338,8 @@ __device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, float* sme
   while (pi + 1 < gg.n && (int)blockIdx.x >= gg.start[pi + 1]) ++pi;
   const GemmArgs& a = gg.g[pi];
   int local = blockIdx.x - gg.start[pi];
-  const int am = gemm_load_mode(a.A, a.M, a.K, a.sa_m, a.sa_k), bm = gemm_load_mode(a.Bm, a.N, a.K, a.sb_n, a.sb_k);
-  if (am != LD_SCALAR && bm != LD_SCALAR) {
+  const int am = gemm_wt_mode(a.A, a.M, a.K, a.sa_m, a.sa_k), bm = gemm_load_mode(a.Bm, a.N, a.K, a.sb_n, a.sb_k);
+  if (gemm_wave_tiles(a)) {
     const int tm = (a.M + 31) / 32, tn = (a.N + 31) / 32;
     const int bx = local % tm; local /= tm;
     const int by = local % tn;
@@ -311,6 +347,8 @@ __device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, float* sme
     if (am == LD_VEC_K && bm == LD_VEC_K) gemm_block_wt<LD_VEC_K, LD_VEC_K, NWT>(a, bx, by, bz, smem);              // x W^T
     else if (am == LD_VEC_K && bm == LD_VEC_ROW) gemm_block_wt<LD_VEC_K, LD_VEC_ROW, NWT>(a, bx, by, bz, smem);     // dy W
     else if (am == LD_VEC_ROW && bm == LD_VEC_ROW) gemm_block_wt<LD_VEC_ROW, LD_VEC_ROW, NWT>(a, bx, by, bz, smem); // dy^T x
+    else if (am == LD_SC_K) gemm_block_wt<LD_SC_K, LD_VEC_ROW, NWT>(a, bx, by, bz, smem);       // dy W, classes % 4 != 0
+    else if (am == LD_SC_ROW) gemm_block_wt<LD_SC_ROW, LD_VEC_ROW, NWT>(a, bx, by, bz, smem);   // dy^T x, classes % 4 != 0
     else gemm_block_wt<LD_VEC_ROW, LD_VEC_K, NWT>(a, bx, by, bz, smem);
     return;
   }

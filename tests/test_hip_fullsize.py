@@ -126,7 +126,7 @@ def test_short_training_run_descends(setup):
 
 
 def test_backward_is_reproducible_run_to_run(setup):
-    """The same eval-mode backward 200 times: split-K atomics may reorder fp32 sums (~1e-6 relative), nothing more.
+    """The same eval-mode backward 200 times: sums meet in a fixed order (no float atomics), so the bound below is loose.
     Guards the two-patches-per-workgroup stage kernels against intra-workgroup races (a lost patch contribution
     shows up as a ~1/B = 1e-3 deviation of the attention parameter gradients in roughly one run out of 150)."""
     m, x, y = setup

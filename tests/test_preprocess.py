@@ -183,8 +183,7 @@ def test_train_step_from_tiles_equals_train_step_from_the_float_batch(B):
     import copy
     rng = np.random.RandomState(3)
     crops = [rng.randint(0, 9000, size=(43, rng.randint(8, 20), rng.randint(8, 20))).astype(np.int16) for _ in range(B)]
-    # (8 classes: score rows of 32 bytes keep the classifier GEMMs on the no-atomics form, so the two paths give the same bits;
-    #  with 6 the split-K float atomics differ in the last bit from run to run and Adam's sign-like first steps amplify that)
+    # (both paths run the same kernels in the same order: the same bits)
     y = torch.from_numpy(rng.randint(0, 8, size=B)).to(_dev())
     x32 = PP.preprocess_batch(crops, 11, train=True)
     xt = PP.preprocess_batch(crops, 11, train=True, tiles=True)

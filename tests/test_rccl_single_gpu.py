@@ -25,7 +25,7 @@ if force:
 from deeptreeattention_amd import Hang2020 as H
 from deeptreeattention_amd.engine import FusedTrainer
 torch.manual_seed(5)
-m = H.Hang2020(40, 12, precision=os.environ["DTA_PREC"]).to(dev).train()      # (12 classes: 16-byte score rows, the no-atomics GEMM form: run-to-run identical bits)
+m = H.Hang2020(40, 12, precision=os.environ["DTA_PREC"]).to(dev).train()
 exch = os.environ.get("DTA_EXCH") or None
 tr = FusedTrainer(m, lr=1e-3, overlap_comm=os.environ["DTA_OVERLAP"] == "1", exchange=exch)
 g = torch.Generator(device=dev); g.manual_seed(7)

@@ -252,6 +252,31 @@ def test_dta_adam_resume_keeps_per_year_step_counts():
         assert rel_l2(v.double().cpu().numpy(), u.double().cpu().numpy()) < 1e-6, k
 
 
+@pytest.mark.parametrize("classes", [7, 199])
+def test_class_counts_that_are_not_a_multiple_of_four_are_reproducible(classes):
+    """Score rows of 7 or 199 floats are not 16-byte loadable: the two head GEMMs that read the score gradient then take
+    the element-wise wave-tile form (no split-K atomics), so reruns give the same bits, as for aligned class counts."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+
+    def run():
+        torch.manual_seed(11)
+        m = H.Hang2020(24, classes, precision="bf16").to(dev()).train()
+        tr = FusedTrainer(m, lr=1e-3, loss_weight=torch.linspace(0.2, 1.0, classes).to(dev()))
+        g = torch.Generator(device=dev())
+        g.manual_seed(3)
+        x = torch.rand(530, 24, 11, 11, device=dev(), generator=g)
+        y = torch.randint(0, classes, (530,), device=dev(), generator=g)
+        for _ in range(3):
+            tr.train_step(x, y)
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    a, b, c = run(), run(), run()
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+
+
 def _ensemble_step_inputs(step, years, B, bands, classes):
     imgs = [prng.uniform01(82 + step, yy, (B, bands, 11, 11)) for yy in range(years)]
     if step == 1:
