@@ -11,7 +11,7 @@ launcher (`python bench.py --gpus N`, no RANK in the environment) it spawns its 
 Synthetic patches (U[0,1), like the reference's min-max-scaled crops) are resident in HBM before the timed region.
 Rank 0 prints ONE JSON line.  `roofline.frac` prices SURVEY.md 8(d)'s COMPULSORY bytes of the conv1 forward (input in +
 output out); the bf16 tile by-product it also writes is in `frac_with_byproduct`.  The one-GPU line also carries, timed
-after the contract's region (20 steps each): `fp32` (the reference's own precision), `ensemble24` (BASELINE configs[4])
+after the contract's region (20 steps each): `fp32` (the reference's own precision), `ensemble24` (BASELINE configs[4]), `metadata` (BASELINE configs[3])
 and `module_path` (the unchanged reference step on the plugin modules with optim.DtaAdam / optim.cross_entropy).  Inside the timed loop the two first-conv kernels are timed with HIP events recorded on their own
 stream: `roofline` = the conv1 forward (the step's longest kernel; HBM-bound since it also converts the fp32 input and
 emits the bf16 tiles), `roofline_mfma` = the conv1 weight gradient (the longest MFMA-bound kernel); `step_roofline`
@@ -248,6 +248,37 @@ def side_fp32(a, dev, steps=20):
            "final_loss": round(float(loss), 5),
            "note": "FusedTrainer, Hang2020(369, 200) precision='fp32' (v_mfma_f32_32x32x2_f32: exact fp32 products), wall clock "
                    "around the steps after 5 warm-up steps"}
+    del tr, m, x
+    torch.cuda.empty_cache()
+    return out
+
+
+def side_metadata(a, dev, steps=20, sites=23):
+    """BASELINE configs[3]: the site-metadata fusion model's train step (reference src/models/metadata.py:26-63:
+    ReLU(Linear(cat[site MLP, Hang2020 scores])), unweighted cross-entropy, Adam) through engine.MetadataTrainer: the HSI
+    branch fused, the 16-wide site MLP + fusion layer a small torch graph joined at the (B, classes) scores."""
+    from deeptreeattention_amd.engine import MetadataTrainer
+    from deeptreeattention_amd.metadata import metadata_sensor_fusion
+    torch.manual_seed(1234)
+    m = metadata_sensor_fusion(bands=BANDS, sites=sites, classes=CLASSES, precision=a.precision).to(dev).train()
+    tr = MetadataTrainer(m, lr=1e-4)
+    g = torch.Generator(device=dev)
+    g.manual_seed(98)
+    x = torch.rand(a.batch, BANDS, HW, HW, device=dev, generator=g)
+    site = torch.randint(0, sites, (a.batch,), device=dev, generator=g)
+    y = torch.randint(0, CLASSES, (a.batch,), device=dev, generator=g)
+    for _ in range(5):
+        tr.train_step(x, site, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.train_step(x, site, y)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    out = {"dtype": a.precision, "steps": steps, "per_gpu_batch": a.batch, "sites": sites, "ms_per_step": round(ms, 4),
+           "patches_per_s": round(a.batch / ms * 1e3, 1), "final_loss": round(float(loss), 5),
+           "note": "MetadataTrainer(metadata_sensor_fusion(369, 23 sites, 200)): HSI branch = the fused Hang2020 step, site MLP + "
+                   "fusion layer + loss = torch ops on (B, 200) tensors; wall clock around the steps after 5 warm-up steps"}
     del tr, m, x
     torch.cuda.empty_cache()
     return out
@@ -674,6 +705,7 @@ def main():
             torch.cuda.empty_cache()
             for name, fn in (("fp32", lambda: side_fp32(a, dev)),
                              ("ensemble24", lambda: main_ensemble24(argparse.Namespace(**dict(vars(a), steps=20, warmup=5, prime_seconds=0.0, batch=1024, site="fwd0")), emit=False)),
+                             ("metadata", lambda: side_metadata(a, dev)),
                              ("module_path", lambda: side_module_path(a, dev, fused_ms))):
                 try:
                     out[name] = fn()

@@ -915,12 +915,14 @@ class MetadataTrainer:
     MetadataModel.training_step defines (:52-63: unweighted F.cross_entropy(model(images, site), y)) with Adam.
     The HSI branch (Hang2020, >99.9 % of the work) runs through the fused C-ABI pieces on flat buffers; the 16-wide
     site MLP and the 2*classes -> classes fusion layer (<0.2 MFLOP per sample) stay a small torch
-    autograd graph with their own torch Adam, joined to the HSI branch at its (B, classes) scores.  Data-parallel: the
-    small parameters' gradients travel in spare slots of the HSI branch's first gradient bucket, so the whole model
-    still exchanges gradients in at most two collectives per step."""
+    autograd graph joined to the HSI branch at its (B, classes) scores -- replayed as ONE hipGraph per step (forward, loss
+    and backward: ~45 launches of a few microseconds each cost the host more than the whole HSI branch when issued one by
+    one).  Their parameters LIVE in spare slots of the HSI branch's flat buffers (values, gradients -- the .grad of each is a
+    persistent view autograd accumulates into --, Adam moments): the one Adam launch steps them, the one gradient exchange
+    sums them, nothing is copied around either."""
 
     def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, process_group=None, overlap_comm=True,
-                 keep_grads=False, exchange=None, exchange_opts=None):
+                 keep_grads=False, exchange=None, exchange_opts=None, graph_head=True):
         from .metadata import metadata_sensor_fusion
         if not isinstance(model, metadata_sensor_fusion):
             raise TypeError("MetadataTrainer needs a deeptreeattention_amd.metadata.metadata_sensor_fusion")
@@ -930,11 +932,30 @@ class MetadataTrainer:
         self.sensor = FusedTrainer(model.sensor_model, lr, None, betas, eps, process_group, overlap_comm, keep_grads,
                                    extra_grad_slots=sum(self.small_sizes), exchange=exchange, exchange_opts=exchange_opts)
         self.sensor.external_loss = True         # the loss is taken on the fused (HSI + site) scores, by torch
-        self.opt = torch.optim.Adam(self.small, lr=lr, betas=betas, eps=eps)
         self.world, self.pg = self.sensor.world, self.sensor.pg
+        self.graph_head = bool(graph_head)
+        self._graph = None                       # (key, CUDAGraph, static scores leaf, site, y, loss)
+        if any(p.dtype != torch.float32 or p.device != self.sensor.device for p in self.small):
+            raise RuntimeError("MetadataTrainer needs the whole model in float32 on the sensor model's device")
+        self._gviews = []
+        off = self.sensor.extra_off
+        with torch.no_grad():
+            for p, k in zip(self.small, self.small_sizes):
+                self.sensor.p_head[off:off + k].copy_(p.reshape(-1))
+                p.data = self.sensor.p_head[off:off + k].view(p.shape)
+                self._gviews.append(self.sensor.g_head[off:off + k].view(p.shape))
+                off += k
+        self._attach_grads()
         if self.world > 1:
             for t in self.small + list(model.metadata_model.buffers()):
                 torch.distributed.broadcast(t.data, 0, group=self.pg)
+
+    def _attach_grads(self):
+        if not self._gviews:
+            raise RuntimeError("MetadataTrainer was closed")
+        for p, g in zip(self.small, self._gviews):
+            if p.grad is not g:
+                p.grad = g
 
     @property
     def lr(self):
@@ -943,35 +964,98 @@ class MetadataTrainer:
     @lr.setter
     def lr(self, value):
         self.sensor.lr = float(value)
-        for gr in self.opt.param_groups:
-            gr["lr"] = float(value)
 
     def _head(self, scores, site):
         meta = self.model.metadata_model(site)
         return torch.relu(self.model.fc1(torch.cat([meta, scores], dim=1)))
 
+    # ---- the small torch graph (site MLP, fusion layer, loss and their backward) as ONE hipGraph ----
+    # torch's semantics are untouched (same kernels, same Philox stream for the dropout): the eager path below is the same
+    # code issued launch by launch, and what a platform without graph capture falls back to.
+    def _capture_head(self, site, y):
+        import torch.nn.functional as F
+        dev = self.sensor.device
+        leaf = self.sensor.logits.detach().requires_grad_(True)        # the HSI scores buffer itself: written by the C ABI each step
+        g_site, g_y = site.clone(), y.clone()
+        bufs = [b for m in (self.model.metadata_model, self.model.fc1) for b in m.buffers()]
+        saved = ([b.clone() for b in bufs], torch.cuda.get_rng_state(dev))
+
+        def one():
+            loss = F.cross_entropy(self._head(leaf, g_site), g_y)
+            loss.backward()
+            return loss
+
+        def restore():
+            with torch.no_grad():
+                for b_, v in zip(bufs, saved[0]):
+                    b_.copy_(v)
+                self.sensor.extra_g.zero_()                             # what the trial backwards accumulated
+            torch.cuda.set_rng_state(saved[1], dev)
+
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                              # torch's capture recipe: warm up on a side stream
+                for _ in range(2):
+                    leaf.grad = None
+                    one()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            restore()
+            leaf.grad = None
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = one()
+        finally:
+            restore()                                                   # (capturing runs nothing; the RNG bookkeeping is reset anyway)
+        return graph, leaf, g_site, g_y, loss
+
+    def _graph_step(self, site, y):
+        key = (self.sensor.logits.data_ptr(), tuple(self.sensor.logits.shape), float(self.model.metadata_model.dropout.p),
+               self.model.training, self.sensor.g_head.data_ptr())
+        if self._graph is None or self._graph[0] != key:
+            self._graph = (key,) + self._capture_head(site, y)
+        _, graph, leaf, g_site, g_y, loss = self._graph
+        g_site.copy_(site)
+        g_y.copy_(y)
+        graph.replay()
+        return leaf.grad, loss
+
     def train_step(self, images, site, y):
         """images (B, bands, 11, 11) float32, site (B,) int64 site indices, y (B,) int64 labels -> loss (0-d tensor)."""
         y = self.sensor._labels(y)
-        scores = self.sensor._forward_scores(images).detach().requires_grad_(True)
-        self.opt.zero_grad(set_to_none=True)
-        loss = torch.nn.functional.cross_entropy(self._head(scores, site), y)
-        loss.backward()                                   # the small graph: MLP / fusion grads and d(loss)/d(scores)
-        if self.world > 1:
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.small]
-            self.sensor._zero_grads()
-            torch.cat([g.reshape(-1) for g in grads], out=self.sensor.extra_g)     # ride in the first bucket
-        self.sensor._backward(scores.grad.contiguous())
-        if self.world > 1:
-            if self.sensor.ex is not None:
-                self.sensor.reduce_now()                  # peer exchange: sums (incl. the spare slots) before they are read
-            chunks = self.sensor.extra_g.split(self.small_sizes)
-            for p, g, c in zip(self.small, grads, chunks):
-                p.grad = g
-                g.copy_(c.view_as(g)).mul_(1.0 / self.world)
-        self.sensor._adam()                               # also clears the spare slots
-        self.opt.step()
-        return loss.detach()
+        site = site if (site.dtype == torch.int64 and site.is_cuda) else site.to(self.sensor.device, torch.int64)
+        scores = self.sensor._forward_scores(images)
+        self.sensor._zero_grads()                 # the small backward accumulates into its slots of the flat gradient buffer
+        self._attach_grads()
+        dscores = loss = None
+        if self.graph_head:
+            try:
+                dscores, loss = self._graph_step(site, y)
+                loss = loss.detach().clone()
+            except RuntimeError as e:             # a platform / torch build without graph capture keeps the eager path
+                import warnings
+                warnings.warn("MetadataTrainer: hipGraph capture of the site / fusion head failed ({}); running it eagerly".format(e))
+                self.graph_head, self._graph = False, None
+        if dscores is None:
+            leaf = scores.detach().requires_grad_(True)
+            loss = torch.nn.functional.cross_entropy(self._head(leaf, site), y)
+            loss.backward()                       # the small graph: MLP / fusion grads (into their slots) and d(loss)/d(scores)
+            dscores, loss = leaf.grad.contiguous(), loss.detach()
+        self.sensor._backward(dscores)            # + the gradient exchange (the slots ride in the first bucket)
+        self.sensor._adam()                       # steps the slots' parameters too, and clears their gradients
+        return loss
+
+    def check_exchange(self):
+        self.sensor.check_exchange()
+
+    def close(self):
+        """Collective (data-parallel): drop the captured graph and the gradient views, release the sensor's exchange."""
+        self._graph = None
+        for p, g in zip(self.small, self._gviews):
+            if p.grad is g:
+                p.grad = None
+        self._gviews = []
+        self.sensor.close()
 
     def training_step(self, batch, batch_idx=0):
         """metadata.py:52-63 unpacking: batch = (individual, {"HSI": images, "site": site}, y)."""

@@ -109,9 +109,10 @@ def test_default_bench_line_carries_the_side_workloads():
                          timeout=600, cwd=REPO)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
-    for k in ("fp32", "ensemble24", "module_path"):
+    for k in ("fp32", "ensemble24", "metadata", "module_path"):
         assert k in d and "error" not in d[k], d.get(k)
     assert d["fp32"]["dtype"] == "fp32" and d["fp32"]["ms_per_step"] > d["ms_per_step"]
+    assert d["metadata"]["sites"] == 23 and 0 < d["metadata"]["ms_per_step"] < 3 * d["ms_per_step"]
     assert d["ensemble24"]["config"]["crop"] == 24 and d["ensemble24"]["roofline"]["frac"] < d["ensemble24"]["roofline"]["frac_with_byproduct"]
     mp = d["module_path"]
     assert mp["hang2020_dta_adam_ms_per_step"] < mp["hang2020_torch_adam_ms_per_step"]
