@@ -915,14 +915,13 @@ class MetadataTrainer:
     MetadataModel.training_step defines (:52-63: unweighted F.cross_entropy(model(images, site), y)) with Adam.
     The HSI branch (Hang2020, >99.9 % of the work) runs through the fused C-ABI pieces on flat buffers; the 16-wide
     site MLP and the 2*classes -> classes fusion layer (<0.2 MFLOP per sample) stay a small torch
-    autograd graph joined to the HSI branch at its (B, classes) scores -- replayed as ONE hipGraph per step (forward, loss
-    and backward: ~45 launches of a few microseconds each cost the host more than the whole HSI branch when issued one by
-    one).  Their parameters LIVE in spare slots of the HSI branch's flat buffers (values, gradients -- the .grad of each is a
+    autograd graph joined to the HSI branch at its (B, classes) scores (graph_head=True replays it as ONE hipGraph per
+    step: for hosts that cannot issue its ~35 small launches in the 0.2 ms they take on the GPU).  Their parameters LIVE in spare slots of the HSI branch's flat buffers (values, gradients -- the .grad of each is a
     persistent view autograd accumulates into --, Adam moments): the one Adam launch steps them, the one gradient exchange
     sums them, nothing is copied around either."""
 
     def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, process_group=None, overlap_comm=True,
-                 keep_grads=False, exchange=None, exchange_opts=None, graph_head=True):
+                 keep_grads=False, exchange=None, exchange_opts=None, graph_head=False):
         from .metadata import metadata_sensor_fusion
         if not isinstance(model, metadata_sensor_fusion):
             raise TypeError("MetadataTrainer needs a deeptreeattention_amd.metadata.metadata_sensor_fusion")
@@ -969,6 +968,11 @@ class MetadataTrainer:
         meta = self.model.metadata_model(site)
         return torch.relu(self.model.fc1(torch.cat([meta, scores], dim=1)))
 
+    @staticmethod
+    def _ce(scores, y):
+        from .optim import cross_entropy
+        return cross_entropy(scores, y)          # loss + d(loss)/d(scores) in one launch
+
     # ---- the small torch graph (site MLP, fusion layer, loss and their backward) as ONE hipGraph ----
     # torch's semantics are untouched (same kernels, same Philox stream for the dropout): the eager path below is the same
     # code issued launch by launch, and what a platform without graph capture falls back to.
@@ -981,7 +985,7 @@ class MetadataTrainer:
         saved = ([b.clone() for b in bufs], torch.cuda.get_rng_state(dev))
 
         def one():
-            loss = F.cross_entropy(self._head(leaf, g_site), g_y)
+            loss = self._ce(self._head(leaf, g_site), g_y)
             loss.backward()
             return loss
 
@@ -1038,7 +1042,7 @@ class MetadataTrainer:
                 self.graph_head, self._graph = False, None
         if dscores is None:
             leaf = scores.detach().requires_grad_(True)
-            loss = torch.nn.functional.cross_entropy(self._head(leaf, site), y)
+            loss = self._ce(self._head(leaf, site), y)
             loss.backward()                       # the small graph: MLP / fusion grads (into their slots) and d(loss)/d(scores)
             dscores, loss = leaf.grad.contiguous(), loss.detach()
         self.sensor._backward(dscores)            # + the gradient exchange (the slots ride in the first bucket)
