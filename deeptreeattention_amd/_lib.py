@@ -60,6 +60,16 @@ class AttentionDesc(C.Structure):
     _fields_ = [("batch", C.c_int), ("filters", C.c_int), ("height", C.c_int), ("width", C.c_int), ("kind", C.c_int)]
 
 
+class MetaParams(C.Structure):      # dta_meta_params
+    _fields_ = [("emb", C.c_void_p), ("bn_w", C.c_void_p), ("bn_b", C.c_void_p), ("bn_rm", C.c_void_p), ("bn_rv", C.c_void_p),
+                ("bn_nbt", C.c_void_p), ("mlp_w", C.c_void_p), ("mlp_b", C.c_void_p), ("fc_w", C.c_void_p), ("fc_b", C.c_void_p)]
+
+
+class MetaGrads(C.Structure):       # dta_meta_grads
+    _fields_ = [("emb", C.c_void_p), ("bn_w", C.c_void_p), ("bn_b", C.c_void_p), ("mlp_w", C.c_void_p), ("mlp_b", C.c_void_p),
+                ("fc_w", C.c_void_p), ("fc_b", C.c_void_p)]
+
+
 PtrArray6 = C.c_void_p * 6
 ScoreTable = (C.c_void_p * 3) * 2
 
@@ -117,6 +127,14 @@ def lib():
         L.dta_preprocess_crops.restype = C.c_int
         L.dta_preprocess_crops.argtypes = [C.POINTER(CropDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
+        L.dta_meta_head_workspace_bytes.restype = C.c_size_t
+        L.dta_meta_head_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.dta_meta_head_forward.restype = C.c_int
+        L.dta_meta_head_forward.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(MetaParams),
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_meta_head_backward.restype = C.c_int
+        L.dta_meta_head_backward.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MetaParams), C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MetaGrads), C.c_void_p, C.c_void_p]
         L.dta_net_loss.restype = C.c_int
         L.dta_net_loss.argtypes = [C.POINTER(NetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

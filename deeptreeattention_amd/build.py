@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["conv.hip", "conv_bf16.hip", "stage.hip", "heads.hip", "capi.hip", "capi_modules.hip", "preprocess.hip", "xchg.hip"]
+SOURCES = ["conv.hip", "conv_bf16.hip", "stage.hip", "heads.hip", "capi.hip", "capi_modules.hip", "preprocess.hip", "xchg.hip", "meta.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "dta_hip.h")]
 LIB = os.path.join(HERE, "libdta_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]

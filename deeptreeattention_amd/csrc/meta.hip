@@ -1,0 +1,358 @@
+// The site-metadata head of the reference's fusion model (src/models/metadata.py:9-44) around the Hang2020 scores:
+//   meta   = ReLU(Linear_16->C(Dropout(BatchNorm1d(Embedding(site)))))                  (metadata.py:9-24)
+//   out    = ReLU(Linear_2C->C(cat[meta, hsi_scores]))                                   (metadata.py:40-44)
+// forward + backward as a handful of launches (the batched linears are the grouped GEMMs of heads.hip): issued as stock
+// torch ops this <0.2 MFLOP-per-sample graph is ~35 launches = 0.17 ms per step, a third of the whole fused HSI branch.
+//
+// BatchNorm1d over the batch of embedding rows needs no pass over the batch: a row depends only on its site, so with
+// n_s = #samples of site s the batch statistics are mean_f = sum_s n_s E[s][f] / B, var_f = sum_s n_s (E[s][f] - mean_f)^2 / B,
+// and the backward's batch sums are sums over sites of per-site gradient sums.  Everything is evaluated in a fixed order
+// (no float atomics): reruns give the same bits.
+#include <string.h>
+
+#include "../../include/dta_hip.h"
+#include "kernels.h"
+
+using namespace dta;
+
+namespace {
+
+constexpr int MW = 16;              // the site branch's width (metadata.py:12)
+constexpr int MAX_SITES = 2048;     // LDS: histogram + 16-wide tables
+
+template <typename T> inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+};
+struct MetaPlan { size_t x16, xhat_t, rstd, hist, meta_pre, joined, out_pre, d_meta, d_x16, total; };
+MetaPlan meta_plan(int B, int C, int S) {
+  MetaPlan p;
+  Carver c;
+  p.x16 = c.take((size_t)B * MW * 4);            // the site branch's input to its Linear (after BN + dropout)
+  p.xhat_t = c.take((size_t)S * MW * 4);         // normalised embedding row per site
+  p.rstd = c.take(MW * 4);
+  p.hist = c.take((size_t)S * 4);
+  p.meta_pre = c.take((size_t)B * C * 4);
+  p.joined = c.take((size_t)B * 2 * C * 4);      // [ReLU(meta_pre) | hsi scores]
+  p.out_pre = c.take((size_t)B * C * 4);
+  p.d_meta = c.take((size_t)B * C * 4);
+  p.d_x16 = c.take((size_t)B * MW * 4);
+  p.total = c.off;
+  return p;
+}
+
+struct FrontArgs {
+  const long long* site; const float* emb; const float* bn_w; const float* bn_b; float* rm; float* rv; long long* nbt;
+  const float* drop;      // [B][16] dropout factors (0 or 1 / (1 - p)) or null
+  float* x16; float* xhat_t; float* rstd; int* hist;
+  int B, S, training; float momentum, eps;
+};
+
+// one workgroup: site histogram -> batch statistics -> per-site normalised rows -> the [B][16] input of the site Linear
+// dynamic LDS: tab [S][16] floats (the embedding table, then the normalised rows), hist [S] ints
+__global__ __launch_bounds__(1024) void k_meta_front(FrontArgs a) {
+  extern __shared__ float tab[];
+  __shared__ float mean[MW], rstd[MW];
+  int* hist = reinterpret_cast<int*>(tab + a.S * MW);
+  const int t = threadIdx.x;
+#pragma unroll 4
+  for (int i = t; i < a.S * MW; i += 1024) tab[i] = a.emb[i];
+  for (int s = t; s < a.S; s += 1024) hist[s] = 0;
+  __syncthreads();
+  if (a.training) {
+#pragma unroll 4
+    for (int b = t; b < a.B; b += 1024) atomicAdd(&hist[(int)a.site[b]], 1);      // integer: order-independent
+  }
+  __syncthreads();
+  if (t < MW) {
+    float m, r;
+    if (a.training) {
+      double s1 = 0;
+#pragma unroll 8
+      for (int s = 0; s < a.S; ++s) s1 += (double)hist[s] * (double)tab[s * MW + t];
+      const double mu = s1 / a.B;
+      double s2 = 0;
+#pragma unroll 8
+      for (int s = 0; s < a.S; ++s) { const double d = (double)tab[s * MW + t] - mu; s2 += (double)hist[s] * d * d; }
+      const double var = s2 / a.B;
+      m = (float)mu; r = (float)(1.0 / sqrt(var + (double)a.eps));
+      if (a.rm) {
+        const double unb = a.B > 1 ? s2 / (a.B - 1) : var;
+        a.rm[t] = (1.f - a.momentum) * a.rm[t] + a.momentum * m;
+        a.rv[t] = (1.f - a.momentum) * a.rv[t] + a.momentum * (float)unb;
+        if (t == 0 && a.nbt) a.nbt[0] += 1;
+      }
+    } else {
+      m = a.rm[t]; r = rsqrtf(a.rv[t] + a.eps);
+    }
+    mean[t] = m; rstd[t] = r;
+    a.rstd[t] = r;
+  }
+  __syncthreads();
+  for (int i = t; i < a.S * MW; i += 1024) {
+    const int f = i & (MW - 1);
+    const float xh = (tab[i] - mean[f]) * rstd[f];
+    tab[i] = xh;
+    a.xhat_t[i] = xh;
+  }
+  if (a.training)
+    for (int s = t; s < a.S; s += 1024) a.hist[s] = hist[s];
+  __syncthreads();
+  const float gw = a.bn_w[t & (MW - 1)], gb = a.bn_b[t & (MW - 1)];      // (i = t + 1024 k: the feature is t mod 16 for every k)
+#pragma unroll 8
+  for (int i = t; i < a.B * MW; i += 1024) {
+    const int b = i >> 4, f = i & (MW - 1), s = (int)a.site[b];
+    float v = tab[s * MW + f] * gw + gb;
+    if (a.drop) v *= a.drop[i];
+    a.x16[i] = v;
+  }
+}
+
+// joined[b] = [ReLU(meta_pre[b]) | scores[b]]
+__global__ void k_meta_join(const float* meta_pre, const float* scores, float* joined, int B, int C) {
+  const size_t n = (size_t)B * 2 * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / (2 * C)), c = (int)(i - (size_t)b * 2 * C);
+    joined[i] = c < C ? fmaxf(meta_pre[(size_t)b * C + c], 0.f) : scores[(size_t)b * C + (c - C)];
+  }
+}
+// out = ReLU(x)
+__global__ void k_relu(const float* x, float* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fmaxf(x[i], 0.f);
+}
+// d = (ref > 0) ? src : 0   (ReLU backward; ref = the ReLU's output or input: same sign test)
+__global__ void k_relu_bwd(const float* src, const float* ref, long ref_pitch, int cols, float* d, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / cols, c = i - r * cols;
+    d[i] = ref[r * ref_pitch + c] > 0.f ? src[i] : 0.f;
+  }
+}
+
+struct BackArgs {
+  const long long* site; const float* bn_w; const float* drop; const float* d_x16; const float* xhat_t; const float* rstd; const int* hist;
+  float* d_emb; float* d_bn_w; float* d_bn_b; int B, S, training;
+};
+// one workgroup: dropout backward, per-site sums of d(BN output), BatchNorm1d backward in closed form, embedding gradient.
+// The per-site sums run over each site's samples IN BATCH ORDER (a fixed order, no atomics): a stable counting sort of the
+// batch by site -- thread (site, part) counts, then lists, the samples of its site in the part-th sixteenth of the batch --
+// and thread (site, feature) adds its site's listed rows.
+// dynamic LDS: D [S][16] floats | off [S + 1] ints | cnt [S][16] ints | list [B] ints | sv [B] ints | dy [B][16] floats
+__global__ __launch_bounds__(1024) void k_meta_back(BackArgs a) {
+  extern __shared__ float D[];
+  __shared__ float dbeta[MW], dgamma[MW];
+  const int t = threadIdx.x, S = a.S, B = a.B;
+  int* off = reinterpret_cast<int*>(D + S * MW);
+  int* cnt = off + S + 1;
+  int* list = cnt + S * MW;
+  int* sv = list + B;
+  float* dy = reinterpret_cast<float*>(sv + B);
+  // (unrolled: eight independent loads in flight per thread instead of one global round trip per iteration)
+#pragma unroll 4
+  for (int b = t; b < B; b += 1024) sv[b] = (int)a.site[b];
+  if (a.drop) {
+#pragma unroll 8
+    for (int i = t; i < B * MW; i += 1024) dy[i] = a.d_x16[i] * a.drop[i];
+  } else {
+#pragma unroll 8
+    for (int i = t; i < B * MW; i += 1024) dy[i] = a.d_x16[i];
+  }
+  __syncthreads();
+  const int per = (B + MW - 1) / MW;                       // samples per part
+  // (every loop below reads LDS at addresses known in advance: unrolled so that the reads overlap -- a dependent LDS
+  //  round trip per iteration made this one-workgroup kernel 25 us)
+  for (int i = t; i < S * MW; i += 1024) {
+    const int s = i >> 4, part = i & (MW - 1), lo = part * per, hi = min(B, lo + per);
+    int c = 0;
+#pragma unroll 8
+    for (int b = lo; b < hi; ++b) c += sv[b] == s;
+    cnt[i] = c;
+  }
+  __syncthreads();
+  // site totals (thread s), then an inclusive scan over the sites (Hillis-Steele, ping-pong between off[] and list[])
+  for (int s = t; s < S; s += 1024) {
+    int tot = 0;
+#pragma unroll
+    for (int part = 0; part < MW; ++part) tot += cnt[s * MW + part];
+    off[s + 1] = tot;
+  }
+  if (t == 0) off[0] = 0;
+  __syncthreads();
+  {
+    int* src = off + 1;                                    // S totals
+    int* tmp = list;                                       // (list[] is free until the fill pass; B >= 1 ints... S may exceed B:
+    int* tmp2 = reinterpret_cast<int*>(D);                 //  the scan's second buffer is D[], S * 16 floats, free until the sums)
+    (void)tmp;
+    int* bufs[2] = {src, tmp2};
+    int cur = 0;
+    for (int d = 1; d < S; d <<= 1) {
+      for (int s = t; s < S; s += 1024) bufs[cur ^ 1][s] = bufs[cur][s] + (s >= d ? bufs[cur][s - d] : 0);
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (cur == 1) {
+      for (int s = t; s < S; s += 1024) src[s] = tmp2[s];
+      __syncthreads();
+    }
+  }
+  for (int i = t; i < S * MW; i += 1024) {
+    const int s = i >> 4, part = i & (MW - 1), lo = part * per, hi = min(B, lo + per);
+    int k = off[s];
+#pragma unroll
+    for (int q = 0; q < MW; ++q) k += q < part ? cnt[s * MW + q] : 0;
+#pragma unroll 8
+    for (int b = lo; b < hi; ++b)
+      if (sv[b] == s) list[k++] = b;
+  }
+  __syncthreads();
+  for (int i = t; i < S * MW; i += 1024) {
+    const int s = i >> 4, f = i & (MW - 1);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = off[s]; k < off[s + 1]; ++k) acc += dy[list[k] * MW + f];
+    D[i] = acc;
+  }
+  __syncthreads();
+  if (t < MW) {
+    float sb = 0.f, sg = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) { sb += D[s * MW + t]; sg += D[s * MW + t] * a.xhat_t[s * MW + t]; }
+    dbeta[t] = sb; dgamma[t] = sg;
+    if (a.d_bn_b) a.d_bn_b[t] = sb;
+    if (a.d_bn_w) a.d_bn_w[t] = sg;
+  }
+  __syncthreads();
+  if (!a.d_emb) return;
+  for (int i = t; i < S * MW; i += 1024) {
+    const int s = i >> 4, f = i & (MW - 1);
+    const float g = a.bn_w[f], r = a.rstd[f];
+    const int n_s = off[s + 1] - off[s];
+    float v;
+    if (a.training) {
+      // d e_b = rstd (g dy_b - g mean_b(dy) - xhat_b g mean_b(dy xhat)), summed over the samples of site s
+      const float m1 = g * dbeta[f] / B, m2 = g * dgamma[f] / B;
+      v = r * (g * D[i] - n_s * m1 - n_s * a.xhat_t[i] * m2);
+    } else {
+      v = r * g * D[i];
+    }
+    a.d_emb[i] = v;
+  }
+}
+
+size_t meta_back_lds(int B, int S) { return ((size_t)S * MW + (S + 1) + (size_t)S * MW + B + B + (size_t)B * MW) * 4; }
+
+int check(int B, int C, int S, const dta_meta_params* p, const long long* site, void* ws, const char* who) {
+  if (B < 1 || C < 1 || S < 1 || !p || !site || !ws) { dta_set_error("%s: bad argument", who); return 1; }
+  if (S > MAX_SITES) { dta_set_error("%s: at most %d sites", who, MAX_SITES); return 1; }
+  if (meta_back_lds(B, S) > 150 * 1024) { dta_set_error("%s: batch %d x %d sites exceeds the head's LDS plan (batch <= ~2000)", who, B, S); return 1; }
+  if (!p->emb || !p->bn_w || !p->bn_b || !p->bn_rm || !p->bn_rv || !p->mlp_w || !p->mlp_b || !p->fc_w || !p->fc_b) {
+    dta_set_error("%s: null parameter", who); return 1; }
+  return 0;
+}
+int grid1d(size_t n) { return (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024); }
+
+}  // namespace
+
+extern "C" {
+
+size_t dta_meta_head_workspace_bytes(int batch, int classes, int sites) {
+  if (batch < 1 || classes < 1 || sites < 1 || sites > MAX_SITES || meta_back_lds(batch, sites) > 150 * 1024) {
+    dta_set_error("dta_meta_head_workspace_bytes: unsupported shape (sites <= %d, batch x sites within the LDS plan)", MAX_SITES); return 0; }
+  return meta_plan(batch, classes, sites).total;
+}
+
+int dta_meta_head_forward(int batch, int classes, int sites, int training, float momentum, float eps, const dta_meta_params* p,
+                          const long long* site, const float* scores, const float* drop, void* workspace, float* out,
+                          void* stream) {
+  const int B = batch, C = classes, S = sites;
+  if (check(B, C, S, p, site, workspace, "dta_meta_head_forward")) return 1;
+  if (!scores || !out) { dta_set_error("dta_meta_head_forward: null scores / out"); return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  const MetaPlan pl = meta_plan(B, C, S);
+  FrontArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.site = site; fa.emb = p->emb; fa.bn_w = p->bn_w; fa.bn_b = p->bn_b; fa.rm = p->bn_rm; fa.rv = p->bn_rv; fa.nbt = p->bn_nbt;
+  fa.drop = training ? drop : nullptr;
+  fa.x16 = at<float>(workspace, pl.x16); fa.xhat_t = at<float>(workspace, pl.xhat_t); fa.rstd = at<float>(workspace, pl.rstd);
+  fa.hist = at<int>(workspace, pl.hist);
+  fa.B = B; fa.S = S; fa.training = training; fa.momentum = momentum; fa.eps = eps;
+  static DevOnce front_once;
+  if (front_once.first()) (void)hipFuncSetAttribute((const void*)k_meta_front, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  hipLaunchKernelGGL(k_meta_front, dim3(1), dim3(1024), (size_t)S * (MW + 1) * 4, st, fa);
+  DTA_CHECK_LAUNCH("k_meta_front");
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));                      // meta_pre[B][C] = x16[B][16] . mlp_w[C][16]^T + mlp_b
+  g.A = fa.x16; g.sa_m = MW; g.sa_k = 1; g.Bm = p->mlp_w; g.sb_k = 1; g.sb_n = MW;
+  g.C = at<float>(workspace, pl.meta_pre); g.sc_m = C; g.sc_n = 1; g.bias = p->mlp_b; g.M = B; g.N = C; g.K = MW; g.ksplit = 1;
+  if (launch_gemm(g, st)) return 1;
+  float* joined = at<float>(workspace, pl.joined);
+  hipLaunchKernelGGL(k_meta_join, dim3(grid1d((size_t)B * 2 * C)), dim3(256), 0, st, g.C, scores, joined, B, C);
+  DTA_CHECK_LAUNCH("k_meta_join");
+  memset(&g, 0, sizeof(g));                      // out_pre[B][C] = joined[B][2C] . fc_w[C][2C]^T + fc_b
+  g.A = joined; g.sa_m = 2 * C; g.sa_k = 1; g.Bm = p->fc_w; g.sb_k = 1; g.sb_n = 2 * C;
+  g.C = at<float>(workspace, pl.out_pre); g.sc_m = C; g.sc_n = 1; g.bias = p->fc_b; g.M = B; g.N = C; g.K = 2 * C; g.ksplit = 1;
+  if (launch_gemm(g, st)) return 1;
+  hipLaunchKernelGGL(k_relu, dim3(grid1d((size_t)B * C)), dim3(256), 0, st, g.C, out, (size_t)B * C);
+  DTA_CHECK_LAUNCH("k_relu");
+  return 0;
+}
+
+int dta_meta_head_backward(int batch, int classes, int sites, int training, const dta_meta_params* p, const long long* site,
+                           const float* drop, void* workspace, const float* out, const float* dout, const dta_meta_grads* grads,
+                           float* dscores, void* stream) {
+  const int B = batch, C = classes, S = sites;
+  if (check(B, C, S, p, site, workspace, "dta_meta_head_backward")) return 1;
+  if (!out || !dout || !grads || !dscores) { dta_set_error("dta_meta_head_backward: null argument"); return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  const MetaPlan pl = meta_plan(B, C, S);
+  float* d_pre = at<float>(workspace, pl.out_pre);          // (the forward's pre-activation is no longer needed: reuse)
+  const float* joined = at<float>(workspace, pl.joined);
+  float* d_meta = at<float>(workspace, pl.d_meta);
+  float* d_x16 = at<float>(workspace, pl.d_x16);
+  const float* x16 = at<float>(workspace, pl.x16);
+  hipLaunchKernelGGL(k_relu_bwd, dim3(grid1d((size_t)B * C)), dim3(256), 0, st, dout, out, (long)C, C, d_pre, (size_t)B * C);
+  DTA_CHECK_LAUNCH("k_relu_bwd");
+  GemmGroup g1;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));                      // d(meta)[B][C] = d_pre[B][C] . fc_w[:, :C]
+  g.A = d_pre; g.sa_m = C; g.sa_k = 1; g.Bm = p->fc_w; g.sb_k = 2 * C; g.sb_n = 1;
+  g.C = d_meta; g.sc_m = C; g.sc_n = 1; g.M = B; g.N = C; g.K = C; g.ksplit = 1;
+  g1.add(g);
+  g.Bm = p->fc_w + C; g.C = dscores;             // d(hsi scores)[B][C] = d_pre . fc_w[:, C:]
+  g1.add(g);
+  if (grads->fc_w) {                             // d fc_w[C][2C] = d_pre^T[C][B] . joined[B][2C], d fc_b = column sums of d_pre
+    memset(&g, 0, sizeof(g));
+    g.A = d_pre; g.sa_m = 1; g.sa_k = C; g.Bm = joined; g.sb_k = 2 * C; g.sb_n = 1;
+    g.C = grads->fc_w; g.sc_m = 2 * C; g.sc_n = 1; g.M = C; g.N = 2 * C; g.K = B; g.ksplit = 1; g.rowsum_out = grads->fc_b;
+    g1.add(g);
+  }
+  if (launch_gemm_group(g1, st)) return 1;
+  // ReLU of the site branch: joined[:, :C] holds ReLU(meta_pre)
+  hipLaunchKernelGGL(k_relu_bwd, dim3(grid1d((size_t)B * C)), dim3(256), 0, st, d_meta, joined, (long)(2 * C), C, d_meta, (size_t)B * C);
+  DTA_CHECK_LAUNCH("k_relu_bwd");
+  GemmGroup g2;
+  memset(&g, 0, sizeof(g));                      // d x16[B][16] = d_meta[B][C] . mlp_w[C][16]
+  g.A = d_meta; g.sa_m = C; g.sa_k = 1; g.Bm = p->mlp_w; g.sb_k = MW; g.sb_n = 1;
+  g.C = d_x16; g.sc_m = MW; g.sc_n = 1; g.M = B; g.N = MW; g.K = C; g.ksplit = 1;
+  g2.add(g);
+  if (grads->mlp_w) {                            // d mlp_w[C][16] = d_meta^T . x16, d mlp_b = column sums of d_meta
+    memset(&g, 0, sizeof(g));
+    g.A = d_meta; g.sa_m = 1; g.sa_k = C; g.Bm = x16; g.sb_k = MW; g.sb_n = 1;
+    g.C = grads->mlp_w; g.sc_m = MW; g.sc_n = 1; g.M = C; g.N = MW; g.K = B; g.ksplit = 1; g.rowsum_out = grads->mlp_b;
+    g2.add(g);
+  }
+  if (launch_gemm_group(g2, st)) return 1;
+  BackArgs ba;
+  memset(&ba, 0, sizeof(ba));
+  ba.site = site; ba.bn_w = p->bn_w; ba.drop = training ? drop : nullptr; ba.d_x16 = d_x16;
+  ba.xhat_t = at<float>(workspace, pl.xhat_t); ba.rstd = at<float>(workspace, pl.rstd); ba.hist = at<int>(workspace, pl.hist);
+  ba.d_emb = grads->emb; ba.d_bn_w = grads->bn_w; ba.d_bn_b = grads->bn_b; ba.B = B; ba.S = S; ba.training = training;
+  const size_t lds = meta_back_lds(B, S);
+  static DevOnce attr_once;
+  if (attr_once.first()) (void)hipFuncSetAttribute((const void*)k_meta_back, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  hipLaunchKernelGGL(k_meta_back, dim3(1), dim3(1024), lds, st, ba);
+  DTA_CHECK_LAUNCH("k_meta_back");
+  return 0;
+}
+
+}  // extern "C"

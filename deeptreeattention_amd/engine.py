@@ -921,15 +921,20 @@ class MetadataTrainer:
     sums them, nothing is copied around either."""
 
     def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, process_group=None, overlap_comm=True,
-                 keep_grads=False, exchange=None, exchange_opts=None, graph_head=False):
+                 keep_grads=False, exchange=None, exchange_opts=None, graph_head=False, native_head=True):
         from .metadata import metadata_sensor_fusion
         if not isinstance(model, metadata_sensor_fusion):
             raise TypeError("MetadataTrainer needs a deeptreeattention_amd.metadata.metadata_sensor_fusion")
         self.model = model
         self.small = list(model.metadata_model.parameters()) + list(model.fc1.parameters())
         self.small_sizes = [p.numel() for p in self.small]
+        small_off, small_n = _aligned_offsets(self.small)       # every tensor on a 16-byte boundary (the head GEMMs' vector loads)
         self.sensor = FusedTrainer(model.sensor_model, lr, None, betas, eps, process_group, overlap_comm, keep_grads,
-                                   extra_grad_slots=sum(self.small_sizes), exchange=exchange, exchange_opts=exchange_opts)
+                                   extra_grad_slots=small_n, exchange=exchange, exchange_opts=exchange_opts)
+        # native_head: the site MLP / fusion layer / loss run as csrc/meta.hip (dta_meta_head_*: ~12 launches); False: the same
+        # graph as stock torch ops (~35 launches), which is also what the parity tests compare the native form with
+        self.native_head = bool(native_head)
+        self._mh = None                           # native head: (key, workspace, out, dlogits, dscores, loss scratch)
         self.sensor.external_loss = True         # the loss is taken on the fused (HSI + site) scores, by torch
         self.world, self.pg = self.sensor.world, self.sensor.pg
         self.graph_head = bool(graph_head)
@@ -937,13 +942,12 @@ class MetadataTrainer:
         if any(p.dtype != torch.float32 or p.device != self.sensor.device for p in self.small):
             raise RuntimeError("MetadataTrainer needs the whole model in float32 on the sensor model's device")
         self._gviews = []
-        off = self.sensor.extra_off
         with torch.no_grad():
-            for p, k in zip(self.small, self.small_sizes):
+            for p, k, o in zip(self.small, self.small_sizes, small_off):
+                off = self.sensor.extra_off + o
                 self.sensor.p_head[off:off + k].copy_(p.reshape(-1))
                 p.data = self.sensor.p_head[off:off + k].view(p.shape)
                 self._gviews.append(self.sensor.g_head[off:off + k].view(p.shape))
-                off += k
         self._attach_grads()
         if self.world > 1:
             for t in self.small + list(model.metadata_model.buffers()):
@@ -1024,6 +1028,68 @@ class MetadataTrainer:
         graph.replay()
         return leaf.grad, loss
 
+    # ---- native head (csrc/meta.hip) ----
+    def _native_tables(self):
+        mm, fc = self.model.metadata_model, self.model.fc1
+        bn = mm.batch_norm
+        P = _lib.MetaParams(mm.embedding.weight.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                            bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), mm.mlp.weight.data_ptr(),
+                            mm.mlp.bias.data_ptr(), fc.weight.data_ptr(), fc.bias.data_ptr())
+        gv = dict(zip([id(p) for p in self.small], self._gviews))
+        g = lambda p: gv[id(p)].data_ptr()
+        G = _lib.MetaGrads(g(mm.embedding.weight), g(bn.weight), g(bn.bias), g(mm.mlp.weight), g(mm.mlp.bias), g(fc.weight), g(fc.bias))
+        return P, G
+
+    def _native_buffers(self, B, classes, sites):
+        L = _lib.lib()
+        key = (B, classes, sites)
+        if self._mh is None or self._mh[0] != key:
+            nbytes = L.dta_meta_head_workspace_bytes(B, classes, sites)
+            if nbytes == 0:
+                raise RuntimeError("dta_meta_head_workspace_bytes: " + L.dta_last_error().decode())
+            dev = self.sensor.device
+            f = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+            self._mh = (key, torch.empty(nbytes, dtype=torch.uint8, device=dev), f(B, classes), f(B, classes), f(B, classes), f(B + 2))
+        return self._mh[1:]
+
+    def _native_forward(self, scores, site, training):
+        """The fused scores (B, classes) of the whole model for HSI scores `scores`; returns (out, drop factors or None)."""
+        L = _lib.lib()
+        mm = self.model.metadata_model
+        B, classes = scores.shape
+        sites = mm.embedding.num_embeddings
+        ws, out, _, _, _ = self._native_buffers(B, classes, sites)
+        bn = mm.batch_norm
+        if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+            raise RuntimeError("MetadataTrainer(native_head=True) supports the reference's BatchNorm1d settings (affine, running statistics, fixed momentum)")
+        drop = None
+        if training and mm.dropout.p > 0:
+            # torch's generator draws the mask (the same Philox stream as the module's own dropout call); the kernels apply it
+            drop = torch.nn.functional.dropout(torch.ones(B, mm.embedding.embedding_dim, dtype=torch.float32, device=scores.device),
+                                               p=mm.dropout.p, training=True)
+        P, _ = self._native_tables()
+        _lib.check(L.dta_meta_head_forward(B, classes, sites, 1 if training else 0, float(bn.momentum), float(bn.eps), C.byref(P),
+                                           _lib.ptr(site), _lib.ptr(scores), _lib.ptr(drop), _lib.ptr(ws), _lib.ptr(out),
+                                           _lib.current_stream_ptr()), "dta_meta_head_forward")
+        return out, drop
+
+    def _native_step(self, scores, site, y):
+        L = _lib.lib()
+        mm = self.model.metadata_model
+        B, classes = scores.shape
+        sites = mm.embedding.num_embeddings
+        ws, out, dlogits, dscores, scratch = self._native_buffers(B, classes, sites)
+        out, drop = self._native_forward(scores, site, True)
+        loss = torch.empty((), dtype=torch.float32, device=scores.device)
+        st = _lib.current_stream_ptr()
+        _lib.check(L.dta_weighted_ce_scaled(_lib.ptr(out), _lib.ptr(y), None, B, classes, 1.0, _lib.ptr(loss), _lib.ptr(dlogits),
+                                            _lib.ptr(scratch), st), "dta_weighted_ce_scaled")
+        P, G = self._native_tables()
+        _lib.check(L.dta_meta_head_backward(B, classes, sites, 1, C.byref(P), _lib.ptr(site), _lib.ptr(drop), _lib.ptr(ws),
+                                            _lib.ptr(out), _lib.ptr(dlogits), C.byref(G), _lib.ptr(dscores), st),
+                   "dta_meta_head_backward")
+        return dscores, loss
+
     def train_step(self, images, site, y):
         """images (B, bands, 11, 11) float32, site (B,) int64 site indices, y (B,) int64 labels -> loss (0-d tensor)."""
         y = self.sensor._labels(y)
@@ -1031,6 +1097,16 @@ class MetadataTrainer:
         scores = self.sensor._forward_scores(images)
         self.sensor._zero_grads()                 # the small backward accumulates into its slots of the flat gradient buffer
         self._attach_grads()
+        if self.native_head and _lib.lib().dta_meta_head_workspace_bytes(
+                scores.shape[0], scores.shape[1], self.model.metadata_model.embedding.num_embeddings) == 0:
+            import warnings
+            warnings.warn("MetadataTrainer: " + _lib.lib().dta_last_error().decode() + "; running the site / fusion head as torch ops")
+            self.native_head = False
+        if self.native_head:
+            dscores, loss = self._native_step(scores, site.contiguous(), y)
+            self.sensor._backward(dscores)
+            self.sensor._adam()
+            return loss
         dscores = loss = None
         if self.graph_head:
             try:
@@ -1071,6 +1147,11 @@ class MetadataTrainer:
         individual, inputs, y = batch
         with torch.no_grad():
             scores = self.sensor._forward_scores(inputs["HSI"])
+            if self.native_head and not self.model.training:
+                site = inputs["site"]
+                site = site if (site.dtype == torch.int64 and site.is_cuda) else site.to(self.sensor.device, torch.int64)
+                out, _ = self._native_forward(scores, site.contiguous(), False)
+                return torch.nn.functional.cross_entropy(out, self.sensor._labels(y))
             return torch.nn.functional.cross_entropy(self._head(scores, inputs["site"]), self.sensor._labels(y))
 
 

@@ -382,6 +382,34 @@ int dta_profile_collect_site(int site, float* ms, int max);
  * DTA_BN_INKERNEL, DTA_FANIN: same-box A/B runs of alternative launch plans) once at load time; this re-reads them. */
 int dta_dev_reload_switches(void);
 
+/* ---- site-metadata head of the fusion model (reference src/models/metadata.py:9-44) --------------------------------
+ * meta = ReLU(Linear(Dropout(BatchNorm1d(Embedding(site)))))  (16 wide), out = ReLU(Linear(cat[meta, hsi_scores])).
+ * Replaces the reference's torch modules `metadata` (:9-24) and the `fc1` fusion layer of `metadata_sensor_fusion` (:26-44)
+ * for the train / validation step of MetadataModel (:52-83); the HSI scores come from dta_net_forward.
+ * All tensors float32, row-major; site: int64 indices in [0, sites).  drop: [batch][16] dropout factors (0 or 1/(1-p)),
+ * or NULL (no dropout / eval) -- drawn by the caller (torch's generator), applied here.  training != 0: batch statistics
+ * (and the running statistics are updated with `momentum`), else running statistics.  The workspace
+ * (dta_meta_head_workspace_bytes) carries the forward's state to the backward. */
+typedef struct dta_meta_params {
+  const float* emb;            /* [sites][16]   metadata_model.embedding.weight */
+  const float* bn_w; const float* bn_b;   /* [16]  metadata_model.batch_norm.weight / bias */
+  float* bn_rm; float* bn_rv; long long* bn_nbt;   /* running_mean / running_var [16], num_batches_tracked (may be NULL) */
+  const float* mlp_w; const float* mlp_b;  /* [classes][16], [classes]   metadata_model.mlp */
+  const float* fc_w; const float* fc_b;    /* [classes][2*classes], [classes]   fc1 (columns: [site scores | hsi scores]) */
+} dta_meta_params;
+typedef struct dta_meta_grads {   /* same shapes; zero-filled on entry (bias gradients are accumulated); NULL = not wanted */
+  float* emb; float* bn_w; float* bn_b; float* mlp_w; float* mlp_b; float* fc_w; float* fc_b;
+} dta_meta_grads;
+size_t dta_meta_head_workspace_bytes(int batch, int classes, int sites);
+/* out[batch][classes] = the fused scores (after the last ReLU) */
+int dta_meta_head_forward(int batch, int classes, int sites, int training, float momentum, float eps, const dta_meta_params* p,
+                          const long long* site, const float* scores, const float* drop, void* workspace, float* out,
+                          void* stream);
+/* dout = d(loss)/d(out); writes the parameter gradients and dscores[batch][classes] = d(loss)/d(hsi scores) */
+int dta_meta_head_backward(int batch, int classes, int sites, int training, const dta_meta_params* p, const long long* site,
+                           const float* drop, void* workspace, const float* out, const float* dout, const dta_meta_grads* grads,
+                           float* dscores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,6 +277,59 @@ def test_class_counts_that_are_not_a_multiple_of_four_are_reproducible(classes):
         assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
 
 
+@pytest.mark.parametrize("classes,sites,B,p_drop", [(200, 23, 64, 0.0), (200, 23, 64, 0.7), (5, 4, 9, 0.0), (7, 300, 33, 0.5)])
+def test_native_metadata_head_vs_torch_autograd(classes, sites, B, p_drop):
+    """csrc/meta.hip (dta_meta_head_forward / backward + optim's cross-entropy launch) against the reference's modules run
+    by torch autograd (metadata.py:9-44: Embedding -> BatchNorm1d -> Dropout -> Linear -> ReLU, cat, Linear, ReLU, unweighted
+    CE): fused scores, loss, d(loss)/d(hsi scores), every parameter gradient and the running statistics -- same Philox
+    draw for the dropout mask (torch's generator, same shape, same position in the stream)."""
+    from deeptreeattention_amd.engine import MetadataTrainer
+    from deeptreeattention_amd.metadata import metadata_sensor_fusion
+    torch.manual_seed(21)
+    bands = 12
+    a = metadata_sensor_fusion(bands=bands, sites=sites, classes=classes).to(dev()).train()
+    a.metadata_model.dropout.p = p_drop
+    with torch.no_grad():
+        a.metadata_model.batch_norm.weight.uniform_(0.5, 1.5)
+        a.metadata_model.batch_norm.bias.uniform_(-0.3, 0.3)
+    b = copy.deepcopy(a)
+    tr = MetadataTrainer(a, lr=1e-3)
+    assert tr.native_head
+    g = torch.Generator(device=dev())
+    g.manual_seed(5)
+    scores = torch.randn(B, classes, device=dev(), generator=g)
+    site = torch.randint(0, sites, (B,), device=dev(), generator=g)
+    y = torch.randint(0, classes, (B,), device=dev(), generator=g)
+    # torch reference (module b), same RNG position for the dropout draw
+    torch.manual_seed(77)
+    leaf = scores.clone().requires_grad_(True)
+    out_ref = torch.relu(b.fc1(torch.cat([b.metadata_model(site), leaf], dim=1)))
+    loss_ref = torch.nn.functional.cross_entropy(out_ref, y)
+    loss_ref.backward()
+    torch.manual_seed(77)
+    tr.sensor._zero_grads()
+    tr._attach_grads()
+    dscores, loss = tr._native_step(scores, site, y)
+    out = tr._mh[2]
+    tol = 2e-5
+    assert rel_l2(out.cpu().numpy(), out_ref.detach().cpu().numpy()) < tol
+    assert abs(float(loss) - float(loss_ref)) < tol * abs(float(loss_ref))
+    assert rel_l2(dscores.cpu().numpy(), leaf.grad.cpu().numpy()) < 1e-4
+    for (k, pa), (_, pb) in zip(list(a.metadata_model.named_parameters()) + list(a.fc1.named_parameters()),
+                                list(b.metadata_model.named_parameters()) + list(b.fc1.named_parameters())):
+        assert rel_l2(pa.grad.cpu().numpy(), pb.grad.cpu().numpy()) < 2e-4, k
+    for k in ("running_mean", "running_var", "num_batches_tracked"):
+        va, vb = getattr(a.metadata_model.batch_norm, k), getattr(b.metadata_model.batch_norm, k)
+        assert rel_l2(va.double().cpu().numpy(), vb.double().cpu().numpy()) < 1e-5, k
+    # eval mode: running statistics, no dropout
+    a.eval(); b.eval()
+    with torch.no_grad():
+        o2, _ = tr._native_forward(scores, site, False)
+        r2 = torch.relu(b.fc1(torch.cat([b.metadata_model(site), scores], dim=1)))
+    assert rel_l2(o2.cpu().numpy(), r2.cpu().numpy()) < tol
+    tr.close()
+
+
 def _ensemble_step_inputs(step, years, B, bands, classes):
     imgs = [prng.uniform01(82 + step, yy, (B, bands, 11, 11)) for yy in range(years)]
     if step == 1:
