@@ -132,6 +132,8 @@ def lib():
         L.dta_meta_head_forward.restype = C.c_int
         L.dta_meta_head_forward.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(MetaParams),
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_meta_head_loss.restype = C.c_int
+        L.dta_meta_head_loss.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dta_meta_head_backward.restype = C.c_int
         L.dta_meta_head_backward.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MetaParams), C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MetaGrads), C.c_void_p, C.c_void_p]

@@ -162,6 +162,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, in
     if (m >= a.M) continue;
     float* c = a.C + (size_t)m * a.sc_m + (size_t)n * a.sc_n;
     float v = off ? 0.f : acc[r] * osc + bias;
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.mask && !(a.mask[(size_t)m * a.mask_m + n] > 0.f)) v = 0.f;
     if (a.ksplit > 1) atomicAdd(c, v);
     else if (a.accumulate) *c += v;
     else *c = v;
@@ -324,6 +326,8 @@ __device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by,
 #pragma unroll
     for (int w = 0; w < NWT; ++w) v += smem[w * WT_REGION + ml * 33 + (t & 31)];
     v = off ? 0.f : v * osc + ((a.bias && bz == 0) ? a.bias[n] : 0.f);
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.mask && !(a.mask[(size_t)m * a.mask_m + n] > 0.f)) v = 0.f;
     float* c = a.C + (size_t)m * a.sc_m + (size_t)n * a.sc_n;
     if (ks > 1) atomicAdd(c, v);
     else if (a.accumulate) *c += v;
@@ -738,7 +742,11 @@ __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
     for (int n = lane, k = 0; n < a.classes; n += 64, ++k) {
       const float z = zget(n, k);
       if (jo && jo != zs) jo[n] = z;
-      if (a.dlogits) a.dlogits[(size_t)row * a.classes + n] = none_kept ? 0.f : sc2 * (__expf(z - mx - lse) - ((ok && n == (int)y) ? 1.f : 0.f));
+      if (a.dlogits) {
+        float dv = none_kept ? 0.f : sc2 * (__expf(z - mx - lse) - ((ok && n == (int)y) ? 1.f : 0.f));
+        if (a.relu_mask && !(z > 0.f)) dv = 0.f;      // the scores are a ReLU's output: the gradient w.r.t. its input
+        a.dlogits[(size_t)row * a.classes + n] = dv;
+      }
     }
   }
   asm volatile("" ::"v"(xold));

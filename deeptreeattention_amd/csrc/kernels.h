@@ -350,6 +350,10 @@ struct GemmArgs {
   // year ensembles with the missing-year decision on the device: gate[0] <= 0 -> every output of this GEMM (and its row
   // sums) is an exact zero, whatever the operands hold (selected, not multiplied: a skipped year's operands may be NaN)
   const float* gate;
+  // epilogue options (plain-store GEMMs only: ksplit == 1, no accumulate): relu != 0 -> C = max(C, 0) after the bias;
+  // mask != null -> C(m, n) is kept where mask[m * mask_m + n] > 0 and zeroed elsewhere (a ReLU's backward, the mask being
+  // the ReLU's output)
+  int relu; const float* mask; long mask_m;
 };
 constexpr int GEMM_GROUP_MAX = 12;
 struct GemmGroup {
@@ -482,6 +486,7 @@ struct BlendCeArgs {
   const long long* labels; const float* weight; float* dlogits; float* loss; float* rowtmp; int B, classes;
   float gscale = 1.f;      // factor on dlogits only (year ensemble: d(mean over kept years) / d(year score))
   const float* gscale_dev = nullptr;   // non-null: the factor is read from the device (decided there: kept years)
+  int relu_mask = 0;                   // the scores are a ReLU's output: dlogits is the gradient w.r.t. the ReLU's INPUT
 };
 int launch_blend_ce(const BlendCeArgs& a, hipStream_t st);
 struct AdamArgs {

@@ -25,7 +25,7 @@ struct Carver {
   size_t off = 0;
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
 };
-struct MetaPlan { size_t x16, xhat_t, rstd, hist, meta_pre, joined, out_pre, d_meta, d_x16, total; };
+struct MetaPlan { size_t x16, xhat_t, rstd, hist, joined, d_meta, d_x16, total; };
 MetaPlan meta_plan(int B, int C, int S) {
   MetaPlan p;
   Carver c;
@@ -33,9 +33,7 @@ MetaPlan meta_plan(int B, int C, int S) {
   p.xhat_t = c.take((size_t)S * MW * 4);         // normalised embedding row per site
   p.rstd = c.take(MW * 4);
   p.hist = c.take((size_t)S * 4);
-  p.meta_pre = c.take((size_t)B * C * 4);
   p.joined = c.take((size_t)B * 2 * C * 4);      // [ReLU(meta_pre) | hsi scores]
-  p.out_pre = c.take((size_t)B * C * 4);
   p.d_meta = c.take((size_t)B * C * 4);
   p.d_x16 = c.take((size_t)B * MW * 4);
   p.total = c.off;
@@ -109,23 +107,29 @@ __global__ __launch_bounds__(1024) void k_meta_front(FrontArgs a) {
   }
 }
 
-// joined[b] = [ReLU(meta_pre[b]) | scores[b]]
-__global__ void k_meta_join(const float* meta_pre, const float* scores, float* joined, int B, int C) {
+// joined[b] = [ReLU(x16[b] . mlp_w^T + mlp_b) | scores[b]]: the 16 -> C linear of the site branch is 16 multiply-adds per
+// output, done here instead of in a GEMM launch of its own
+__global__ __launch_bounds__(256) void k_meta_join(const float* x16, const float* w, const float* bias, const float* scores,
+                                                   float* joined, int B, int C) {
   const size_t n = (size_t)B * 2 * C;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / (2 * C)), c = (int)(i - (size_t)b * 2 * C);
-    joined[i] = c < C ? fmaxf(meta_pre[(size_t)b * C + c], 0.f) : scores[(size_t)b * C + (c - C)];
-  }
-}
-// out = ReLU(x)
-__global__ void k_relu(const float* x, float* out, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fmaxf(x[i], 0.f);
-}
-// d = (ref > 0) ? src : 0   (ReLU backward; ref = the ReLU's output or input: same sign test)
-__global__ void k_relu_bwd(const float* src, const float* ref, long ref_pitch, int cols, float* d, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = i / cols, c = i - r * cols;
-    d[i] = ref[r * ref_pitch + c] > 0.f ? src[i] : 0.f;
+    float v;
+    if (c < C) {
+      const f32x4* xr = reinterpret_cast<const f32x4*>(x16 + (size_t)b * MW);      // (workspace rows: 64-byte aligned)
+      const float* wr = w + (size_t)c * MW;
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < MW / 4; ++q) {
+        const f32x4 xv = xr[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += xv[j] * wr[4 * q + j];
+      }
+      v = fmaxf(acc + bias[c], 0.f);
+    } else {
+      v = scores[(size_t)b * C + (c - C)];
+    }
+    joined[i] = v;
   }
 }
 
@@ -280,21 +284,25 @@ int dta_meta_head_forward(int batch, int classes, int sites, int training, float
   if (front_once.first()) (void)hipFuncSetAttribute((const void*)k_meta_front, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   hipLaunchKernelGGL(k_meta_front, dim3(1), dim3(1024), (size_t)S * (MW + 1) * 4, st, fa);
   DTA_CHECK_LAUNCH("k_meta_front");
-  GemmArgs g;
-  memset(&g, 0, sizeof(g));                      // meta_pre[B][C] = x16[B][16] . mlp_w[C][16]^T + mlp_b
-  g.A = fa.x16; g.sa_m = MW; g.sa_k = 1; g.Bm = p->mlp_w; g.sb_k = 1; g.sb_n = MW;
-  g.C = at<float>(workspace, pl.meta_pre); g.sc_m = C; g.sc_n = 1; g.bias = p->mlp_b; g.M = B; g.N = C; g.K = MW; g.ksplit = 1;
-  if (launch_gemm(g, st)) return 1;
   float* joined = at<float>(workspace, pl.joined);
-  hipLaunchKernelGGL(k_meta_join, dim3(grid1d((size_t)B * 2 * C)), dim3(256), 0, st, g.C, scores, joined, B, C);
+  hipLaunchKernelGGL(k_meta_join, dim3(grid1d((size_t)B * 2 * C)), dim3(256), 0, st, fa.x16, p->mlp_w, p->mlp_b, scores, joined, B, C);
   DTA_CHECK_LAUNCH("k_meta_join");
-  memset(&g, 0, sizeof(g));                      // out_pre[B][C] = joined[B][2C] . fc_w[C][2C]^T + fc_b
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));                      // out[B][C] = ReLU(joined[B][2C] . fc_w[C][2C]^T + fc_b)
   g.A = joined; g.sa_m = 2 * C; g.sa_k = 1; g.Bm = p->fc_w; g.sb_k = 1; g.sb_n = 2 * C;
-  g.C = at<float>(workspace, pl.out_pre); g.sc_m = C; g.sc_n = 1; g.bias = p->fc_b; g.M = B; g.N = C; g.K = 2 * C; g.ksplit = 1;
+  g.C = out; g.sc_m = C; g.sc_n = 1; g.bias = p->fc_b; g.M = B; g.N = C; g.K = 2 * C; g.ksplit = 1; g.relu = 1;
   if (launch_gemm(g, st)) return 1;
-  hipLaunchKernelGGL(k_relu, dim3(grid1d((size_t)B * C)), dim3(256), 0, st, g.C, out, (size_t)B * C);
-  DTA_CHECK_LAUNCH("k_relu");
   return 0;
+}
+
+int dta_meta_head_loss(int batch, int classes, const float* out, const long long* labels, float* loss, float* dout, float* scratch,
+                       void* stream) {
+  if (batch < 1 || classes < 1 || !out || !labels || !loss || !scratch) { dta_set_error("dta_meta_head_loss: bad argument"); return 1; }
+  BlendCeArgs a;
+  a.spec = out; a.spat = nullptr; a.alpha = nullptr; a.joint = nullptr;
+  a.labels = labels; a.weight = nullptr; a.dlogits = dout; a.loss = loss; a.rowtmp = scratch;
+  a.B = batch; a.classes = classes; a.gscale = 1.f; a.relu_mask = 1;
+  return launch_blend_ce(a, (hipStream_t)stream);
 }
 
 int dta_meta_head_backward(int batch, int classes, int sites, int training, const dta_meta_params* p, const long long* site,
@@ -302,22 +310,23 @@ int dta_meta_head_backward(int batch, int classes, int sites, int training, cons
                            float* dscores, void* stream) {
   const int B = batch, C = classes, S = sites;
   if (check(B, C, S, p, site, workspace, "dta_meta_head_backward")) return 1;
-  if (!out || !dout || !grads || !dscores) { dta_set_error("dta_meta_head_backward: null argument"); return 1; }
+  if (!dout || !grads || !dscores) { dta_set_error("dta_meta_head_backward: null argument"); return 1; }
+  (void)out;
   hipStream_t st = (hipStream_t)stream;
   const MetaPlan pl = meta_plan(B, C, S);
-  float* d_pre = at<float>(workspace, pl.out_pre);          // (the forward's pre-activation is no longer needed: reuse)
+  const float* d_pre = dout;                                // (dta_meta_head_loss already applied the last ReLU's backward)
   const float* joined = at<float>(workspace, pl.joined);
   float* d_meta = at<float>(workspace, pl.d_meta);
   float* d_x16 = at<float>(workspace, pl.d_x16);
   const float* x16 = at<float>(workspace, pl.x16);
-  hipLaunchKernelGGL(k_relu_bwd, dim3(grid1d((size_t)B * C)), dim3(256), 0, st, dout, out, (long)C, C, d_pre, (size_t)B * C);
-  DTA_CHECK_LAUNCH("k_relu_bwd");
   GemmGroup g1;
   GemmArgs g;
   memset(&g, 0, sizeof(g));                      // d(meta)[B][C] = d_pre[B][C] . fc_w[:, :C]
   g.A = d_pre; g.sa_m = C; g.sa_k = 1; g.Bm = p->fc_w; g.sb_k = 2 * C; g.sb_n = 1;
   g.C = d_meta; g.sc_m = C; g.sc_n = 1; g.M = B; g.N = C; g.K = C; g.ksplit = 1;
+  g.mask = joined; g.mask_m = 2 * C;             // ... through the site branch's ReLU: joined[:, :C] holds its output
   g1.add(g);
+  g.mask = nullptr; g.mask_m = 0;
   g.Bm = p->fc_w + C; g.C = dscores;             // d(hsi scores)[B][C] = d_pre . fc_w[:, C:]
   g1.add(g);
   if (grads->fc_w) {                             // d fc_w[C][2C] = d_pre^T[C][B] . joined[B][2C], d fc_b = column sums of d_pre
@@ -327,9 +336,6 @@ int dta_meta_head_backward(int batch, int classes, int sites, int training, cons
     g1.add(g);
   }
   if (launch_gemm_group(g1, st)) return 1;
-  // ReLU of the site branch: joined[:, :C] holds ReLU(meta_pre)
-  hipLaunchKernelGGL(k_relu_bwd, dim3(grid1d((size_t)B * C)), dim3(256), 0, st, d_meta, joined, (long)(2 * C), C, d_meta, (size_t)B * C);
-  DTA_CHECK_LAUNCH("k_relu_bwd");
   GemmGroup g2;
   memset(&g, 0, sizeof(g));                      // d x16[B][16] = d_meta[B][C] . mlp_w[C][16]
   g.A = d_meta; g.sa_m = C; g.sa_k = 1; g.Bm = p->mlp_w; g.sb_k = MW; g.sb_n = 1;

@@ -1082,8 +1082,8 @@ class MetadataTrainer:
         out, drop = self._native_forward(scores, site, True)
         loss = torch.empty((), dtype=torch.float32, device=scores.device)
         st = _lib.current_stream_ptr()
-        _lib.check(L.dta_weighted_ce_scaled(_lib.ptr(out), _lib.ptr(y), None, B, classes, 1.0, _lib.ptr(loss), _lib.ptr(dlogits),
-                                            _lib.ptr(scratch), st), "dta_weighted_ce_scaled")
+        _lib.check(L.dta_meta_head_loss(B, classes, _lib.ptr(out), _lib.ptr(y), _lib.ptr(loss), _lib.ptr(dlogits),
+                                        _lib.ptr(scratch), st), "dta_meta_head_loss")
         P, G = self._native_tables()
         _lib.check(L.dta_meta_head_backward(B, classes, sites, 1, C.byref(P), _lib.ptr(site), _lib.ptr(drop), _lib.ptr(ws),
                                             _lib.ptr(out), _lib.ptr(dlogits), C.byref(G), _lib.ptr(dscores), st),

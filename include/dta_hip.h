@@ -405,7 +405,12 @@ size_t dta_meta_head_workspace_bytes(int batch, int classes, int sites);
 int dta_meta_head_forward(int batch, int classes, int sites, int training, float momentum, float eps, const dta_meta_params* p,
                           const long long* site, const float* scores, const float* drop, void* workspace, float* out,
                           void* stream);
-/* dout = d(loss)/d(out); writes the parameter gradients and dscores[batch][classes] = d(loss)/d(hsi scores) */
+/* unweighted cross-entropy of the fused scores (MetadataModel.training_step, metadata.py:52-63) in one launch: loss (0-d) and
+ * dout[batch][classes] = d(loss)/d(the last ReLU's INPUT), i.e. the ReLU's backward is applied; scratch: batch + 2 floats,
+ * word batch + 1 zero on entry (left zero).  dout may be NULL (validation). */
+int dta_meta_head_loss(int batch, int classes, const float* out, const long long* labels, float* loss, float* dout, float* scratch,
+                       void* stream);
+/* dout = what dta_meta_head_loss wrote; writes the parameter gradients and dscores[batch][classes] = d(loss)/d(hsi scores) */
 int dta_meta_head_backward(int batch, int classes, int sites, int training, const dta_meta_params* p, const long long* site,
                            const float* drop, void* workspace, const float* out, const float* dout, const dta_meta_grads* grads,
                            float* dscores, void* stream);
