@@ -47,13 +47,17 @@ struct FrontArgs {
   int B, S, training; float momentum, eps;
 };
 
-// one workgroup: site histogram -> batch statistics -> per-site normalised rows -> the [B][16] input of the site Linear
+// one workgroup: site histogram -> batch statistics -> per-site normalised rows (the [B][16] input of the site Linear is
+// formed from them by the join kernel below: a single workgroup streams 200 KB through one CU in 6 us)
 // dynamic LDS: tab [S][16] floats (the embedding table, then the normalised rows), hist [S] ints
 __global__ __launch_bounds__(1024) void k_meta_front(FrontArgs a) {
   extern __shared__ float tab[];
   __shared__ float mean[MW], rstd[MW];
   int* hist = reinterpret_cast<int*>(tab + a.S * MW);
   const int t = threadIdx.x;
+  // (running statistics requested up front: the kernel is one dependent chain)
+  float rm0 = 0.f, rv0 = 1.f;
+  if (t < MW && a.rm) { rm0 = a.rm[t]; rv0 = a.rv[t]; }
 #pragma unroll 4
   for (int i = t; i < a.S * MW; i += 1024) tab[i] = a.emb[i];
   for (int s = t; s < a.S; s += 1024) hist[s] = 0;
@@ -74,15 +78,15 @@ __global__ __launch_bounds__(1024) void k_meta_front(FrontArgs a) {
 #pragma unroll 8
       for (int s = 0; s < a.S; ++s) { const double d = (double)tab[s * MW + t] - mu; s2 += (double)hist[s] * d * d; }
       const double var = s2 / a.B;
-      m = (float)mu; r = (float)(1.0 / sqrt(var + (double)a.eps));
+      m = (float)mu; r = 1.f / sqrtf((float)var + a.eps);      // (torch's invstd: float)
       if (a.rm) {
-        const double unb = a.B > 1 ? s2 / (a.B - 1) : var;
-        a.rm[t] = (1.f - a.momentum) * a.rm[t] + a.momentum * m;
-        a.rv[t] = (1.f - a.momentum) * a.rv[t] + a.momentum * (float)unb;
+        const float unb = a.B > 1 ? (float)s2 / (float)(a.B - 1) : (float)var;
+        a.rm[t] = (1.f - a.momentum) * rm0 + a.momentum * m;
+        a.rv[t] = (1.f - a.momentum) * rv0 + a.momentum * unb;
         if (t == 0 && a.nbt) a.nbt[0] += 1;
       }
     } else {
-      m = a.rm[t]; r = rsqrtf(a.rv[t] + a.eps);
+      m = rm0; r = rsqrtf(rv0 + a.eps);
     }
     mean[t] = m; rstd[t] = r;
     a.rstd[t] = r;
@@ -96,32 +100,30 @@ __global__ __launch_bounds__(1024) void k_meta_front(FrontArgs a) {
   }
   if (a.training)
     for (int s = t; s < a.S; s += 1024) a.hist[s] = hist[s];
-  __syncthreads();
-  const float gw = a.bn_w[t & (MW - 1)], gb = a.bn_b[t & (MW - 1)];      // (i = t + 1024 k: the feature is t mod 16 for every k)
-#pragma unroll 8
-  for (int i = t; i < a.B * MW; i += 1024) {
-    const int b = i >> 4, f = i & (MW - 1), s = (int)a.site[b];
-    float v = tab[s * MW + f] * gw + gb;
-    if (a.drop) v *= a.drop[i];
-    a.x16[i] = v;
-  }
 }
 
-// joined[b] = [ReLU(x16[b] . mlp_w^T + mlp_b) | scores[b]]: the 16 -> C linear of the site branch is 16 multiply-adds per
+// joined[b] = [ReLU(x16[b] . mlp_w^T + mlp_b) | scores[b]] with x16[b] = (xhat[site_b] * gamma + beta) * dropout factors formed on
+// the fly (and written out once per row for the backward): the 16 -> C linear of the site branch is 16 multiply-adds per
 // output, done here instead of in a GEMM launch of its own
-__global__ __launch_bounds__(256) void k_meta_join(const float* x16, const float* w, const float* bias, const float* scores,
-                                                   float* joined, int B, int C) {
+__global__ __launch_bounds__(256) void k_meta_join(const float* xhat_t, const float* bn_w, const float* bn_b, const long long* site,
+                                                   const float* drop, const float* w, const float* bias, const float* scores,
+                                                   float* joined, float* x16, int B, int C) {
   const size_t n = (size_t)B * 2 * C;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / (2 * C)), c = (int)(i - (size_t)b * 2 * C);
     float v;
     if (c < C) {
-      const f32x4* xr = reinterpret_cast<const f32x4*>(x16 + (size_t)b * MW);      // (workspace rows: 64-byte aligned)
+      const f32x4* xr = reinterpret_cast<const f32x4*>(xhat_t + (size_t)site[b] * MW);      // (workspace rows: 64-byte aligned)
+      const f32x4* dr = drop ? reinterpret_cast<const f32x4*>(drop + (size_t)b * MW) : nullptr;
       const float* wr = w + (size_t)c * MW;
       float acc = 0.f;
 #pragma unroll
       for (int q = 0; q < MW / 4; ++q) {
-        const f32x4 xv = xr[q];
+        f32x4 xv = xr[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = xv[j] * bn_w[4 * q + j] + bn_b[4 * q + j];
+        if (dr) { const f32x4 dv = dr[q]; xv *= dv; }
+        if (c == 0) reinterpret_cast<f32x4*>(x16 + (size_t)b * MW)[q] = xv;
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc += xv[j] * wr[4 * q + j];
       }
@@ -141,7 +143,7 @@ struct BackArgs {
 // The per-site sums run over each site's samples IN BATCH ORDER (a fixed order, no atomics): a stable counting sort of the
 // batch by site -- thread (site, part) counts, then lists, the samples of its site in the part-th sixteenth of the batch --
 // and thread (site, feature) adds its site's listed rows.
-// dynamic LDS: D [S][16] floats | off [S + 1] ints | cnt [S][16] ints | list [B] ints | sv [B] ints | dy [B][16] floats
+// dynamic LDS: D [S][16] floats | off [S + 1] ints | cnt [S][16] ints | list [B] ints | sv [B] ints | dy [B][16] floats | xhat [S][16] floats
 __global__ __launch_bounds__(1024) void k_meta_back(BackArgs a) {
   extern __shared__ float D[];
   __shared__ float dbeta[MW], dgamma[MW];
@@ -151,26 +153,33 @@ __global__ __launch_bounds__(1024) void k_meta_back(BackArgs a) {
   int* list = cnt + S * MW;
   int* sv = list + B;
   float* dy = reinterpret_cast<float*>(sv + B);
-  // (unrolled: eight independent loads in flight per thread instead of one global round trip per iteration)
+  // every global value this workgroup needs is requested here, in one go (the kernel is one dependent chain: each later
+  // global load would add a round trip to it): sites, dy (x dropout), the normalised table, gamma / rstd of this thread's feature
+  float* xh = dy + (size_t)B * MW;                         // [S][16] normalised embedding rows (LDS copy)
+  const float gam = a.bn_w[t & (MW - 1)], rs = a.rstd[t & (MW - 1)];
+#pragma unroll 4
+  for (int i = t; i < S * MW; i += 1024) xh[i] = a.xhat_t[i];
 #pragma unroll 4
   for (int b = t; b < B; b += 1024) sv[b] = (int)a.site[b];
   if (a.drop) {
-#pragma unroll 8
+#pragma unroll 16
     for (int i = t; i < B * MW; i += 1024) dy[i] = a.d_x16[i] * a.drop[i];
   } else {
-#pragma unroll 8
+#pragma unroll 16
     for (int i = t; i < B * MW; i += 1024) dy[i] = a.d_x16[i];
   }
   __syncthreads();
   const int per = (B + MW - 1) / MW;                       // samples per part
   // (every loop below reads LDS at addresses known in advance: unrolled so that the reads overlap -- a dependent LDS
   //  round trip per iteration made this one-workgroup kernel 25 us)
+  // (lane -> site, so that the lanes of a wave read the SAME sv[b] -- a broadcast; with lane -> part the sixteen parts'
+  //  addresses are 64 words apart: one bank, 16-way conflicts, 4.8 + 6.1 us for the two passes)
   for (int i = t; i < S * MW; i += 1024) {
-    const int s = i >> 4, part = i & (MW - 1), lo = part * per, hi = min(B, lo + per);
+    const int part = i / S, s = i - part * S, lo = part * per, hi = min(B, lo + per);
     int c = 0;
 #pragma unroll 8
     for (int b = lo; b < hi; ++b) c += sv[b] == s;
-    cnt[i] = c;
+    cnt[s * MW + part] = c;
   }
   __syncthreads();
   // site totals (thread s), then an inclusive scan over the sites (Hillis-Steele, ping-pong between off[] and list[])
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(1024) void k_meta_back(BackArgs a) {
     }
   }
   for (int i = t; i < S * MW; i += 1024) {
-    const int s = i >> 4, part = i & (MW - 1), lo = part * per, hi = min(B, lo + per);
+    const int part = i / S, s = i - part * S, lo = part * per, hi = min(B, lo + per);
     int k = off[s];
 #pragma unroll
     for (int q = 0; q < MW; ++q) k += q < part ? cnt[s * MW + q] : 0;
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(1024) void k_meta_back(BackArgs a) {
   if (t < MW) {
     float sb = 0.f, sg = 0.f;
 #pragma unroll 8
-    for (int s = 0; s < S; ++s) { sb += D[s * MW + t]; sg += D[s * MW + t] * a.xhat_t[s * MW + t]; }
+    for (int s = 0; s < S; ++s) { sb += D[s * MW + t]; sg += D[s * MW + t] * xh[s * MW + t]; }
     dbeta[t] = sb; dgamma[t] = sg;
     if (a.d_bn_b) a.d_bn_b[t] = sb;
     if (a.d_bn_w) a.d_bn_w[t] = sg;
@@ -228,14 +237,14 @@ __global__ __launch_bounds__(1024) void k_meta_back(BackArgs a) {
   __syncthreads();
   if (!a.d_emb) return;
   for (int i = t; i < S * MW; i += 1024) {
-    const int s = i >> 4, f = i & (MW - 1);
-    const float g = a.bn_w[f], r = a.rstd[f];
+    const int s = i >> 4;
+    const float g = gam, r = rs;                            // (i = t + 1024 k: the feature is t mod 16 for every k)
     const int n_s = off[s + 1] - off[s];
     float v;
     if (a.training) {
       // d e_b = rstd (g dy_b - g mean_b(dy) - xhat_b g mean_b(dy xhat)), summed over the samples of site s
-      const float m1 = g * dbeta[f] / B, m2 = g * dgamma[f] / B;
-      v = r * (g * D[i] - n_s * m1 - n_s * a.xhat_t[i] * m2);
+      const float m1 = g * dbeta[t & (MW - 1)] / B, m2 = g * dgamma[t & (MW - 1)] / B;
+      v = r * (g * D[i] - n_s * m1 - n_s * xh[i] * m2);
     } else {
       v = r * g * D[i];
     }
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(1024) void k_meta_back(BackArgs a) {
   }
 }
 
-size_t meta_back_lds(int B, int S) { return ((size_t)S * MW + (S + 1) + (size_t)S * MW + B + B + (size_t)B * MW) * 4; }
+size_t meta_back_lds(int B, int S) { return ((size_t)S * MW + (S + 1) + (size_t)S * MW + B + B + (size_t)B * MW + (size_t)S * MW) * 4; }
 
 int check(int B, int C, int S, const dta_meta_params* p, const long long* site, void* ws, const char* who) {
   if (B < 1 || C < 1 || S < 1 || !p || !site || !ws) { dta_set_error("%s: bad argument", who); return 1; }
@@ -285,7 +294,8 @@ int dta_meta_head_forward(int batch, int classes, int sites, int training, float
   hipLaunchKernelGGL(k_meta_front, dim3(1), dim3(1024), (size_t)S * (MW + 1) * 4, st, fa);
   DTA_CHECK_LAUNCH("k_meta_front");
   float* joined = at<float>(workspace, pl.joined);
-  hipLaunchKernelGGL(k_meta_join, dim3(grid1d((size_t)B * 2 * C)), dim3(256), 0, st, fa.x16, p->mlp_w, p->mlp_b, scores, joined, B, C);
+  hipLaunchKernelGGL(k_meta_join, dim3(grid1d((size_t)B * 2 * C)), dim3(256), 0, st, fa.xhat_t, p->bn_w, p->bn_b, site, fa.drop,
+                     p->mlp_w, p->mlp_b, scores, joined, fa.x16, B, C);
   DTA_CHECK_LAUNCH("k_meta_join");
   GemmArgs g;
   memset(&g, 0, sizeof(g));                      // out[B][C] = ReLU(joined[B][2C] . fc_w[C][2C]^T + fc_b)
