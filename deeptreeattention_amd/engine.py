@@ -230,6 +230,54 @@ class FusedTrainer:
             self.sync.rccl.close()
             self.sync.rccl = None
 
+    # ---- optimizer state in torch.optim.Adam's layout (Lightning checkpoints: "optimizer_states") ----
+    def _moment_views(self, p):
+        """(exp_avg, exp_avg_sq) of a parameter of the model as views of the flat moment buffers."""
+        if self.hang and p is self.alpha:
+            return self.alpha_m, self.alpha_v
+        for pbuf, mbuf, vbuf in ((self.p_head, self.m_head, self.v_head), (self.p_tail, self.m_tail, self.v_tail)):
+            off = (p.data_ptr() - pbuf.data_ptr()) // 4
+            if 0 <= off and off + p.numel() <= pbuf.numel() and p.data_ptr() >= pbuf.data_ptr():
+                return mbuf[off:off + p.numel()].view(p.shape), vbuf[off:off + p.numel()].view(p.shape)
+        raise KeyError("not a parameter of this trainer")
+
+    def optimizer_state_dict(self):
+        """state_dict() of the torch.optim.Adam(self.model.parameters(), lr) the reference builds (src/main.py:135-137) after
+        the same steps: loads into that optimizer, and into optim.DtaAdam."""
+        params = list(self.model.parameters())
+        state = {}
+        for i, p in enumerate(params):
+            m, v = self._moment_views(p)
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(params)))}
+        return {"state": state if self.step_count > 0 else {}, "param_groups": [group]}
+
+    @torch.no_grad()
+    def load_optimizer_state_dict(self, sd):
+        """Resume from a torch.optim.Adam / optim.DtaAdam / FusedTrainer optimizer state dict over self.model.parameters()."""
+        params = list(self.model.parameters())
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(params):
+            raise ValueError("expected one parameter group over the model's {} parameters".format(len(params)))
+        g = groups[0]
+        if g.get("weight_decay") or g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("the fused step is Adam without weight decay / amsgrad / maximize (the reference's setting)")
+        steps = set()
+        for key, p in zip(g["params"], params):
+            st = sd["state"].get(key)
+            m, v = self._moment_views(p)
+            if st is None:                    # never stepped by torch (grad None every time): zero moments
+                m.zero_(); v.zero_()
+                continue
+            m.copy_(st["exp_avg"].to(m)); v.copy_(st["exp_avg_sq"].to(v))
+            if float(st["step"]) > 0:
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("parameters carry different step counts: {}".format(sorted(steps)))
+        self.step_count = steps.pop() if steps else 0
+        self.lr, self.betas, self.eps = float(g["lr"]), tuple(g["betas"]), float(g["eps"])
+
     def grad_of(self, param):
         """Gradient view (inside the flat gradient buffer) of one of the model's fp32 parameters.  After train_step
         it holds the step's gradient only when the trainer was built with keep_grads=True (by default the optimizer

@@ -181,6 +181,68 @@ def test_dta_adam_resumes_from_its_own_and_from_torch_adam_state_dict():
         assert rel_l2(v.double().cpu().numpy(), want[k]) < 2e-3, k
 
 
+def test_fused_trainer_optimizer_state_interoperates_with_torch_adam():
+    """FusedTrainer.optimizer_state_dict() / load_optimizer_state_dict() in torch.optim.Adam's layout (what a Lightning
+    checkpoint's optimizer_states holds): two fused steps -> torch Adam takes the third, and two torch steps -> the fused
+    trainer takes the third; both land on three uninterrupted fused steps."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    bands, classes, B, lr = 14, 8, 5, 1e-3
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=45)
+    batches = [(torch.from_numpy(prng.uniform01(700 + s, 1, (B, bands, 11, 11))).to(dev()),
+                torch.from_numpy(prng.randint(700 + s, 2, (B,), classes)).to(dev())) for s in range(3)]
+    full = load(H.Hang2020(bands, classes), p).train()
+    tf = FusedTrainer(full, lr=lr)
+    for x, y in batches:
+        tf.train_step(x, y)
+    want = {k: v.detach().double().cpu().numpy() for k, v in full.state_dict().items()}
+
+    def close(m, tol):
+        for k, v in m.state_dict().items():
+            if k.endswith("conv_layer.bias") or "classifier1" in k or "classifier2" in k:
+                continue
+            assert rel_l2(v.double().cpu().numpy(), want[k]) < tol, k
+
+    # fused -> torch
+    a = load(H.Hang2020(bands, classes), p).train()
+    ta = FusedTrainer(a, lr=lr)
+    for x, y in batches[:2]:
+        ta.train_step(x, y)
+    osd, msd = copy.deepcopy(ta.optimizer_state_dict()), copy.deepcopy(a.state_dict())
+    b = H.Hang2020(bands, classes).to(dev()).train()
+    b.load_state_dict(msd)
+    ob = torch.optim.Adam(b.parameters(), lr=lr * 5)
+    ob.load_state_dict(copy.deepcopy(osd))                # (torch keeps the 'step' tensors it is handed and steps them in place)
+    assert ob.param_groups[0]["lr"] == lr
+    x, y = batches[2]
+    ob.zero_grad()
+    torch.nn.functional.cross_entropy(b(x), y).backward()
+    ob.step()
+    close(b, 2e-3)
+    # torch -> fused
+    c = load(H.Hang2020(bands, classes), p).train()
+    oc = torch.optim.Adam(c.parameters(), lr=lr)
+    for x, y in batches[:2]:
+        oc.zero_grad()
+        torch.nn.functional.cross_entropy(c(x), y).backward()
+        oc.step()
+    d = H.Hang2020(bands, classes).to(dev()).train()
+    d.load_state_dict(copy.deepcopy(c.state_dict()))
+    td = FusedTrainer(d, lr=lr * 3)
+    td.load_optimizer_state_dict(copy.deepcopy(oc.state_dict()))
+    assert td.lr == lr and td.step_count == 2
+    td.train_step(*batches[2])
+    close(d, 2e-3)
+    # fused -> fused is exact
+    e = H.Hang2020(bands, classes).to(dev()).train()
+    e.load_state_dict(msd)
+    te = FusedTrainer(e, lr=lr)
+    te.load_optimizer_state_dict(osd)
+    te.train_step(*batches[2])
+    for k, v in e.state_dict().items():
+        assert torch.equal(v, full.state_dict()[k]), k
+
+
 def test_torch_adam_resumes_from_a_dta_adam_state_dict():
     """The other direction: a DtaAdam state dict loads into torch.optim.Adam (same group keys, same state layout) and
     the third step there lands on the uninterrupted DtaAdam run."""
