@@ -709,6 +709,60 @@ class EnsembleTrainer:
                 return t._gview[id(param)]
         raise KeyError("not a parameter of this ensemble")
 
+    # ---- optimizer state in torch.optim.Adam's layout (one Adam per level over the ensemble's parameters,
+    #      reference multi_stage.py:258-275); a year torch never stepped has no state there, step 0 and zero moments here ----
+    def _year_of(self):
+        owner = {}
+        for i, t in enumerate(self.years):
+            for p in t.model.parameters():
+                owner[id(p)] = i
+        return owner
+
+    def optimizer_state_dict(self):
+        params = list(self.model.parameters())
+        owner, counts = self._year_of(), self.step_counts()
+        state = {}
+        for k, p in enumerate(params):
+            i = owner[id(p)]
+            if counts[i] == 0:
+                continue
+            m, v = self.years[i]._moment_views(p)
+            state[k] = {"step": torch.tensor(float(counts[i])), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    @torch.no_grad()
+    def load_optimizer_state_dict(self, sd):
+        params = list(self.model.parameters())
+        g = sd["param_groups"][0]
+        if len(sd["param_groups"]) != 1 or len(g["params"]) != len(params):
+            raise ValueError("expected one parameter group over the ensemble's {} parameters".format(len(params)))
+        if g.get("weight_decay") or g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("the fused step is Adam without weight decay / amsgrad / maximize (the reference's setting)")
+        owner = self._year_of()
+        counts = [set() for _ in self.years]
+        for key, p in zip(g["params"], params):
+            i = owner[id(p)]
+            m, v = self.years[i]._moment_views(p)
+            st = sd["state"].get(key)
+            if st is None:
+                m.zero_(); v.zero_()
+                continue
+            m.copy_(st["exp_avg"].to(m)); v.copy_(st["exp_avg_sq"].to(v))
+            if float(st["step"]) > 0:
+                counts[i].add(int(float(st["step"])))
+        if any(len(c) > 1 for c in counts):
+            raise ValueError("parameters of one year carry different step counts")
+        per_year = [c.pop() if c else 0 for c in counts]
+        for t, n in zip(self.years, per_year):
+            t.step_count = n
+        self.dev_steps[:] = torch.tensor(per_year, dtype=torch.int32, device=self.dev_steps.device)
+        self.lr = float(g["lr"])
+        self.betas, self.eps = tuple(g["betas"]), float(g["eps"])
+        for t in self.years:
+            t.betas, t.eps = self.betas, self.eps
+
     def _kept(self, images, present):
         if len(images) != len(self.years):
             raise ValueError("expected one image tensor per year ({}), got {}".format(len(self.years), len(images)))

@@ -243,6 +243,54 @@ def test_fused_trainer_optimizer_state_interoperates_with_torch_adam():
         assert torch.equal(v, full.state_dict()[k]), k
 
 
+def test_ensemble_trainer_optimizer_state_round_trip():
+    """EnsembleTrainer's Adam state in torch.optim.Adam's layout: per-year step counts survive (a year skipped once is one
+    step behind), a fresh trainer resumes bit for bit, and torch.optim.Adam / optim.DtaAdam accept the same dict."""
+    from deeptreeattention_amd.engine import EnsembleTrainer
+    from deeptreeattention_amd.optim import DtaAdam
+    from deeptreeattention_amd.year import learned_ensemble
+    years, bands, classes, B, lr = 3, 16, 8, 6, 1e-3
+    p = O.init_params(O.learned_ensemble_spec(years, bands, classes), seed=83)
+    cfg = {"pretrain_state_dict": None, "bands": bands}
+    w = torch.ones(classes)
+
+    def batch(step):
+        imgs, y = _ensemble_step_inputs(step, years, B, bands, classes)
+        return [torch.from_numpy(a).to(dev()) for a in imgs], torch.from_numpy(y).to(dev())
+
+    full = load(learned_ensemble(years=years, classes=classes, config=cfg), p).train()
+    tf = EnsembleTrainer(full, lr=lr, loss_weight=w)
+    for step in range(4):
+        xs, y = batch(step)
+        tf.train_step(xs, y, [bool(float(x.abs().sum()) > 0) for x in xs])
+    a = load(learned_ensemble(years=years, classes=classes, config=cfg), p).train()
+    ta = EnsembleTrainer(a, lr=lr, loss_weight=w)
+    for step in range(2):
+        xs, y = batch(step)
+        ta.train_step(xs, y, [bool(float(x.abs().sum()) > 0) for x in xs])
+    assert ta.step_counts() == [2, 2, 1]
+    osd, msd = copy.deepcopy(ta.optimizer_state_dict()), copy.deepcopy(a.state_dict())
+    b = learned_ensemble(years=years, classes=classes, config=cfg).to(dev()).train()
+    b.load_state_dict(msd)
+    tb = EnsembleTrainer(b, lr=lr * 2, loss_weight=w)
+    tb.load_optimizer_state_dict(copy.deepcopy(osd))
+    assert tb.lr == lr and tb.step_counts() == [2, 2, 1]
+    for step in (2, 3):
+        xs, y = batch(step)
+        tb.train_step(xs, y, [bool(float(x.abs().sum()) > 0) for x in xs])
+    assert tb.step_counts() == tf.step_counts() == [3, 4, 3]
+    for (k, v), (_, u) in zip(b.state_dict().items(), full.state_dict().items()):
+        assert torch.equal(v, u), k
+    # the same dict in the reference's optimizer and in the drop-in one
+    c = learned_ensemble(years=years, classes=classes, config=cfg).to(dev()).train()
+    c.load_state_dict(msd)
+    torch.optim.Adam(c.parameters(), lr=lr).load_state_dict(copy.deepcopy(osd))
+    oc = DtaAdam(c.parameters(), lr=lr)
+    oc.load_state_dict(copy.deepcopy(osd))
+    assert oc.step_counts() == [2, 2, 1]
+    oc.close()
+
+
 def test_torch_adam_resumes_from_a_dta_adam_state_dict():
     """The other direction: a DtaAdam state dict loads into torch.optim.Adam (same group keys, same state layout) and
     the third step there lands on the uninterrupted DtaAdam run."""
