@@ -1230,6 +1230,44 @@ class MetadataTrainer:
     def check_exchange(self):
         self.sensor.check_exchange()
 
+    # ---- optimizer state of the WHOLE fusion model in torch.optim.Adam's layout (metadata.py:85-87: one Adam over
+    #      self.model.parameters()); the small parameters' moments sit in the spare slots of the sensor's buffers ----
+    def optimizer_state_dict(self):
+        params = list(self.model.parameters())
+        n = self.sensor.step_count
+        state = {}
+        for k, p in enumerate(params):
+            m, v = self.sensor._moment_views(p)
+            state[k] = {"step": torch.tensor(float(n)), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.sensor.betas), "eps": self.sensor.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(params)))}
+        return {"state": state if n > 0 else {}, "param_groups": [group]}
+
+    @torch.no_grad()
+    def load_optimizer_state_dict(self, sd):
+        params = list(self.model.parameters())
+        g = sd["param_groups"][0]
+        if len(sd["param_groups"]) != 1 or len(g["params"]) != len(params):
+            raise ValueError("expected one parameter group over the model's {} parameters".format(len(params)))
+        if g.get("weight_decay") or g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("the fused step is Adam without weight decay / amsgrad / maximize (the reference's setting)")
+        steps = set()
+        for key, p in zip(g["params"], params):
+            m, v = self.sensor._moment_views(p)
+            st = sd["state"].get(key)
+            if st is None:
+                m.zero_(); v.zero_()
+                continue
+            m.copy_(st["exp_avg"].to(m)); v.copy_(st["exp_avg_sq"].to(v))
+            if float(st["step"]) > 0:
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("parameters carry different step counts: {}".format(sorted(steps)))
+        self.sensor.step_count = steps.pop() if steps else 0
+        self.lr = float(g["lr"])
+        self.sensor.betas, self.sensor.eps = tuple(g["betas"]), float(g["eps"])
+
     def close(self):
         """Collective (data-parallel): drop the captured graph and the gradient views, release the sensor's exchange."""
         self._graph = None

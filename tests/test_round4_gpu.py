@@ -291,6 +291,40 @@ def test_ensemble_trainer_optimizer_state_round_trip():
     oc.close()
 
 
+def test_metadata_trainer_optimizer_state_round_trip():
+    """MetadataTrainer's Adam state over the whole fusion model (site MLP, HSI branch, fusion layer) in torch's layout:
+    a fresh trainer resumes bit for bit (dropout off: no random op in the step), and torch.optim.Adam accepts the dict."""
+    from deeptreeattention_amd.engine import MetadataTrainer
+    from deeptreeattention_amd.metadata import metadata_sensor_fusion
+    bands, classes, sites, B, lr = 12, 8, 5, 16, 1e-3
+    torch.manual_seed(9)
+    base = metadata_sensor_fusion(bands=bands, sites=sites, classes=classes).to(dev()).train()
+    base.metadata_model.dropout.p = 0.0
+    g = torch.Generator(device=dev())
+    g.manual_seed(2)
+    batches = [(torch.rand(B, bands, 11, 11, device=dev(), generator=g), torch.randint(0, sites, (B,), device=dev(), generator=g),
+                torch.randint(0, classes, (B,), device=dev(), generator=g)) for _ in range(3)]
+    full = copy.deepcopy(base)
+    tf = MetadataTrainer(full, lr=lr)
+    for x, s_, y in batches:
+        tf.train_step(x, s_, y)
+    a = copy.deepcopy(base)
+    ta = MetadataTrainer(a, lr=lr)
+    for x, s_, y in batches[:2]:
+        ta.train_step(x, s_, y)
+    osd, msd = copy.deepcopy(ta.optimizer_state_dict()), copy.deepcopy(a.state_dict())
+    b = copy.deepcopy(base)
+    b.load_state_dict(msd)
+    tb = MetadataTrainer(b, lr=lr * 4)
+    tb.load_optimizer_state_dict(copy.deepcopy(osd))
+    assert tb.lr == lr and tb.sensor.step_count == 2
+    tb.train_step(*batches[2])
+    for (k, v), (_, u) in zip(b.state_dict().items(), full.state_dict().items()):
+        assert torch.equal(v, u), k
+    c = copy.deepcopy(base)
+    torch.optim.Adam(c.parameters(), lr=lr).load_state_dict(copy.deepcopy(osd))
+
+
 def test_torch_adam_resumes_from_a_dta_adam_state_dict():
     """The other direction: a DtaAdam state dict loads into torch.optim.Adam (same group keys, same state layout) and
     the third step there lands on the uninterrupted DtaAdam run."""
