@@ -402,3 +402,49 @@ def test_metadata_sensor_fusion_vs_reference_golden(golden):
     for k, b in m.named_buffers():
         if f"train/buf/{k}" in g:
             assert rel_l2(b.cpu().numpy(), g[f"train/buf/{k}"]) < TIGHT, k
+
+
+def test_native_metadata_head_vs_reference_golden(golden):
+    """The same reference golden (tests/golden/metadata.npz, made by importing src/models/metadata.py) through the NATIVE head
+    of MetadataTrainer (csrc/meta.hip): eval-mode fused scores, and the train step's fused scores, loss, every gradient of
+    the site branch / fusion layer, the HSI branch's gradient norms and the BatchNorm1d running statistics."""
+    from deeptreeattention_amd.engine import MetadataTrainer
+    from deeptreeattention_amd.metadata import metadata_sensor_fusion
+    g = golden("metadata.npz")
+    bands, classes, sites, B = 12, 5, 4, 6
+    m = metadata_sensor_fusion(bands=bands, sites=sites, classes=classes)
+    sd = {"sensor_model." + k: torch.from_numpy(np.array(v)) for k, v in
+          O.init_params(O.hang2020_spec(bands, classes), seed=9).items()}
+    sd.update({k[len("init/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("init/")})
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    m.metadata_model.dropout.p = 0.0
+    x = torch.from_numpy(prng.uniform01(10, 1, (B, bands, 11, 11))).to(dev())
+    site = torch.from_numpy(prng.randint(10, 2, (B,), sites)).to(dev())
+    y = torch.from_numpy(prng.randint(10, 3, (B,), classes)).to(dev())
+    tr = MetadataTrainer(m, lr=1e-3, keep_grads=True)
+    assert tr.native_head
+    m.eval()
+    with torch.no_grad():
+        scores = m.sensor_model(x)
+        out, _ = tr._native_forward(scores, site, False)
+    assert rel_l2(out.cpu().numpy(), g["eval/out"]) < TIGHT
+    m.train()
+    loss = tr.train_step(x, site, y)                       # keep_grads: the step's gradients stay readable
+    assert rel_l2(tr._mh[2].cpu().numpy(), g["train/out"]) < TIGHT
+    assert abs(float(loss) - float(g["train/loss"])) < TIGHT * abs(float(g["train/loss"]))
+    none = set(g["train/none"].tolist())
+    small = {id(p): gv for p, gv in zip(tr.small, tr._gviews)}
+    for k, prm in m.named_parameters():
+        if k in none or k.endswith("conv_layer.bias") or k == "sensor_model.alpha":
+            continue
+        grad = small[id(prm)] if id(prm) in small else tr.sensor.grad_of(prm)
+        ref = float(g[f"train/gnorm/{k}"])
+        assert abs(float(grad.double().norm()) - ref) <= TOL * max(ref, 1e-9), k
+        if f"train/g/{k}" in g:
+            assert rel_l2(grad.cpu().numpy(), g[f"train/g/{k}"]) < TOL, k
+    for k, b in m.named_buffers():
+        if f"train/buf/{k}" in g and k.startswith("metadata_model"):
+            assert rel_l2(b.cpu().numpy(), g[f"train/buf/{k}"]) < TIGHT, k
+    tr.close()
+
