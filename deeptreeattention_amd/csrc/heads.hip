@@ -162,7 +162,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int bx, int by, in
     if (m >= a.M) continue;
     float* c = a.C + (size_t)m * a.sc_m + (size_t)n * a.sc_n;
     float v = off ? 0.f : acc[r] * osc + bias;
-    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.relu) v = v < 0.f ? 0.f : v;      // (NaN stays NaN, as torch.relu; fmaxf would return 0)
     if (a.mask && !(a.mask[(size_t)m * a.mask_m + n] > 0.f)) v = 0.f;
     if (a.ksplit > 1) atomicAdd(c, v);
     else if (a.accumulate) *c += v;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by,
 #pragma unroll
     for (int w = 0; w < NWT; ++w) v += smem[w * WT_REGION + ml * 33 + (t & 31)];
     v = off ? 0.f : v * osc + ((a.bias && bz == 0) ? a.bias[n] : 0.f);
-    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.relu) v = v < 0.f ? 0.f : v;      // (NaN stays NaN, as torch.relu; fmaxf would return 0)
     if (a.mask && !(a.mask[(size_t)m * a.mask_m + n] > 0.f)) v = 0.f;
     float* c = a.C + (size_t)m * a.sc_m + (size_t)n * a.sc_n;
     if (ks > 1) atomicAdd(c, v);

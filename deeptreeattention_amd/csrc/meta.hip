@@ -64,7 +64,10 @@ __global__ __launch_bounds__(1024) void k_meta_front(FrontArgs a) {
   __syncthreads();
   if (a.training) {
 #pragma unroll 4
-    for (int b = t; b < a.B; b += 1024) atomicAdd(&hist[(int)a.site[b]], 1);      // integer: order-independent
+    for (int b = t; b < a.B; b += 1024) {
+      const long long sb = a.site[b];
+      if (sb >= 0 && sb < a.S) atomicAdd(&hist[(int)sb], 1);                      // integer: order-independent
+    }
   }
   __syncthreads();
   if (t < MW) {
@@ -107,13 +110,17 @@ __global__ __launch_bounds__(1024) void k_meta_front(FrontArgs a) {
 // output, done here instead of in a GEMM launch of its own
 __global__ __launch_bounds__(256) void k_meta_join(const float* xhat_t, const float* bn_w, const float* bn_b, const long long* site,
                                                    const float* drop, const float* w, const float* bias, const float* scores,
-                                                   float* joined, float* x16, int B, int C) {
+                                                   float* joined, float* x16, int B, int C, int S) {
+  // (a site index outside [0, sites) is a caller bug -- torch's Embedding device-asserts: the row's outputs become NaN so that
+  //  it cannot train silently, and nothing is read out of bounds)
   const size_t n = (size_t)B * 2 * C;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / (2 * C)), c = (int)(i - (size_t)b * 2 * C);
     float v;
     if (c < C) {
-      const f32x4* xr = reinterpret_cast<const f32x4*>(xhat_t + (size_t)site[b] * MW);      // (workspace rows: 64-byte aligned)
+      const long long sb = site[b];
+      const bool okb = sb >= 0 && sb < S;
+      const f32x4* xr = reinterpret_cast<const f32x4*>(xhat_t + (size_t)(okb ? sb : 0) * MW);      // (workspace rows: 64-byte aligned)
       const f32x4* dr = drop ? reinterpret_cast<const f32x4*>(drop + (size_t)b * MW) : nullptr;
       const float* wr = w + (size_t)c * MW;
       float acc = 0.f;
@@ -127,7 +134,8 @@ __global__ __launch_bounds__(256) void k_meta_join(const float* xhat_t, const fl
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc += xv[j] * wr[4 * q + j];
       }
-      v = fmaxf(acc + bias[c], 0.f);
+      const float pre = acc + bias[c];
+      v = okb ? (pre < 0.f ? 0.f : pre) : __builtin_nanf("");      // (NaN inputs stay NaN, as torch.relu)
     } else {
       v = scores[(size_t)b * C + (c - C)];
     }
@@ -295,7 +303,7 @@ int dta_meta_head_forward(int batch, int classes, int sites, int training, float
   DTA_CHECK_LAUNCH("k_meta_front");
   float* joined = at<float>(workspace, pl.joined);
   hipLaunchKernelGGL(k_meta_join, dim3(grid1d((size_t)B * 2 * C)), dim3(256), 0, st, fa.xhat_t, p->bn_w, p->bn_b, site, fa.drop,
-                     p->mlp_w, p->mlp_b, scores, joined, fa.x16, B, C);
+                     p->mlp_w, p->mlp_b, scores, joined, fa.x16, B, C, S);
   DTA_CHECK_LAUNCH("k_meta_join");
   GemmArgs g;
   memset(&g, 0, sizeof(g));                      // out[B][C] = ReLU(joined[B][2C] . fc_w[C][2C]^T + fc_b)

@@ -719,3 +719,18 @@ def test_dta_adam_data_parallel_equals_the_fused_trainer(kind):
         if "running_" in k or "num_batches_tracked" in k:
             continue
         assert rel_l2(out[(kind, 0)][k], out[(kind, 1)][k]) < 1e-6, k
+
+
+def test_native_metadata_head_poisons_an_out_of_range_site():
+    """A site index outside [0, sites) (torch's Embedding device-asserts there): the loss becomes NaN instead of training on
+    garbage, and nothing is read out of bounds."""
+    from deeptreeattention_amd.engine import MetadataTrainer
+    from deeptreeattention_amd.metadata import metadata_sensor_fusion
+    torch.manual_seed(3)
+    m = metadata_sensor_fusion(bands=12, sites=4, classes=8).to(dev()).train()
+    tr = MetadataTrainer(m, lr=1e-3)
+    x = torch.rand(6, 12, 11, 11, device=dev())
+    y = torch.randint(0, 8, (6,), device=dev())
+    site = torch.tensor([0, 1, 2, 3, 9, -1], device=dev())
+    assert not np.isfinite(float(tr.train_step(x, site, y)))
+    tr.close()
