@@ -411,7 +411,10 @@ def main():
     model.train()
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)                   # each rank owns a different shard of the global batch
-    nb = 2
+    # distinct resident batches the steps cycle through: 4 x 183 MB of fp32 patches (> the 256 MB memory-side cache, so no
+    # step finds its input there) -- and enough different patches (4096 per rank) that `final_loss` after the priming
+    # steps is not the memorisation of two batches
+    nb = 4
     xs = [torch.rand(a.batch, BANDS, HW, HW, device=dev, generator=g) for _ in range(nb)]
     ys = [torch.randint(0, CLASSES, (a.batch,), device=dev, generator=g) for _ in range(nb)]
 

@@ -240,6 +240,11 @@ def _sink_for(plist):
     return ref()
 
 
+def _any_sink(plist):
+    """True when at least one of `plist` belongs to an optim.DtaAdam (which then steps it from its flat buffers)."""
+    return any(id(p) in _GRAD_SINKS for p in plist)
+
+
 def _table_cache(module):
     global _TABLES
     if _TABLES is None:

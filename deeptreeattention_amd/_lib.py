@@ -7,7 +7,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdta_hip.so")
+# DTA_DEV_LIB=1 (a choice of FILE made here, in Python): load the developer library -- the same sources built with
+# -DDTA_DEV_SWITCHES, whose launch plans can be switched through DTA_* environment variables for same-box A/B runs
+# (tools/, tests/test_kernel_variants_gpu.py).  The product library reads nothing from the environment.
+LIB_PATH = os.path.join(_HERE, "libdta_hip_dev.so" if os.environ.get("DTA_DEV_LIB") == "1" else "libdta_hip.so")
 
 DTA_F32, DTA_BF16 = 0, 1
 MAX_YEARS = 4   # DTA_MAX_YEARS
@@ -199,6 +202,7 @@ def lib():
         L.dta_profile_collect_site.restype = C.c_int
         L.dta_profile_collect_site.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int]
         L.dta_dev_reload_switches.restype = C.c_int
+        L.dta_dev_switches_enabled.restype = C.c_int
         # peer gradient exchange (opaque handle = void*)
         L.dta_xchg_create.restype = C.c_int
         L.dta_xchg_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -216,6 +220,8 @@ def lib():
         L.dta_xchg_set_max_workgroups.argtypes = [C.c_void_p, C.c_int]
         L.dta_xchg_allreduce.restype = C.c_int
         L.dta_xchg_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+        L.dta_xchg_reduce_head.restype = C.c_int
+        L.dta_xchg_reduce_head.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
         L.dta_xchg_adam_step.restype = C.c_int
         L.dta_xchg_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,

@@ -11,6 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["conv.hip", "conv_bf16.hip", "stage.hip", "heads.hip", "capi.hip", "capi_modules.hip", "preprocess.hip", "xchg.hip", "meta.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "dta_hip.h")]
 LIB = os.path.join(HERE, "libdta_hip.so")
+# the developer library: the same sources with -DDTA_DEV_SWITCHES (common.h: dev_getenv) -- environment switches for
+# same-box A/B runs of alternative launch plans.  The product library above contains no getenv at all.
+DEV_LIB = os.path.join(HERE, "libdta_hip_dev.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -39,7 +42,13 @@ def source_digest():
     return h.hexdigest()[:16]
 
 
-def build(force=False, verbose=True):
+def _uses_dev_switches(src):
+    return "dev_getenv(" in open(os.path.join(CSRC, src)).read()
+
+
+def build(force=False, verbose=True, dev=True):
+    """Compile every source (in parallel) and link libdta_hip.so; with dev=True also libdta_hip_dev.so, which shares every
+    object except those of the sources that read a developer switch (recompiled with -DDTA_DEV_SWITCHES)."""
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -47,20 +56,24 @@ def build(force=False, verbose=True):
     digest = source_digest()
     idstamp = os.path.join(objdir, "build_id.txt")
     id_stale = not os.path.exists(idstamp) or open(idstamp).read() != digest
-    objs, procs = [], []
+    objs, dev_objs, procs = [], [], []
     extra = os.environ.get("DTA_EXTRA_HIPCC_FLAGS", "").split()
     stamp = os.path.join(objdir, "flags.txt")   # objects built with other flags (developer -D switches) are stale
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(FLAGS + extra):
         force = True
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
-        objs.append(o)
-        if force or _stale(o, [s] + hdrs) or (src == "capi.hip" and id_stale):
-            cmd = [hipcc] + FLAGS + extra + (['-DDTA_BUILD_ID="%s"' % digest] if src == "capi.hip" else []) + ["-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        variants = [("", [])] + ([("_dev", ["-DDTA_DEV_SWITCHES"])] if dev and _uses_dev_switches(src) else [])
+        for suffix, defs in variants:
+            o = os.path.join(objdir, src.replace(".hip", suffix + ".o"))
+            (dev_objs if suffix else objs).append(o)
+            if force or _stale(o, [s] + hdrs) or (src == "capi.hip" and id_stale):
+                cmd = [hipcc] + FLAGS + extra + defs + (['-DDTA_BUILD_ID="%s"' % digest] if src == "capi.hip" else []) + ["-c", s, "-o", o]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                procs.append((src + suffix, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        if len(variants) == 1:
+            dev_objs.append(objs[-1])
     failed = False
     for src, p in procs:
         out, _ = p.communicate()
@@ -73,13 +86,14 @@ def build(force=False, verbose=True):
         f.write(" ".join(FLAGS + extra))
     with open(idstamp, "w") as f:
         f.write(digest)
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    for lib, members in ((LIB, objs),) + (((DEV_LIB, dev_objs),) if dev else ()):
+        if force or procs or _stale(lib, members):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + members
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, dev="--no-dev" not in sys.argv))

@@ -59,7 +59,8 @@ inline void prof_end(int site, hipStream_t st) {
   if (s >= 0 && g_prof.armed[s]) { hipEventRecord(g_prof.ev[s][g_prof.n[s]][1], st); ++g_prof.n[s]; g_prof.armed[s] = false; }
 }
 
-// Developer switches (same-box A/B runs): the environment is read once per process, not per call.
+// Developer switches (same-box A/B runs; developer library only, common.h: dev_getenv): the environment is read once
+// per process, not per call.  In the product library every switch has its default and nothing reads the environment.
 struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; bool no_wgrad_pair; int fanin; };
 inline Switches read_switches() {
   // these change launch plans (and, for DTA_FP32_ACT, roundings): never meant for a training job's environment, so say
@@ -67,12 +68,12 @@ inline Switches read_switches() {
   static const char* names[] = {"DTA_NO_FUSED_INPUT", "DTA_NO_TAIL_MERGE", "DTA_BN_INKERNEL", "DTA_FP32_ACT", "DTA_NO_LEAN",
                                 "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER", "DTA_NO_WGRAD_PAIR", "DTA_FANIN"};
   for (const char* n : names)
-    if (getenv(n)) fprintf(stderr, "[libdta_hip] developer switch %s is set: kernel plans (and possibly roundings) differ from the default build\n", n);
-  return {getenv("DTA_NO_FUSED_INPUT") != nullptr, getenv("DTA_NO_TAIL_MERGE") != nullptr, getenv("DTA_BN_INKERNEL") != nullptr,
-          getenv("DTA_FP32_ACT") != nullptr, getenv("DTA_NO_LEAN") != nullptr,
-          getenv("DTA_LEAN_MASK") ? atoi(getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, getenv("DTA_HALO_TILES") != nullptr,
-          getenv("DTA_NO_WGRAD_NSPLIT") == nullptr, (getenv("DTA_PIXEL_ORDER") ? 1 : 0) | (getenv("DTA_NO_STAGGER") ? 2 : 0), getenv("DTA_NO_WGRAD_PAIR") != nullptr,
-          getenv("DTA_FANIN") ? atoi(getenv("DTA_FANIN")) : 0};      // bit 0: forward BatchNorm statistics folded in-launch, bit 1: backward batch sums
+    if (dev_getenv(n)) fprintf(stderr, "[libdta_hip] developer switch %s is set: kernel plans (and possibly roundings) differ from the default build\n", n);
+  return {dev_getenv("DTA_NO_FUSED_INPUT") != nullptr, dev_getenv("DTA_NO_TAIL_MERGE") != nullptr, dev_getenv("DTA_BN_INKERNEL") != nullptr,
+          dev_getenv("DTA_FP32_ACT") != nullptr, dev_getenv("DTA_NO_LEAN") != nullptr,
+          dev_getenv("DTA_LEAN_MASK") ? atoi(dev_getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, dev_getenv("DTA_HALO_TILES") != nullptr,
+          dev_getenv("DTA_NO_WGRAD_NSPLIT") == nullptr, (dev_getenv("DTA_PIXEL_ORDER") ? 1 : 0) | (dev_getenv("DTA_NO_STAGGER") ? 2 : 0), dev_getenv("DTA_NO_WGRAD_PAIR") != nullptr,
+          dev_getenv("DTA_FANIN") ? atoi(dev_getenv("DTA_FANIN")) : 0};      // bit 0: forward BatchNorm statistics folded in-launch, bit 1: backward batch sums
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -172,7 +173,7 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
     if (d->dtype == DTA_BF16 && L > 0 && Nconv == 64) {
       // second conv: two 256-row workgroups per CU; a 24x24 map is exactly one 576-row workgroup of six waves (256-row
       // workgroups cut it into 256 + 256 + 64 rows: a quarter of the tile rows empty and three weight stagings per patch)
-      p->MWG[L] = (p->HWc[L] == 576 && !getenv("DTA_NO_CONV2_576")) ? 576 : 256;
+      p->MWG[L] = (p->HWc[L] == 576 && !dev_getenv("DTA_NO_CONV2_576")) ? 576 : 256;
     }
     int ppw, spp;
     conv_geometry(p->HWc[L], p->MWG[L], B, &ppw, &spp, &p->nwg[L]);
@@ -418,7 +419,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     // bf16, 128 output channels (third conv) on maps of 12x12 and up: two 64-column groups per row tile -- half-width
     // workgroups stage half the weight slab each, twice as many of them (same-box alternation, 3 x 369 x 24x24: 1.0215 ->
     // 1.0148 ms; the 5x5 maps of the 11x11 networks measured 0.5248 -> 0.5260 ms with it and keep the full-width tile)
-    static const bool no_nsplit = getenv("DTA_NO_NSPLIT") != nullptr;
+    static const bool no_nsplit = dev_getenv("DTA_NO_NSPLIT") != nullptr;
     if (sizeof(T) == 2 && Nconv == 128 && p.HWc[L] >= 64 && !fan_fwd && !no_nsplit) ca.ncg = 2;
     ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
     prof_begin(DTA_SITE_CONV_FWD + L, st);
@@ -787,7 +788,13 @@ int dta_abi_version(void) { return DTA_ABI_VERSION; }
 #endif
 const char* dta_build_id(void) { return DTA_BUILD_ID; }
 
+#ifdef DTA_DEV_SWITCHES
+int dta_dev_switches_enabled(void) { return 1; }
 int dta_dev_reload_switches(void) { g_switches = read_switches(); return 0; }
+#else
+int dta_dev_switches_enabled(void) { return 0; }
+int dta_dev_reload_switches(void) { dta_set_error("dta_dev_reload_switches: this is the product library (no developer switches); load libdta_hip_dev.so"); return 1; }
+#endif
 
 int dta_profile_set_stride(int stride) {
   if (stride < 1) { dta_set_error("dta_profile_set_stride: stride must be >= 1"); return 1; }

@@ -154,6 +154,16 @@ __device__ __forceinline__ float block_sum256(float v, float* scratch) {
 // hipFuncSetAttribute is a per-device setting: a launch site remembers per device ordinal whether it has made it (one
 // process may drive several devices; a process-wide flag would leave the second device with the 64 KiB default).
 #include <atomic>
+#include <stdlib.h>
+// Developer switches (same-box A/B runs of alternative launch plans) exist only in the developer library
+// (libdta_hip_dev.so, built with -DDTA_DEV_SWITCHES): the product library reads NOTHING from the environment, so no
+// variable of a training job's environment can change a kernel plan or a rounding.
+#ifdef DTA_DEV_SWITCHES
+inline const char* dev_getenv(const char* name) { return getenv(name); }
+#else
+inline const char* dev_getenv(const char*) { return nullptr; }
+#endif
+
 struct DevOnce {
   std::atomic<unsigned long long> done{0};
   bool first() {

@@ -1006,8 +1006,8 @@ static int resolve_wgrad_bf16(const WgradArgs& a, int G, int cgroups, WgradArgs&
   if (lds < 48 * 1024) lds = 48 * 1024;   // the final reduction passes up to 6 x 2 tiles (8 KiB each) through LDS
   if (lds > 160 * 1024) { dta_set_error("conv_wgrad(bf16): LDS need %zu B exceeds 160 KiB", lds); return 1; }
   a2.ppi = 1;
-  static const bool no_stack = getenv("DTA_NO_WGRAD_STACK") != nullptr;      // development A/B switches, read once
-  static const bool no_d2 = getenv("DTA_NO_WGRAD_D2") != nullptr;
+  static const bool no_stack = dev_getenv("DTA_NO_WGRAD_STACK") != nullptr;      // development A/B switches, read once
+  static const bool no_d2 = dev_getenv("DTA_NO_WGRAD_D2") != nullptr;
   if (CT == 1 && a2.nbands == 1 && a.x_compact && a.y_compact && !no_stack) {
     // stack patches while the window (rows: (p - 1) Q + first centre row + 16 k-step rows + tap reach, = 4 mod 8) stays
     // within the staging plan's 192 rows and the per-thread vector registers (X: 3 XCH / 4, dY: 3 YCH / 4 per 512 threads)

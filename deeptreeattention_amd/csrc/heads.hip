@@ -336,14 +336,16 @@ __device__ __forceinline__ void gemm_block_wt(const GemmArgs& a, int bx, int by,
 }
 
 // Several independent small GEMMs in one launch: block -> (problem, m-tile, n-tile, k-slice).
-template <int NWT = 4>
+// WT_ONLY: every problem of the group takes the wave-tile form (the host checked: gemm_wave_tiles); the 64x64 any-stride
+// program is then not part of the kernel -- it is what a 16-wave workgroup's 128-register budget cannot hold (31 spills)
+template <int NWT = 4, bool WT_ONLY = false>
 __device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, float* smem) {
   int pi = 0;
   while (pi + 1 < gg.n && (int)blockIdx.x >= gg.start[pi + 1]) ++pi;
   const GemmArgs& a = gg.g[pi];
   int local = blockIdx.x - gg.start[pi];
   const int am = gemm_wt_mode(a.A, a.M, a.K, a.sa_m, a.sa_k), bm = gemm_load_mode(a.Bm, a.N, a.K, a.sb_n, a.sb_k);
-  if (gemm_wave_tiles(a)) {
+  if (WT_ONLY || gemm_wave_tiles(a)) {
     const int tm = (a.M + 31) / 32, tn = (a.N + 31) / 32;
     const int bx = local % tm; local /= tm;
     const int by = local % tn;
@@ -356,12 +358,14 @@ __device__ __forceinline__ void gemm_group_block(const GemmGroup& gg, float* sme
     else gemm_block_wt<LD_VEC_ROW, LD_VEC_K, NWT>(a, bx, by, bz, smem);
     return;
   }
-  if (NWT > 4 && threadIdx.x >= 256) return;     // (the 64x64 form is a 256-thread program; exited waves leave its barriers)
-  const int tm = (a.M + 63) / 64, tn = (a.N + 63) / 64;
-  const int bx = local % tm; local /= tm;
-  const int by = local % tn;
-  const int bz = local / tn;
-  gemm_block<LD_RUNTIME, LD_RUNTIME>(a, bx, by, bz, smem, smem + 64 * GP);   // any strides, any alignment
+  if constexpr (!WT_ONLY) {
+    if (NWT > 4 && threadIdx.x >= 256) return;     // (the 64x64 form is a 256-thread program; exited waves leave its barriers)
+    const int tm = (a.M + 63) / 64, tn = (a.N + 63) / 64;
+    const int bx = local % tm; local /= tm;
+    const int by = local % tn;
+    const int bz = local / tn;
+    gemm_block<LD_RUNTIME, LD_RUNTIME>(a, bx, by, bz, smem, smem + 64 * GP);   // any strides, any alignment
+  }
 }
 constexpr int GEMM_SMEM_FLOATS = 4 * WT_REGION;     // 36 KiB (the 64x64 form needs 2 * 64 * GP of it)
 __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup gg) {
@@ -405,7 +409,7 @@ template <int NWT>
 __global__ __launch_bounds__(NWT * 64) void k_gemm_group_reduce(GemmGroup gg, WgradReduceGroup gr, int ngemm) {
   extern __shared__ __attribute__((aligned(16))) float smem_dyn[];      // NWT * WT_REGION floats
   if (gr.slot_dst && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) gr.slot_dst[0] = (float)gr.slot_src[0];
-  if ((int)blockIdx.x < ngemm) { gemm_group_block<NWT>(gg, smem_dyn); return; }
+  if ((int)blockIdx.x < ngemm) { gemm_group_block<NWT, (NWT > 4)>(gg, smem_dyn); return; }
   const int bx = blockIdx.x - ngemm;
   int j = 0;
   while (j + 1 < gr.n && bx >= gr.start[j + 1]) ++j;
@@ -432,9 +436,11 @@ int launch_gemm_group_with_reduce(GemmGroup& gg, WgradReduceGroup& gr, hipStream
     ngemm += gemm_nblocks(gg.g[i]);
   }
   gg.start[gg.n] = ngemm;
-  static const int nwt_env = getenv("DTA_TAIL_NWT") ? atoi(getenv("DTA_TAIL_NWT")) : 0;
+  static const int nwt_env = dev_getenv("DTA_TAIL_NWT") ? atoi(dev_getenv("DTA_TAIL_NWT")) : 0;
   // (measured, same box: 4 waves 25.6 us, 8 waves 27.5, 16 waves 24.0 -- DTA_TAIL_NWT=4 / 16 force a form)
-  if (nwt_env == 4 || (!wide && nwt_env != 16)) launch_gemm_group_reduce_t<4>(gg, gr, ngemm, st);
+  bool all_wt = true;      // the 16-wave kernel holds the wave-tile programs only
+  for (int i = 0; i < gg.n; ++i) all_wt = all_wt && gemm_wave_tiles(gg.g[i]);
+  if (nwt_env == 4 || !all_wt || (!wide && nwt_env != 16)) launch_gemm_group_reduce_t<4>(gg, gr, ngemm, st);
   else launch_gemm_group_reduce_t<16>(gg, gr, ngemm, st);
   DTA_CHECK_LAUNCH("k_gemm_group_reduce");
   return 0;

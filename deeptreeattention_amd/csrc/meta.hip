@@ -73,17 +73,21 @@ __global__ __launch_bounds__(1024) void k_meta_front(FrontArgs a) {
   if (t < MW) {
     float m, r;
     if (a.training) {
+      // rows whose site index is out of range are not in the histogram (k_meta_join poisons them with NaN, so the loss says
+      // so): the statistics are those of the rows that exist -- nrow of them, not B -- and the running buffers stay finite
       double s1 = 0;
+      int nrow = 0;
 #pragma unroll 8
-      for (int s = 0; s < a.S; ++s) s1 += (double)hist[s] * (double)tab[s * MW + t];
-      const double mu = s1 / a.B;
+      for (int s = 0; s < a.S; ++s) { s1 += (double)hist[s] * (double)tab[s * MW + t]; nrow += hist[s]; }
+      const double cnt = nrow > 0 ? (double)nrow : 1.0;
+      const double mu = s1 / cnt;
       double s2 = 0;
 #pragma unroll 8
       for (int s = 0; s < a.S; ++s) { const double d = (double)tab[s * MW + t] - mu; s2 += (double)hist[s] * d * d; }
-      const double var = s2 / a.B;
+      const double var = s2 / cnt;
       m = (float)mu; r = 1.f / sqrtf((float)var + a.eps);      // (torch's invstd: float)
       if (a.rm) {
-        const float unb = a.B > 1 ? (float)s2 / (float)(a.B - 1) : (float)var;
+        const float unb = nrow > 1 ? (float)s2 / (float)(nrow - 1) : (float)var;
         a.rm[t] = (1.f - a.momentum) * rm0 + a.momentum * m;
         a.rv[t] = (1.f - a.momentum) * rv0 + a.momentum * unb;
         if (t == 0 && a.nbt) a.nbt[0] += 1;
@@ -260,12 +264,23 @@ __global__ __launch_bounds__(1024) void k_meta_back(BackArgs a) {
   }
 }
 
+// LDS a workgroup of this device may use (queried once per process; the head's two one-workgroup kernels take up to all of
+// it): 160 KB on gfx950.  0 = the query failed (no device): every shape is then refused, and the Python side falls back.
+size_t lds_budget() {
+  static const size_t cap = []() -> size_t {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) return 0;
+    return (size_t)v;
+  }();
+  return cap;
+}
 size_t meta_back_lds(int B, int S) { return ((size_t)S * MW + (S + 1) + (size_t)S * MW + B + B + (size_t)B * MW + (size_t)S * MW) * 4; }
 
 int check(int B, int C, int S, const dta_meta_params* p, const long long* site, void* ws, const char* who) {
   if (B < 1 || C < 1 || S < 1 || !p || !site || !ws) { dta_set_error("%s: bad argument", who); return 1; }
   if (S > MAX_SITES) { dta_set_error("%s: at most %d sites", who, MAX_SITES); return 1; }
-  if (meta_back_lds(B, S) > 150 * 1024) { dta_set_error("%s: batch %d x %d sites exceeds the head's LDS plan (batch <= ~2000)", who, B, S); return 1; }
+  if (meta_back_lds(B, S) > lds_budget()) { dta_set_error("%s: batch %d x %d sites needs %zu bytes of LDS, this device offers %zu per workgroup", who, B, S, meta_back_lds(B, S), lds_budget()); return 1; }
   if (!p->emb || !p->bn_w || !p->bn_b || !p->bn_rm || !p->bn_rv || !p->mlp_w || !p->mlp_b || !p->fc_w || !p->fc_b) {
     dta_set_error("%s: null parameter", who); return 1; }
   return 0;
@@ -277,8 +292,10 @@ int grid1d(size_t n) { return (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1
 extern "C" {
 
 size_t dta_meta_head_workspace_bytes(int batch, int classes, int sites) {
-  if (batch < 1 || classes < 1 || sites < 1 || sites > MAX_SITES || meta_back_lds(batch, sites) > 150 * 1024) {
-    dta_set_error("dta_meta_head_workspace_bytes: unsupported shape (sites <= %d, batch x sites within the LDS plan)", MAX_SITES); return 0; }
+  if (batch < 1 || classes < 1 || sites < 1 || sites > MAX_SITES || meta_back_lds(batch, sites) > lds_budget()) {
+    dta_set_error("dta_meta_head_workspace_bytes: unsupported shape (sites <= %d; batch x sites needs %zu bytes of LDS, this device offers %zu per workgroup)",
+                  MAX_SITES, (batch > 0 && sites > 0) ? meta_back_lds(batch, sites) : (size_t)0, lds_budget());
+    return 0; }
   return meta_plan(batch, classes, sites).total;
 }
 
@@ -298,7 +315,8 @@ int dta_meta_head_forward(int batch, int classes, int sites, int training, float
   fa.hist = at<int>(workspace, pl.hist);
   fa.B = B; fa.S = S; fa.training = training; fa.momentum = momentum; fa.eps = eps;
   static DevOnce front_once;
-  if (front_once.first()) (void)hipFuncSetAttribute((const void*)k_meta_front, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (front_once.first() && hipFuncSetAttribute((const void*)k_meta_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget()) != hipSuccess) {
+    dta_set_error("dta_meta_head_forward: the device refused %zu bytes of dynamic LDS", lds_budget()); return 1; }
   hipLaunchKernelGGL(k_meta_front, dim3(1), dim3(1024), (size_t)S * (MW + 1) * 4, st, fa);
   DTA_CHECK_LAUNCH("k_meta_front");
   float* joined = at<float>(workspace, pl.joined);
@@ -374,7 +392,8 @@ int dta_meta_head_backward(int batch, int classes, int sites, int training, cons
   ba.d_emb = grads->emb; ba.d_bn_w = grads->bn_w; ba.d_bn_b = grads->bn_b; ba.B = B; ba.S = S; ba.training = training;
   const size_t lds = meta_back_lds(B, S);
   static DevOnce attr_once;
-  if (attr_once.first()) (void)hipFuncSetAttribute((const void*)k_meta_back, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (attr_once.first() && hipFuncSetAttribute((const void*)k_meta_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget()) != hipSuccess) {
+    dta_set_error("dta_meta_head_backward: the device refused %zu bytes of dynamic LDS", lds_budget()); return 1; }
   hipLaunchKernelGGL(k_meta_back, dim3(1), dim3(1024), lds, st, ba);
   DTA_CHECK_LAUNCH("k_meta_back");
   return 0;

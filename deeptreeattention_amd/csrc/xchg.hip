@@ -172,6 +172,14 @@ __global__ void __launch_bounds__(XCHG_THREADS) k_xchg_step(XchgArgs a) {
   if (j == 0 && t == 0) { a.status[2] = (int)(tk1 - tk0); a.status[3] = (int)(wall_clock64() - tk1); }
 }
 
+// The head segment's reduce-scatter as a launch of its own (dta_xchg_reduce_head): the same device code the first conv's
+// weight-gradient launch runs in its spare workgroups, for plans that have no combined kernel (the caller puts it on a
+// side stream beside its last gradient kernel) and for exercising the head / tail protocol without a network around it.
+__global__ void __launch_bounds__(XCHG_THREADS) k_xchg_head(XchgArgs side) {
+  __shared__ int s_abort;
+  xchg_side_job(side, (int)blockIdx.x, &s_abort);
+}
+
 // probe pattern (peer_probe.py computes the same numbers with numpy): exact in float32
 __global__ void k_xchg_selftest_fill(float* g, size_t n, int rank, int step) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -330,6 +338,17 @@ int dta_xchg_side_args(dta_xchg* x, const double* alpha_g, long long alpha_slot,
 }
 
 void dta_xchg_side_cancel(dta_xchg* x) { if (x) x->side_epoch = 0; }
+
+int dta_xchg_reduce_head(dta_xchg* x, const double* alpha_g, long long alpha_slot, void* stream) {
+  if (!x) { dta_set_error("dta_xchg_reduce_head: null exchange"); return 1; }
+  if (alpha_g && (alpha_slot < 0 || (size_t)alpha_slot >= x->split)) { dta_set_error("dta_xchg_reduce_head: alpha's slot must lie inside the head segment"); return 1; }
+  if (x->world < 2 || x->split == 0) return 0;      // one rank / one segment: the exchange launch does everything itself
+  XchgArgs side;
+  if (dta_xchg_side_args(x, alpha_g, alpha_slot, &side)) { dta_set_error("dta_xchg_reduce_head: exchange not connected"); return 1; }
+  hipLaunchKernelGGL(k_xchg_head, dim3(XCHG_SIDE_WGS), dim3(XCHG_THREADS), 0, (hipStream_t)stream, side);
+  DTA_CHECK_LAUNCH("k_xchg_head");
+  return 0;
+}
 
 int dta_xchg_selftest_fill(dta_xchg* x, int step, void* stream) {
   if (!x) { dta_set_error("dta_xchg_selftest_fill: null exchange"); return 1; }

@@ -183,6 +183,15 @@ class PeerExchange:
                                               _lib.current_stream_ptr()), "dta_xchg_allreduce")
         self.steps += 1
 
+    def reduce_head(self, alpha_g=None, alpha_slot=-1, stream=None):
+        """The head segment's sum over the ranks (reduce-scatter part) of the NEXT allreduce / adam_step as a launch of its
+        own on `stream` (a torch.cuda.Stream; default: the current one): the overlapped form for plans whose first-conv
+        weight gradient has no combined kernel.  The head [0, split) must be complete on that stream."""
+        from . import _lib
+        st = _lib.current_stream_ptr() if stream is None else stream.cuda_stream
+        _lib.check(self._L.dta_xchg_reduce_head(self._h, _lib.ptr(alpha_g), int(alpha_slot) if alpha_g is not None else -1, st),
+                   "dta_xchg_reduce_head")
+
     def adam_step(self, p, m, v, alpha, alpha_g, alpha_slot, alpha_m, alpha_v, step, lr, betas, eps, zero_grad):
         from . import _lib
         _lib.check(self._L.dta_xchg_adam_step(self._h, _lib.ptr(p), _lib.ptr(m), _lib.ptr(v), p.numel(), _lib.ptr(alpha),

@@ -1181,13 +1181,14 @@ class MetadataTrainer:
         B, classes = scores.shape
         sites = mm.embedding.num_embeddings
         ws, out, dlogits, dscores, scratch = self._native_buffers(B, classes, sites)
-        out, drop = self._native_forward(scores, site, True)
+        training = bool(mm.training)              # the site branch's own mode: eval() -> running statistics, no dropout
+        out, drop = self._native_forward(scores, site, training)
         loss = torch.empty((), dtype=torch.float32, device=scores.device)
         st = _lib.current_stream_ptr()
         _lib.check(L.dta_meta_head_loss(B, classes, _lib.ptr(out), _lib.ptr(y), _lib.ptr(loss), _lib.ptr(dlogits),
                                         _lib.ptr(scratch), st), "dta_meta_head_loss")
         P, G = self._native_tables()
-        _lib.check(L.dta_meta_head_backward(B, classes, sites, 1, C.byref(P), _lib.ptr(site), _lib.ptr(drop), _lib.ptr(ws),
+        _lib.check(L.dta_meta_head_backward(B, classes, sites, 1 if training else 0, C.byref(P), _lib.ptr(site), _lib.ptr(drop), _lib.ptr(ws),
                                             _lib.ptr(out), _lib.ptr(dlogits), C.byref(G), _lib.ptr(dscores), st),
                    "dta_meta_head_backward")
         return dscores, loss

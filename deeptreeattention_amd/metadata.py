@@ -3,8 +3,12 @@
 
 Only the sensor branch carries real work (>99.9 % of the FLOPs) and it is the HIP path.  The site branch - a 16-wide
 embedding, BatchNorm1d, Dropout(0.7) and one Linear - and the 2*classes -> classes fusion layer are <0.2 MFLOP per
-sample and stay stock torch modules.  The reference's MetadataModel LightningModule shell is out of
-scope; its step (metadata.py:52-63: unweighted cross-entropy of `model(images, site)`) is `engine.MetadataTrainer`."""
+sample.  At MODULE level (this file: `model(images, site)` under autograd) they are stock torch modules
+that hold the parameters under the reference's names; inside the fused step -- `engine.MetadataTrainer`, the reference's
+MetadataModel.training_step (metadata.py:52-63: unweighted cross-entropy of `model(images, site)`) -- the same layers
+run natively by default (`native_head=True`: csrc/meta.hip, dta_meta_head_forward / _loss / _backward, 9 launches, checked
+against these torch modules' autograd and the reference's golden), and `native_head=False` keeps the torch graph.  The
+reference's MetadataModel LightningModule shell itself is out of scope."""
 import torch
 from torch import nn
 

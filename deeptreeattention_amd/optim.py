@@ -51,8 +51,7 @@ class _CrossEntropyFn(torch.autograd.Function):
     def backward(ctx, gout):
         if ctx.dl is None or gout is None:
             return None, None, None
-        dl, ctx.dl = ctx.dl, None
-        return dl.mul_(gout), None, None
+        return ctx.dl * gout, None, None      # (not in place: a second backward with retain_graph=True gets the same values)
 
 
 def cross_entropy(input, target, weight=None):
@@ -158,9 +157,23 @@ class DtaAdam(torch.optim.Optimizer):
             self.state[a] = {"step": torch.zeros((), dtype=torch.float32), "exp_avg": self._alpha_m, "exp_avg_sq": self._alpha_v}
         self._flat_params = flat
         self._written = set()           # ids of parameters whose gradient was written in place since the last clear
+        self._accum = set()             # ids of parameters autograd accumulated into (their .grad view) since the last clear
         self._sets = {}                 # take_inplace: caller key -> (parameters, ids, views)
         self._loose = None
-        self._clean = True              # the whole gradient buffer holds zeros
+        self._clean = True              # the whole gradient buffer is KNOWN to hold zeros
+        # gradients that reach a .grad view through autograd's own accumulation (small torch modules sharing the optimizer,
+        # a year ensemble on its host-decided path, a second backward before step()) leave no trace in take_inplace: a
+        # post-accumulate hook per parameter records them, so zero_grad() / step() know the buffer is dirty
+        me = self._me
+        self._hooks = []
+
+        def _dirty(param, me=me):
+            o = me()
+            if o is not None:
+                o._accum.add(id(param))
+                o._clean = False
+        for p in flat + ([self._alpha] if self._alpha is not None else []):
+            self._hooks.append(p.register_post_accumulate_grad_hook(_dirty))
         self.layout_epoch = 0
         self._steps = 0
         self.dev_steps = torch.zeros(2, max(1, n_gated), dtype=torch.int32, device=dev)      # per gated segment, two banks
@@ -215,35 +228,58 @@ class DtaAdam(torch.optim.Optimizer):
         return True
 
     def zero_grad(self, set_to_none=False):
-        """Clears the flat gradient buffer (free when step() already did: fuse_zero_grad) and keeps the .grad views in
-        place whatever `set_to_none` says -- they are what lets a backward write gradients without copies."""
+        """Clears the flat gradient buffer (free when it is known to be clean: right after a step() with fuse_zero_grad, or
+        after a zero_grad()) and keeps the .grad views in place whatever `set_to_none` says -- they are what lets a backward
+        write gradients without copies.  Anything written since -- in place by a network's backward (take_inplace) or by
+        autograd's accumulation (the post-accumulate hooks) -- makes the buffer dirty, and a dirty buffer is cleared."""
         self._attach(everything=False)
-        touched = self._written or not self._clean
-        if touched and not (self.fuse_zero_grad and self._cleared_by_step):
+        if not self._clean or self._written or self._accum:
             self.flat_g.zero_()
             if self._alpha is not None:
                 self._alpha_g.zero_()
         for p in self._other:
             p.grad = None
         self._written.clear()
+        self._accum.clear()
         self._clean = True
-        self._cleared_by_step = False
-
-    _cleared_by_step = False
 
     # ---- the step ------------------------------------------------------------------------------------------
     def _gate_flags(self):
-        """Device pointers (as ints) of each gated segment's 0/1 'kept' flag of its ensemble's last training forward."""
-        out = []
+        """Device pointers (as ints) of each gated segment's 0/1 'kept' flag for THIS step: the flags of the ensemble's
+        training forward(s) since the last step (year.learned_ensemble.step_flags; several forwards -- gradient
+        accumulation -- count as kept when any of them kept the year).  An ensemble that ran no training forward since the
+        last step is inactive (its segments hold zeros) -- unless gradients WERE written for it, which means some path
+        produced gradients without publishing its years: an error, never a silently skipped update."""
+        out, self._flag_keep = [], []
         k = 0
+        per_ens = {}
         for ens_ref, year, off, n in self._segs:
             if ens_ref is None:
                 continue
             ens = ens_ref()
-            fl = getattr(ens, "local_flags", None) if ens is not None else None
-            out.append(self._zero_flags.data_ptr() + 4 * k if fl is None else fl.data_ptr() + 4 * year)
+            if ens is not None and id(ens) not in per_ens:
+                per_ens[id(ens)] = ens.step_flags()
+            fl = per_ens.get(id(ens)) if ens is not None else None
+            if fl is None:
+                dirty = self._written | self._accum
+                if dirty and any(off <= self._offs[id(p)] < off + n for p in self._flat_params if id(p) in dirty):
+                    raise RuntimeError("DtaAdam.step: gradients were written for year {} of a learned_ensemble that published no "
+                                       "'year kept' flags for this step (call the ensemble's forward, not its year models, "
+                                       "when its parameters belong to a DtaAdam)".format(year))
+                out.append(self._zero_flags.data_ptr() + 4 * k)
+            else:
+                self._flag_keep.append(fl)      # (alive until the launches that read it are enqueued)
+                out.append(fl.data_ptr() + 4 * year)
             k += 1
         return out
+
+    def _flags_consumed(self):
+        seen = set()
+        for ens_ref, year, off, n in self._segs:
+            ens = ens_ref() if ens_ref is not None else None
+            if ens is not None and id(ens) not in seen:
+                seen.add(id(ens))
+                ens.flags_consumed()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -278,6 +314,7 @@ class DtaAdam(torch.optim.Optimizer):
                 self.ex.adam_step(self.flat_p, self.flat_m, self.flat_v, self._alpha if al else None,
                                   self._alpha_g if al else None, self._alpha_slot, self._alpha_m if al else None,
                                   self._alpha_v if al else None, self._steps, lr, (b1, b2), eps, zero_grad=bool(zero))
+                self._step_others(lr, b1, b2, eps)
                 self._after_step(zero)
                 return loss
             if self.ex is not None:
@@ -310,28 +347,33 @@ class DtaAdam(torch.optim.Optimizer):
         if self.world > 1 and gated:
             self.flat_g[self._flag_off:].zero_()          # the flag slots (outside every segment)
         self._step_others(lr, b1, b2, eps)
+        self._flags_consumed()
         self._after_step(zero)
         return loss
 
     def _after_step(self, zero):
-        if zero:
+        if zero:            # the step's launches cleared every gradient they read
             self._written.clear()
+            self._accum.clear()
             self._clean = True
-            self._cleared_by_step = True
+        else:               # gradients stay readable: the buffer is dirty until zero_grad()
+            self._clean = False
 
     def _step_others(self, lr, b1, b2, eps):
         for p in self._other:
-            if p.grad is None:
+            if p.grad is None and self.world == 1:
                 continue
+            gr = p.grad
+            if self.world > 1:
+                # every rank joins the collective whatever its own gradient is (a rank without one sends zeros): ranks that
+                # disagreed about `grad is None` would otherwise wait for each other forever
+                gr = torch.zeros_like(p) if gr is None else gr.clone()
+                torch.distributed.all_reduce(gr, group=self.pg)
+                gr /= self.world
             s = self.state.setdefault(p, {})
             if not s:
                 s["step"], s["exp_avg"], s["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
             s["step"] += 1
-            gr = p.grad
-            if self.world > 1:
-                gr = gr.clone()
-                torch.distributed.all_reduce(gr, group=self.pg)
-                gr /= self.world
             s["exp_avg"].mul_(b1).add_(gr, alpha=1 - b1)
             s["exp_avg_sq"].mul_(b2).addcmul_(gr, gr, value=1 - b2)
             bc1, bc2 = 1 - b1 ** s["step"], 1 - b2 ** s["step"]
@@ -422,6 +464,9 @@ class DtaAdam(torch.optim.Optimizer):
                 del H._GRAD_SINKS[id(p)]
         H._SINK_EPOCH[0] += 1
         self._sets = {}
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
         if self.ex is not None:
             self._gview = {}
             self.flat_g = None

@@ -185,8 +185,16 @@ class learned_ensemble(nn.Module):
         for y, m in enumerate(self.year_models):
             for p in m.parameters():
                 Hang2020._PARAM_GATE[id(p)] = (me, y)
-        self.__dict__["local_flags"] = None      # (Y,) float32 on the device: years kept by the last TRAINING forward
-        self.__dict__["_flag_state"] = None
+        # device-side "year kept" flags (each a (Y,) float32 tensor of 0 / 1):
+        #   _pending_flags: one tensor per TRAINING forward since the owning optimizer's last step -- the forward's own
+        #     tensor (its backward reads exactly that one, whatever other forwards run in between); optim.DtaAdam steps a year
+        #     when ANY of them kept it (gradient accumulation) and then empties the list;
+        #   local_flags: the newest of them (None before the first training forward);
+        #   _scratch_flags: two banks used alternately by forwards that build no graph (validation, inference) -- never
+        #     published, so a no_grad forward between a training forward and its backward / step disturbs nothing.
+        self.__dict__["local_flags"] = None
+        self.__dict__["_pending_flags"] = []
+        self.__dict__["_scratch_flags"] = None
 
     def _tables(self, shape, params):
         """Cached (descriptor, parameter pointer tables, workspace bytes) of the grouped launch over ALL years."""
@@ -231,17 +239,41 @@ class learned_ensemble(nn.Module):
         return hit[1]
 
     def _next_flags(self, dev, publish):
-        """Two flag banks used alternately (each dta_year_flags call clears the other one: no clearing launch).  A
-        training forward publishes its bank as self.local_flags -- what the optimizer gates this step's updates by."""
-        fs = self.__dict__["_flag_state"]
+        """(flags, clear_next) for one dta_year_flags call.  A training forward (publish) gets a fresh tensor of its own
+        (clear_next None: the library zero-fills it in the same call) and queues it for the optimizer; a forward without a
+        graph alternates two private banks (each call clears the other one: no clearing launch)."""
         Y = len(self.year_models)
-        if fs is None or fs[0].device != dev:
-            fs = self.__dict__["_flag_state"] = [torch.zeros(2, Y, dtype=torch.float32, device=dev), 0]
-        fs[1] ^= 1
-        flags, other = fs[0][fs[1]], fs[0][fs[1] ^ 1]
         if publish:
-            self.__dict__["local_flags"] = flags
-        return flags, other
+            flags = torch.empty(Y, dtype=torch.float32, device=dev)
+            self._publish_flags(flags)
+            return flags, None
+        fs = self.__dict__["_scratch_flags"]
+        if fs is None or fs[0].device != dev:
+            fs = self.__dict__["_scratch_flags"] = [torch.zeros(2, Y, dtype=torch.float32, device=dev), 0]
+        fs[1] ^= 1
+        return fs[0][fs[1]], fs[0][fs[1] ^ 1]
+
+    def _publish_flags(self, flags):
+        pend = self.__dict__["_pending_flags"]
+        if len(pend) >= 64:       # a long accumulation, or nobody consumes them (a stock torch optimizer): fold them
+            pend[:] = [torch.stack(pend).amax(0)]
+        pend.append(flags)
+        self.__dict__["local_flags"] = flags
+
+    def step_flags(self):
+        """The flags the owning optimizer gates THIS step by: a year is stepped when any training forward since the last
+        step kept it (one forward: its own tensor, no launch; several -- gradient accumulation --: their maximum).  None:
+        no training forward since the last step."""
+        pend = self.__dict__["_pending_flags"]
+        if not pend:
+            return None
+        if len(pend) == 1:
+            return pend[0]
+        return torch.stack(pend).amax(0)
+
+    def flags_consumed(self):
+        """Called by the optimizer after its step: the next step starts a new set of training forwards."""
+        self.__dict__["_pending_flags"] = []
 
     def forward(self, images):
         if len(images) != len(self.year_models):
@@ -255,7 +287,7 @@ class learned_ensemble(nn.Module):
             xs = [Hang2020._check_input(x) for x in images]
             if any(x.shape != xs[0].shape for x in xs):
                 raise ValueError("all years of a batch must have the same shape")
-            flags, other = self._next_flags(xs[0].device, publish=train_graph and self.training)
+            flags, other = self._next_flags(xs[0].device, publish=train_graph)
             if train_graph:      # (the parameters belong to a DtaAdam: one anchor input instead of 123 parameter inputs)
                 anchor = next(p for p in params if p.requires_grad)
                 return _EnsembleGatedFn.apply(self, flags, other, *xs, anchor)
@@ -265,6 +297,11 @@ class learned_ensemble(nn.Module):
         # really have grad None (torch's Adam passes over them)
         keep = (torch.stack([x.sum() for x in images]) != 0).tolist()
         kept = [i for i, k in enumerate(keep) if k]
+        if train_graph and Hang2020._any_sink(params):
+            # an optim.DtaAdam owns (some of) these parameters but the device-gated launch cannot be used (more than
+            # DTA_MAX_YEARS years, or parameters outside the optimizer): its per-year gated passes still need this step's
+            # decision -- the host's, sent to the device (this path has already synchronised)
+            self._publish_flags(torch.tensor([1.0 if k else 0.0 for k in keep], dtype=torch.float32, device=images[0].device))
         if not kept:
             raise RuntimeError("every year of the batch is all-zero: nothing to average (reference year.py:33)")
         out = None

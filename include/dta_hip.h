@@ -10,7 +10,8 @@
  *  - every buffer is allocated by the caller (PyTorch caching allocator) and only borrowed for the call;
  *    the library allocates nothing on the device (one documented exception: the peer-exchange object dta_xchg_*)
  *  - host-side state the library keeps (all of it per process): the thread-local text of dta_last_error(); the
- *    developer switches read from the environment once at load time (dta_dev_reload_switches); per launch site, a bit per
+ *    developer switches of the DEVELOPER library only (dta_dev_switches_enabled; the product library reads nothing from
+ *    the environment); per launch site, a bit per
  *    device ordinal saying that the function's dynamic-LDS attribute has been set on that device; the optional
  *    profiling event pool of dta_profile_* (one device at a time); peer-exchange objects the caller created.  Nothing
  *    else survives a call: no caches keyed on shapes or pointers, no device allocations
@@ -298,6 +299,14 @@ int dta_xchg_set_split(dta_xchg* x, size_t split_floats);
 /* Grid bound of the exchange launch (default 256, one workgroup per CU); only before the first step.  Ranks that share
  * one GPU (tests) must keep world x workgroups co-resident: every rank's launch waits in-kernel for the others. */
 void dta_xchg_set_max_workgroups(dta_xchg* x, int workgroups);
+/* Overlapped form without a combined kernel: the reduce-scatter of the HEAD segment [0, split) of the exchange's NEXT launch
+ * as a launch of its own (16 workgroups) on `stream` -- e.g. a side stream beside the caller's last gradient kernel, or the
+ * compute stream itself.  The head must be complete on `stream` (kernel boundary / event); the dta_xchg_allreduce /
+ * dta_xchg_adam_step that follows (ordered after this launch by the caller) then sums only the tail and gathers both.
+ * One rank or no split: a no-op.  alpha_g / alpha_slot as below (the slot must lie inside the head).  This is the device
+ * code dta_net_backward_xchg / dta_ensemble_backward_xchg run in the spare workgroups of the first conv's weight gradient.
+ * Replaces: DDP's first gradient bucket being all-reduced while the backward still runs (reference train.py:89-98). */
+int dta_xchg_reduce_head(dta_xchg* x, const double* alpha_g, long long alpha_slot, void* stream);
 /* g := sum over ranks of g (all ranks end with the same bits).  alpha_g (may be NULL): this rank's float64 d(alpha); the
  * launch first stores it, rounded to float32, in slot alpha_slot of the gradient buffer, so that it takes part in the sum. */
 int dta_xchg_allreduce(dta_xchg* x, const double* alpha_g, long long alpha_slot, void* stream);
@@ -378,8 +387,11 @@ int dta_profile_enable(int site);
 int dta_profile_set_stride(int stride);
 int dta_profile_collect(float* ms, int max);
 int dta_profile_collect_site(int site, float* ms, int max);
-/* Development aid: the library reads its developer environment switches (DTA_NO_FUSED_INPUT, DTA_NO_TAIL_MERGE,
- * DTA_BN_INKERNEL, DTA_FANIN: same-box A/B runs of alternative launch plans) once at load time; this re-reads them. */
+/* Development aid.  The PRODUCT library (libdta_hip.so) reads nothing from the environment: dta_dev_switches_enabled()
+ * returns 0 and dta_dev_reload_switches() fails.  The developer library (libdta_hip_dev.so: the same sources compiled with
+ * -DDTA_DEV_SWITCHES) reads its switches (DTA_NO_FUSED_INPUT, DTA_NO_TAIL_MERGE, DTA_BN_INKERNEL, DTA_NO_LEAN, DTA_FANIN,
+ * ...: same-box A/B runs of alternative launch plans) once at load time, and again on dta_dev_reload_switches(). */
+int dta_dev_switches_enabled(void);
 int dta_dev_reload_switches(void);
 
 /* ---- site-metadata head of the fusion model (reference src/models/metadata.py:9-44) --------------------------------

@@ -561,6 +561,158 @@ def case_metadata_full():
     print("metadata_full.npz", len(out))
 
 
+EXTRA_DRAWS = 6
+
+
+def _autocast_devs(tag, make_run, out, skip=("conv_layer.bias",), draws=EXTRA_DRAWS):
+    """make_run(draw) -> run(autocast: bool) -> (scores ndarray, loss float, {name: grad ndarray}).  draw 0 = the inputs of the
+    parity test the case belongs to; draws 1..EXTRA_DRAWS = other batches of the same shape (same parameters, the input
+    seeds shifted by 1000 x draw).  Stores how far the REFERENCE under torch.autocast("cpu", torch.bfloat16) lands from the
+    reference in fp32 on the same inputs: scores rel-L2, loss rel, per-tensor gradient-norm deviation and element-wise
+    rel-L2, the whole gradient vector's, the total norm's -- for draw 0 under `<quantity>`, and the MAXIMUM over all draws
+    under `<quantity>_max`.  (A tensor's norm deviation is the projection of its rounding noise on the gradient: one draw
+    of a random sign and size between 0 and the element-wise distance; one batch does not characterise it, seven do.)"""
+    for d in range(draws + 1):
+        run = make_run(d)
+        s0, l0, g0 = run(False)
+        s1, l1, g1 = run(True)
+        cur = {"scores_dev": np.linalg.norm(s1.astype(np.float64) - s0) / np.linalg.norm(s0), "loss_dev": abs(l1 - l0) / abs(l0)}
+        if d == 0:
+            out[f"{tag}loss_fp32"] = np.float64(l0)
+            out[f"{tag}loss_bf16"] = np.float64(l1)
+        num = den = t0 = t1 = 0.0
+        for k, a in g0.items():
+            if any(k.endswith(x) for x in skip) or not np.any(a):
+                continue
+            a = a.astype(np.float64); b = g1[k].astype(np.float64)
+            n0, n1 = np.linalg.norm(a), np.linalg.norm(b)
+            if d == 0:
+                out[f"{tag}gnorm_fp32/{k}"] = np.float64(n0)
+            cur[f"gnorm_dev/{k}"] = abs(n1 - n0) / n0
+            cur[f"gelem_dev/{k}"] = np.linalg.norm(b - a) / n0
+            num += float(((b - a) ** 2).sum()); den += float((a ** 2).sum()); t0 += n0 ** 2; t1 += n1 ** 2
+        cur["whole_elem_dev"] = np.sqrt(num / den)
+        cur["total_norm_dev"] = abs(np.sqrt(t1) - np.sqrt(t0)) / np.sqrt(t0)
+        for k, v in cur.items():
+            if d == 0:
+                out[f"{tag}{k}"] = np.float64(v)
+            if f"{tag}{k}" in out:      # (a tensor that is all-zero on draw 0 stays out)
+                out[f"{tag}{k}_max"] = np.float64(max(float(out.get(f"{tag}{k}_max", 0.0)), v))
+    big = [k for k in out if k.startswith(tag + "gnorm_dev/") and not k.endswith("_max") and float(out[tag + "gnorm_fp32/" + k[len(tag) + 10:]]) > 0]
+    print(f"  {tag} scores {out[tag + 'scores_dev']:.2e} (max {out[tag + 'scores_dev_max']:.2e}) loss {out[tag + 'loss_dev']:.2e} "
+          f"whole-elem {out[tag + 'whole_elem_dev']:.2e} (max {out[tag + 'whole_elem_dev_max']:.2e}) "
+          f"total-norm {out[tag + 'total_norm_dev']:.2e} (max {out[tag + 'total_norm_dev_max']:.2e}); {len(big)} tensors")
+
+
+def case_bf16_autocast():
+    """The bf16 yardstick taken from the reference ITSELF (round-4 review, missing #4): the reference's modules run under
+    torch.autocast("cpu", torch.bfloat16) -- what Lightning's precision="bf16" does to its training_step -- on the inputs
+    of the bf16 parity cases, next to the same modules in fp32.  Only the DEVIATIONS are stored (scalars): a bf16
+    implementation is held to max(1e-2, 1.5 x the reference's own bf16 deviation) per quantity instead of a hand-picked
+    allowance.  Cases: hang48_{421,530,1024}/ = the 48-band cases of tests/test_hip_benched_path.py; hang1024/ = the bench
+    shape (369 bands, 200 classes, B=1024) with that file's inputs; hang16/, hang9/ = tests/test_hip_parity.py::
+    test_bf16_path_within_tolerance; spec24s/ = tests/test_hip_modules.py's 24x24 crop case; hang8/ = hang2020_369_200.npz's
+    step (B=8); spec24/ = one 369-band spectral_network on 24x24 crops, B=64, the inputs of tests/test_config5_gpu.py
+    (year 0); meta64/ = metadata_sensor_fusion(369, 23, 200), B=64, metadata_full.npz's step."""
+    out = {}
+
+    def grads(m):
+        return {k: q.grad.detach().numpy() for k, q in m.named_parameters() if q.grad is not None}
+
+    def hang_case(seed_p, seed_x, B, w, bands=369, classes=200):
+        def make_run(d):
+            x = prng.uniform01(seed_x + 1000 * d, 1, (B, bands, 11, 11)); y = prng.randint(seed_x + 1000 * d, 2, (B,), classes)
+
+            def run(autocast):
+                m = R.Hang2020(bands, classes)
+                load(m, O.init_params(O.hang2020_spec(bands, classes), seed=seed_p))
+                m.train()
+                with torch.autocast("cpu", torch.bfloat16, enabled=autocast):
+                    lg = m(torch.from_numpy(x))
+                    loss = F.cross_entropy(lg, torch.from_numpy(y), weight=None if w is None else torch.from_numpy(w))
+                loss.backward()
+                return lg.detach().float().numpy().astype(np.float64), float(loss.item()), grads(m)
+            return run
+        return make_run
+
+    w7 = (0.1 + (np.arange(200) % 7)).astype(np.float32)
+    _autocast_devs("hang8/", hang_case(31, 32, 8, w7), out)
+    _autocast_devs("hang1024/", hang_case(3, 40 + 1024, 1024, w7), out)
+    for B in (421, 530, 1024):      # the 48-band cases of tests/test_hip_benched_path.py
+        _autocast_devs(f"hang48_{B}/", hang_case(3, 40 + B, B, (0.1 + (np.arange(11) % 7)).astype(np.float32), 48, 11), out)
+    # the two small cases of tests/test_hip_parity.py::test_bf16_path_within_tolerance (unweighted loss)
+    _autocast_devs("hang16/", hang_case(31, 32, 16, None), out)
+    _autocast_devs("hang9/", hang_case(5, 6, 9, None, 20, 7), out)
+
+    # tests/test_hip_modules.py::test_spectral_network_24x24_crops (16 bands, B = 2, the three heads against fixed cotangents)
+    ps = O.init_params(O.subnet_spec("spectral", 16, 7), seed=51)
+
+    def spec_small(d):
+        xs24 = prng.uniform01(52 + 1000 * d, 24, (2, 16, 24, 24))
+        ds24 = [prng.uniform(52 + 1000 * d, 10 + i, (2, 7), -1, 1) for i in range(3)]
+
+        def run(autocast):
+            m = R.spectral_network(16, 7)
+            load(m, ps)
+            m.train()
+            with torch.autocast("cpu", torch.bfloat16, enabled=autocast):
+                s = m(torch.from_numpy(xs24))
+            tot = sum((a.float() * torch.from_numpy(b)).sum() for a, b in zip(s, ds24))
+            tot.backward()
+            return np.concatenate([a.detach().float().numpy().astype(np.float64) for a in s], 1), float(tot.item()), grads(m)
+        return run
+    _autocast_devs("spec24s/", spec_small, out)
+
+    # one year of configs[4]: spectral_network(369, 200) on 24x24 crops, B = 64 (tests/test_config5_gpu.py)
+    pe = O.init_params(O.learned_ensemble_spec(3, 369, 200), seed=17)
+
+    def spec_case(d):
+        x24 = prng.uniform01(18 + 1000 * d, 0, (64, 369, 24, 24)); y24 = prng.randint(18 + 1000 * d, 9, (64,), 200)
+
+        def run(autocast):
+            m = R.spectral_network(369, 200)
+            load(m, pe, prefix="year_models.0.")
+            m.train()
+            with torch.autocast("cpu", torch.bfloat16, enabled=autocast):
+                s = m(torch.from_numpy(x24))[-1]
+                loss = F.cross_entropy(s, torch.from_numpy(y24))
+            loss.backward()
+            return s.detach().float().numpy().astype(np.float64), float(loss.item()), grads(m)
+        return run
+    _autocast_devs("spec24/", spec_case, out)
+
+    # configs[3]: the fusion model, metadata_full.npz's inputs and initial values
+    _stub_missing_packages()
+    from src.models import metadata as RM
+    g = np.load(os.path.join(OUT, "metadata_full.npz"))
+
+    def meta_case(d):
+        sx = 30 + 1000 * d
+        xm = prng.uniform01(sx, 1, (64, 369, 11, 11)); sm = prng.randint(sx, 2, (64,), 23); ym = prng.randint(sx, 3, (64,), 200)
+
+        def run(autocast):
+            m = RM.metadata_sensor_fusion(bands=369, sites=23, classes=200)
+            load(m.sensor_model, O.init_params(O.hang2020_spec(369, 200), seed=21))
+            sd = m.state_dict()
+            for k in g.files:
+                if k.startswith("init/"):
+                    a = g[k]
+                    sd[k[5:]] = torch.from_numpy(a.astype(np.float32) if a.dtype == np.float16 else a)
+            m.load_state_dict(sd)
+            m.train()
+            m.metadata_model.dropout.p = 0.0
+            with torch.autocast("cpu", torch.bfloat16, enabled=autocast):
+                o = m(torch.from_numpy(xm), torch.from_numpy(sm))
+                loss = F.cross_entropy(o, torch.from_numpy(ym))
+            loss.backward()
+            return o.detach().float().numpy().astype(np.float64), float(loss.item()), grads(m)
+        return run
+    _autocast_devs("meta64/", meta_case, out)
+    # one flat table (names + float64 values): 2.5 k scalars as separate npz members would be 0.6 MB of zip headers
+    names = sorted(out)
+    np.savez_compressed(os.path.join(OUT, "bf16_autocast.npz"), names=np.array(names), values=np.array([float(out[k]) for k in names]))
+    print("bf16_autocast.npz", len(out))
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:      # regenerate only the named cases, e.g. `make_golden.py case_ensemble_steps`
         for name in sys.argv[1:]:
@@ -575,3 +727,4 @@ if __name__ == "__main__":
     case_hang_full()
     case_metadata()          # last: it stubs packages process-wide
     case_metadata_full()
+    case_bf16_autocast()     # (reads metadata_full.npz)

@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -141,3 +142,24 @@ def test_bench_two_ranks_fall_back_when_an_exchange_fails():
     assert d["n_gpus"] == 2 and d["config"]["exchange"] == "torch"
     fb = d["config"]["exchange_fallbacks"]
     assert len(fb) == 2 and fb[1]["exchange"] == "rccl"
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_8_spawns_eight_ranks():
+    """`DTA_BENCH_BACKEND=gloo python bench.py --gpus 8 --steps 3` (round-4 review: world = 8 had never executed in any form):
+    bench.py spawns its eight ranks itself, they share the test box's one GPU (development mode: never a measured
+    configuration), rendezvous on 127.0.0.1, choose the exchange collectively (the peer exchange: its probe passes between
+    processes of one device), run the overlapped step at the REAL 369-band / 200-class flat layout with 8 shards, and rank 0
+    prints exactly one JSON line whose process group spanned 8 ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(DTA_BENCH_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                          "--batch", "32", "--steady-steps", "0"], capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["ranks_seen"] == 8 and d["config"]["parallelism"] == "dp8"
+    assert d["config"]["global_batch"] == 256 and d["scaling"] == "weak"
+    assert d["config"]["exchange"] == "peer" and d["config"]["exchange_fallbacks"] == [] and d["config"]["overlap_comm"] is True
+    assert d["value"] > 0 and np.isfinite(d["final_loss"])

@@ -43,8 +43,13 @@ def _batch():
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 1e-2)])
-def test_metadata_fusion_full_size_vs_reference_golden(golden, precision, tol):
+def test_metadata_fusion_full_size_vs_reference_golden(golden, bf16_yardstick, precision, tol):
+    """fp32: 1e-3 against the reference's golden.  bf16: against the same EXACT golden, every quantity within
+    max(1e-2, 1.5 x the deviation of the reference's own bf16-autocast run of this very step) -- tests/golden/
+    bf16_autocast.npz, case meta64/ (conftest.Bf16Yardstick): no hand-picked allowance."""
     g = golden("metadata_full.npz")
+    yard = bf16_yardstick
+    bf16 = precision == "bf16"
     m = _model(g, precision)
     x, site, y = _batch()
     m.eval()
@@ -56,8 +61,8 @@ def test_metadata_fusion_full_size_vs_reference_golden(golden, precision, tol):
     out = m(x, site)
     loss = torch.nn.functional.cross_entropy(out, y)
     loss.backward()
-    assert rel_l2(out.detach().cpu().numpy(), g["train/out"]) < tol
-    assert abs(float(loss.detach()) - float(g["train/loss"])) < tol * abs(float(g["train/loss"]))
+    assert rel_l2(out.detach().cpu().numpy(), g["train/out"]) < (yard.bound("meta64/scores_dev") if bf16 else tol)
+    assert abs(float(loss.detach()) - float(g["train/loss"])) < (yard.bound("meta64/loss_dev") if bf16 else tol) * abs(float(g["train/loss"]))
     none = set(g["train/none"].tolist())
     tot = ref_tot = 0.0
     for k, prm in m.named_parameters():
@@ -70,25 +75,26 @@ def test_metadata_fusion_full_size_vs_reference_golden(golden, precision, tol):
         got = float(prm.grad.double().norm())
         tot += got ** 2
         ref_tot += ref ** 2
-        if precision == "bf16" and prm.numel() >= 1000:
-            print(f"bf16 vs reference: {k:70s} {prm.numel():7d} norm rel err {abs(got - ref) / ref:.2e}")
-        # bf16 against the EXACT reference at batch 64: the conv and classifier weights (96 % of the parameters) and the
-        # total keep the 1e-2 budget; the spectral-attention matrices are mat-vecs on 32..128 pooled values whose
-        # gradients cancel heavily, and operand rounding upstream moves their norms by 1-3 % in ANY implementation --
-        # the oracle with the same roundings is as far (the next test pins the kernels to it at 1e-2): 5e-2 here
-        if precision == "fp32" or k.endswith("conv_layer.weight") or k.endswith("fc1.weight") or k.endswith("mlp.weight"):
+        if bf16 and prm.numel() >= 1000:
+            print(f"bf16 vs reference: {k:70s} {prm.numel():7d} norm rel err {abs(got - ref) / ref:.2e} "
+                  f"(the reference's own bf16 run: {yard.ref('meta64/gnorm_dev/' + k):.2e})")
+        if not bf16:
             assert abs(got - ref) <= tol * max(ref, 1e-9), (k, got, ref)
         elif prm.numel() >= 1000:
-            assert abs(got - ref) <= 5e-2 * ref, (k, got, ref)
+            # the spectral-attention matrices are mat-vecs on 32..128 pooled values whose gradients cancel heavily: the
+            # reference's own bf16 run moves their norms by 0.7-2.7 % at this batch, the conv / classifier weights by <= 0.6 %
+            assert abs(got - ref) <= yard.bound("meta64/gnorm_dev/" + k) * ref, (k, got, ref)
         if f"train/g/{k}" in g.files and precision == "fp32":
             assert rel_l2(prm.grad.cpu().numpy(), g[f"train/g/{k}"]) < tol, k
-    assert abs(np.sqrt(tot) - np.sqrt(ref_tot)) <= tol * np.sqrt(ref_tot)
+    assert abs(np.sqrt(tot) - np.sqrt(ref_tot)) <= (yard.bound("meta64/total_norm_dev") if bf16 else tol) * np.sqrt(ref_tot)
 
 
-def test_metadata_hsi_branch_bf16_vs_bf16_mode_oracle(golden):
-    """The HSI branch at 369 / 200 / B=64 in bf16 against the oracle with the same roundings, driven by the reference's
-    own d(loss)/d(HSI scores): logits 1e-3; every >= 1000-element gradient tensor's norm 1e-2; whole gradient vector
-    1.5e-2 (two float accumulations of the SAME rounded step are 8e-3 apart at this width, tools/bf16diag2.py)."""
+def test_metadata_hsi_branch_bf16_vs_bf16_mode_oracle(golden, bf16_yardstick):
+    """The HSI branch at 369 / 200 / B=64 in bf16, driven by the reference's own d(loss)/d(HSI scores).  (1) Against the
+    EXACT oracle: every >= 1000-element gradient tensor (norm and element-wise), the whole vector and the total norm within
+    max(1e-2, 1.5 x the reference's own bf16-autocast deviation on this step) (bf16_autocast.npz, meta64/).  (2) Against
+    the oracle with the kernels' roundings (an implementation-exactness extra): logits 1e-3, norms 1e-2, whole vector
+    1.5e-2 -- which is 0.12 x what the reference's own bf16 run moves that vector (1.26e-1)."""
     from deeptreeattention_amd import Hang2020 as H
     g = golden("metadata_full.npz")
     p = O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=21)
@@ -98,6 +104,12 @@ def test_metadata_hsi_branch_bf16_vs_bf16_mode_oracle(golden):
     x = prng.uniform01(30, 1, (B, BANDS, 11, 11))
     scores = m(torch.from_numpy(x).to(dev()))
     scores.backward(torch.from_numpy(g["train/dhsi"]).to(dev()))
+    got_all = {k: prm.grad.detach().double().cpu().numpy() for k, prm in m.named_parameters() if prm.grad is not None}
+    e_logits, e_cache, _ = O.hang2020_fwd(p, x, True, np.float64)
+    exact = O.hang2020_bwd(p, e_cache, g["train/dhsi"].astype(np.float64), np.float64)
+    assert rel_l2(scores.detach().cpu().numpy(), e_logits) < bf16_yardstick.bound("meta64/scores_dev")
+    bf16_yardstick.check_gradients("meta64/", got_all, {k: v for k, v in exact.items() if k in got_all}, prefix="sensor_model.")
+    del e_cache, exact
     O.bf16_mode(True)
     try:
         logits, cache, _ = O.hang2020_fwd(p, x, True, np.float64)
@@ -116,8 +128,10 @@ def test_metadata_hsi_branch_bf16_vs_bf16_mode_oracle(golden):
         if v.size >= 1000:
             assert abs(np.linalg.norm(got) - np.linalg.norm(v)) <= 1e-2 * np.linalg.norm(v), k
     whole = np.sqrt(num / den)
-    print(f"config 4 HSI branch bf16 vs bf16-mode oracle: whole-gradient rel-L2 {whole:.2e}")
-    assert whole < 1.5e-2
+    ref_whole = bf16_yardstick.ref("meta64/whole_elem_dev")
+    print(f"config 4 HSI branch bf16 vs bf16-mode oracle: whole-gradient rel-L2 {whole:.2e} = {whole / ref_whole:.2f} x the "
+          f"reference's own bf16 deviation ({ref_whole:.2e})")
+    assert whole < min(1.5e-2, 0.25 * ref_whole)
 
 
 def test_metadata_trainer_bf16_full_size_vs_module_level_step(golden):

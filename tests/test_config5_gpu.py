@@ -33,7 +33,7 @@ def ensemble():
     return m.to(dev()).train(), p, imgs, y
 
 
-def test_one_year_of_the_grouped_launch_vs_oracle(ensemble):
+def test_one_year_of_the_grouped_launch_vs_oracle(ensemble, bf16_yardstick):
     m, p, imgs, y = ensemble
     w = np.ones(CLASSES, np.float32)
     xs = [torch.from_numpy(imgs[0]).to(dev())] + [torch.zeros(B, BANDS, HW, HW, device=dev()) for _ in range(YEARS - 1)]
@@ -69,10 +69,21 @@ def test_one_year_of_the_grouped_launch_vs_oracle(ensemble):
             assert abs(np.linalg.norm(a) - np.linalg.norm(b)) <= 1e-2 * np.linalg.norm(b), k
     whole = np.sqrt(num / den)
     print(f"config 5 (24x24, 369 bands, B={B}): year 0 whole-gradient rel-L2 vs bf16-mode oracle {whole:.2e}, worst {worst}")
-    # element-wise: fixed 2e-2 (observed 1.46e-2): the resolution of two float accumulations of the same rounded step at
-    # 369 bands is 8e-3 on 11x11 maps (tests/test_hip_benched_path.py explains the figure) and grows with the 576-pixel
-    # maps' longer BatchNorm sums; the 1e-2 budget is asserted on every tensor's norm above
-    assert whole < 2e-2
+    # element-wise against the oracle with the kernels' own roundings (implementation exactness; observed 1.46e-2: the
+    # resolution of two float accumulations of the same rounded step, tests/test_hip_benched_path.py) -- 0.11 x what the
+    # reference's own bf16-autocast run moves this vector (1.28e-1, bf16_autocast.npz spec24/)
+    ref_whole = bf16_yardstick.ref("spec24/whole_elem_dev")
+    print(f"  = {whole / ref_whole:.2f} x the reference's own bf16 deviation ({ref_whole:.2e})")
+    assert whole < min(2e-2, 0.25 * ref_whole)
+    # the parity criterion proper: against the EXACT oracle, within max(1e-2, 1.5 x the reference's own bf16 deviation)
+    e_heads, e_cache, _ = O.subnet_fwd(p, pre, "spectral", imgs[0], True, np.float64)
+    e_loss, e_dl = O.weighted_cross_entropy(e_heads[2], y, w)
+    e_g = O.subnet_bwd(p, pre, e_cache, [None, None, e_dl.astype(np.float64)], np.float64)
+    del e_cache
+    assert rel_l2(scores.detach().cpu().numpy(), e_heads[2]) <= bf16_yardstick.bound("spec24/scores_dev")
+    assert abs(loss.item() - e_loss) / e_loss <= bf16_yardstick.bound("spec24/loss_dev")
+    got = {k[len(pre):]: q.grad.double().cpu().numpy() for k, q in m.named_parameters() if k.startswith(pre) and q.grad is not None}
+    bf16_yardstick.check_gradients("spec24/", got, {k[len(pre):]: v for k, v in e_g.items() if k[len(pre):] in got})
     sd = m.state_dict()
     for k, v in upd.items():
         assert rel_l2(sd[k].cpu().numpy(), v) < 2e-3, k
@@ -175,7 +186,7 @@ def test_ensemble_trainer_full_size_two_steps_vs_bf16_oracle():
                 # after step 1 Adam has moved every weight by ~lr with the SIGN of its gradient: elements whose tiny gradients
                 # differ in the last bits move the other way, so step 2's batch statistics see slightly different weights
                 # (observed 7e-3 on a running mean; the one-step buffer check at 2e-3 is the test above)
-                assert rel_l2(a, b) < 1.5e-2, k
+                assert rel_l2(a, b) < 1e-2, k
                 continue
             num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum())
         print(f"config 5 trainer, year {yy}: parameters after 2 bf16 steps vs per-year oracle Adam: rel-L2 {np.sqrt(num / den):.2e}")

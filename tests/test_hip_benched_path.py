@@ -64,7 +64,7 @@ def _oracle(p, x, y, w, quantized):
 
 
 @pytest.mark.parametrize("bands,classes,B", [(48, 11, 421), (48, 11, 530), (48, 11, 1024), (369, 200, 1024)])
-def test_fused_input_bf16_step_vs_oracle(bands, classes, B):
+def test_fused_input_bf16_step_vs_oracle(bands, classes, B, bf16_yardstick):
     """421: fused fp32-input conv1 + one-patch stage kernels (ragged: 421 = 105 x 4 + 1); 530: fused conv1 + two-patch
     stage kernels with a ragged tail; 1024: the bench batch; (369, 200, 1024): exactly the shape bench.py times (the
     NumPy oracle needs well under a minute for it)."""
@@ -91,7 +91,10 @@ def test_fused_input_bf16_step_vs_oracle(bands, classes, B):
     # oracle against itself -- are 8.0e-3 apart at 369 bands (1.3e-3 at 48), because ~2 % of the half-precision conv
     # outputs round the other way and BatchNorm's backward cancels all but ~1 % of the weight-gradient sums
     # (tools/bf16diag2.py prints the three pairwise distances); 48 bands keep the 1e-2 of the budget.
-    assert whole < (1.5e-2 if bands > 100 else 1e-2)
+    tag = "hang1024/" if bands == 369 else f"hang48_{B}/"      # the reference's own bf16-autocast run of this very step
+    ref_whole = bf16_yardstick.ref(tag + "whole_elem_dev")
+    print(f"B={B}: that is {whole / ref_whole:.2f} x the reference's own bf16 deviation from fp32 ({ref_whole:.2e})")
+    assert whole < (min(1.5e-2, 0.25 * ref_whole) if bands > 100 else 1e-2)
     tot_q = tot_g = 0.0
     for k, v in q_g.items():        # per-tensor gradient norms (tensors that are more than a handful of scalars)
         if k.endswith("conv_layer.bias") or not np.any(v):
@@ -113,7 +116,7 @@ def test_fused_input_bf16_step_vs_oracle(bands, classes, B):
     whole32, _ = _whole(got, g32)
     self32, _ = _whole(g32, q_g)
     print(f"B={B}: bf16 HIP vs float32-accumulating oracle {whole32:.2e}; that oracle vs its float64 run {self32:.2e}")
-    assert whole32 < (1.5e-2 if bands > 100 else 1e-2)
+    assert whole32 < (min(1.5e-2, 0.25 * ref_whole) if bands > 100 else 1e-2)
     for k, v in g32.items():
         if np.asarray(v).size >= 1000 and not k.endswith("conv_layer.bias") and np.any(v):
             n_q, n_g = np.linalg.norm(np.asarray(v, np.float64)), np.linalg.norm(np.asarray(got[k], np.float64))
@@ -136,7 +139,12 @@ def test_fused_input_bf16_step_vs_oracle(bands, classes, B):
     print(f"B={B}: bf16 HIP vs exact oracle: whole-gradient rel-L2 {whole_e:.2e} (rounded-operand oracle vs exact: "
           f"{whole_q:.2e}; worst tensor {worst_e}), total norm rel err {abs(tot - tot_e) / tot_e:.2e}")
     assert abs(tot - tot_e) / tot_e < 1e-2
-    assert whole_e < 1.1 * whole_q + 2e-3
+    # the yardstick is the reference itself: its modules under torch.autocast("cpu", torch.bfloat16) on these very inputs
+    # (tests/golden/bf16_autocast.npz): scores, loss, every >= 1000-element tensor (norm and element-wise), the whole
+    # vector and the total norm within max(1e-2, 1.5 x the reference's own bf16 deviation)
+    assert rel_l2(lg, e_logits) <= bf16_yardstick.bound(tag + "scores_dev")
+    assert abs(loss.item() - e_loss) / e_loss <= bf16_yardstick.bound(tag + "loss_dev")
+    bf16_yardstick.check_gradients(tag, {k: v for k, v in got.items() if v is not None}, {k: v for k, v in e_g.items() if got.get(k) is not None})
 
 
 @pytest.mark.parametrize("B", [530, 1024])
@@ -208,7 +216,7 @@ def _train_grads(m, x, y):
             {k: v.detach().double().cpu().numpy() for k, v in m.state_dict().items() if "running_" in k})
 
 
-def test_full_size_bf16_gradients_vs_fp32(full):
+def test_full_size_bf16_gradients_vs_fp32(full, bf16_yardstick):
     """B=1024, 369 bands, 200 classes, TRAIN mode (batch-statistics BatchNorm backward over 256 conv partials and
     1024 per-patch partials): bf16 path against the fp32 path of the same library (which the small cases pin to the
     oracle at 1e-5): logits, loss, every BatchNorm buffer and the whole gradient vector within the bf16 budget."""
@@ -225,19 +233,16 @@ def test_full_size_bf16_gradients_vs_fp32(full):
     print(f"full size: bf16 vs fp32 whole-gradient rel-L2 {whole:.2e} (worst {worst}); total norm rel "
           f"{abs(tot16 - tot32) / tot32:.2e}; logits {rel_l2(o16, o32):.2e}")
     assert abs(tot16 - tot32) / tot32 < 1e-2
-    # element-wise the bf16-operand gradient sits ~0.1 away from the fp32 one at this width (K = 3321 products of
-    # rounded operands feeding cancelling sums; test_fused_input_bf16_step_vs_oracle pins the SAME shape to the
-    # rounded-operand oracle at 1e-2): here the norms carry the budget
+    # a consistency check of the two precision modes of the SAME kernels at the bench shape (random torch-default weights,
+    # not a parity case: bf16 parity at this shape is test_fused_input_bf16_step_vs_oracle).  The allowances are the
+    # reference's own: its bf16-autocast run at this shape and batch (bf16_autocast.npz, hang1024/) moves each tensor's
+    # norm / the whole vector by the figures below; max(1e-2, 1.5 x that) is what the bf16 mode may differ from the fp32 mode
     for k, v in g32.items():
         if v.size < 1000 or k.endswith("conv_layer.bias"):
             continue
-        # conv / classifier weights: 1e-2; the spectral-attention matrices (cancelling mat-vec gradients on pooled
-        # values): 5e-2 against the unrounded computation, see tests/test_config4_gpu.py
-        tol = 1e-2 if (k.endswith("conv_layer.weight") or k.endswith("fc1.weight")) else 5e-2
-        assert abs(np.linalg.norm(g16[k]) - np.linalg.norm(g32[k])) <= tol * np.linalg.norm(g32[k]), k
-    # (a consistency check of the two precision modes of the SAME kernels, not parity: bf16-vs-oracle parity at this
-    # shape is test_fused_input_bf16_step_vs_oracle; the element-wise distance is what operand rounding costs)
-    assert whole < 0.15
+        tol = bf16_yardstick.bound("hang1024/gnorm_dev/" + k)
+        assert abs(np.linalg.norm(g16[k]) - np.linalg.norm(g32[k])) <= tol * np.linalg.norm(g32[k]), (k, tol)
+    assert whole < bf16_yardstick.bound("hang1024/whole_elem_dev")
     for k in b32:
         assert rel_l2(b16[k], b32[k]) < 1e-2, k
 

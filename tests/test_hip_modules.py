@@ -141,7 +141,7 @@ def test_metadata_sensor_fusion_eval_matches_oracle_composition():
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_spectral_network_24x24_crops(golden, precision):
+def test_spectral_network_24x24_crops(golden, precision, bf16_yardstick):
     """BASELINE config 5 geometry: spectral_network is size-agnostic (reference Hang2020.py:226-240); 24x24 crops take
     the banded weight-gradient path and the large-map stage kernels.  fp32 against the reference's golden, bf16
     against the oracle run with the same operand rounding."""
@@ -177,7 +177,11 @@ def test_spectral_network_24x24_crops(golden, precision):
             continue
         num += float(((prm.grad.double().cpu().numpy() - rg[k]) ** 2).sum())
         den += float((np.asarray(rg[k], np.float64) ** 2).sum())
-    assert np.sqrt(num / den) < 5e-2
+    # (implementation exactness on a B = 2 batch; the reference's own bf16 run moves this vector by 4.6e-2)
+    assert np.sqrt(num / den) < min(5e-2, 1.5 * bf16_yardstick.ref("spec24s/whole_elem_dev"))
+    # parity proper: against the reference's fp32 golden itself, within max(1e-2, 1.5 x the reference's own bf16 deviation)
+    got = {k: prm.grad.double().cpu().numpy() for k, prm in m.named_parameters()}
+    bf16_yardstick.check_gradients("spec24s/", got, {k: g[f"spectral24/g/{k}"] for k in got}, norms=False)
 
 
 def test_predict_softmax_top2():

@@ -282,7 +282,7 @@ def test_fused_trainer_zero_grad_pass_is_equivalent():
 
 
 @pytest.mark.parametrize("bands,classes,B,seed", [(369, 200, 16, 31), (20, 7, 9, 5)])
-def test_bf16_path_within_tolerance(bands, classes, B, seed):
+def test_bf16_path_within_tolerance(bands, classes, B, seed, bf16_yardstick):
     """bf16 mode: conv operands (inputs, weights, output gradients) are rounded to bf16, accumulation/BN/attention/
     loss stay fp32.  north_star bar: logits, loss and gradient norm within 1e-2 of the reference arithmetic.
     Implementation exactness is pinned separately: against the oracle run with the same operand rounding
@@ -306,6 +306,12 @@ def test_bf16_path_within_tolerance(bands, classes, B, seed):
     tot = np.sqrt(sum(float(q.grad.double().pow(2).sum()) for q in m.parameters() if q.grad is not None))
     print("bf16 total grad norm rel err vs exact", abs(tot - tot_ref) / tot_ref)
     assert abs(tot - tot_ref) / tot_ref < BF16_TOL
+    # the yardstick is the reference itself (its modules under torch.autocast("cpu", torch.bfloat16) on these inputs,
+    # tests/golden/bf16_autocast.npz): every quantity within max(1e-2, 1.5 x the reference's own bf16 deviation)
+    tag = "hang16/" if bands == 369 else "hang9/"
+    assert e <= bf16_yardstick.bound(tag + "scores_dev")
+    got_all = {k: v for k, v in grads_of(m).items() if v is not None}
+    bf16_yardstick.check_gradients(tag, got_all, {k: v for k, v in ref_g.items() if k in got_all}, norms=False)
     # same operand rounding in the oracle -> tensor-by-tensor agreement
     O.bf16_mode(True)
     try:
@@ -328,13 +334,16 @@ def test_bf16_path_within_tolerance(bands, classes, B, seed):
         # per tensor this is not exactly zero: fp32 (HIP) vs fp64 (oracle) values that straddle a bf16 rounding
         # boundary or a ReLU / max-pool decision round differently; on 1..49-element stencil gradients at these tiny
         # batches that is worth several percent, so the tight bound is on the whole gradient vector
+        # (an implementation-exactness extra; the bound is the reference's own element-wise bf16 deviation of the tensor,
+        #  0.05-0.17 at these batches: the kernels sit closer to the model of their roundings than the reference's bf16 run
+        #  sits to its fp32 one)
         if np.asarray(v).size >= 1000:
-            assert e < 0.15, (k, e)
+            assert e < max(1e-2, bf16_yardstick.ref(tag + "gelem_dev/" + k)), (k, e)
     print("bf16 whole-gradient rel-L2 vs bf16-operand oracle", np.sqrt(num / den))
     # observed 1e-3 (bands=20) and 1.9e-2 (bands=369, B=16: K=3321 fp32-vs-fp64 accumulation differences flip ~2 % of
     # the bf16 roundings of the gated maps, and these tiny-batch gradients amplify operand noise ~30x, cf. the
     # 13 % bf16-vs-exact deviation of the same tensors); the forward agrees to 1e-3 above
-    assert np.sqrt(num / den) < 5 * BF16_TOL
+    assert np.sqrt(num / den) < min(5 * BF16_TOL, 0.5 * bf16_yardstick.ref(tag + "whole_elem_dev"))
     print("bf16 worst grad rel-L2 vs bf16-operand oracle", worst)
 
 
@@ -345,8 +354,9 @@ def test_no_cpu_fallback():
         m(torch.zeros(2, 3, 11, 11))
 
 
+@pytest.mark.devlib
 @pytest.mark.parametrize("B", [421, 530])      # the fused path needs >= 100 first-conv workgroups (4 patches each)
-def test_fused_input_conv_equals_separate_pack_pass(B, monkeypatch):
+def test_fused_input_conv_equals_separate_pack_pass(B, monkeypatch, devlib):
     """bf16: the first conv that converts the fp32 NCHW input while staging it (and leaves the bf16 tiles behind for
     the weight gradient) against the separate pack pass it replaced (developer switch DTA_NO_FUSED_INPUT): same tiles,
     so logits and every gradient agree to reordering noise; ragged batches leave workgroups partly empty."""
@@ -388,8 +398,9 @@ def test_fused_input_conv_equals_separate_pack_pass(B, monkeypatch):
                   g2["spectral_network.conv1.conv_layer.weight"].cpu().numpy()) < 5e-4
 
 
+@pytest.mark.devlib
 @pytest.mark.parametrize("kind,bands", [("vanilla", 5), ("vanilla", 37), ("spectral", 16), ("spatial", 33)])
-def test_fused_input_conv_other_networks_and_band_counts(kind, bands, monkeypatch):
+def test_fused_input_conv_other_networks_and_band_counts(kind, bands, monkeypatch, devlib):
     """The fused fp32-input first conv for the single-branch networks and for band counts that leave the last
     16-channel chunk mostly padding (5, 33, 37 bands: the clamped copies of the last real band meet zero weights)."""
     from deeptreeattention_amd import Hang2020 as H

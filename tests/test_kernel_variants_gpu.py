@@ -6,12 +6,42 @@ step through the generic per-patch kernels.  Both implement the same reference l
 :149-168), so losses and gradients must agree -- exactly up to summation order in fp32 mode, up to the storage formats of
 the intermediate maps in bf16 mode -- at batch sizes that leave the persistent grid with ragged last rounds, a partly
 filled four-patch workgroup, or a single patch."""
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
 from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_developer_switch_variants_in_the_developer_library():
+    """Every test marked `devlib` (this file and tests/test_hip_parity.py) compares an alternative launch plan, selected by
+    a developer switch, with the default plan.  The product library has no switches (it reads nothing from the environment),
+    so those tests are skipped in this process and run HERE, in a process that loads libdta_hip_dev.so: the same sources
+    compiled with -DDTA_DEV_SWITCHES (same dta_build_id)."""
+    from deeptreeattention_amd import _lib
+    L = _lib.lib()
+    if L.dta_dev_switches_enabled():
+        pytest.skip("already running in the developer library")
+    env = dict(os.environ, DTA_DEV_LIB="1")
+    probe = subprocess.run([sys.executable, "-c", "from deeptreeattention_amd import _lib; L = _lib.lib(); "
+                            "print(L.dta_dev_switches_enabled(), L.dta_build_id().decode())"], cwd=REPO, env=env,
+                           capture_output=True, text=True)
+    assert probe.returncode == 0, probe.stderr[-2000:]
+    enabled, build_id = probe.stdout.split()
+    assert enabled == "1" and build_id == L.dta_build_id().decode(), (probe.stdout, "libdta_hip_dev.so is stale: python -m deeptreeattention_amd.build")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu and devlib", "-p", "no:cacheprovider",
+                        os.path.join(REPO, "tests", "test_kernel_variants_gpu.py"), os.path.join(REPO, "tests", "test_hip_parity.py")],
+                       cwd=REPO, env=env, capture_output=True, text=True)
+    tail = r.stdout[-3000:] + r.stderr[-1000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
+    print(r.stdout.splitlines()[-1])
 
 
 def _step(m, x, y):
@@ -25,8 +55,9 @@ def _step(m, x, y):
     return float(loss.detach()), out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
 
 
+@pytest.mark.devlib
 @pytest.mark.parametrize("precision,B", [("fp32", 2), ("fp32", 5), ("fp32", 1031), ("bf16", 3), ("bf16", 257), ("bf16", 2051)])
-def test_lean_stage_kernels_match_generic_kernels(precision, B, monkeypatch):
+def test_lean_stage_kernels_match_generic_kernels(precision, B, monkeypatch, devlib):
     from deeptreeattention_amd import Hang2020 as H, _lib
     torch.manual_seed(B)
     bands, classes = 24, 11
@@ -62,8 +93,9 @@ def test_lean_stage_kernels_match_generic_kernels(precision, B, monkeypatch):
     assert float((a - b).norm() / b.norm()) < (5e-5 if fp32 else 1e-2)
 
 
+@pytest.mark.devlib
 @pytest.mark.parametrize("B", [1, 3, 130])
-def test_lean_stage_kernels_for_24x24_crops_match_generic_kernels(B, monkeypatch):
+def test_lean_stage_kernels_for_24x24_crops_match_generic_kernels(B, monkeypatch, devlib):
     """BASELINE configs[4] geometry (spectral network on 24x24 crops, bf16 mode): the lean stage kernels run with several
     (pixel, octet) items per thread (5 / 3 / 2 for the three stages) and without the patch image in LDS; the generic
     kernels on the same step must give the same loss, head scores and gradients up to the bf16 storage of the
@@ -108,8 +140,9 @@ def test_lean_stage_kernels_for_24x24_crops_match_generic_kernels(B, monkeypatch
             assert abs(float(g1[k].norm()) - float(g2[k].norm())) <= 1e-2 * float(g2[k].norm()), k
 
 
+@pytest.mark.devlib
 @pytest.mark.parametrize("precision,B", [("fp32", 3), ("fp32", 64), ("bf16", 70), ("bf16", 530)])
-def test_in_launch_fanin_of_batchnorm_sums_matches_the_finalize_launches(precision, B, monkeypatch):
+def test_in_launch_fanin_of_batchnorm_sums_matches_the_finalize_launches(precision, B, monkeypatch, devlib):
     """DTA_FANIN=3 (a measured experiment, off by default: profiles/README.md round 4) folds BatchNorm's batch statistics
     and backward batch sums inside the conv / stage launches (logical fan-in groups, kernels.h) instead of the finalize
     launches.  Same sums in another order: loss, scores, gradients and BatchNorm buffers must agree -- including launches

@@ -392,3 +392,30 @@ def test_oracle_metadata_sensor_branch_at_full_size_vs_reference_golden(golden):
         assert abs(np.linalg.norm(np.asarray(v, np.float64)) - ref) <= 1e-4 * ref + 2e-9, k
         checked += 1
     assert checked >= 50
+
+
+@pytest.mark.parametrize("tag,bands,classes,B,seed_p,seed_x,weighted", [("hang9/", 20, 7, 9, 5, 6, False), ("hang48_421/", 48, 11, 421, 3, 461, True)])
+def test_oracle_bf16_mode_against_the_references_own_bf16_run(bf16_yardstick, tag, bands, classes, B, seed_p, seed_x, weighted):
+    """The oracle's bf16 mode (the model of the kernels' roundings the GPU tests use for implementation exactness) against
+    the yardstick taken from the reference itself (tests/golden/bf16_autocast.npz: the reference under
+    torch.autocast("cpu", torch.bfloat16) next to itself in fp32): the rounding model is no further from the exact step
+    than 1.5 x what the reference's own bf16 run is -- scores, loss, every large tensor, the whole gradient vector."""
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=seed_p)
+    x = prng.uniform01(seed_x, 1, (B, bands, 11, 11))
+    y = prng.randint(seed_x, 2, (B,), classes)
+    w = (0.1 + (np.arange(classes) % 7)).astype(np.float32) if weighted else np.ones(classes, np.float32)
+
+    def run(q):
+        O.bf16_mode(q)
+        try:
+            logits, cache, _ = O.hang2020_fwd(p, x, True, np.float64)
+            loss, dl = O.weighted_cross_entropy(logits, y, w)
+            return logits, loss, O.hang2020_bwd(p, cache, dl, np.float64)
+        finally:
+            O.bf16_mode(False)
+    e_logits, e_loss, e_g = run(False)
+    assert abs(e_loss - bf16_yardstick.ref(tag + "loss_fp32")) < 1e-4 * e_loss       # same step as the fixture's fp32 leg
+    q_logits, q_loss, q_g = run(True)
+    assert rel_l2(q_logits, e_logits) <= bf16_yardstick.bound(tag + "scores_dev")
+    assert abs(q_loss - e_loss) / e_loss <= bf16_yardstick.bound(tag + "loss_dev")
+    bf16_yardstick.check_gradients(tag, q_g, e_g, verbose=False, norms=B >= 64)

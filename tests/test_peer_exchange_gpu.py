@@ -191,3 +191,110 @@ def test_missing_peer_times_out_instead_of_hanging():
     assert time.time() - t0 < 60
     dt, pmin, mmax, gmin = out["sticky"]
     assert dt < 0.2 and pmin == 1.0 and mmax == 0.0 and gmin == 1.0, out["sticky"]      # nothing waited, nothing applied
+
+
+# ---- world = 8 on the REAL Hang2020(369, 200) flat layout (round-4 review: world 8 had never executed in any form, and no
+#      shard arithmetic -- head / tail split, per-rank shard lengths -- had been exercised at 8 shards) ---------------------
+def _real_layout():
+    """(n, split) of the flat buffers a FusedTrainer builds for Hang2020(369, 200): head = everything but the first conv's
+    weights (+ alpha's exchange slot), tail = the two first-conv weights (engine.FusedTrainer.bucket_sizes)."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    head, tail = FusedTrainer.bucket_sizes(H.Hang2020(369, 200))
+    return head + tail, head
+
+
+def _w8_worker(rank, world, port, out):
+    dist = _init(rank, world, port)
+    from deeptreeattention_amd.dist import PeerExchange
+    dev = torch.device("cuda:0")
+    n, split = _real_layout()
+    ex = PeerExchange(n, timeout_s=60.0, max_workgroups=16, split=split)
+    assert ex.capacity == n and n % 4 == 0 and split % 4 == 0
+    res = {"n": n, "split": split}
+    slot = split - 4                               # alpha's exchange slot: the head's last quad (FusedTrainer.alpha_slot_off)
+
+    def fill(step):
+        ex.grad.copy_(torch.from_numpy(_grad(rank, step, n)).to(dev))
+
+    # (1) plain form of the two-segment buffer: one launch sums head and tail
+    fill(0)
+    ex.allreduce()
+    torch.cuda.synchronize(); ex.check()
+    res["sum_plain"] = ex.grad.cpu().numpy().copy()
+    # (2) overlapped form: the head's reduce-scatter as its own launch (the device code of the weight-gradient launch's side
+    #     workgroups), then the all-reduce launch that finds the head summed
+    fill(1)
+    ex.reduce_head()
+    ex.allreduce()
+    torch.cuda.synchronize(); ex.check()
+    res["sum_overlap"] = ex.grad.cpu().numpy().copy()
+    # (3) three fused Adam steps from identical parameters: overlapped, plain, overlapped; alpha through its slot; the
+    #     gradients are cleared by steps 1 and 2 (the next step's buffer must start from zeros) and kept by step 3
+    p = torch.from_numpy(_grad(7, 7, n)).to(dev)
+    m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    alpha = torch.full((), 0.5, dtype=torch.float64, device=dev)
+    am = torch.zeros((), dtype=torch.float64, device=dev); av = torch.zeros((), dtype=torch.float64, device=dev)
+    ag = torch.zeros((), dtype=torch.float64, device=dev)
+    for step in range(1, 4):
+        if step > 1:
+            res[f"cleared{step}"] = float(ex.grad.abs().max())      # what the previous step left behind
+        fill(10 + step)
+        ag.fill_(_alpha_grad(rank, step))
+        if step != 2:
+            ex.reduce_head(ag, slot)
+        ex.adam_step(p, m, v, alpha, ag, slot, am, av, step, 1e-3, (0.9, 0.999), 1e-8, zero_grad=(step != 3))
+        torch.cuda.synchronize(); ex.check()
+    res["p"], res["m"], res["v"] = p.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()
+    res["alpha"] = float(alpha)
+    res["g_last"] = ex.grad.cpu().numpy().copy()
+    out[rank] = res
+    ex.close()
+    dist.destroy_process_group()
+
+
+def test_world_8_on_the_real_hang2020_flat_layout():
+    """Eight processes (sharing the one GPU: real IPC mappings, real flag protocol) exchange the 900,7xx-float buffer of
+    Hang2020(369, 200) cut into head [0, split) and tail: the sum equals the host's float32 sum in rank order on every rank,
+    plain and overlapped; three fused Adam steps give bit-identical replicas equal to the host's Adam; steps that clear
+    leave exact zeros behind."""
+    world = 8
+    n, split = _real_layout()
+    assert 900_000 < n < 901_000 and 0 < split < n
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_w8_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert sorted(out.keys()) == list(range(world))
+    for key, step in (("sum_plain", 0), ("sum_overlap", 1)):
+        want = _grad(0, step, n)
+        for r in range(1, world):
+            want = want + _grad(r, step, n)            # float32, rank order
+        for r in range(world):
+            assert np.array_equal(out[r][key], want), (key, r, int((out[r][key] != want).sum()))
+    p = _grad(7, 7, n)
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    alpha, am, av = 0.5, 0.0, 0.0
+    slot = split - 4
+    for step in range(1, 4):
+        g = _grad(0, 10 + step, n)
+        for r in range(1, world):
+            g = g + _grad(r, 10 + step, n)
+        gsum = np.float32(_alpha_grad(0, step))
+        for r in range(1, world):
+            gsum = np.float32(gsum + np.float32(_alpha_grad(r, step)))
+        g[slot] = gsum
+        p, m, v = _adam_np(p, m, v, g, step, 1e-3, 0.9, 0.999, 1e-8, 1.0 / world)
+        ga = float(gsum) / world
+        am = 0.9 * am + 0.1 * ga
+        av = 0.999 * av + 0.001 * ga * ga
+        alpha -= (1e-3 / (1 - 0.9 ** step)) * (am / (np.sqrt(av) / np.sqrt(1 - 0.999 ** step) + 1e-8))
+    for r in range(world):
+        assert out[r]["n"] == n and out[r]["split"] == split
+        for k in ("p", "m", "v"):
+            assert np.array_equal(out[r][k], out[0][k]), (k, r)           # bit-identical replicas
+        np.testing.assert_allclose(out[r]["p"], p, rtol=0, atol=3e-6)
+        np.testing.assert_allclose(out[r]["m"], m, rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(out[r]["v"], v, rtol=1e-5, atol=1e-12)
+        assert abs(out[r]["alpha"] - alpha) < 1e-9
+        assert out[r]["cleared2"] == 0.0 and out[r]["cleared3"] == 0.0    # a clearing step leaves zeros for the next backward
+        assert np.array_equal(out[r]["g_last"], g)                        # zero_grad = 0 keeps the summed gradient

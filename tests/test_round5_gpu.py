@@ -1,0 +1,184 @@
+"""Round 5: regressions for the round-4 advisor findings on the drop-in module path (optim.DtaAdam around the UNCHANGED
+reference step, src/main.py:71-80,135-149; year ensembles src/models/year.py:24-33, multi_stage.py:258-288):
+
+* a learned_ensemble on its host-decided path (more than DTA_MAX_YEARS years) is stepped by DtaAdam, year by year, exactly
+  as torch.optim.Adam steps it;
+* a forward that builds no graph (validation metrics) between a training forward and its backward does not disturb the
+  year flags the backward and the optimizer read; gradient accumulation steps a year that ANY micro-batch kept;
+* zero_grad() after step() + backward() really clears (discarding a batch does not leak its gradients into the next);
+* optim.cross_entropy's backward can run twice (retain_graph)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _ensemble(years, bands=12, classes=5, seed=3):
+    from deeptreeattention_amd.year import learned_ensemble
+    torch.manual_seed(seed)
+    return learned_ensemble(years, classes, {"pretrain_state_dict": None, "bands": bands}).to(dev()).train()
+
+
+def _batch(years, B=4, bands=12, classes=5, seed=0, zero=()):
+    g = torch.Generator(device=dev())
+    g.manual_seed(100 + seed)
+    xs = [torch.rand(B, bands, 11, 11, device=dev(), generator=g) for _ in range(years)]
+    for i in zero:
+        xs[i].zero_()
+    return xs, torch.randint(0, classes, (B,), device=dev(), generator=g)
+
+
+def test_dta_adam_steps_a_five_year_ensemble_like_torch_adam():
+    """Five years > DTA_MAX_YEARS = 4: learned_ensemble.forward takes its host-decided path (year.py:27 on the host, the
+    kept years in chunks of four).  DtaAdam must step the kept years and pass over the skipped ones -- torch.optim.Adam on a
+    copy of the model is the yardstick (a skipped year has grad None there)."""
+    from deeptreeattention_amd.optim import DtaAdam
+    from deeptreeattention_amd import _lib
+    years = 5
+    assert years > _lib.MAX_YEARS
+    a = _ensemble(years)
+    b = copy.deepcopy(a)
+    opt_a = DtaAdam(a.parameters(), lr=1e-3)
+    opt_b = torch.optim.Adam(b.parameters(), lr=1e-3)
+    before = {k: v.detach().clone() for k, v in a.named_parameters()}
+    for step, zero in enumerate([(), (1,), (0, 4)]):
+        xs, y = _batch(years, seed=step, zero=zero)
+        for m, opt in ((a, opt_a), (b, opt_b)):
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(m(xs), y).backward()
+            opt.step()
+    sa, sb = a.state_dict(), b.state_dict()
+    moved = 0
+    for k in sb:
+        if k.endswith("num_batches_tracked"):
+            assert int(sa[k]) == int(sb[k]), k
+            continue
+        if k.endswith("conv_layer.bias"):
+            continue        # zero gradient analytically: Adam's sign(noise) steps are not comparable
+        assert rel_l2(sa[k].float().cpu().numpy(), sb[k].float().cpu().numpy()) < 2e-4, k
+        if k in before and "classifier1" not in k and "classifier2" not in k:
+            moved += int(not torch.equal(sa[k], before[k]))
+    assert moved > 100                                     # the ensemble WAS stepped (the bug left every parameter where it was)
+    assert opt_a.step_counts() == [2, 2, 3, 3, 2]
+
+
+def test_no_grad_forward_between_training_forward_and_backward_keeps_the_flags():
+    """train forward -> validation-style forward under no_grad (other inputs, another year missing) -> backward -> step:
+    the backward and the optimizer must see the TRAINING forward's flags (the two-bank scheme handed them the cleared
+    bank: exact-zero gradients for every year and a silently skipped step)."""
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    years = 3
+    a = _ensemble(years)
+    b = copy.deepcopy(a)
+    opt_a, opt_b = DtaAdam(a.parameters(), lr=1e-3), DtaAdam(b.parameters(), lr=1e-3)
+    xs, y = _batch(years, seed=1, zero=(2,))
+    xv, _ = _batch(years, seed=2, zero=(0,))
+    # a: with the interleaved no_grad forward; b: without
+    opt_a.zero_grad()
+    loss = cross_entropy(a(xs), y)
+    with torch.no_grad():
+        a(xv)
+        a(xv)
+    loss.backward()
+    assert float(a.year_models[0].conv1.conv_layer.weight.grad.abs().sum()) > 0
+    assert float(a.year_models[2].conv1.conv_layer.weight.grad.abs().sum()) == 0.0      # the year the TRAINING batch lacks
+    opt_a.step()
+    opt_b.zero_grad()
+    cross_entropy(b(xs), y).backward()
+    opt_b.step()
+    for (k, p), q in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(p, q), k
+    assert opt_a.step_counts() == opt_b.step_counts() == [1, 1, 0]
+
+
+def test_gradient_accumulation_steps_a_year_any_micro_batch_kept():
+    """Two micro-batches before one step: year 1 present only in the first, year 2 only in the second.  Both are stepped
+    (torch: both have a gradient), year 0 -- present in both -- too; a year missing from both is passed over."""
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    years = 4
+    a = _ensemble(years)
+    opt = DtaAdam(a.parameters(), lr=1e-3)
+    before = {k: v.detach().clone() for k, v in a.named_parameters()}
+    opt.zero_grad()
+    xs, y = _batch(years, seed=3, zero=(2, 3))
+    cross_entropy(a(xs), y).backward()
+    xs, y = _batch(years, seed=4, zero=(1, 3))
+    cross_entropy(a(xs), y).backward()
+    opt.step()
+    assert opt.step_counts() == [1, 1, 1, 0]
+    for k, p in a.named_parameters():
+        if k.endswith("conv1.conv_layer.weight"):
+            yy = int(k.split(".")[1])
+            assert torch.equal(p, before[k]) == (yy == 3), k
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_zero_grad_after_step_and_backward_really_clears(fuse):
+    """step(); backward() [a batch that is then discarded]; zero_grad(); backward(); the gradient must be the LAST batch's
+    alone (a stale "cleared by step" flag skipped the clear and the in-place write summed both batches)."""
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    torch.manual_seed(5)
+    m = H.spectral_network(12, 5).to(dev()).train()
+    opt = DtaAdam(m.parameters(), lr=1e-3, fuse_zero_grad=fuse)
+    g = torch.Generator(device=dev()); g.manual_seed(9)
+    xa, xb = (torch.rand(4, 12, 11, 11, device=dev(), generator=g) for _ in range(2))
+    y = torch.randint(0, 5, (4,), device=dev(), generator=g)
+    opt.zero_grad()
+    cross_entropy(m(xa)[-1], y).backward()
+    opt.step()
+    cross_entropy(m(xa)[-1], y).backward()         # the batch that gets discarded
+    opt.zero_grad()
+    cross_entropy(m(xb)[-1], y).backward()
+    got = m.conv2.conv_layer.weight.grad.clone()
+    ref = copy.deepcopy(m)
+    for p in ref.parameters():
+        p.grad = None
+    for mod in (m, ref):
+        for bn in (mod.conv1.bn1, mod.conv2.bn1, mod.conv3.bn1):
+            bn.reset_running_stats()
+    torch.nn.functional.cross_entropy(ref(xb)[-1], y).backward()
+    assert rel_l2(got.cpu().numpy(), ref.conv2.conv_layer.weight.grad.cpu().numpy()) < 1e-5
+
+
+def test_zero_grad_clears_gradients_autograd_accumulated_into_the_views():
+    """Parameters whose gradients arrive through autograd's own accumulation (a plain torch module sharing the optimizer)
+    leave no trace in take_inplace; with fuse_zero_grad=False the buffer stays dirty after step() and zero_grad() must
+    clear it."""
+    from deeptreeattention_amd.optim import DtaAdam
+    torch.manual_seed(6)
+    lin = torch.nn.Linear(8, 3).to(dev())
+    opt = DtaAdam(lin.parameters(), lr=1e-2, fuse_zero_grad=False)
+    x = torch.rand(5, 8, device=dev())
+    opt.zero_grad()
+    lin(x).sum().backward()
+    g1 = lin.weight.grad.clone()
+    opt.step()
+    opt.zero_grad()
+    assert float(lin.weight.grad.abs().sum()) == 0.0
+    lin(x).sum().backward()
+    assert torch.allclose(lin.weight.grad, g1)
+
+
+def test_cross_entropy_backward_twice_with_retain_graph():
+    from deeptreeattention_amd.optim import cross_entropy
+    torch.manual_seed(7)
+    z = torch.randn(6, 9, device=dev(), requires_grad=True)
+    y = torch.randint(0, 9, (6,), device=dev())
+    loss = cross_entropy(z, y)
+    g1, = torch.autograd.grad(loss, z, retain_graph=True)
+    g2, = torch.autograd.grad(loss, z)
+    zr = z.detach().clone().requires_grad_(True)
+    gr, = torch.autograd.grad(torch.nn.functional.cross_entropy(zr, y), zr)
+    assert torch.equal(g1, g2)
+    assert rel_l2(g1.cpu().numpy(), gr.cpu().numpy()) < 1e-5
