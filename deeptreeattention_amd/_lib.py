@@ -143,6 +143,10 @@ def lib():
         L.dta_net_loss.restype = C.c_int
         L.dta_net_loss.argtypes = [C.POINTER(NetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_net_forward_loss.restype = C.c_int
+        L.dta_net_forward_loss.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
         L.dta_weighted_ce.restype = C.c_int
         L.dta_weighted_ce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
@@ -173,6 +177,9 @@ def lib():
         L.dta_ensemble_backward_gated.restype = C.c_int
         L.dta_ensemble_backward_gated.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams), C.c_void_p,
                                                   C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p, C.c_int, C.c_void_p]
+        L.dta_ensemble_backward_xchg.restype = C.c_int
+        L.dta_ensemble_backward_xchg.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams), C.c_void_p,
+                                                 C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p, C.c_void_p, C.c_void_p]
         vp = C.c_void_p
         L.dta_conv_module_workspace_bytes.restype = C.c_size_t
         L.dta_conv_module_workspace_bytes.argtypes = [C.POINTER(ConvModuleDesc)]

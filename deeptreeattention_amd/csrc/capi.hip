@@ -61,19 +61,20 @@ inline void prof_end(int site, hipStream_t st) {
 
 // Developer switches (same-box A/B runs; developer library only, common.h: dev_getenv): the environment is read once
 // per process, not per call.  In the product library every switch has its default and nothing reads the environment.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; bool no_wgrad_pair; int fanin; };
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; bool no_wgrad_pair; int fanin; bool no_tail; };
 inline Switches read_switches() {
   // these change launch plans (and, for DTA_FP32_ACT, roundings): never meant for a training job's environment, so say
   // so once, loudly, when one is set
   static const char* names[] = {"DTA_NO_FUSED_INPUT", "DTA_NO_TAIL_MERGE", "DTA_BN_INKERNEL", "DTA_FP32_ACT", "DTA_NO_LEAN",
-                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER", "DTA_NO_WGRAD_PAIR", "DTA_FANIN"};
+                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER", "DTA_NO_WGRAD_PAIR", "DTA_FANIN", "DTA_NO_TAIL"};
   for (const char* n : names)
     if (dev_getenv(n)) fprintf(stderr, "[libdta_hip] developer switch %s is set: kernel plans (and possibly roundings) differ from the default build\n", n);
   return {dev_getenv("DTA_NO_FUSED_INPUT") != nullptr, dev_getenv("DTA_NO_TAIL_MERGE") != nullptr, dev_getenv("DTA_BN_INKERNEL") != nullptr,
           dev_getenv("DTA_FP32_ACT") != nullptr, dev_getenv("DTA_NO_LEAN") != nullptr,
           dev_getenv("DTA_LEAN_MASK") ? atoi(dev_getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, dev_getenv("DTA_HALO_TILES") != nullptr,
           dev_getenv("DTA_NO_WGRAD_NSPLIT") == nullptr, (dev_getenv("DTA_PIXEL_ORDER") ? 1 : 0) | (dev_getenv("DTA_NO_STAGGER") ? 2 : 0), dev_getenv("DTA_NO_WGRAD_PAIR") != nullptr,
-          dev_getenv("DTA_FANIN") ? atoi(dev_getenv("DTA_FANIN")) : 0};      // bit 0: forward BatchNorm statistics folded in-launch, bit 1: backward batch sums
+          dev_getenv("DTA_FANIN") ? atoi(dev_getenv("DTA_FANIN")) : 0,       // bit 0: forward BatchNorm statistics folded in-launch, bit 1: backward batch sums
+          dev_getenv("DTA_NO_TAIL") != nullptr};                             // the fused forward tail (stage.hip: k_tail_fwd) off: stage 3 + head GEMMs + blend / loss launches
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -111,6 +112,7 @@ struct Plan {
   // BatchNorm statistics / batch sums folded inside the producing launches (kernels.h, FanIn): arrival counters (zeroed by
   // the forward's prep launch, self re-arming), per layer FAN_R rows of forward sums and of backward sums
   size_t fan_cnt, fan_cnt_bytes, fan_ctr, fan_fwd[3], fan_bwd[3];      // fan_cnt..: the cleared range (rows, then the counters at fan_ctr)
+  size_t fct; int fct_ld;              // Hang2020: the two last heads' weights transposed, [128 + 512][classes padded to 4] (fused forward tail)
   size_t total;
 };
 
@@ -283,6 +285,8 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
     int launchG = (L == 0 && p->shared_x) ? 1 : G;
     p->wpart[L] = c.take((size_t)launchG * p->S[L] * 9 * p->CpadW[L] * Nconv * 4);
   }
+  p->fct_ld = (p->classes + 3) / 4 * 4;
+  p->fct = d->kind == DTA_NET_HANG2020 ? c.take((size_t)(p->F[0][2] + p->F[1][2]) * p->fct_ld * 4) : 0;
   p->total = c.off;
   return 0;
 }
@@ -336,10 +340,23 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
   return s;
 }
 
+// the loss of a single-score network, taken in the same call as its forward (dta_net_forward_loss)
+struct LossArgs { const long long* labels; const float* weight; float* loss; float* dlogits; float* scratch; };
+
+// Does this forward end in the fused tail launch (stage.hip: k_tail_fwd)?  A two-branch Hang2020 on 11x11 patches in
+// training mode whose caller wants the last heads only and lets the workspace hold the branch scores.
+bool tail_plan(const Plan& p, const dta_net_desc* d, float* const (*scores)[3]) {
+  if (d->kind != DTA_NET_HANG2020 || !d->training || (d->heads_mask & 7) != 4 || (d->heads_mask & DTA_FORWARD_ONLY)) return false;
+  if (switches().no_tail || switches().no_lean || !(switches().lean_mask & 1) || switches().bn_inkernel || (switches().fanin & 1)) return false;
+  if (scores && (scores[0][2] || scores[1][2])) return false;
+  if (p.H != 11 || p.W != 11 || p.F[0][2] != 128 || p.F[1][2] != 512) return false;
+  return true;
+}
+
 template <typename T>
 int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha,
               const float* const* xs, void* ws, float* const (*scores)[3], float* joint, hipStream_t st,
-              const void* x_tiles = nullptr, const float* gate = nullptr) {
+              const void* x_tiles = nullptr, const float* gate = nullptr, const LossArgs* loss = nullptr) {
   // x_tiles: the network input already as halo-free bf16 conv tiles (dta_preprocess_crops_tiles): no fp32 input at all
   if (x_tiles && !(p.esz == 2 && p.x_compact && (p.shared_x || p.G == 1))) {
     dta_set_error("input tiles need the bf16 mode, 11x11-class patches and a single input tensor");
@@ -347,6 +364,12 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
   }
   const int G = p.G, B = p.B;
   GemmGroup heads;
+  bool tail = tail_plan(p, d, scores);
+  if (tail) {
+    StageArgs s3 = stage_args(p, d, nets, ws, 2);
+    tail = tail_fwd_supported(s3, G, p.classes);
+  }
+  bool loss_done = false;
   // ---- all weight re-layouts of the step in two launches (forward forms, and when training the transposed
   //      forms the input-gradient convs will need) ----
   PackWGroup packs;
@@ -384,6 +407,15 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
     pa.x_compact = p.x_compact;
     pa.packs = packs; pa.spacks = spacks;
+    if (tail) {      // the last heads' weights [classes][F] -> [F][classes padded to 4], spectral rows first
+      for (int g = 0; g < 2; ++g) {
+        if (!nets[g].fc_w[2] || !nets[g].fc_b[2]) { dta_set_error("Hang2020 forward: the last heads' parameters are missing"); return 1; }
+        pa.trans.src[g] = nets[g].fc_w[2];
+        pa.trans.dst[g] = at<float>(ws, p.fct) + (size_t)(g ? p.F[0][2] : 0) * p.fct_ld;
+        pa.trans.rows[g] = p.classes; pa.trans.cols[g] = p.F[g][2]; pa.trans.ld[g] = p.fct_ld;
+      }
+      pa.trans.n = 2;
+    }
     // the split-K GEMM targets (and, for the DTA_FANIN experiment, the fan-in rows and counters directly in front of them)
     if (switches().fanin) { pa.zero = at<float>(ws, p.fan_cnt); pa.zero_n4 = (p.fan_cnt_bytes + (d->heads_mask ? p.scores_bytes : 0) + 15) / 16; }
     else if (d->heads_mask) { pa.zero = at<float>(ws, p.scores_all); pa.zero_n4 = (p.scores_bytes + 15) / 16; }
@@ -447,6 +479,29 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     else if ((!d->training || switches().bn_inkernel) && p.nwg[L] <= BN_INKERNEL_MAX_NWG) { sa.bn_inkernel = 1; sa.bnfin = bn_finalize_kargs(bf); }
     else if (launch_bn_finalize(bf, G, st)) return 1;
     if (d->heads_mask & DTA_FORWARD_ONLY) sa.attsave = nullptr;   // attention state is kept for the backward only
+    if (L == 2 && tail) {
+      // third stage of both branches + the two last heads + blend (+ loss) in ONE launch
+      TailArgs ta;
+      memset(&ta, 0, sizeof(ta));
+      ta.st = sa;
+      ta.wt = at<float>(ws, p.fct); ta.ldw = p.fct_ld;
+      for (int g = 0; g < 2; ++g) { ta.bias[g] = nets[g].fc_b[2]; ta.scores[g] = at<float>(ws, p.scores[g][2]); }
+      ta.alpha = alpha; ta.classes = p.classes;
+      ta.ce.gscale = 1.f;
+      if (loss) {
+        if (!alpha) { dta_set_error("Hang2020 forward + loss needs alpha"); return 1; }
+        ta.ce.labels = loss->labels; ta.ce.weight = loss->weight; ta.ce.loss = loss->loss; ta.ce.dlogits = loss->dlogits;
+        ta.ce.rowtmp = loss->scratch; ta.ce.joint = joint;
+        loss_done = true;
+      } else if (!(d->heads_mask & DTA_SKIP_BLEND)) {
+        if (!joint || !alpha) { dta_set_error("Hang2020 forward needs head 3, alpha and a joint output"); return 1; }
+        ta.ce.joint = joint;
+      }
+      prof_begin(DTA_SITE_STAGE_FWD + L, st);
+      if (launch_tail_fwd(ta, st)) return 1;
+      prof_end(DTA_SITE_STAGE_FWD + L, st);
+      continue;
+    }
     prof_begin(DTA_SITE_STAGE_FWD + L, st);
     if (launch_stage_fwd<T>(sa, G, st)) return 1;
     prof_end(DTA_SITE_STAGE_FWD + L, st);
@@ -478,6 +533,25 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
   prof_begin(DTA_SITE_GEMM, st);
   if (launch_gemm_group(heads, st)) return 1;   // all classifier heads of all branches in one launch
   prof_end(DTA_SITE_GEMM, st);
+  if (tail) return (loss && !loss_done) ? 1 : 0;      // (blend and loss happened in the tail launch)
+  if (loss) {
+    // no fused tail for this plan: the loss launch dta_net_loss would issue (blend + CE in one)
+    BlendCeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gscale = 1.f;
+    if (d->kind == DTA_NET_HANG2020) {
+      if (!alpha || !(d->heads_mask & 4)) { dta_set_error("Hang2020 forward + loss needs head 3 and alpha"); return 1; }
+      a.spec = (scores && scores[0][2]) ? scores[0][2] : at<float>(ws, p.scores[0][2]);
+      a.spat = (scores && scores[1][2]) ? scores[1][2] : at<float>(ws, p.scores[1][2]);
+      a.alpha = alpha; a.joint = joint;
+    } else {
+      if (!joint) { dta_set_error("forward + loss: the scores of a single-branch network are passed in `joint`"); return 1; }
+      a.spec = joint; a.joint = joint;
+    }
+    a.labels = loss->labels; a.weight = loss->weight; a.dlogits = loss->dlogits; a.loss = loss->loss; a.rowtmp = loss->scratch;
+    a.B = B; a.classes = p.classes;
+    return launch_blend_ce(a, st);
+  }
   if (d->kind == DTA_NET_HANG2020 && !(d->heads_mask & DTA_SKIP_BLEND)) {
     if (!(d->heads_mask & 4) || !joint || !alpha) { dta_set_error("Hang2020 forward needs head 3, alpha and a joint output"); return 1; }
     BlendArgs ba;
@@ -875,6 +949,26 @@ int dta_net_forward_tiles(const dta_net_desc* d, const dta_subnet_params* nets, 
   return forward_t<bf16_t>(p, d, nets, alpha, xs, workspace, scores, joint, (hipStream_t)stream, x_tiles);
 }
 
+int dta_net_forward_loss(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const float* x,
+                         const void* x_tiles, void* workspace, const long long* labels, const float* weight, float* joint,
+                         float* loss, float* dlogits, float* scratch, void* stream) {
+  Plan p;
+  if (!d || !nets || (!x && !x_tiles) || !workspace || !labels || !loss || !scratch) { dta_set_error("dta_net_forward_loss: null argument"); return 1; }
+  if (d->kind != DTA_NET_HANG2020 && d->kind != DTA_NET_VANILLA) { dta_set_error("dta_net_forward_loss: single-score networks only (Hang2020, vanilla_CNN)"); return 1; }
+  if (d->kind == DTA_NET_VANILLA && !joint) { dta_set_error("dta_net_forward_loss: vanilla_CNN's scores are written to `joint`"); return 1; }
+  if (build_plan(d, &p)) return 1;
+  if (x_tiles && d->dtype != DTA_BF16) { dta_set_error("dta_net_forward_loss: tile input is bf16 mode only"); return 1; }
+  dta_net_desc dd = *d;
+  if (d->kind == DTA_NET_HANG2020) dd.heads_mask |= DTA_SKIP_BLEND;      // the blend belongs to the loss launch (or the fused tail)
+  const LossArgs la = {labels, weight, loss, dlogits, scratch};
+  hipStream_t st = (hipStream_t)stream;
+  const float* xs[MAXG] = {x, x, x, x};
+  if (dd.dtype == DTA_BF16) return forward_t<bf16_t>(p, &dd, nets, alpha, xs, workspace, nullptr, joint, st, x_tiles, nullptr, &la);
+  if (dd.dtype == DTA_F32) return forward_t<float>(p, &dd, nets, alpha, xs, workspace, nullptr, joint, st, nullptr, nullptr, &la);
+  dta_set_error("unknown dtype %d", d->dtype);
+  return 1;
+}
+
 int dta_net_backward_tiles(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const void* x_tiles,
                            void* workspace, const float* const dscores[2][3], const float* djoint,
                            const dta_subnet_grads* grads, double* dalpha, int phases, void* stream) {
@@ -958,6 +1052,21 @@ int dta_ensemble_backward_gated(const dta_net_desc* d, int years, const dta_subn
   hipStream_t st = (hipStream_t)stream;
   if (dd.dtype == DTA_BF16) return backward_t<bf16_t>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, phases, st, nullptr, nullptr, gate);
   if (dd.dtype == DTA_F32) return backward_t<float>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, phases, st, nullptr, nullptr, gate);
+  dta_set_error("unknown dtype %d", dd.dtype);
+  return 1;
+}
+
+int dta_ensemble_backward_xchg(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
+                               const float* dscore, const dta_subnet_grads* grads, const float* gate, dta_xchg* xchg,
+                               void* stream) {
+  Plan p; dta_net_desc dd;
+  if (!nets || !workspace || !dscore || !grads || !xchg) { dta_set_error("dta_ensemble_backward_xchg: null argument"); return 1; }
+  if (ensemble_desc(d, years, &dd, &p, "dta_ensemble_backward_xchg")) return 1;
+  const float* dsc[MAXG][3] = {};
+  for (int g = 0; g < years; ++g) dsc[g][2] = dscore;
+  hipStream_t st = (hipStream_t)stream;
+  if (dd.dtype == DTA_BF16) return backward_t<bf16_t>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, 3, st, nullptr, nullptr, gate, xchg, -1);
+  if (dd.dtype == DTA_F32) return backward_t<float>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, 3, st, nullptr, nullptr, gate, xchg, -1);
   dta_set_error("unknown dtype %d", dd.dtype);
   return 1;
 }

@@ -185,6 +185,8 @@ __global__ __launch_bounds__(256) void k_forward_prep(PrepArgs a) {
   if (y < a.packs.n) { pack_conv_w_job<T>(a.packs.job[y], (T*)a.packs.dst[y], tid, nthreads); return; }
   y -= a.packs.n;
   if (y < a.spacks.n) { pack_spectral_att_job(a.spacks, y, tid, nthreads); return; }
+  y -= a.spacks.n;
+  if (y < a.trans.n) { transpose_job(a.trans, y, tid, nthreads); return; }
   if (a.zero) {
     float4* z = (float4*)a.zero;   // workspace regions are 256-byte aligned and padded
     for (size_t i = tid; i < a.zero_n4; i += nthreads) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -196,7 +198,7 @@ int launch_forward_prep(PrepArgs a, hipStream_t st) {
   size_t lds;
   if (pack_input_plan(a.C, a.H, a.W, &a.NC, &a.CG, &lds)) return 1;
   a.ncg = (a.NC + a.CG - 1) / a.CG;
-  dim3 grid(a.B, a.ncg * a.nx + a.packs.n + a.spacks.n + (a.zero ? 1 : 0));
+  dim3 grid(a.B, a.ncg * a.nx + a.packs.n + a.spacks.n + a.trans.n + (a.zero ? 1 : 0));
   hipLaunchKernelGGL(k_forward_prep<T>, grid, dim3(256), lds, st, a);
   DTA_CHECK_LAUNCH("k_forward_prep");
   return 0;

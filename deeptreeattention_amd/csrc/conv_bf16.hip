@@ -954,13 +954,16 @@ __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16_pair(WgradArgs a, Wg
 }
 
 // The first conv's weight gradient with the data-parallel exchange's head segment riding along: blocks [0, nmain) are the
-// weight gradient (one 512-thread workgroup per CU, 240 of the 256 CUs for Hang2020), the XCHG_SIDE_WGS blocks behind
-// them pull and sum this rank's shard of every rank's head bucket -- 76 % of the gradient bytes, complete before this
-// launch -- through peer memory while the matrix cores work (xchg_dev.h; reference train.py:89-98: DDP overlaps the
-// gradient all-reduce with the backward).  The main workgroups never wait for the side ones.
+// weight gradient (one 512-thread workgroup per CU: 240 of the 256 CUs for Hang2020, 216 for a three-year ensemble), the
+// XCHG_SIDE_WGS blocks behind them pull and sum this rank's shard of every rank's head bucket -- everything but the first
+// convs' weights, complete before this launch -- through peer memory while the matrix cores work (xchg_dev.h; reference
+// train.py:89-98: DDP overlaps the gradient all-reduce with the backward).  The main workgroups never wait for the side ones.
+// Instantiated for the programs a first conv resolves to: <2,2,D2> (Hang2020: both branches' 64 columns, 11x11),
+// <4,1> plain windows (a spectral network / the years of an ensemble, 11x11) and <4,1> wide windows (24x24 crops).
+template <int CT, int NTT, bool BIGW, bool STACK, bool D2>
 __global__ __launch_bounds__(512, 1) void k_conv_wgrad_bf16_xchg(WgradArgs a, XchgArgs side, int nmain) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if ((int)blockIdx.x < nmain) { wgrad_bf16_body<2, 2, false, false, true>(a, blockIdx.x, smem); return; }
+  if ((int)blockIdx.x < nmain) { wgrad_bf16_body<CT, NTT, BIGW, STACK, D2>(a, blockIdx.x, smem); return; }
   xchg_side_job(side, (int)blockIdx.x - nmain, reinterpret_cast<int*>(smem));
 }
 
@@ -1038,22 +1041,34 @@ static int resolve_wgrad_bf16(const WgradArgs& a, int G, int cgroups, WgradArgs&
 }
 
 // Weight gradient of the first conv + the exchange's side job in one launch.  Returns 0 = launched, 2 = this plan does not
-// resolve to the program the combined kernel is built from (the caller launches the plain weight gradient and lets the
-// exchange sum its head segment itself), 1 = error.
+// resolve to a program the combined kernel is instantiated for, or leaves no CU for the side workgroups (the caller launches
+// the plain weight gradient and lets the exchange sum its head segment itself), 1 = error.
+template <int CT, int NTT, bool BIGW, bool D2>
+static int launch_wgrad_xchg_t(const WgradArgs& a2, size_t lds, int total, const XchgArgs& side, hipStream_t st) {
+  static DevOnce attr_once;
+  if (attr_once.first()) hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_xchg<CT, NTT, BIGW, false, D2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int nmain = 8 * ((total + 7) / 8);
+  hipLaunchKernelGGL((k_conv_wgrad_bf16_xchg<CT, NTT, BIGW, false, D2>), dim3(nmain + XCHG_SIDE_WGS), dim3(512), lds, st, a2, side, nmain);
+  DTA_CHECK_LAUNCH("k_conv_wgrad_bf16_xchg");
+  return 0;
+}
 int launch_conv_wgrad_bf16_xchg(const WgradArgs& a, int G, const XchgArgs& side, hipStream_t st) {
-  if (a.N != 64 || (a.Cpad <= 32)) return 2;
   const int cpw = wgrad_cpw(a.N), cgroups = (a.Cpad + cpw - 1) / cpw;
   WgradArgs a2;
   size_t lds;
   int variant, total;
-  if (resolve_wgrad_bf16<2, 2>(a, G, cgroups, a2, lds, variant, total)) return 1;
-  if (variant != WV_D2) return 2;
-  static DevOnce attr_once;
-  if (attr_once.first()) hipFuncSetAttribute((const void*)k_conv_wgrad_bf16_xchg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const int nmain = 8 * ((total + 7) / 8);
-  hipLaunchKernelGGL(k_conv_wgrad_bf16_xchg, dim3(nmain + XCHG_SIDE_WGS), dim3(512), lds, st, a2, side, nmain);
-  DTA_CHECK_LAUNCH("k_conv_wgrad_bf16_xchg");
-  return 0;
+  if (a.N == 64 && a.Cpad > 32) {
+    if (resolve_wgrad_bf16<2, 2>(a, G, cgroups, a2, lds, variant, total)) return 1;
+    if (variant != WV_D2 || 8 * ((total + 7) / 8) + XCHG_SIDE_WGS > 256) return 2;
+    return launch_wgrad_xchg_t<2, 2, false, true>(a2, lds, total, side, st);
+  }
+  if (a.N == 32) {
+    if (resolve_wgrad_bf16<4, 1>(a, G, cgroups, a2, lds, variant, total)) return 1;
+    if (8 * ((total + 7) / 8) + XCHG_SIDE_WGS > 256) return 2;      // (one 512-thread workgroup per CU: the side ones need CUs of their own)
+    if (variant == WV_PLAIN) return launch_wgrad_xchg_t<4, 1, false, false>(a2, lds, total, side, st);
+    if (variant == WV_BIGW) return launch_wgrad_xchg_t<4, 1, true, false>(a2, lds, total, side, st);
+  }
+  return 2;
 }
 
 template <>

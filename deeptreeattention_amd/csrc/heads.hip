@@ -3,6 +3,7 @@
 // sigmoid(alpha) blend (:260-261), class-weighted cross-entropy (src/main.py:78) and Adam (src/main.py:136).
 #include <stdlib.h>
 #include "kernels.h"
+#include "ce_dev.h"
 
 namespace dta {
 
@@ -487,15 +488,7 @@ int launch_pack_spectral_att(const float* w1, const float* w2, int C, int K, flo
 // ------------------------------------------------------------------------------------------------
 // Hang2020 blend: joint = spec * sigmoid(alpha) + spat * (1 - sigmoid(alpha)); alpha is float64.
 // ------------------------------------------------------------------------------------------------
-// The Hang2020 blend (reference Hang2020.py:260-261) exactly as torch evaluates it: sigmoid and 1 - sigmoid in double (alpha
-// is a float64 0-dim tensor), each rounded to float when it meets the float32 scores, then two products and a sum with
-// no fused multiply-add.  ONE definition for every kernel that blends, so that the stand-alone blend (module path) and
-// the blend folded into the loss kernel (fused path) produce the same bits.
-__device__ __forceinline__ float blend2(float zs, float zt, float w, float w1) {
-#pragma clang fp contract(off)      // (hipcc contracts a * b + c into an FMA by default, site by site; HIP's __fmul_rn is a plain product)
-  const float ps = zs * w, pt = zt * w1;
-  return ps + pt;
-}
+// (blend2: ce_dev.h -- ONE definition for every kernel that blends)
 __global__ void k_blend(BlendArgs a) {
   const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
   const float w = (float)wd, w1 = (float)(1.0 - wd);
@@ -675,112 +668,10 @@ __global__ __launch_bounds__(256) void k_ce_fin(CeArgs a) {
 // that block): one launch instead of k_blend + k_ce_rows + k_ce_fin.  The row terms cross workgroups / XCDs through
 // device-scope atomics (the per-XCD L2s are not coherent for plain accesses); the summation order of the loss is fixed.
 __global__ __launch_bounds__(256) void k_blend_ce(BlendCeArgs a) {
-  __shared__ float sc[4];
+  __shared__ float sc[8];
   __shared__ double sd[256];
   __shared__ int is_last;
-  const int t = threadIdx.x, lane = t & 63, row = blockIdx.x * 4 + (t >> 6);
-  // normaliser sum_i w[y_i] (every block needs it for its gradient rows): label loads of four strides in flight at
-  // once, then their weight gathers -- two dependent round trips per 1024 labels instead of eight
-  // this wave's row first: its score loads, label and blend weight go out together with the normaliser's label loads
-  // (behind the normaliser's barrier they would be one more dependent round trip of an all-latency launch)
-  const int rowc = row < a.B ? row : a.B - 1;
-  const double alpha0 = a.spat ? a.alpha[0] : 0.0;
-  const float* zs = a.spec + (size_t)rowc * a.classes;
-  const float* zt = a.spat ? a.spat + (size_t)rowc * a.classes : nullptr;
-  float zsr[4], ztr[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int n = lane + 64 * k;
-    zsr[k] = n < a.classes ? zs[n] : 0.f;
-    ztr[k] = (zt && n < a.classes) ? zt[n] : 0.f;
-  }
-  const long long y = a.labels[rowc];
-  // the normaliser's first 1024 labels (usually all of them) are requested here, their weight gathers after the row's
-  // softmax below: the row arithmetic runs under the sweep's two dependent round trips instead of behind its barrier
-  long long yy0[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) yy0[k] = (t + 256 * k < a.B) ? a.labels[t + 256 * k] : -1;
-  const bool ok = y >= 0 && y < a.classes;
-  const double wd = 1.0 / (1.0 + exp(-alpha0));
-  const float w = (float)wd, w1 = (float)(1.0 - wd);
-  auto zval = [&](int n) { return zt ? blend2(zs[n], zt[n], w, w1) : zs[n]; };
-  // the first 256 classes of the row live in registers (four per lane); wider rows re-read the rest
-  float zc[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { const int n = lane + 64 * k; zc[k] = n < a.classes ? (zt ? blend2(zsr[k], ztr[k], w, w1) : zsr[k]) : -3.4e38f; }
-  auto zget = [&](int n, int k) { return k < 4 ? zc[k] : zval(n); };
-  float mx = -3.4e38f;
-  for (int n = lane, k = 0; n < a.classes; n += 64, ++k) mx = fmaxf(mx, zget(n, k));
-  mx = wave_max(mx);
-  float se = 0.f;
-  for (int n = lane, k = 0; n < a.classes; n += 64, ++k) se += __expf(zget(n, k) - mx);
-  se = wave_sum(se);
-  const float lse = __logf(se);
-  const float wy = ok ? (a.weight ? a.weight[y] : 1.f) : 0.f;
-  float part = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (yy0[k] >= 0 && yy0[k] < a.classes) part += a.weight ? a.weight[yy0[k]] : 1.f;
-  for (int i0 = t + 1024; i0 < a.B; i0 += 1024) {
-    long long yy[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) yy[k] = (i0 + 256 * k < a.B) ? a.labels[i0 + 256 * k] : -1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (yy[k] >= 0 && yy[k] < a.classes) part += a.weight ? a.weight[yy[k]] : 1.f;
-  }
-  const float poison = (ok || y == -100) ? 0.f : __builtin_nanf("");
-  float xold = 0.f;
-  if (row < a.B && lane == 0) {
-    // device-scope exchange: performed at the coherence point (the per-XCD L2s are not coherent for plain stores); issued
-    // before the normaliser's reduction, its return value consumed after it (the wave must not reach the counter below
-    // before the exchange HAS been performed)
-    xold = __hip_atomic_exchange(a.rowtmp + row, ok ? wy * (lse + mx - zval((int)y)) : poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  const float den = block_sum256(part, sc);
-  if (row < a.B) {
-    float* jo = a.joint ? a.joint + (size_t)row * a.classes : nullptr;
-    // device-decided factor (1 / kept years): an infinite one says this rank kept NO year -- its scores are NaN (an empty
-    // mean, as the reference raises there) and it must contribute nothing to a data-parallel gradient sum: exact zeros
-    const float gs = a.gscale_dev ? a.gscale_dev[0] : a.gscale;
-    const bool none_kept = a.gscale_dev && !(gs < 3.0e38f);
-    const float sc2 = (den > 0.f ? wy / den : 0.f) * gs + poison;
-    for (int n = lane, k = 0; n < a.classes; n += 64, ++k) {
-      const float z = zget(n, k);
-      if (jo && jo != zs) jo[n] = z;
-      if (a.dlogits) {
-        float dv = none_kept ? 0.f : sc2 * (__expf(z - mx - lse) - ((ok && n == (int)y) ? 1.f : 0.f));
-        if (a.relu_mask && !(z > 0.f)) dv = 0.f;      // the scores are a ReLU's output: the gradient w.r.t. its input
-        a.dlogits[(size_t)row * a.classes + n] = dv;
-      }
-    }
-  }
-  asm volatile("" ::"v"(xold));
-  // the last block to arrive sums the row terms (fixed order) into the loss.  No fence: a device-scope release would
-  // write back this XCD's whole L2 (measured: 28 us for this kernel); the row terms and the counter are all device-scope
-  // atomics, ordered by the waits above and the barrier
-  __syncthreads();
-  unsigned* counter = reinterpret_cast<unsigned*>(a.rowtmp + a.B + 1);
-  // (-DDTA_STRICT_ORDER: the same hand-over by the letter of the memory model -- a release/acquire pair on the counter,
-  //  i.e. an L2 write-back per block; for ports to targets whose device-scope atomics are not performed at a common
-  //  coherence point.  tests/test_round2_gpu.py compares the fused loss with the three-launch route over many launches.)
-#ifdef DTA_STRICT_ORDER
-  constexpr int CNT_ORDER = __ATOMIC_ACQ_REL;
-#else
-  constexpr int CNT_ORDER = __ATOMIC_RELAXED;
-#endif
-  if (t == 0) is_last = (__hip_atomic_fetch_add(counter, 1u, CNT_ORDER, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
-  __syncthreads();
-  if (!is_last) return;
-  double acc = 0;
-  for (int r = t; r < a.B; r += 256) acc += (double)__hip_atomic_load(a.rowtmp + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  sd[t] = acc;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (t < o) sd[t] += sd[t + o]; __syncthreads(); }
-  if (t == 0) {
-    a.loss[0] = (float)(sd[0] / (double)den);
-    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-  }
+  blend_ce_body(a, sc, sd, &is_last);
 }
 int launch_blend_ce(const BlendCeArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_blend_ce, dim3((a.B + 3) / 4), dim3(256), 0, st, a);

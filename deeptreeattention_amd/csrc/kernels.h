@@ -449,11 +449,24 @@ __device__ __forceinline__ void pack_spectral_att_job(const SpecPackGroup& gr, i
   }
 }
 #endif
+// dst[c * ld + r] = src[r * cols + c] (r < rows; columns rows..ld-1 of every dst row are zero-filled): the last heads'
+// classifier weights [classes][F] as [F][classes padded to 4] for the fused forward tail (lanes read consecutive classes)
+struct TransposeGroup { const float* src[4]; float* dst[4]; int rows[4], cols[4], ld[4]; int n = 0; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ void transpose_job(const TransposeGroup& tg, int j, size_t i0, size_t stride) {
+  const int rows = tg.rows[j], cols = tg.cols[j], ld = tg.ld[j];
+  const float* src = tg.src[j]; float* dst = tg.dst[j];
+  for (size_t i = i0; i < (size_t)cols * ld; i += stride) {
+    const int c = (int)(i / ld), r = (int)(i - (size_t)c * ld);
+    dst[i] = r < rows ? src[(size_t)r * cols + c] : 0.f;
+  }
+}
+#endif
 // one launch for everything the forward needs before its first conv (conv.hip)
 struct PrepArgs {
   const float* x[MAXG]; int nx; size_t x_tl_gs;   // nx inputs (one per group with its own input), tile group stride in bytes
   void* x_tl; int B, C, H, W, NC, CG, ncg, x_compact;
-  PackWGroup packs; SpecPackGroup spacks;
+  PackWGroup packs; SpecPackGroup spacks; TransposeGroup trans;
   float* zero; size_t zero_n4;         // float4 count to clear, or zero == null
 };
 template <typename T> int launch_forward_prep(PrepArgs a, hipStream_t st);
@@ -489,6 +502,22 @@ struct BlendCeArgs {
   int relu_mask = 0;                   // the scores are a ReLU's output: dlogits is the gradient w.r.t. the ReLU's INPUT
 };
 int launch_blend_ce(const BlendCeArgs& a, hipStream_t st);
+// ---- stage.hip: fused forward tail of Hang2020 on 11x11 patches ------------------------------------------------------
+// The third stage of BOTH branches (BatchNorm -> ReLU -> 2x2 pool -> spectral / spatial attention -> features), the two
+// last-head classifiers, the sigmoid(alpha) blend and -- when ce.labels is set -- the class-weighted cross-entropy with
+// its gradient and the loss, in ONE launch: a workgroup owns four patches x two branches, everything between the third
+// conv's output and the scores stays in registers / LDS (reference Hang2020.py:24-31, :105-124, :149-168, :55-66, :256-261;
+// src/main.py:78).  Replaces k_stage_fwd_lean<128,5,5> + k_gemm_group + k_blend (or k_blend_ce).
+struct TailArgs {
+  StageArgs st;                        // stage 3 (groups: 0 spectral, 1 spatial): y, coef, att, feat, attsave
+  const float* wt; int ldw;            // [128 + 512][ldw] transposed last-head weights (TransposeGroup), ldw = classes padded to 4
+  const float* bias[2];                // the two heads' biases
+  float* scores[2];                    // out: branch scores [B][classes] (the backward's d(alpha) reads them)
+  const double* alpha; int classes;
+  BlendCeArgs ce;                      // ce.labels == null: blend only (ce.joint = the blended scores, required)
+};
+bool tail_fwd_supported(const StageArgs& st3, int G, int classes);
+int launch_tail_fwd(const TailArgs& a, hipStream_t st);
 struct AdamArgs {
   float* p; const float* g; float* m; float* v; size_t n;
   double* alpha_p; const double* alpha_g; double* alpha_m; double* alpha_v;

@@ -264,14 +264,15 @@ __global__ __launch_bounds__(1024) void k_meta_back(BackArgs a) {
   }
 }
 
-// LDS a workgroup of this device may use (queried once per process; the head's two one-workgroup kernels take up to all of
-// it): 160 KB on gfx950.  0 = the query failed (no device): every shape is then refused, and the Python side falls back.
+// Dynamic LDS a workgroup of the head's two one-workgroup kernels may use on this device (queried once per process): the
+// device's per-workgroup limit (160 KB on gfx950) minus 4 KB for their static part.  0 = the query failed (no device): every shape is then refused, and the Python side falls back.
 size_t lds_budget() {
   static const size_t cap = []() -> size_t {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) return 0;
-    return (size_t)v;
+    // (the two kernels also hold a few hundred bytes of static LDS: the dynamic part gets the device's limit minus 4 KB)
+    return (size_t)v > 8192 ? (size_t)v - 4096 : 0;
   }();
   return cap;
 }

@@ -5,6 +5,7 @@
 // Restates /root/reference/src/models/Hang2020.py:24-31 (conv_module after the conv), :105-124
 // (spatial_attention.forward) and :149-168 (spectral_attention.forward).
 #include "kernels.h"
+#include "ce_dev.h"
 
 namespace dta {
 #ifdef DTA_TICKS
@@ -2452,5 +2453,325 @@ int launch_stage_fwd_lean(const StageArgs& a, int G, hipStream_t st) {
 }
 template int launch_stage_fwd_lean<float>(const StageArgs&, int, hipStream_t);
 template int launch_stage_fwd_lean<bf16_t>(const StageArgs&, int, hipStream_t);
+
+// ================================================================================================
+// Fused forward tail of Hang2020 on 11x11 patches (kernels.h: TailArgs).
+//
+// One workgroup = 4 patches x 2 branches = 8 waves; wave (slot, g) owns patch slot `slot` of branch g (0 spectral,
+// 1 spatial), lane = (pooled pixel p, channel octet o) as in the lean stage kernels.  Phases (all 512 threads pass every
+// barrier):
+//   0  conv output (2x2 pool windows) -> BatchNorm -> ReLU -> max-pool in registers.  Spectral waves: pooled spectrum
+//      (two shuffles).  Spatial waves finish their whole stage alone: channel pool (DPP / shuffles), the two 3x3 stencils
+//      on the 2x2 map in registers, gate, gated map = the 512 class-pool features.
+//   1-4 the two 128 x 128 spectral mat-vecs for the four slots with all 512 threads: thread (4 outputs, 8 inputs), weight
+//      slices requested at kernel entry, partial sums met in LDS.
+//   5  both last heads as ONE [640] x [640][classes] product per slot: thread (4 classes, 64 inputs) streams the transposed
+//      weights with 16-byte loads (a wave reads whole rows), the features come as LDS broadcasts ([input][slot] float4).
+//   6  blend + weighted cross-entropy + gradient + loss (ce_dev.h, the code of k_blend_ce) on the four score rows in LDS.
+// The third conv's output is read once; features, attention state and branch scores are still written for the backward.
+// ================================================================================================
+constexpr int TAIL_KS = 10, TAIL_KROWS = 64, TAIL_TPS = 512 / TAIL_KS;      // head product: k-slices, rows per slice, threads per slice
+static_assert(TAIL_KS * TAIL_KROWS == 640 && 128 % TAIL_KROWS == 0, "tail: slices must not straddle the two heads");
+__host__ __device__ inline size_t tail_lds_floats(int ldw) {
+  const size_t red = (size_t)16 * 128 * 4 > (size_t)TAIL_KS * 4 * ldw ? (size_t)16 * 128 * 4 : (size_t)TAIL_KS * 4 * ldw;
+  return 512 + 2560 + 512 + 512 + red + (size_t)8 * ldw + 16 + 512;      // coef | X | pooled | h | partials | scores | ce scratch (sc, flag, sd)
+}
+
+#ifdef DTA_TICKS
+__device__ long long g_tail_ticks[2][16];
+#define TTICK(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200)) g_tail_ticks[blockIdx.x ? 1 : 0][i] = wall_clock64(); } while (0)
+extern "C" int dta_debug_tail_ticks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_ticks), sizeof(long long) * 32); }
+#else
+#define TTICK(i) do { } while (0)
+#endif
+template <int YF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))      // (up to 256 registers: the head product keeps 16 weight vectors in flight)
+void k_tail_fwd(TailArgs a) {
+  constexpr int C = 128;
+  TTICK(0);
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, slot = wave & 3, g = wave >> 2;
+  const int B = a.st.B, N = a.classes, ldw = a.ldw;
+  const int b = blockIdx.x * 4 + slot;
+  const bool live = b < B;
+  float* coefL = sm;                       // [2][C][2] scale, shift
+  float* X = coefL + 512;                  // [640][4]: features of the four slots, input-major (0..127 spectral, 128..639 spatial)
+  float* pooledT = X + 2560;               // [C][4]
+  float* hT = pooledT + 512;               // [C][4]
+  float* red = hT + 512;                   // mat-vec partials [16][C][4]; later the head product's [KS][4][ldw]
+  const size_t redn = (size_t)16 * 128 * 4 > (size_t)TAIL_KS * 4 * ldw ? (size_t)16 * 128 * 4 : (size_t)TAIL_KS * 4 * ldw;
+  float* scS = red + redn;                 // [4][N] spectral scores (row pitch N: what blend_ce_body indexes)
+  float* scT = scS + 4 * (size_t)ldw;      // [4][N] spatial scores
+  float* cesc = scT + 4 * (size_t)ldw;     // 8 floats + flag, then 256 doubles
+  int* is_last = reinterpret_cast<int*>(cesc + 8);
+  double* sd = reinterpret_cast<double*>(cesc + 16);
+
+  // ---- everything that depends on nothing goes out first: mat-vec weight slices, the conv output, coefficients ----
+  const int o4 = (t & 31) * 4, q = t >> 5;                 // mat-vec thread: outputs o4..o4+3, inputs 8q..8q+7
+  f32x4 w1[8], w2[8];
+  const float* A1 = a.st.att[0].p[0]; const float* A2 = a.st.att[0].p[2];      // input-major centre-tap matrices
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w1[k] = *reinterpret_cast<const f32x4*>(A1 + (size_t)(8 * q + k) * C + o4);
+  const int p = lane >> 4, o = lane & 15;                  // item: pooled pixel, channel octet
+  float yraw[4][8];
+  {
+    const size_t ypatch = (size_t)g * a.st.y_gs + (size_t)(live ? b : 0) * 25 * a.st.y_rs;
+    const int p00 = (2 * (p >> 1)) * 5 + 2 * (p & 1);
+    const int po[4] = {p00, p00 + 1, p00 + 5, p00 + 6};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lean_ld8<YF, true>(yraw[k], a.st.y, ypatch + (size_t)po[k] * a.st.y_rs + o * 8);
+  }
+  {
+    const int gi = t >> 8, j = t & 255;
+    coefL[t] = a.st.coef[(size_t)gi * a.st.coef_gs + (j >> 1) * 4 + (j & 1)];
+  }
+  float wcv[8];
+  if (g == 1) {
+    const f32x4 u0 = *reinterpret_cast<const f32x4*>(a.st.att[1].p[0] + o * 8), u1 = *reinterpret_cast<const f32x4*>(a.st.att[1].p[0] + o * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wcv[e] = u0[e]; wcv[4 + e] = u1[e]; }
+  }
+  // the head product's first two batches of weight rows (they depend on nothing either): thread (k-slice hks, classes 4 htt ..)
+  constexpr int TB = 8, NBLK = TAIL_KROWS / TB;
+  const int hks = t / TAIL_TPS, htt = t - hks * TAIL_TPS;
+  const bool hact = hks < TAIL_KS && htt * 4 < ldw;
+  const float* hwp = a.wt + (size_t)((hact ? hks : 0) * TAIL_KROWS) * ldw + (hact ? htt : 0) * 4;
+  f32x4 wb[2][TB];
+#pragma unroll
+  for (int r = 0; r < TB; ++r) wb[0][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(hwp + (size_t)r * ldw));
+  // ... and what the loss needs besides the scores: labels, class weights, this thread's share of the normaliser
+  BlendCeArgs cea = a.ce;
+  cea.spec = scS - (size_t)blockIdx.x * 4 * N; cea.spat = scT - (size_t)blockIdx.x * 4 * N; cea.alpha = a.alpha;
+  cea.B = B; cea.classes = N;
+  CePre cpre = {};
+  if (a.ce.labels) ce_prefetch(cea, cpre);
+  __syncthreads();
+  TTICK(1);
+  // ---- BatchNorm -> ReLU -> 2x2 max-pool ----
+  float z[8];
+  {
+    const float* cf = coefL + g * 256 + o * 16;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(cf + e * 2);
+      const float sc0 = c4[0], sh0 = c4[1], sc1 = c4[2], sh1 = c4[3];
+      float m0 = yraw[0][e] * sc0 + sh0, m1 = yraw[0][e + 1] * sc1 + sh1;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) { m0 = max_nan(m0, yraw[k][e] * sc0 + sh0); m1 = max_nan(m1, yraw[k][e + 1] * sc1 + sh1); }
+      z[e] = live ? relu_nan(m0) : 0.f; z[e + 1] = live ? relu_nan(m1) : 0.f;
+    }
+  }
+  float* save = (a.st.attsave && live) ? a.st.attsave + ((size_t)g * B + b) * a.st.attsave_ld : nullptr;
+  if (g == 0) {
+    // pooled spectrum: mean over the four pooled pixels (lanes o, o + 16, o + 32, o + 48)
+    float ps[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { float x = z[e]; x += __shfl_xor(x, 16); x += __shfl_xor(x, 32); ps[e] = x * 0.25f; }
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pooledT[(o * 8 + e) * 4 + slot] = ps[e];
+      if (save) {
+        __builtin_nontemporal_store(f32x4{ps[0], ps[1], ps[2], ps[3]}, reinterpret_cast<f32x4*>(save + o * 8));
+        __builtin_nontemporal_store(f32x4{ps[4], ps[5], ps[6], ps[7]}, reinterpret_cast<f32x4*>(save + o * 8 + 4));
+      }
+    }
+  } else {
+    // spatial attention on the 2x2 map, all of it inside the wave (reference Hang2020.py:105-124 with k = 3, pool 1)
+    const float bc = a.st.att[1].p[1][0], b1 = a.st.att[1].p[3][0], b2 = a.st.att[1].p[5][0];
+    const float* k1 = a.st.att[1].p[2]; const float* k2 = a.st.att[1].p[4];
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += wcv[e] * z[e];
+    acc = lean_octet_sum<16>(acc);
+    const float m = relu_nan(acc + bc);                    // every lane of pixel p holds m[p]
+    float mm[4], t1[4], ss[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mm[i] = __shfl(m, 16 * i);
+    // a 3x3 "same" stencil on a 2x2 map: out[h][w] = sum_{h', w'} k[(h' - h + 1) * 3 + (w' - w + 1)] * in[h'][w']
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s1 += k1[((j >> 1) - (i >> 1) + 1) * 3 + ((j & 1) - (i & 1) + 1)] * mm[j];
+      t1[i] = relu_nan(s1 + b1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s2 += k2[((j >> 1) - (i >> 1) + 1) * 3 + ((j & 1) - (i & 1) + 1)] * t1[j];
+      ss[i] = sigmoidf_(s2 + b2);
+    }
+    const float sp = p == 0 ? ss[0] : p == 1 ? ss[1] : p == 2 ? ss[2] : ss[3];
+    float* feat = (a.st.feat && live) ? a.st.feat + (size_t)a.st.feat_gs + (size_t)b * 512 : nullptr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = z[e] * sp;
+      const int i = (o * 8 + e) * 4 + p;                   // class-pool size 1: feature (c, ph, pw) = gated map (reference flatten order)
+      X[(128 + i) * 4 + slot] = v;
+      if (feat) feat[i] = v;
+    }
+    if (save && lane < 16) {                               // m | t1 as zero-bordered 4x4 maps, then s: what the backward reads back
+      const int hh = lane >> 2, ww = lane & 3;
+      const bool in = hh >= 1 && hh <= 2 && ww >= 1 && ww <= 2;
+      const int pi = in ? (hh - 1) * 2 + (ww - 1) : 0;
+      const float mv = pi == 0 ? mm[0] : pi == 1 ? mm[1] : pi == 2 ? mm[2] : mm[3];
+      const float tv = pi == 0 ? t1[0] : pi == 1 ? t1[1] : pi == 2 ? t1[2] : t1[3];
+      __builtin_nontemporal_store(in ? mv : 0.f, save + lane);
+      __builtin_nontemporal_store(in ? tv : 0.f, save + a.st.vslot + lane);
+      if (lane < 4) __builtin_nontemporal_store(lane == 0 ? ss[0] : lane == 1 ? ss[1] : lane == 2 ? ss[2] : ss[3], save + 2 * a.st.vslot + lane);
+    }
+  }
+  __syncthreads();
+  TTICK(2);
+  // (the conv output's registers are free now: the second mat-vec's weights go out)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w2[k] = *reinterpret_cast<const f32x4*>(A2 + (size_t)(8 * q + k) * C + o4);
+  // ---- spectral mat-vecs: h = relu(A1 pooled + c1), gate = sigmoid(A2 h + c2), for the four slots ----
+  auto matvec = [&](const f32x4 (&w)[8], const float* xT) {
+    float acc[4][4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[s_][e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xT + (8 * q + k) * 4);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[s_][e] += w[k][e] * xv[s_];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      *reinterpret_cast<f32x4*>(red + ((size_t)q * C + o4 + e) * 4) = f32x4{acc[0][e], acc[1][e], acc[2][e], acc[3][e]};
+  };
+  const int mo = t >> 2, ms = t & 3, mb = blockIdx.x * 4 + ms;     // meeting point: (output, slot)
+  float* msave = (a.st.attsave && mb < B) ? a.st.attsave + (size_t)mb * a.st.attsave_ld : nullptr;      // (group 0)
+  matvec(w1, pooledT);
+  __syncthreads();
+  TTICK(3);
+  {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[((size_t)k * C + mo) * 4 + ms];
+    v = relu_nan(v + a.st.att[0].p[1][mo]);
+    hT[t] = v;
+    if (msave) __builtin_nontemporal_store(v, msave + C + mo);
+  }
+  __syncthreads();
+  TTICK(4);
+  matvec(w2, hT);
+  __syncthreads();
+  TTICK(5);
+  {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[((size_t)k * C + mo) * 4 + ms];
+    const float gate = sigmoidf_(v + a.st.att[0].p[3][mo]);
+    const float f = gate * pooledT[t];                     // mean_p(z * gate) = gate * mean_p(z)
+    X[t] = f;
+    if (msave) __builtin_nontemporal_store(gate, msave + 2 * C + mo);
+    if (a.st.feat && mb < B) a.st.feat[(size_t)mb * C + mo] = f;
+  }
+  __syncthreads();
+  TTICK(6);
+  // ---- both last heads: out[slot][n] = sum_k X[k][slot] * Wt[k][n], k-slices of 64 inputs ----
+  // The slice's 64 weight rows arrive in batches of TB loads, one batch ahead of the one being multiplied (left to itself
+  // the compiler waits for every single load before issuing the next: 64 exposed L2 round trips, 19.6 of 32 us); the first
+  // batch was requested at kernel entry.
+  if (hks < TAIL_KS) {
+    for (int n4 = htt; n4 * 4 < ldw; n4 += TAIL_TPS) {
+      float acc[4][4];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[s_][e] = 0.f;
+      const float* wp = a.wt + (size_t)(hks * TAIL_KROWS) * ldw + n4 * 4;
+      const float* xp = X + (size_t)(hks * TAIL_KROWS) * 4;
+      if (n4 != htt) {      // (more than 4 * TAIL_TPS classes: the later class groups fetch their first batch here)
+#pragma unroll
+        for (int r = 0; r < TB; ++r) wb[0][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (size_t)r * ldw));
+      }
+#pragma unroll
+      for (int blk = 0; blk < NBLK; ++blk) {
+        if (blk + 1 < NBLK) {
+#pragma unroll
+          for (int r = 0; r < TB; ++r)
+            wb[(blk + 1) & 1][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (size_t)((blk + 1) * TB + r) * ldw));
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler must not sink the batch's loads to their uses)
+#pragma unroll
+        for (int r = 0; r < TB; ++r) {
+          const f32x4 w = wb[blk & 1][r];
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + (blk * TB + r) * 4);
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[s_][e] += w[e] * xv[s_];
+        }
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+        *reinterpret_cast<f32x4*>(red + ((size_t)hks * 4 + s_) * ldw + n4 * 4) = f32x4{acc[s_][0], acc[s_][1], acc[s_][2], acc[s_][3]};
+    }
+  }
+  __syncthreads();
+  TTICK(7);
+  for (int i = t; i < 4 * ldw; i += 512) {
+    const int s_ = i / ldw, n = i - s_ * ldw;
+    if (n >= N) continue;
+    float vs = red[((size_t)0 * 4 + s_) * ldw + n] + red[((size_t)1 * 4 + s_) * ldw + n];
+    float vt = 0.f;
+#pragma unroll
+    for (int k = 2; k < TAIL_KS; ++k) vt += red[((size_t)k * 4 + s_) * ldw + n];
+    vs += a.bias[0][n]; vt += a.bias[1][n];
+    scS[(size_t)s_ * N + n] = vs; scT[(size_t)s_ * N + n] = vt;
+    const int bb = blockIdx.x * 4 + s_;
+    if (bb < B) { a.scores[0][(size_t)bb * N + n] = vs; a.scores[1][(size_t)bb * N + n] = vt; }
+  }
+  __syncthreads();
+  TTICK(8);
+  // ---- blend (+ loss): the four score rows are addressed as rows 4 blockIdx.x .. + 3 of a [B][N] matrix ----
+  if (a.ce.labels) {
+    blend_ce_body(cea, cesc, sd, is_last, &cpre);
+  } else if (a.ce.joint) {      // (neither: the caller blends in its own loss launch, dta_net_loss)
+    const double wd = 1.0 / (1.0 + exp(-a.alpha[0]));
+    const float w = (float)wd, w1_ = (float)(1.0 - wd);
+    for (int i = t; i < 4 * N; i += 512) {
+      const int bb = blockIdx.x * 4 + i / N;
+      if (bb < B) a.ce.joint[(size_t)blockIdx.x * 4 * N + i] = blend2(scS[i], scT[i], w, w1_);
+    }
+  }
+  TTICK(15);
+}
+
+// The fused tail serves the third stage of a two-branch Hang2020 on 11x11 patches in training mode (coefficients from the
+// BatchNorm finalize launch), with the lean kernels' storage formats.
+bool tail_fwd_supported(const StageArgs& st3, int G, int classes) {
+  if (G != 2 || st3.kind[0] != KIND_SPECTRAL || st3.kind[1] != KIND_SPATIAL) return false;
+  if (st3.C != 128 || st3.Hc != 5 || st3.Wc != 5 || !st3.pool || !st3.apply_bn || !st3.relu || st3.bn_inkernel) return false;
+  if (st3.att_k[1] != 3 || st3.att_pool[1] != 1 || st3.F[0] != 128 || st3.F[1] != 512) return false;
+  if (!(st3.y_fmt == FMT_F32 || st3.y_fmt == FMT_F16) || !(st3.lean & 1)) return false;
+  const int ldw = (classes + 3) / 4 * 4;
+  return classes >= 1 && tail_lds_floats(ldw) * 4 <= 150 * 1024;
+}
+
+int launch_tail_fwd(const TailArgs& a_in, hipStream_t st) {
+  TailArgs a = a_in;
+  a.st.vslot = stage_vslot_for(a.st, 2);
+  if (!tail_fwd_supported(a.st, 2, a.classes) || a.ldw != (a.classes + 3) / 4 * 4) { dta_set_error("tail_fwd: unsupported configuration"); return 1; }
+  const size_t lds = tail_lds_floats(a.ldw) * 4;
+  static DevOnce attr_once;
+  if (attr_once.first()) {
+    hipFuncSetAttribute((const void*)k_tail_fwd<FMT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)k_tail_fwd<FMT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  }
+  const dim3 grid((a.st.B + 3) / 4);
+  if (a.st.y_fmt == FMT_F16) hipLaunchKernelGGL(k_tail_fwd<FMT_F16>, grid, dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(k_tail_fwd<FMT_F32>, grid, dim3(512), lds, st, a);
+  DTA_CHECK_LAUNCH("k_tail_fwd");
+  return 0;
+}
 
 }  // namespace dta

@@ -55,7 +55,7 @@ class GradSync:
 
     _warned_skip = False
 
-    def _ar(self, t):
+    def _ar(self, t, side=False):
         if self.skip_allreduce:      # development: the phase split without the collectives
             if not GradSync._warned_skip:
                 import warnings
@@ -64,7 +64,10 @@ class GradSync:
                 GradSync._warned_skip = True
             return
         if self.rccl is not None:
-            self.rccl.all_reduce(t)
+            if side:                 # overlapped: on RcclDirect's side stream, forked from the compute stream here
+                self.rccl.all_reduce_side(t)
+            else:
+                self.rccl.all_reduce(t)
         else:
             self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.collectives += 1
@@ -75,20 +78,26 @@ class GradSync:
         if alpha_grad is not None:
             alpha_slot.copy_(alpha_grad.reshape(1))
             self._post.append((alpha_grad, alpha_slot))
-        self._ar(flat_head)
+        self._ar(flat_head, side=True)
 
     def reduce_late(self, flat_tail):
-        self._ar(flat_tail)
+        self._ar(flat_tail, side=True)
 
     def reduce_all(self, flat, alpha_grad=None, alpha_slot=None):
-        """Single-bucket mode (no overlap): one collective over the whole flat gradient."""
-        self.reduce_early(flat, alpha_grad, alpha_slot)
+        """Single-bucket mode (no overlap): one collective over the whole flat gradient (RCCL direct: on the compute stream
+        itself, nothing to wait for afterwards)."""
+        if alpha_grad is not None:
+            alpha_slot.copy_(alpha_grad.reshape(1))
+            self._post.append((alpha_grad, alpha_slot))
+        self._ar(flat)
 
     def finish(self):
         """Make the compute stream wait for the reductions before the optimizer kernel."""
         for w in self._pending:
             w.wait()
         self._pending.clear()
+        if self.rccl is not None:
+            self.rccl.join()
         for ag, slot in self._post:
             ag.copy_(slot.reshape(ag.shape))
         self._post.clear()
@@ -278,6 +287,41 @@ class RcclDirect:
         self._ok(self._lib.ncclAllReduce(ptr, ptr, t.numel(), self.NCCL_FLOAT, self.NCCL_SUM, self._comm,
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ncclAllReduce")
         self.collectives += 1
+
+    # ---- north_star's literal form: "RCCL all-reduce of gradients over xGMI overlapped with backward on a side HIP
+    #      stream" (reference train.py:89-98: DDP reduces its buckets while earlier layers still back-propagate).  Plain
+    #      HIP streams and events (torch.cuda.Stream / Event are those), no torch.distributed work objects: the side stream
+    #      is forked from the compute stream by one event per bucket, and joined by one event before the optimizer ----
+    def _side_objects(self):
+        if getattr(self, "_stream", None) is None:
+            self._stream = torch.cuda.Stream()
+            self._ev_fork = [torch.cuda.Event(), torch.cuda.Event()]
+            self._ev_join = torch.cuda.Event()
+            self._k, self._side_pending = 0, False
+        return self._stream
+
+    def all_reduce_side(self, t):
+        """In-place sum of `t` on the side stream, ordered after everything the compute stream has been given so far; the
+        compute stream carries on (the first conv's weight gradient) and meets the result in join()."""
+        import ctypes as C
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        side = self._side_objects()
+        ev = self._ev_fork[self._k]
+        self._k ^= 1
+        ev.record(torch.cuda.current_stream())
+        side.wait_event(ev)
+        ptr = C.c_void_p(t.data_ptr())
+        self._ok(self._lib.ncclAllReduce(ptr, ptr, t.numel(), self.NCCL_FLOAT, self.NCCL_SUM, self._comm,
+                                         C.c_void_p(side.cuda_stream)), "ncclAllReduce")
+        self.collectives += 1
+        self._side_pending = True
+
+    def join(self):
+        """The compute stream waits for the side stream's collectives (one event)."""
+        if getattr(self, "_side_pending", False):
+            self._ev_join.record(self._stream)
+            torch.cuda.current_stream().wait_event(self._ev_join)
+            self._side_pending = False
 
     def close(self):
         if self._comm is not None:

@@ -87,7 +87,10 @@ class FusedTrainer:
         self.exchange = None           # "peer" / "rccl" / "torch" when this trainer exchanges gradients itself
         if self.comm and storage is None:
             self.exchange = choose_exchange(exchange, process_group) if self.world > 1 else (exchange or "torch")
-        self.overlap = overlap_comm and self.comm and (self.exchange in (None, "torch") or (self.exchange == "peer" and self.world > 1))
+        # overlapped exchange: "peer": the head bucket's sum rides in the first conv's weight-gradient launch; "rccl" / "torch":
+        # two buckets, the first all-reduced on a side stream while the first conv's weight gradient is computed
+        # (a one-rank group under DTA_FORCE_COLLECTIVES takes the overlapped launch order too: that is what its cost measurement is for)
+        self.overlap = bool(overlap_comm and self.comm and self.exchange in (None, "torch", "rccl", "peer"))
         self.hang = model._net_code == _lib.NET_HANG2020
         self.single_score = model._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
         self.three_head = bool(three_head_loss)
@@ -124,7 +127,7 @@ class FusedTrainer:
                 # the gradient buffer is the exchange's: library-owned device memory every peer has mapped; with
                 # overlap_comm its head segment [everything but the first conv's weights] is summed over the ranks by side
                 # workgroups of the first conv's weight-gradient launch (dta_net_backward_xchg)
-                self.ex = PeerExchange(n, process_group, split=(self.split if (overlap_comm and self.world > 1) else 0),
+                self.ex = PeerExchange(n, process_group, split=(self.split if self.overlap else 0),
                                        **(exchange_opts or {}))
                 assert self.ex.capacity == n
                 self.flat_g = self.ex.grad
@@ -397,6 +400,28 @@ class FusedTrainer:
             self.logits = self.head_scores[0, 2]
         return self.logits
 
+    def _forward_and_loss(self, x, y, want_grad):
+        """Forward + class-weighted cross-entropy of a single-score network in ONE C-ABI call (dta_net_forward_loss: the
+        reference's `y_hat = model.forward(images); loss = F.cross_entropy(y_hat, y, weight)`, src/main.py:77-78).  For a
+        training-mode Hang2020 on 11x11 patches the third stage of both branches, the last heads, the blend and the loss
+        are one launch.  Scores land in self.logits, the loss in self.loss, d(loss)/d(scores) in self.dlogits."""
+        L = _lib.lib()
+        tiles = getattr(x, "tiles", None)
+        if tiles is not None:
+            if self.model.precision != "bf16":
+                raise RuntimeError("PatchTiles inputs need a bf16-mode network")
+        else:
+            x = H._check_input(x)
+        self._tiles = tiles
+        self._prepare(x)
+        self.loss = torch.empty((), dtype=torch.float32, device=self.device)      # fresh per step (see _loss)
+        _lib.check(L.dta_net_forward_loss(C.byref(self.desc), self.nets, _lib.ptr(self.alpha) if self.hang else None,
+                                          None if tiles is not None else _lib.ptr(x), _lib.ptr(tiles), _lib.ptr(self._ws),
+                                          _lib.ptr(y), _lib.ptr(self.loss_weight), _lib.ptr(self.logits), _lib.ptr(self.loss),
+                                          _lib.ptr(self.dlogits) if want_grad else None, _lib.ptr(self.ce_scratch),
+                                          _lib.current_stream_ptr()), "dta_net_forward_loss")
+        return self.logits
+
     def _loss_heads(self, y, want_grad):
         """Sum over all heads of the class-weighted cross-entropy; d(loss)/d(head scores) in self.head_dscores."""
         L = _lib.lib()
@@ -553,13 +578,18 @@ class FusedTrainer:
         y = self._labels(y)
         if self.broadcast_buffers and self.world > 1:
             self.sync_buffers()            # DDP's per-forward buffer broadcast from rank 0
-        logits = self._forward_scores(x)
-        if self.three_head:
-            self._loss_heads(y, True)
-            self._backward(None)
-        else:
-            self._loss(logits, y, True)
+        self._describe(x)
+        if self.fused_loss:
+            self._forward_and_loss(x, y, True)
             self._backward(self.dlogits)
+        else:
+            logits = self._forward_scores(x)
+            if self.three_head:
+                self._loss_heads(y, True)
+                self._backward(None)
+            else:
+                self._loss(logits, y, True)
+                self._backward(self.dlogits)
         self._adam()
         return self.loss
 
@@ -576,6 +606,10 @@ class FusedTrainer:
 
     def forward_loss(self, x, y):
         """Forward + loss only (validation_step, reference src/main.py:82-94); returns fresh (logits, loss) tensors."""
+        self._describe(x)
+        if self.fused_loss:
+            logits = self._forward_and_loss(x, self._labels(y), False)
+            return logits.clone(), self.loss
         logits = self._forward_scores(x)
         loss = self._loss_heads(self._labels(y), False) if self.three_head else self._loss(logits, self._labels(y), False)
         return logits.clone(), loss
@@ -622,14 +656,22 @@ class EnsembleTrainer:
             world = torch.distributed.get_world_size(process_group)
         self.flat = [torch.zeros(_round4(n_head + Y) + n_tail, dtype=torch.float32, device=dev) for _ in range(4)]   # p g m v
         self.ex, self.exchange = None, None
-        if world > 1:
-            self.exchange = choose_exchange(exchange, process_group)
+        # DTA_FORCE_COLLECTIVES=1 (development measurement switch, as for FusedTrainer): a one-rank process group still takes the
+        # data-parallel path -- exchange launch, device-gated optimizer passes -- so that its fixed cost can be measured
+        self.comm = world > 1 or (os.environ.get("DTA_FORCE_COLLECTIVES") == "1" and torch.distributed.is_available()
+                                  and torch.distributed.is_initialized())
+        if self.comm:
+            self.exchange = choose_exchange(exchange, process_group) if world > 1 else (exchange or "torch")
             if self.exchange == "peer":
-                self.ex = PeerExchange(self.flat[1].numel(), process_group, **(exchange_opts or {}))
+                # overlap_comm: the buffer is exchanged as head [all years' first segments | year flags] + tail [the years'
+                # first-conv weights]; the head's sum over the ranks rides in the years' grouped first-conv weight-gradient
+                # launch (dta_ensemble_backward_xchg), as FusedTrainer's does in dta_net_backward_xchg
+                self.ex = PeerExchange(self.flat[1].numel(), process_group, split=(_round4(n_head + Y) if overlap_comm else 0),
+                                       **(exchange_opts or {}))
                 assert self.ex.capacity == self.flat[1].numel()
                 self.flat[1] = self.ex.grad           # the gradient buffer every peer has mapped
         self.years = []
-        if world == 1:
+        if not self.comm:
             # no exchange: each year's two segments adjacent, so its optimizer pass is one launch; flags unused
             off = 0
             for m, (h, t) in zip(mods, sizes):
@@ -651,9 +693,11 @@ class EnsembleTrainer:
                 to += t
         first = self.years[0]
         self.device, self.world, self.pg = first.device, first.world, first.pg
-        self.overlap, self.keep_grads = first.overlap and self.exchange in (None, "torch"), bool(keep_grads)
+        self.overlap, self.keep_grads = bool(overlap_comm) and self.exchange in ("torch", "rccl"), bool(keep_grads)
+        self.overlap_comm = bool(self.overlap or (self.ex is not None and self.ex.split))      # what bench.py reports
         self.betas, self.eps = betas, float(eps)
         self.sync = first.sync if self.exchange != "rccl" else GradSync(world, process_group, rccl=RcclDirect(process_group))
+        self.world = world
         self.loss_weight = first.loss_weight
         self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self._shape = None
@@ -663,14 +707,15 @@ class EnsembleTrainer:
         # other); single process: only the device-decided steps (present=None) use them, see _counters_to
         self.dev_steps = torch.zeros(2, Y, dtype=torch.int32, device=dev)
         self._bank = 0
-        self._counters_on = "device" if self.world > 1 else "host"
+        self._counters_on = "device" if self.comm else "host"
         # this rank's 0/1 year flags (dta_year_flags): two banks used alternately, each call clears the other one
         self._flag_banks = torch.zeros(2, Y, dtype=torch.float32, device=dev)
         self._flag_bank = 0
         self.local_flags = self._flag_banks[0]
         self.kept_dev = torch.zeros(2, dtype=torch.float32, device=dev)        # {years kept, 1 / years kept} of the last forward
-        if self.world > 1:
-            self.sync.broadcast([self.flat[0]] + list(model.buffers()), 0)
+        if self.comm:
+            if self.world > 1:
+                self.sync.broadcast([self.flat[0]] + list(model.buffers()), 0)
             # the 2^Y possible flag vectors, resident on the device: setting the flags is a device-to-device copy
             self._flag_table = torch.tensor([[(mask >> i) & 1 for i in range(Y)] for mask in range(1 << Y)],
                                             dtype=torch.float32, device=dev)
@@ -694,7 +739,7 @@ class EnsembleTrainer:
         """Single process: steps with `present=` count on the host (one optimizer launch per kept year), device-decided
         steps (present=None) on the device.  Mixing the two moves the counts across once per switch (one small transfer,
         device -> host being a synchronisation); a loop that sticks to one form never pays it."""
-        if self.world > 1 or where == self._counters_on:
+        if self.comm or where == self._counters_on:
             return
         if where == "device":
             self.dev_steps[self._bank].copy_(torch.tensor([t.step_count for t in self.years], dtype=torch.int32))
@@ -767,7 +812,7 @@ class EnsembleTrainer:
         if len(images) != len(self.years):
             raise ValueError("expected one image tensor per year ({}), got {}".format(len(self.years), len(images)))
         local = [bool(k) for k in present]      # (present=None never comes here: that decision is taken on the device)
-        if not any(local) and self.world == 1:
+        if not any(local) and not self.comm:
             raise RuntimeError("every year of the batch is all-zero: the reference has nothing to average (year.py:33)")
         return local
 
@@ -848,6 +893,18 @@ class EnsembleTrainer:
         self._live = xs
         return list(range(Y))
 
+    def _backward_xchg(self, kept, gate=None):
+        """The whole backward with the exchange's head segment (every gradient but the years' first-conv weights, and the
+        year flags) summed over the ranks by spare workgroups of the years' first-conv weight-gradient launch."""
+        L = _lib.lib()
+        for i in kept:
+            self.years[i]._zero_grads()
+        _lib.check(L.dta_ensemble_backward_xchg(C.byref(self._desc), len(kept), self._nets, _lib.ptr(self._ws),
+                                                _lib.ptr(self.dscores), self._grads, _lib.ptr(gate), self.ex._h,
+                                                _lib.current_stream_ptr()), "dta_ensemble_backward_xchg")
+        for i in kept:
+            self.years[i]._grads_clear = False
+
     def _backward(self, kept, phases=3, gate=None):
         """gate (device, float[len(kept)]): this rank's year flags of a device-decided step -- a year whose flag is 0 gets
         EXACT-ZERO gradients (reference year.py:27-28: a skipped year has no gradient), so a data-parallel rank whose
@@ -918,7 +975,7 @@ class EnsembleTrainer:
             self._counters_to("device")
             kept = self._forward_gated(images)
             self._ce(y, True, None)
-            if self.world == 1:
+            if not self.comm:
                 self._backward(kept)
                 self._adam_gated(self.local_flags)
                 return self.loss
@@ -927,7 +984,7 @@ class EnsembleTrainer:
             local = self._kept(images, present)
             kept = self._forward(images, local)
             self._ce(y, True, len(kept))
-            if self.world == 1:
+            if not self.comm:
                 self._counters_to("host")
                 self._backward(kept)
                 for i, t in enumerate(self.years):
@@ -937,9 +994,12 @@ class EnsembleTrainer:
             local_flags = self._flag_table[sum(1 << i for i, k in enumerate(local) if k)]
         # data-parallel: every rank issues the same collectives whatever it kept; skipped years send their zeros
         if self.ex is not None:
-            self._backward(kept, 3, gate)
-            self.flags.copy_(local_flags)
-            self.ex.allreduce()                 # gradients and year flags summed over the ranks in one launch
+            self.flags.copy_(local_flags)       # (before the backward: the flags ride in the head segment)
+            if self.ex.split:
+                self._backward_xchg(kept, gate) # head summed beside the first convs' weight gradients
+            else:
+                self._backward(kept, 3, gate)
+            self.ex.allreduce()                 # gradients and year flags summed over the ranks in one launch (head done: the tail)
         elif self.overlap:
             self._backward(kept, 1, gate)
             self.flags.copy_(local_flags)

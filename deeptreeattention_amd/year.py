@@ -178,13 +178,7 @@ class learned_ensemble(nn.Module):
             else:
                 base_model = Hang2020.spectral_network(bands=config["bands"], classes=classes)
             self.year_models.append(base_model)
-        # an optimizer built from .parameters() (optim.DtaAdam) finds each year's parameters through this registry and
-        # steps them under that year's device-side "kept" flag
-        import weakref
-        me = weakref.ref(self)
-        for y, m in enumerate(self.year_models):
-            for p in m.parameters():
-                Hang2020._PARAM_GATE[id(p)] = (me, y)
+        self._register_gates()
         # device-side "year kept" flags (each a (Y,) float32 tensor of 0 / 1):
         #   _pending_flags: one tensor per TRAINING forward since the owning optimizer's last step -- the forward's own
         #     tensor (its backward reads exactly that one, whatever other forwards run in between); optim.DtaAdam steps a year
@@ -195,6 +189,24 @@ class learned_ensemble(nn.Module):
         self.__dict__["local_flags"] = None
         self.__dict__["_pending_flags"] = []
         self.__dict__["_scratch_flags"] = None
+
+    def _register_gates(self):
+        """An optimizer built from .parameters() (optim.DtaAdam) finds each year's parameters through this registry and
+        steps them under that year's device-side "kept" flag.  Keyed by Parameter OBJECT: repeated wherever the objects
+        can change -- construction, copy.deepcopy / unpickling (__setstate__), load_state_dict(assign=True) (_plist)."""
+        import weakref
+        me = weakref.ref(self)
+        for y, m in enumerate(self.year_models):
+            for p in m.parameters():
+                Hang2020._PARAM_GATE[id(p)] = (me, y)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        # a copy starts with no training forward pending, its own scratch banks, and ITS parameters in the registry
+        self.__dict__["local_flags"] = None
+        self.__dict__["_pending_flags"] = []
+        self.__dict__["_scratch_flags"] = None
+        self._register_gates()
 
     def _tables(self, shape, params):
         """Cached (descriptor, parameter pointer tables, workspace bytes) of the grouped launch over ALL years."""
@@ -236,6 +248,7 @@ class learned_ensemble(nn.Module):
         hit = cache.get("plist")
         if hit is None or hit[0] != epoch:
             hit = cache["plist"] = (epoch, [p for m in self.year_models for p in m._param_list()])
+            self._register_gates()
         return hit[1]
 
     def _next_flags(self, dev, publish):

@@ -145,6 +145,17 @@ int dta_net_backward_xchg(const dta_net_desc* d, const dta_subnet_params* nets, 
  *  scratch : batch + 2 floats; the LAST 32-bit word must be zero on entry and is zero again on return (block counter) */
 int dta_net_loss(const dta_net_desc* d, const double* alpha, void* workspace, const long long* labels, const float* weight,
                  float* joint, float* loss, float* dlogits, float* scratch, void* stream);
+/* Forward AND loss of a single-score network (Hang2020, vanilla_CNN) in one call: what TreeModel.training_step does in
+ * `y_hat = self.model.forward(images); loss = F.cross_entropy(y_hat, y, weight=self.loss_weight)` (reference src/main.py:77-78;
+ * validation_step :88-89 with dlogits = NULL).  Same results as dta_net_forward (built with DTA_SKIP_BLEND) followed by
+ * dta_net_loss.  For a training-mode Hang2020 on 11x11 patches the third stage of both branches, the two last heads, the
+ * blend and the loss are ONE launch (the forward ends two launches earlier than dta_net_forward + dta_net_loss).
+ *  x / x_tiles : the input as float32 NCHW [batch][bands][H][W], or (bf16 mode, x = NULL) as the first conv's tiles
+ *                (dta_preprocess_crops_tiles) -- exactly one of the two
+ *  labels, weight, joint, loss, dlogits, scratch : as for dta_net_loss (vanilla_CNN: joint receives the scores, required) */
+int dta_net_forward_loss(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, const float* x,
+                         const void* x_tiles, void* workspace, const long long* labels, const float* weight, float* joint,
+                         float* loss, float* dlogits, float* scratch, void* stream);
 
 /* ---- Year ensemble (reference src/models/year.py:9-33): `years` (1..DTA_MAX_YEARS) spectral_networks, each on its own
  * input, run as the groups of ONE set of launches (a third of the launches of `years` separate dta_net_* calls);
@@ -189,6 +200,17 @@ int dta_ensemble_backward_phased(const dta_net_desc* d, int years, const dta_sub
 int dta_ensemble_backward_gated(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
                                 const float* dscore, const dta_subnet_grads* grads, const float* gate, int phases,
                                 void* stream);
+/* dta_ensemble_backward_gated (phases = 3) for a data-parallel caller whose gradients live in a peer exchange object with a
+ * head / tail split (dta_xchg_set_split; declared below): the head -- every gradient of every year except the years'
+ * first-conv weights, plus whatever the caller keeps in it (its year flags) -- is complete before the years' grouped
+ * first-conv weight-gradient launch, whose spare workgroups sum this rank's shard of the head over the ranks through
+ * peer memory while the matrix cores work (as dta_net_backward_xchg does for one network; reference multi_stage.py:277-288
+ * under train.py:89-98's DDP).  The dta_xchg_allreduce that follows finds the head summed.  Plans without a combined
+ * kernel (fp32 mode, launches that fill every CU): exactly dta_ensemble_backward_gated, the exchange sums both segments. */
+struct dta_xchg;
+int dta_ensemble_backward_xchg(const dta_net_desc* d, int years, const dta_subnet_params* nets, void* workspace,
+                               const float* dscore, const dta_subnet_grads* grads, const float* gate, struct dta_xchg* xchg,
+                               void* stream);
 
 /* ---- Crop preprocessing on the device: replaces load_image / preprocess_image (src/utils.py:36-79: drop the first and
  * last `clip` bands when there are more than 3, float32, per-pixel min-max over the bands as

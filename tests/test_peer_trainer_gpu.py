@@ -140,13 +140,20 @@ def _pair_worker(rank, world, port, kind, exchange, out):
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     torch.manual_seed(11)
+    tag = exchange
+    overlap = exchange != "peer0"          # "peer0": the peer exchange without the overlapped head segment
+    exchange = "peer" if exchange == "peer0" else exchange
     opts = {"max_workgroups": 32, "timeout_s": 30.0} if exchange == "peer" else None
     B, bands, classes = 6, 20, 7
     losses = []
     if kind == "ensemble":
         from deeptreeattention_amd.year import learned_ensemble
         m = learned_ensemble(3, classes, {"pretrain_state_dict": None, "bands": bands}).to(dev).train()
-        tr = EnsembleTrainer(m, lr=1e-3, exchange=exchange, exchange_opts=opts)
+        for net in m.year_models:
+            net.precision = "bf16"         # (the combined weight-gradient + exchange kernel is a bf16 program)
+        tr = EnsembleTrainer(m, lr=1e-3, exchange=exchange, exchange_opts=opts, overlap_comm=overlap)
+        if exchange == "peer":             # overlapped: head = all years' first segments + the year flags
+            assert (tr.ex.split == tr.n_head and tr.overlap_comm) if overlap else (tr.ex.split == 0 and not tr.overlap_comm)
         for step in range(3):
             imgs = [torch.from_numpy(prng.uniform01(500 + 10 * step + rank, yy, (B, bands, 11, 11))).to(dev) for yy in range(3)]
             if rank == 0:
@@ -162,7 +169,10 @@ def _pair_worker(rank, world, port, kind, exchange, out):
         for mod in m.modules():
             if isinstance(mod, torch.nn.Dropout):
                 mod.p = 0.0
-        tr = MetadataTrainer(m, lr=1e-3, exchange=exchange, exchange_opts=opts)
+        m.sensor_model.precision = m.sensor_model.spectral_network.precision = m.sensor_model.spatial_network.precision = "bf16"
+        tr = MetadataTrainer(m, lr=1e-3, exchange=exchange, exchange_opts=opts, overlap_comm=overlap)
+        if exchange == "peer":             # overlapped: the small parameters' slots ride in the head segment
+            assert (tr.sensor.ex.split == tr.sensor.split and tr.sensor.overlap) if overlap else tr.sensor.ex.split == 0
         for step in range(3):
             x = torch.from_numpy(prng.uniform01(600 + 10 * step + rank, 1, (B, bands, 11, 11))).to(dev)
             site = torch.from_numpy(prng.randint(600 + rank, 3, (B,), 4)).to(dev)
@@ -171,7 +181,7 @@ def _pair_worker(rank, world, port, kind, exchange, out):
         steps = None
     torch.cuda.synchronize()
     (tr if kind == "ensemble" else tr.sensor).close()
-    out[(exchange, rank)] = ({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, losses, steps)
+    out[(tag, rank)] = ({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, losses, steps)
     dist.destroy_process_group()
 
 
@@ -182,16 +192,19 @@ def test_peer_exchange_matches_collective_path(kind):
     ranks: a + b in either order) the same bits."""
     mgr = mp.Manager()
     out = mgr.dict()
-    for exchange in ("torch", "peer"):
-        mp.spawn(_pair_worker, args=(2, _free_port(), kind, exchange, out), nprocs=2, join=True)
+    for exchange in ("torch", "peer", "peer0"):      # torch.distributed buckets; peer overlapped (head summed beside the first
+        mp.spawn(_pair_worker, args=(2, _free_port(), kind, exchange, out), nprocs=2, join=True)      # convs' weight gradients); peer plain
     for rank in range(2):
-        a, b = out[("torch", rank)], out[("peer", rank)]
-        assert a[1] == b[1] and a[2] == b[2]
-        for k in a[0]:
-            if kind == "metadata":
-                # (the metadata trainer's small torch parameters ride through different collectives on the two paths)
-                assert np.allclose(a[0][k], b[0][k], rtol=1e-5, atol=1e-7), (rank, k)
-            else:
-                assert np.array_equal(a[0][k], b[0][k]), (rank, k)
+        for form in ("peer", "peer0"):
+            a, b = out[("torch", rank)], out[(form, rank)]
+            assert a[1] == b[1] and a[2] == b[2], form
+            for k in a[0]:
+                if kind == "metadata":
+                    # (the metadata trainer's small torch parameters ride through different collectives on the two paths)
+                    assert np.allclose(a[0][k], b[0][k], rtol=1e-5, atol=1e-7), (form, rank, k)
+                else:
+                    assert np.array_equal(a[0][k], b[0][k]), (form, rank, k)
+        for k in out[("peer", rank)][0]:                  # the two peer forms sum in the same (rank) order: same bits
+            assert np.array_equal(out[("peer", rank)][0][k], out[("peer0", rank)][0][k]), (rank, k)
     if kind == "ensemble":
-        assert out[("peer", 0)][2] == [3, 3, 2]
+        assert out[("peer", 0)][2] == [3, 3, 2] and out[("peer0", 0)][2] == [3, 3, 2]

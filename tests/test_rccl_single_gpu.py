@@ -87,6 +87,22 @@ def test_one_rank_direct_exchanges_match_plain_step(tmp_path, exch):
             assert torch.allclose(ref[k].float(), got[k].float(), rtol=1e-4, atol=1e-6), k
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_one_rank_rccl_side_stream_overlap_matches_plain_step(tmp_path, prec):
+    """north_star's literal design: ncclAllReduce (librccl called directly) of the first bucket on a SIDE HIP stream, forked
+    from the compute stream by an event after backward phase 1, running beside the first conv's weight gradient; the second
+    bucket behind it; one event joins the compute stream before the optimizer (dist.RcclDirect.all_reduce_side / join: HIP
+    streams and events only, no torch.distributed work objects).  One rank: the sums are identities, so the three steps
+    must reproduce the plain single-process step; two collectives per step."""
+    ref = _run(tmp_path, "plain", False, True, prec)
+    got = _run(tmp_path, "rccl_overlap", True, True, prec, "rccl")
+    for k in ref:
+        if k == "alpha":
+            assert abs(float(ref[k]) - float(got[k])) < 1e-7
+        else:
+            assert torch.allclose(ref[k].float(), got[k].float(), rtol=1e-4, atol=1e-6), k
+
+
 @pytest.mark.parametrize("mode", ["plain", "rccl", "torch", "peer"])
 def test_reruns_in_separate_processes_are_bit_identical(tmp_path, mode):
     """Three bf16 steps, twice, each in its own process: every tensor of the state dict has the same bits -- no float atomics
