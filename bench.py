@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--rccl-side-stream", action="store_true",
+                    help="with --exchange rccl: two buckets on a side HIP stream overlapped with the backward (default: one collective on the compute stream)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "peer", "rccl", "torch"],
                     help="gradient exchange when data-parallel: peer = sum over ranks + Adam in one launch through "
                          "IPC-mapped peer memory (csrc/xchg.hip), rccl = one ncclAllReduce on the compute stream, torch = "

@@ -63,6 +63,14 @@ class AttentionDesc(C.Structure):
     _fields_ = [("batch", C.c_int), ("filters", C.c_int), ("height", C.c_int), ("width", C.c_int), ("kind", C.c_int)]
 
 
+class AdamSegment(C.Structure):     # dta_adam_segment
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_size_t),
+                ("active", C.c_void_p), ("dev_step", C.c_void_p), ("dev_step_next", C.c_void_p), ("step", C.c_int)]
+
+
+ADAM_MAX_SEGMENTS = 8   # DTA_ADAM_MAX_SEGMENTS
+
+
 class MetaParams(C.Structure):      # dta_meta_params
     _fields_ = [("emb", C.c_void_p), ("bn_w", C.c_void_p), ("bn_b", C.c_void_p), ("bn_rm", C.c_void_p), ("bn_rv", C.c_void_p),
                 ("bn_nbt", C.c_void_p), ("mlp_w", C.c_void_p), ("mlp_b", C.c_void_p), ("fc_w", C.c_void_p), ("fc_b", C.c_void_p)]
@@ -143,6 +151,13 @@ def lib():
         L.dta_net_loss.restype = C.c_int
         L.dta_net_loss.argtypes = [C.POINTER(NetDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_ensemble_forward_loss.restype = C.c_int
+        L.dta_ensemble_forward_loss.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(SubnetParams), C.POINTER(C.c_void_p), C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]
+        L.dta_adam_step_multi.restype = C.c_int
+        L.dta_adam_step_multi.argtypes = [C.c_int, C.POINTER(AdamSegment), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          C.c_int, C.c_void_p]
         L.dta_net_forward_loss.restype = C.c_int
         L.dta_net_forward_loss.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1013,6 +1013,29 @@ static int ensemble_forward_impl(const dta_net_desc* d, int years, const dta_sub
   return launch_mean_scores(ma, st);
 }
 
+int dta_ensemble_forward_loss(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
+                              const float* gate, void* workspace, const long long* labels, const float* weight,
+                              float* mean_scores, float* kept, float* loss, float* dscore, float* scratch, void* stream) {
+  Plan p; dta_net_desc dd;
+  if (!nets || !x || !workspace || !labels || !loss || !scratch) { dta_set_error("dta_ensemble_forward_loss: null argument"); return 1; }
+  if (ensemble_desc(d, years, &dd, &p, "dta_ensemble_forward_loss")) return 1;
+  for (int g = 0; g < years; ++g)
+    if (!x[g]) { dta_set_error("dta_ensemble_forward_loss: null input for year %d", g); return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (dd.dtype == DTA_BF16) rc = forward_t<bf16_t>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st, nullptr, gate);
+  else if (dd.dtype == DTA_F32) rc = forward_t<float>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st, nullptr, gate);
+  else { dta_set_error("unknown dtype %d", dd.dtype); return 1; }
+  if (rc) return rc;
+  BlendCeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gscale = 1.f;
+  for (int g = 0; g < years; ++g) a.src[g] = at<float>(workspace, p.scores[g][2]);
+  a.nsrc = years; a.src_gate = gate; a.kept_out = kept; a.joint = mean_scores;
+  a.labels = labels; a.weight = weight; a.dlogits = dscore; a.loss = loss; a.rowtmp = scratch; a.B = p.B; a.classes = p.classes;
+  return launch_blend_ce(a, st);
+}
+
 int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
                          void* workspace, float* mean_scores, void* stream) {
   return ensemble_forward_impl(d, years, nets, x, nullptr, workspace, mean_scores, nullptr, stream);
@@ -1200,6 +1223,31 @@ int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const 
   if (dev_step_next == dev_step) { dta_set_error("dta_adam_step_gated: dev_step_next must be a different word than dev_step"); return 1; }
   return adam_step_impl(p, g, zero_grad ? g : nullptr, m, v, n, nullptr, nullptr, nullptr, nullptr, nullptr, 0, lr, beta1, beta2, eps,
                         grad_scale, stream, active, dev_step, nullptr, dev_step_next);
+}
+
+int dta_adam_step_multi(int nseg, const dta_adam_segment* segs, float lr, float beta1, float beta2, float eps, float grad_scale,
+                        int zero_grad, void* stream) {
+  if (nseg < 1 || nseg > DTA_ADAM_MAX_SEGMENTS || !segs) { dta_set_error("dta_adam_step_multi: 1..%d segments", DTA_ADAM_MAX_SEGMENTS); return 1; }
+  static_assert(DTA_ADAM_MAX_SEGMENTS == ADAM_MAX_SEG, "header and kernel disagree");
+  AdamMulti mm;
+  memset(&mm, 0, sizeof(mm));
+  mm.n = nseg;
+  for (int i = 0; i < nseg; ++i) {
+    const dta_adam_segment& sgm = segs[i];
+    if (sgm.n && (!sgm.p || !sgm.g || !sgm.m || !sgm.v)) { dta_set_error("dta_adam_step_multi: segment %d: null buffer", i); return 1; }
+    if (sgm.active ? !sgm.dev_step : sgm.step < 1) { dta_set_error("dta_adam_step_multi: segment %d: a gated segment needs a device step counter, an ungated one a step count >= 1", i); return 1; }
+    if (sgm.dev_step_next && sgm.dev_step_next == sgm.dev_step) { dta_set_error("dta_adam_step_multi: segment %d: dev_step_next must be a different word than dev_step", i); return 1; }
+    AdamArgs& a = mm.seg[i];
+    a.p = sgm.p; a.g = sgm.g; a.m = sgm.m; a.v = sgm.v; a.n = sgm.n;
+    a.gz = zero_grad ? sgm.g : nullptr;
+    a.active = sgm.active; a.dev_step = sgm.dev_step; a.dev_step_out = sgm.dev_step_next;
+    a.g_inactive = sgm.active ? sgm.g : nullptr;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
+    const int step = sgm.active ? 1 : sgm.step;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  }
+  return launch_adam_multi(mm, (hipStream_t)stream);
 }
 
 int dta_adam_step_zero_grad(float* p, float* g, float* m, float* v, size_t n, double* alpha_p, double* alpha_g,

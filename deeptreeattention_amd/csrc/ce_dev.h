@@ -75,11 +75,26 @@ __device__ __forceinline__ void blend_ce_body(const BlendCeArgs& a, float* sc, d
   const double alpha0 = pre ? pre->alpha0 : (a.spat ? a.alpha[0] : 0.0);
   const float* zs = a.spec + (size_t)rowc * a.classes;
   const float* zt = a.spat ? a.spat + (size_t)rowc * a.classes : nullptr;
+  // year ensemble: mean over the kept sources, the arithmetic of k_mean_scores (heads.hip)
+  float mkept = 0.f;
+  unsigned muse = 0u;
+#pragma unroll
+  for (int k = 0; k < MAXG; ++k)
+    if (k < a.nsrc && (!a.src_gate || a.src_gate[k] > 0.f)) { muse |= 1u << k; mkept += 1.f; }
+  const float minv = 1.f / mkept;
+  auto mean_at = [&](int n) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXG; ++k)
+      if ((muse >> k) & 1u) acc += a.src[k][(size_t)rowc * a.classes + n];
+    return acc * minv;
+  };
+  if (a.nsrc > 0 && a.kept_out && blockIdx.x == 0 && t == 0) { a.kept_out[0] = mkept; a.kept_out[1] = minv; }
   float zsr[4], ztr[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int n = lane + 64 * k;
-    zsr[k] = n < a.classes ? zs[n] : 0.f;
+    zsr[k] = n < a.classes ? (a.nsrc > 0 ? mean_at(n) : zs[n]) : 0.f;
     ztr[k] = (zt && n < a.classes) ? zt[n] : 0.f;
   }
   const long long y = pre ? pre->y : a.labels[rowc];
@@ -91,7 +106,7 @@ __device__ __forceinline__ void blend_ce_body(const BlendCeArgs& a, float* sc, d
   const bool ok = y >= 0 && y < a.classes;
   const double wd = 1.0 / (1.0 + exp(-alpha0));
   const float w = (float)wd, w1 = (float)(1.0 - wd);
-  auto zval = [&](int n) { return zt ? blend2(zs[n], zt[n], w, w1) : zs[n]; };
+  auto zval = [&](int n) { return a.nsrc > 0 ? mean_at(n) : (zt ? blend2(zs[n], zt[n], w, w1) : zs[n]); };
   // the first 256 classes of the row live in registers (four per lane); wider rows re-read the rest
   float zc[4];
 #pragma unroll
@@ -130,12 +145,12 @@ __device__ __forceinline__ void blend_ce_body(const BlendCeArgs& a, float* sc, d
     float* jo = a.joint ? a.joint + (size_t)row * a.classes : nullptr;
     // device-decided factor (1 / kept years): an infinite one says this rank kept NO year -- its scores are NaN (an empty
     // mean, as the reference raises there) and it must contribute nothing to a data-parallel gradient sum: exact zeros
-    const float gs = a.gscale_dev ? a.gscale_dev[0] : a.gscale;
-    const bool none_kept = a.gscale_dev && !(gs < 3.0e38f);
+    const float gs = a.nsrc > 0 ? minv : (a.gscale_dev ? a.gscale_dev[0] : a.gscale);
+    const bool none_kept = (a.nsrc > 0 || a.gscale_dev) && !(gs < 3.0e38f);
     const float sc2 = (den > 0.f ? wy / den : 0.f) * gs + poison;
     for (int n = lane, k = 0; n < a.classes; n += 64, ++k) {
       const float z = zget(n, k);
-      if (jo && jo != zs) jo[n] = z;
+      if (jo && (a.nsrc > 0 || jo != zs)) jo[n] = z;
       if (a.dlogits) {
         float dv = none_kept ? 0.f : sc2 * (__expf(z - mx - lse) - ((ok && n == (int)y) ? 1.f : 0.f));
         if (a.relu_mask && !(z > 0.f)) dv = 0.f;      // the scores are a ReLU's output: the gradient w.r.t. its input

@@ -741,7 +741,7 @@ int launch_softmax_top2(const float* logits, int B, int classes, float* probs, l
 // ------------------------------------------------------------------------------------------------
 // torch.optim.Adam (defaults: no weight decay, no amsgrad) over one flat fp32 buffer + the fp64 alpha.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_adam(AdamArgs a) {
+__device__ __forceinline__ void adam_block(const AdamArgs& a) {
   float bc1 = a.bc1, bc2 = a.bc2;
   if (a.active) {
     // the step count advances on the device too: dev_step = steps taken so far, dev_step_out (a DIFFERENT word, read
@@ -813,6 +813,21 @@ __global__ void k_adam(AdamArgs a) {
     if (a.gz) a.gz[i] = 0.f;
   }
   if (a.alpha_p && !a.alpha_g32 && blockIdx.x == 0 && threadIdx.x == 0) alpha_update(a.alpha_g[0]);
+}
+__global__ void k_adam(AdamArgs a) { adam_block(a); }
+// several parameter groups in one launch (a year ensemble's per-year optimizers): blockIdx.y picks the group
+__global__ void k_adam_multi(AdamMulti m) { adam_block(m.seg[blockIdx.y]); }
+int launch_adam_multi(const AdamMulti& m, hipStream_t st) {
+  size_t most = 1;
+  for (int i = 0; i < m.n; ++i) {
+    const AdamArgs& a = m.seg[i];
+    const bool vec = (a.n & 3) == 0 && ((((size_t)a.p | (size_t)a.g | (size_t)a.m | (size_t)a.v | (size_t)a.gz) & 15) == 0);
+    const size_t items = vec ? a.n / 4 : a.n;
+    most = max(most, min((size_t)2048, (items + 255) / 256));
+  }
+  hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)most, m.n), dim3(256), 0, st, m);
+  DTA_CHECK_LAUNCH("k_adam_multi");
+  return 0;
 }
 int launch_adam(const AdamArgs& a, hipStream_t st) {
   // (workgroups for the 16-byte form: a quad per thread)

@@ -355,7 +355,9 @@ struct GemmArgs {
   // the ReLU's output)
   int relu; const float* mask; long mask_m;
 };
-constexpr int GEMM_GROUP_MAX = 12;
+// (22: the 21 deferred parameter-gradient GEMMs of a three-year ensemble ride in the step's last launch instead of forcing a
+//  flush in the middle of the backward; 22 x 160 B + the slab-reduction jobs stay inside the 4 KB kernel-argument segment)
+constexpr int GEMM_GROUP_MAX = 22;
 struct GemmGroup {
   GemmArgs g[GEMM_GROUP_MAX];
   int start[GEMM_GROUP_MAX + 1];
@@ -500,6 +502,11 @@ struct BlendCeArgs {
   float gscale = 1.f;      // factor on dlogits only (year ensemble: d(mean over kept years) / d(year score))
   const float* gscale_dev = nullptr;   // non-null: the factor is read from the device (decided there: kept years)
   int relu_mask = 0;                   // the scores are a ReLU's output: dlogits is the gradient w.r.t. the ReLU's INPUT
+  // year ensemble (nsrc > 0): the scores are the MEAN over the kept sources (reference year.py:33), formed on the fly exactly as
+  // k_mean_scores forms it (sum in source order, selected by src_gate > 0 -- NULL = all --, times 1 / kept); `joint` receives
+  // the mean, kept_out (may be NULL) {kept, 1 / kept}, and dlogits = d(loss)/d(ONE source's scores) = d(loss)/d(mean) / kept
+  // (gscale / gscale_dev are ignored); nothing kept: NaN scores and loss, exact-zero dlogits
+  const float* src[MAXG] = {nullptr, nullptr, nullptr, nullptr}; int nsrc = 0; const float* src_gate = nullptr; float* kept_out = nullptr;
 };
 int launch_blend_ce(const BlendCeArgs& a, hipStream_t st);
 // ---- stage.hip: fused forward tail of Hang2020 on 11x11 patches ------------------------------------------------------
@@ -532,6 +539,9 @@ struct AdamArgs {
   float* g_inactive = nullptr;         // gated: a group that is not stepped has no gradient -- its buffer is cleared whatever gz says
 };
 int launch_adam(const AdamArgs& a, hipStream_t st);
+constexpr int ADAM_MAX_SEG = 8;
+struct AdamMulti { AdamArgs seg[ADAM_MAX_SEG]; int n; };
+int launch_adam_multi(const AdamMulti& m, hipStream_t st);      // blockIdx.y = segment
 int launch_softmax_top2(const float* logits, int B, int classes, float* probs, long long* top_idx, float* top_score,
                         hipStream_t st);
 

@@ -90,7 +90,14 @@ class FusedTrainer:
         # overlapped exchange: "peer": the head bucket's sum rides in the first conv's weight-gradient launch; "rccl" / "torch":
         # two buckets, the first all-reduced on a side stream while the first conv's weight gradient is computed
         # (a one-rank group under DTA_FORCE_COLLECTIVES takes the overlapped launch order too: that is what its cost measurement is for)
-        self.overlap = bool(overlap_comm and self.comm and self.exchange in (None, "torch", "rccl", "peer"))
+        # "rccl": the side-stream two-bucket form (north_star's literal design) only on request, exchange_opts={"side_stream":
+        # True}: measured with one rank (tools/dp_one_rank.py, profiles/r05_dp_one_rank.txt) its two event forks and the join cost
+        # +43 us per 0.52 ms step before a byte moves, the single collective on the compute stream +3 us -- more than the
+        # ~25 us of wire time the overlap can hide at 8 ranks
+        opts = dict(exchange_opts or {})
+        side_stream = bool(opts.pop("side_stream", False))
+        exchange_opts = opts or None
+        self.overlap = bool(overlap_comm and self.comm and (self.exchange in (None, "torch", "peer") or (self.exchange == "rccl" and side_stream)))
         self.hang = model._net_code == _lib.NET_HANG2020
         self.single_score = model._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
         self.three_head = bool(three_head_loss)
@@ -667,7 +674,7 @@ class EnsembleTrainer:
                 # first-conv weights]; the head's sum over the ranks rides in the years' grouped first-conv weight-gradient
                 # launch (dta_ensemble_backward_xchg), as FusedTrainer's does in dta_net_backward_xchg
                 self.ex = PeerExchange(self.flat[1].numel(), process_group, split=(_round4(n_head + Y) if overlap_comm else 0),
-                                       **(exchange_opts or {}))
+                                       **{k: v for k, v in (exchange_opts or {}).items() if k != "side_stream"})
                 assert self.ex.capacity == self.flat[1].numel()
                 self.flat[1] = self.ex.grad           # the gradient buffer every peer has mapped
         self.years = []
@@ -693,7 +700,9 @@ class EnsembleTrainer:
                 to += t
         first = self.years[0]
         self.device, self.world, self.pg = first.device, first.world, first.pg
-        self.overlap, self.keep_grads = bool(overlap_comm) and self.exchange in ("torch", "rccl"), bool(keep_grads)
+        side_stream = bool((exchange_opts or {}).get("side_stream", False))      # (rccl: see FusedTrainer)
+        self.overlap = bool(overlap_comm) and (self.exchange == "torch" or (self.exchange == "rccl" and side_stream))
+        self.keep_grads = bool(keep_grads)
         self.overlap_comm = bool(self.overlap or (self.ex is not None and self.ex.split))      # what bench.py reports
         self.betas, self.eps = betas, float(eps)
         self.sync = first.sync if self.exchange != "rccl" else GradSync(world, process_group, rccl=RcclDirect(process_group))
@@ -823,8 +832,10 @@ class EnsembleTrainer:
             self.ce_scratch = torch.zeros(B + 2, dtype=torch.float32, device=self.device)   # (last word: block counter)
             self._shape = (B, classes)
 
-    def _forward(self, images, local):
-        """All kept years as the groups of one set of launches (dta_ensemble_forward); self.scores = their mean."""
+    def _forward(self, images, local, loss_y=None, want_grad=True):
+        """All kept years as the groups of one set of launches (dta_ensemble_forward); self.scores = their mean.
+        loss_y (labels): also the level's weighted cross-entropy -> self.loss, d(loss)/d(one year's scores) -> self.dscores,
+        in the same C-ABI call (dta_ensemble_forward_loss)."""
         L = _lib.lib()
         kept = [i for i, k in enumerate(local) if k]
         if not kept:
@@ -849,12 +860,20 @@ class EnsembleTrainer:
                 raise RuntimeError("dta_ensemble_workspace_bytes: " + L.dta_last_error().decode())
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._ws_key = ws_key
-        _lib.check(L.dta_ensemble_forward(C.byref(self._desc), n, self._nets, self._xptr, _lib.ptr(self._ws),
-                                          _lib.ptr(self.scores), _lib.current_stream_ptr()), "dta_ensemble_forward")
+        if loss_y is not None:
+            # forward + the level's loss in one call: the mean over the years is formed inside the loss launch
+            self.loss = torch.empty((), dtype=torch.float32, device=self.device)      # fresh per step (see FusedTrainer._loss)
+            _lib.check(L.dta_ensemble_forward_loss(C.byref(self._desc), n, self._nets, self._xptr, None, _lib.ptr(self._ws),
+                                                   _lib.ptr(loss_y), _lib.ptr(self.loss_weight), _lib.ptr(self.scores), None,
+                                                   _lib.ptr(self.loss), _lib.ptr(self.dscores) if want_grad else None,
+                                                   _lib.ptr(self.ce_scratch), _lib.current_stream_ptr()), "dta_ensemble_forward_loss")
+        else:
+            _lib.check(L.dta_ensemble_forward(C.byref(self._desc), n, self._nets, self._xptr, _lib.ptr(self._ws),
+                                              _lib.ptr(self.scores), _lib.current_stream_ptr()), "dta_ensemble_forward")
         self._live = xs     # inputs stay referenced until the step's launches are enqueued
         return kept
 
-    def _forward_gated(self, images):
+    def _forward_gated(self, images, loss_y=None, want_grad=True):
         """All years as the groups of one set of launches, the missing-year decision (reference year.py:27) taken ON THE
         DEVICE: dta_year_flags -> self.local_flags, dta_ensemble_forward_gated (a flagged-off year is left out of the mean
         and keeps its BatchNorm statistics), 1 / kept years left in self.kept_dev[1] for the loss launch.  No host
@@ -887,9 +906,17 @@ class EnsembleTrainer:
         self.local_flags = self._flag_banks[self._flag_bank]
         _lib.check(L.dta_year_flags(self._xptr, Y, xs[0].numel(), _lib.ptr(self.local_flags),
                                     _lib.ptr(self._flag_banks[self._flag_bank ^ 1]), st), "dta_year_flags")
-        _lib.check(L.dta_ensemble_forward_gated(C.byref(self._desc), Y, self._nets, self._xptr, _lib.ptr(self.local_flags),
-                                                _lib.ptr(self._ws), _lib.ptr(self.scores), _lib.ptr(self.kept_dev), st),
-                   "dta_ensemble_forward_gated")
+        if loss_y is not None:
+            self.loss = torch.empty((), dtype=torch.float32, device=self.device)
+            _lib.check(L.dta_ensemble_forward_loss(C.byref(self._desc), Y, self._nets, self._xptr, _lib.ptr(self.local_flags),
+                                                   _lib.ptr(self._ws), _lib.ptr(loss_y), _lib.ptr(self.loss_weight),
+                                                   _lib.ptr(self.scores), _lib.ptr(self.kept_dev), _lib.ptr(self.loss),
+                                                   _lib.ptr(self.dscores) if want_grad else None, _lib.ptr(self.ce_scratch), st),
+                       "dta_ensemble_forward_loss")
+        else:
+            _lib.check(L.dta_ensemble_forward_gated(C.byref(self._desc), Y, self._nets, self._xptr, _lib.ptr(self.local_flags),
+                                                    _lib.ptr(self._ws), _lib.ptr(self.scores), _lib.ptr(self.kept_dev), st),
+                       "dta_ensemble_forward_gated")
         self._live = xs
         return list(range(Y))
 
@@ -919,46 +946,56 @@ class EnsembleTrainer:
         for i in kept:
             self.years[i]._grads_clear = False
 
-    def _ce(self, y, want_grad, kept_years=1):
-        """Loss of the mean scores and, in the same launch, d(loss)/d(one year's scores) = d(loss)/d(mean) / kept years
-        (kept_years=None: the count the device decided, read from self.kept_dev by the launch)."""
+    @staticmethod
+    def _year_segments(t):
+        """(p, g, m, v, n) of one year's flat segments: one when head and tail are adjacent (single process), else two."""
+        if all(h.data_ptr() + 4 * t.split == tl.data_ptr() for h, tl in
+               ((t.p_head, t.p_tail), (t.g_head, t.g_tail), (t.m_head, t.m_tail), (t.v_head, t.v_tail))):
+            return ((t.p_head, t.g_head, t.m_head, t.v_head, t.n),)
+        return ((t.p_head, t.g_head, t.m_head, t.v_head, t.split), (t.p_tail, t.g_tail, t.m_tail, t.v_tail, t.n_first))
+
+    def _adam_multi(self, segs):
+        """All of `segs` (_lib.AdamSegment entries) in launches of up to DTA_ADAM_MAX_SEGMENTS parameter groups: the years of an
+        ensemble are stepped by ONE launch instead of one per year and segment (3 x 369 x 24x24, B = 256: three k_adam
+        launches of 5.6 us + two boundaries -> one)."""
         L = _lib.lib()
-        self.loss = torch.empty((), dtype=torch.float32, device=self.device)      # fresh per step (see FusedTrainer._loss)
-        if kept_years is None:
-            _lib.check(L.dta_weighted_ce_scaled_dev(_lib.ptr(self.scores), _lib.ptr(y), _lib.ptr(self.loss_weight),
-                                                    self.scores.shape[0], self.scores.shape[1],
-                                                    C.c_void_p(self.kept_dev.data_ptr() + 4), _lib.ptr(self.loss),
-                                                    _lib.ptr(self.dscores) if want_grad else None, _lib.ptr(self.ce_scratch),
-                                                    _lib.current_stream_ptr()), "dta_weighted_ce_scaled_dev")
-            return
-        _lib.check(L.dta_weighted_ce_scaled(_lib.ptr(self.scores), _lib.ptr(y), _lib.ptr(self.loss_weight),
-                                            self.scores.shape[0], self.scores.shape[1], 1.0 / kept_years, _lib.ptr(self.loss),
-                                            _lib.ptr(self.dscores) if want_grad else None, _lib.ptr(self.ce_scratch),
-                                            _lib.current_stream_ptr()), "dta_weighted_ce_scaled")
+        lr = self.years[0].lr
+        for lo in range(0, len(segs), _lib.ADAM_MAX_SEGMENTS):
+            part = segs[lo:lo + _lib.ADAM_MAX_SEGMENTS]
+            arr = (_lib.AdamSegment * len(part))(*part)
+            _lib.check(L.dta_adam_step_multi(len(part), arr, lr, self.betas[0], self.betas[1], self.eps, self.sync.grad_scale,
+                                             0 if self.keep_grads else 1, _lib.current_stream_ptr()), "dta_adam_step_multi")
 
     def _adam_gated(self, flags=None):
-        """One gated optimizer pass per year and segment, driven by `flags` (data-parallel: the reduced year flags in the
-        gradient buffer; single process: this rank's dta_year_flags) and the device step counters."""
-        L = _lib.lib()
-        st = _lib.current_stream_ptr()
+        """The gated optimizer passes of all years and segments in one launch, driven by `flags` (data-parallel: the reduced
+        year flags in the gradient buffer; single process: this rank's dta_year_flags) and the device step counters."""
         flags = self.flags if flags is None else flags
         Y = len(self.years)
         cur, nxt = self._bank, 1 - self._bank
+        segs = []
         for i, t in enumerate(self.years):
-            active = C.c_void_p(flags.data_ptr() + 4 * i)
-            step = C.c_void_p(self.dev_steps.data_ptr() + 4 * (cur * Y + i))
-            step_next = C.c_void_p(self.dev_steps.data_ptr() + 4 * (nxt * Y + i))
-            if all(h.data_ptr() + 4 * t.split == tl.data_ptr() for h, tl in
-                   ((t.p_head, t.p_tail), (t.g_head, t.g_tail), (t.m_head, t.m_tail), (t.v_head, t.v_tail))):
-                segs = ((t.p_head, t.g_head, t.m_head, t.v_head, t.n),)       # adjacent segments (single process): one pass
-            else:
-                segs = ((t.p_head, t.g_head, t.m_head, t.v_head, t.split), (t.p_tail, t.g_tail, t.m_tail, t.v_tail, t.n_first))
-            for k, (p, g, m, v, n) in enumerate(segs):
-                _lib.check(L.dta_adam_step_gated(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, active, step,
-                                                 step_next if k == 0 else None, t.lr, self.betas[0], self.betas[1], self.eps,
-                                                 self.sync.grad_scale, 0 if self.keep_grads else 1, st), "dta_adam_step_gated")
+            active = flags.data_ptr() + 4 * i
+            step = self.dev_steps.data_ptr() + 4 * (cur * Y + i)
+            step_next = self.dev_steps.data_ptr() + 4 * (nxt * Y + i)
+            for k, (p, g, m, v, n) in enumerate(self._year_segments(t)):
+                segs.append(_lib.AdamSegment(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, active, step,
+                                             step_next if k == 0 else None, 0))
             t._grads_clear = not self.keep_grads
+        self._adam_multi(segs)
         self._bank = nxt
+
+    def _adam_present(self, local):
+        """Host-counted steps (present=[...], single process): the kept years' passes in one launch."""
+        segs = []
+        for i, t in enumerate(self.years):
+            if not local[i]:
+                continue
+            t.step_count += 1
+            for p, g, m, v, n in self._year_segments(t):
+                segs.append(_lib.AdamSegment(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, None, None, None, t.step_count))
+            t._grads_clear = not self.keep_grads
+        if segs:
+            self._adam_multi(segs)
 
     def train_step(self, images, y, present=None):
         """images: list of (B, bands, H, W) float32 device tensors, one per year; y: int64 labels.  Returns the loss
@@ -973,8 +1010,7 @@ class EnsembleTrainer:
         gate = None
         if present is None:
             self._counters_to("device")
-            kept = self._forward_gated(images)
-            self._ce(y, True, None)
+            kept = self._forward_gated(images, y, True)
             if not self.comm:
                 self._backward(kept)
                 self._adam_gated(self.local_flags)
@@ -982,14 +1018,11 @@ class EnsembleTrainer:
             local_flags = gate = self.local_flags      # all years are launched: the flags zero the missing ones' gradients
         else:
             local = self._kept(images, present)
-            kept = self._forward(images, local)
-            self._ce(y, True, len(kept))
+            kept = self._forward(images, local, y, True)
             if not self.comm:
                 self._counters_to("host")
                 self._backward(kept)
-                for i, t in enumerate(self.years):
-                    if local[i]:
-                        t._adam()
+                self._adam_present(local)
                 return self.loss
             local_flags = self._flag_table[sum(1 << i for i, k in enumerate(local) if k)]
         # data-parallel: every rank issues the same collectives whatever it kept; skipped years send their zeros
@@ -1035,11 +1068,11 @@ class EnsembleTrainer:
 
     def forward_loss(self, images, y, present=None):
         """validation_step of the level (multi_stage.py:290-304): ensemble scores + weighted CE, no update."""
+        y = self.years[0]._labels(y)
         if present is None:
-            self._forward_gated(images)
+            self._forward_gated(images, y, False)
         else:
-            self._forward(images, self._kept(images, present))
-        self._ce(self.years[0]._labels(y), False)
+            self._forward(images, self._kept(images, present), y, False)
         return self.scores.clone(), self.loss
 
 

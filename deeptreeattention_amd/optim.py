@@ -329,20 +329,25 @@ class DtaAdam(torch.optim.Optimizer):
         slot = C.c_void_p(self.flat_g.data_ptr() + 4 * self._alpha_slot) if (al and self.world > 1) else None
         cur, nxt = self._bank, 1 - self._bank
         k = 0
+        multi = []                  # the gated segments (one per year of an ensemble): ONE launch for all of them
         for ens_ref, year, off, n in self._segs:
-            ptrs = [C.c_void_p(t.data_ptr() + 4 * off) for t in (self.flat_p, self.flat_g, self.flat_m, self.flat_v)]
+            base = [t.data_ptr() + 4 * off for t in (self.flat_p, self.flat_g, self.flat_m, self.flat_v)]
             if ens_ref is None:
                 # the ungated segment (alpha's exchange slot is its last element)
+                ptrs = [C.c_void_p(b) for b in base]
                 _lib.check(L.dta_adam_step_dp(*ptrs, n, _lib.ptr(self._alpha) if al else None,
                                               _lib.ptr(self._alpha_g) if al else None, slot,
                                               _lib.ptr(self._alpha_m) if al else None, _lib.ptr(self._alpha_v) if al else None,
                                               self._steps, lr, b1, b2, eps, scale, zero, st), "dta_adam_step_dp")
             else:
-                step_ptr = C.c_void_p(self.dev_steps.data_ptr() + 4 * (cur * self.dev_steps.shape[1] + k))
-                next_ptr = C.c_void_p(self.dev_steps.data_ptr() + 4 * (nxt * self.dev_steps.shape[1] + k))
-                _lib.check(L.dta_adam_step_gated(*ptrs, n, C.c_void_p(flags[k]), step_ptr, next_ptr, lr, b1, b2, eps, scale,
-                                                 zero, st), "dta_adam_step_gated")
+                step_ptr = self.dev_steps.data_ptr() + 4 * (cur * self.dev_steps.shape[1] + k)
+                next_ptr = self.dev_steps.data_ptr() + 4 * (nxt * self.dev_steps.shape[1] + k)
+                multi.append(_lib.AdamSegment(base[0], base[1], base[2], base[3], n, flags[k], step_ptr, next_ptr, 0))
                 k += 1
+        for lo in range(0, len(multi), _lib.ADAM_MAX_SEGMENTS):
+            part = multi[lo:lo + _lib.ADAM_MAX_SEGMENTS]
+            arr = (_lib.AdamSegment * len(part))(*part)
+            _lib.check(L.dta_adam_step_multi(len(part), arr, lr, b1, b2, eps, scale, zero, st), "dta_adam_step_multi")
         self._bank = nxt
         if self.world > 1 and gated:
             self.flat_g[self._flag_off:].zero_()          # the flag slots (outside every segment)

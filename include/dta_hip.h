@@ -184,6 +184,16 @@ int dta_year_flags(const float* const* x, int years, size_t n_per_year, float* f
  * gradient scale dta_weighted_ce_scaled_dev takes.  No year kept: mean_scores are NaN (the reference raises there). */
 int dta_ensemble_forward_gated(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
                                const float* gate, void* workspace, float* mean_scores, float* kept, void* stream);
+/* Forward of the year ensemble AND the level's loss in one call (reference multi_stage.py:283-285: `y_hat = self.models[..]
+ * .forward(images); loss = F.cross_entropy(y_hat, y, weight=self.loss_weight[..])`): dta_ensemble_forward(_gated) with the mean
+ * over the kept years formed inside the loss launch instead of a launch of its own -- same values, bit for bit.
+ *  gate    : float[years] year flags (dta_year_flags) or NULL = every year is kept
+ *  mean_scores [batch][classes] (may be NULL), kept {kept years, 1 / kept} (may be NULL): outputs as in the gated forward
+ *  dscore  : d(loss)/d(ONE year's scores) = d(loss)/d(mean) / kept years -- what dta_ensemble_backward* take; may be NULL
+ *  labels / weight / loss / scratch : as for dta_net_loss.  Nothing kept: NaN loss, exact-zero dscore. */
+int dta_ensemble_forward_loss(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
+                              const float* gate, void* workspace, const long long* labels, const float* weight,
+                              float* mean_scores, float* kept, float* loss, float* dscore, float* scratch, void* stream);
 /* Backward of the above.  dscore: d(loss)/d(one year's scores) = d(loss)/d(mean_scores) / years, float32
  * [batch][classes], shared by all years.  grads: `years` entries, every non-null buffer ZERO-FILLED on entry;
  * classifier1/2 gradients are not produced (those heads never reach the loss). */
@@ -289,6 +299,19 @@ int dta_adam_step_dp(float* p, float* g, float* m, float* v, size_t n, double* a
 int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const float* active, const int* dev_step,
                         int* dev_step_next, float lr, float beta1, float beta2, float eps, float grad_scale, int zero_grad,
                         void* stream);
+/* Several parameter groups in ONE launch: the per-year optimizers of a year ensemble (reference multi_stage.py:258-275: one
+ * Adam per level over all years' parameters; years the step skipped are passed over) instead of one launch per year and
+ * segment.  Each segment is stepped exactly as dta_adam_step (active == NULL: host step count `step` >= 1) or as
+ * dta_adam_step_gated (active != NULL: device gate + device step counter; `step` ignored) would step it; zero_grad and the
+ * hyper-parameters are common.  1 <= nseg <= DTA_ADAM_MAX_SEGMENTS. */
+#define DTA_ADAM_MAX_SEGMENTS 8
+typedef struct dta_adam_segment {
+  float* p; float* g; float* m; float* v; size_t n;
+  const float* active; const int* dev_step; int* dev_step_next;   /* gated form, or all NULL */
+  int step;                                                        /* host step count (ungated form) */
+} dta_adam_segment;
+int dta_adam_step_multi(int nseg, const dta_adam_segment* segs, float lr, float beta1, float beta2, float eps, float grad_scale,
+                        int zero_grad, void* stream);
 
 /* ---- Peer gradient exchange: data-parallel training with one process per GPU of ONE node (reference train.py:89-98:
  * Lightning DDP all-reduces every parameter's gradient between loss.backward() and optimizer.step()).  Here the sum over

@@ -178,3 +178,57 @@ def test_in_launch_fanin_of_batchnorm_sums_matches_the_finalize_launches(precisi
     assert (num / den) ** 0.5 < (2e-5 if precision == "fp32" else 5e-3)
     for k in b1:
         assert rel_l2(b2[k].double().cpu().numpy(), b1[k].double().cpu().numpy()) < 1e-5, k
+
+
+@pytest.mark.devlib
+@pytest.mark.parametrize("precision,B", [("fp32", 3), ("fp32", 130), ("bf16", 5), ("bf16", 1026)])
+def test_fused_forward_tail_matches_the_separate_launches(precision, B, monkeypatch, devlib):
+    """The fused forward tail (stage.hip k_tail_fwd: third stage of both branches + the two last heads + blend + weighted CE in
+    one launch) against the launches it replaces (developer switch DTA_NO_TAIL: k_stage_fwd_lean<128,5,5>, k_gemm_group,
+    k_blend_ce): the same reference lines (Hang2020.py:24-31, :105-124, :149-168, :55-66, :256-261; src/main.py:78), sums in
+    another order -- scores, loss, every gradient and the parameters after two fused steps agree to float32 reordering noise
+    (bf16 mode: the tail itself computes in float32 on both routes); ragged batches leave slots of the last workgroup empty."""
+    import copy
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    torch.manual_seed(B)
+    bands, classes = 24, 11
+    m0 = H.Hang2020(bands, classes, precision=precision).cuda().train()
+    x = torch.rand(B, bands, 11, 11, device="cuda")
+    y = torch.randint(0, classes, (B,), device="cuda")
+    w = (0.1 + (torch.arange(classes) % 5)).float()
+    L = devlib
+
+    def run():
+        m = copy.deepcopy(m0)
+        tr = FusedTrainer(m, lr=1e-3, loss_weight=w, keep_grads=True)
+        l1 = float(tr.train_step(x, y))
+        out = tr.logits.clone()
+        g = {k: tr.grad_of(p).clone() for k, p in m.named_parameters() if p.dtype == torch.float32}
+        l2 = float(tr.train_step(x, y))
+        return l1, l2, out, g, {k: v.clone() for k, v in m.state_dict().items()}
+
+    monkeypatch.delenv("DTA_NO_TAIL", raising=False)
+    L.dta_dev_reload_switches()
+    a = run()
+    monkeypatch.setenv("DTA_NO_TAIL", "1")
+    L.dta_dev_reload_switches()
+    try:
+        b = run()
+    finally:
+        monkeypatch.delenv("DTA_NO_TAIL", raising=False)
+        L.dta_dev_reload_switches()
+    tol = 2e-5 if precision == "fp32" else 2e-3
+    assert abs(a[0] - b[0]) < tol * max(1.0, abs(b[0])) and abs(a[1] - b[1]) < 5 * tol * max(1.0, abs(b[1]))
+    assert rel_l2(a[2].cpu().numpy(), b[2].cpu().numpy()) < tol
+    num = den = 0.0
+    for k in b[3]:
+        if k.endswith("conv_layer.bias"):
+            continue
+        ga, gb = a[3][k].double().cpu().numpy(), b[3][k].double().cpu().numpy()
+        num += float(((ga - gb) ** 2).sum()); den += float((gb ** 2).sum())
+    assert (num / den) ** 0.5 < (2e-5 if precision == "fp32" else 5e-3)
+    for k in b[4]:
+        if k.endswith("conv_layer.bias") or k.endswith("num_batches_tracked"):
+            continue
+        assert rel_l2(a[4][k].double().cpu().numpy(), b[4][k].double().cpu().numpy()) < (1e-4 if precision == "fp32" else 5e-3), k

@@ -27,7 +27,8 @@ from deeptreeattention_amd.engine import FusedTrainer
 torch.manual_seed(5)
 m = H.Hang2020(40, 12, precision=os.environ["DTA_PREC"]).to(dev).train()
 exch = os.environ.get("DTA_EXCH") or None
-tr = FusedTrainer(m, lr=1e-3, overlap_comm=os.environ["DTA_OVERLAP"] == "1", exchange=exch)
+tr = FusedTrainer(m, lr=1e-3, overlap_comm=os.environ["DTA_OVERLAP"] == "1", exchange=exch,
+                  exchange_opts={"side_stream": True} if exch == "rccl" else None)
 g = torch.Generator(device=dev); g.manual_seed(7)
 x = torch.rand(24, 40, 11, 11, device=dev, generator=g)
 y = torch.randint(0, 12, (24,), device=dev, generator=g)

@@ -182,3 +182,24 @@ def test_cross_entropy_backward_twice_with_retain_graph():
     gr, = torch.autograd.grad(torch.nn.functional.cross_entropy(zr, y), zr)
     assert torch.equal(g1, g2)
     assert rel_l2(g1.cpu().numpy(), gr.cpu().numpy()) < 1e-5
+
+
+def test_ensemble_forward_loss_in_one_call_equals_forward_then_loss():
+    """dta_ensemble_forward_loss (EnsembleTrainer.forward_loss / train_step: the mean over the kept years formed inside the
+    loss launch) against the module path's two calls (learned_ensemble.forward -> k_mean_scores, then optim.cross_entropy ->
+    k_blend_ce): the same float operations in the same order, so the scores and the loss have the same bits -- all years
+    present, one year missing (device-decided), and with `present=` flags."""
+    from deeptreeattention_amd.engine import EnsembleTrainer
+    from deeptreeattention_amd.optim import cross_entropy
+    years = 3
+    a = _ensemble(years)
+    w = (0.1 + (torch.arange(5) % 3)).float().to(dev())
+    tr = EnsembleTrainer(a, lr=1e-3, loss_weight=w)
+    for zero, present in (((), None), ((1,), None), ((2,), [True, True, False])):
+        xs, y = _batch(years, seed=11 + len(zero), zero=zero)
+        scores, loss = tr.forward_loss(xs, y, present)
+        with torch.no_grad():
+            ref_scores = a(xs)
+        ref_loss = cross_entropy(ref_scores, y, weight=w)
+        assert torch.equal(scores, ref_scores), zero
+        assert torch.equal(loss, ref_loss), (zero, float(loss), float(ref_loss))

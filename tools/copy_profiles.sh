@@ -6,12 +6,16 @@ cp $S/bench_wgrad0.json profiles/${R}_bench_bf16_site_wgrad0.json
 cp $S/bench_ensemble24.json profiles/${R}_bench_ensemble24.json
 cp $S/bench_ensemble24_wgrad0.json profiles/${R}_bench_ensemble24_site_wgrad0.json
 cp $S/dp_one_rank.txt profiles/${R}_dp_one_rank.txt
-cp $S/ab_fanin.txt profiles/${R}_ab_fanin.txt
-cp $S/ab_ensemble24.txt profiles/${R}_ab_ensemble24.txt
-cp $S/ensemble24_private_segment.txt profiles/${R}_ensemble24_private_segment.txt
+cp $S/batch_sweep.txt profiles/${R}_batch_sweep.txt
+cp $S/ab_tail.txt profiles/${R}_ab_tail_artifact_box.txt
+cp $S/private_segment.txt profiles/${R}_private_segment.txt
 cp $S/infer.txt profiles/${R}_inference.txt
 cp $S/kernel_trace.txt profiles/${R}_kernel_trace_bf16_B1024.txt
-cp $S/kernel_trace_fanin.txt profiles/${R}_kernel_trace_bf16_B1024_fanin.txt
 cp $S/kernel_trace_ensemble24.txt profiles/${R}_kernel_trace_ensemble24.txt
+cp $S/kernel_trace_dispatches.csv profiles/${R}_kernel_trace_bf16_B1024_dispatches.csv
+cp $S/kernel_trace_ensemble24_dispatches.csv profiles/${R}_kernel_trace_ensemble24_dispatches.csv
+cp $S/pmc_fetch.csv profiles/${R}_pmc_fetch.csv
+cp $S/pmc_write.csv profiles/${R}_pmc_write.csv
+cp $S/pmc_sq.csv profiles/${R}_pmc_sq.csv
 cp $S/traffic_step.json profiles/${R}_traffic_step.json
 [ -f $S/gpu_tests.txt ] && cp $S/gpu_tests.txt profiles/${R}_gpu_tests.txt

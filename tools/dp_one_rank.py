@@ -13,6 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 STEPS = 200
+OPTS = {"rccl": {"side_stream": True}}      # (rccl + overlap_comm=True: the side-stream two-bucket form)
 
 
 def median_ms(step):
@@ -34,13 +35,13 @@ def build(kind, exchange, overlap):
     g = torch.Generator(device=dev); g.manual_seed(2)
     if kind == "hang":
         m = H.Hang2020(369, 200, precision="bf16").to(dev).train()
-        tr = FusedTrainer(m, lr=1e-4, loss_weight=torch.ones(200), exchange=exchange, overlap_comm=overlap)
+        tr = FusedTrainer(m, lr=1e-4, loss_weight=torch.ones(200), exchange=exchange, overlap_comm=overlap, exchange_opts=OPTS.get(exchange))
         x = torch.rand(1024, 369, 11, 11, device=dev, generator=g); y = torch.randint(0, 200, (1024,), device=dev, generator=g)
         return tr, (lambda: tr.train_step(x, y)), bool(tr.overlap)
     if kind == "metadata":
         from deeptreeattention_amd.metadata import metadata_sensor_fusion
         m = metadata_sensor_fusion(bands=369, sites=23, classes=200, precision="bf16").to(dev).train()
-        tr = MetadataTrainer(m, lr=1e-4, exchange=exchange, overlap_comm=overlap)
+        tr = MetadataTrainer(m, lr=1e-4, exchange=exchange, overlap_comm=overlap, exchange_opts=OPTS.get(exchange))
         x = torch.rand(1024, 369, 11, 11, device=dev, generator=g); y = torch.randint(0, 200, (1024,), device=dev, generator=g)
         site = torch.randint(0, 23, (1024,), device=dev, generator=g)
         return tr, (lambda: tr.train_step(x, site, y)), bool(tr.sensor.overlap)
@@ -49,7 +50,7 @@ def build(kind, exchange, overlap):
     for net in m.year_models:
         net.precision = "bf16"
     m = m.to(dev).train()
-    tr = EnsembleTrainer(m, lr=1e-4, loss_weight=torch.ones(200), exchange=exchange, overlap_comm=overlap)
+    tr = EnsembleTrainer(m, lr=1e-4, loss_weight=torch.ones(200), exchange=exchange, overlap_comm=overlap, exchange_opts=OPTS.get(exchange))
     xs = [torch.rand(256, 369, 24, 24, device=dev, generator=g) for _ in range(3)]
     y = torch.randint(0, 200, (256,), device=dev, generator=g)
     return tr, (lambda: tr.train_step(xs, y, present=[True, True, True])), bool(getattr(tr, "overlap_comm", False))
