@@ -92,7 +92,7 @@ class FusedTrainer:
         # (a one-rank group under DTA_FORCE_COLLECTIVES takes the overlapped launch order too: that is what its cost measurement is for)
         # "rccl": the side-stream two-bucket form (north_star's literal design) only on request, exchange_opts={"side_stream":
         # True}: measured with one rank (tools/dp_one_rank.py, profiles/r05_dp_one_rank.txt) its two event forks and the join cost
-        # +43 us per 0.52 ms step before a byte moves, the single collective on the compute stream +3 us -- more than the
+        # +35 us per 0.52 ms step before a byte moves, the single collective on the compute stream about nothing -- more than the
         # ~25 us of wire time the overlap can hide at 8 ranks
         opts = dict(exchange_opts or {})
         side_stream = bool(opts.pop("side_stream", False))
