@@ -4,9 +4,10 @@ trainer trusts the exchange on an unknown node:
     python deeptreeattention_amd/peer_probe.py <rendezvous dir> <rank> <world> <device ordinal>
 
 The ranks' probes find each other through files in the rendezvous directory (IPC handles, two barriers), map each
-other's buffers, run three all-reduces over 256 Ki floats with known contents (written by a kernel on the exchange's own
-stream immediately before it, as a train step's gradients are) and compare the result bit for bit with the sum in rank
-order.  Exit code 0 = the exchange works between these devices.  A GPU memory fault, a missing peer
+other's buffers, run all-reduces over 256 Ki floats with known contents (written by a kernel on the exchange's own
+stream immediately before it, as a train step's gradients are) -- three with the one-segment buffer, then four with the
+head / tail split of the overlapped trainers, the last two with the head's reduce-scatter as a launch of its own
+(the overlapped form's flags and staging area) -- and compare every result bit for bit with the sum in rank order.  Exit code 0 = the exchange works between these devices.  A GPU memory fault, a missing peer
 mapping or a wrong sum ends only the probe process; the parent (dist.probe_peer_exchange) then falls back to RCCL.
 No torch import here: ctypes on libdta_hip.so and libamdhip64.so only, so a probe starts in well under a second."""
 import ctypes as C
@@ -40,34 +41,36 @@ def _put(d, name, data=b"1"):
     os.rename(tmp, os.path.join(d, name))
 
 
-def main(d, rank, world, device, budget_s=60.0):
-    import _lib          # the package's ctypes binding, imported by path: the package itself would pull in torch
-    deadline = time.time() + budget_s
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    if hip.hipSetDevice(int(device)) != 0:
-        raise RuntimeError("hipSetDevice failed")
-    L = _lib.lib()
+def _phase(L, hip, d, rank, world, deadline, tag, split):
+    """One exchange object: handles through files, three (split = 0: the one-segment form the non-overlapped trainers use) or
+    four all-reduces with known contents; with a split the last two run the HEAD segment's reduce-scatter as its own
+    launch first (dta_xchg_reduce_head: the device code the first conv's weight-gradient launch carries in its spare
+    workgroups) -- the overlapped form's flags and staging between these very devices."""
+    import _lib
     h = C.c_void_p()
     _lib.check(L.dta_xchg_create(rank, world, N, C.byref(h)), "dta_xchg_create")
     L.dta_xchg_set_timeout(h, 10.0)
     L.dta_xchg_set_max_workgroups(h, 32)          # the probes of a shared-GPU test box must stay co-resident
+    if split:
+        _lib.check(L.dta_xchg_set_split(h, split), "dta_xchg_set_split")
     mine = C.create_string_buffer(_lib.XCHG_HANDLE_BYTES)
     _lib.check(L.dta_xchg_export(h, mine), "dta_xchg_export")
-    _put(d, f"h{rank}", mine.raw)
-    _wait_files(d, "h", world, deadline)
-    blob = b"".join(open(os.path.join(d, f"h{r}"), "rb").read() for r in range(world))
+    _put(d, f"{tag}h{rank}", mine.raw)
+    _wait_files(d, f"{tag}h", world, deadline)
+    blob = b"".join(open(os.path.join(d, f"{tag}h{r}"), "rb").read() for r in range(world))
     _lib.check(L.dta_xchg_connect(h, C.create_string_buffer(blob, len(blob))), "dta_xchg_connect")
-    _put(d, f"c{rank}")
-    _wait_files(d, "c", world, deadline)
+    _put(d, f"{tag}c{rank}")
+    _wait_files(d, f"{tag}c", world, deadline)
     g = L.dta_xchg_grad_buffer(h)
     out = np.empty(N, np.float32)
     ok = True
-    for step in range(3):
+    for step in range(4 if split else 3):
         # the buffer is written BY A KERNEL on the exchange's own stream and the exchange follows it with no host
         # synchronisation in between: exactly the train step's situation (csrc/xchg.hip relies on the kernel-boundary
         # write-back making the gradients visible to the peers' system-scope loads)
         _lib.check(L.dta_xchg_selftest_fill(h, step, None), "dta_xchg_selftest_fill")
+        if split and step >= 2:
+            _lib.check(L.dta_xchg_reduce_head(h, None, -1, None), "dta_xchg_reduce_head")
         _lib.check(L.dta_xchg_allreduce(h, None, -1, None), "dta_xchg_allreduce")
         if hip.hipDeviceSynchronize() != 0:
             raise RuntimeError("exchange kernel failed")
@@ -79,9 +82,23 @@ def main(d, rank, world, device, budget_s=60.0):
         for r in range(1, world):
             want = want + _pattern(r, step, N)
         ok = ok and np.array_equal(out, want)
-    _put(d, f"d{rank}")
-    _wait_files(d, "d", world, deadline)        # nobody unmaps while a peer may still read
+    _put(d, f"{tag}d{rank}")
+    _wait_files(d, f"{tag}d", world, deadline)        # nobody unmaps while a peer may still read
     L.dta_xchg_destroy(h)
+    return ok
+
+
+def main(d, rank, world, device, budget_s=60.0):
+    import _lib          # the package's ctypes binding, imported by path: the package itself would pull in torch
+    deadline = time.time() + budget_s
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    if hip.hipSetDevice(int(device)) != 0:
+        raise RuntimeError("hipSetDevice failed")
+    L = _lib.lib()
+    ok = _phase(L, hip, d, rank, world, deadline, "a", 0)
+    # the two-segment buffer of the overlapped trainers: head = 3/4 of the buffer (a multiple of 4 floats), plain and overlapped
+    ok = _phase(L, hip, d, rank, world, deadline, "b", (3 * N // 4) & ~3) and ok
     return 0 if ok else 3
 
 
