@@ -61,12 +61,13 @@ inline void prof_end(int site, hipStream_t st) {
 
 // Developer switches (same-box A/B runs; developer library only, common.h: dev_getenv): the environment is read once
 // per process, not per call.  In the product library every switch has its default and nothing reads the environment.
-struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; bool no_wgrad_pair; int fanin; bool no_tail; };
+#define DTA_LEAD_DEFAULT 0      // (measured: -1 us per step for two launches fewer, profiles/README.md round 5 -- an experiment, off)
+struct Switches { bool no_fused_input, no_tail_merge, bn_inkernel, fp32_act, no_lean; int lean_mask; bool halo_tiles, wgrad_nsplit; int conv_order; bool no_wgrad_pair; int fanin; bool no_tail; int lead; };
 inline Switches read_switches() {
   // these change launch plans (and, for DTA_FP32_ACT, roundings): never meant for a training job's environment, so say
   // so once, loudly, when one is set
   static const char* names[] = {"DTA_NO_FUSED_INPUT", "DTA_NO_TAIL_MERGE", "DTA_BN_INKERNEL", "DTA_FP32_ACT", "DTA_NO_LEAN",
-                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER", "DTA_NO_WGRAD_PAIR", "DTA_FANIN", "DTA_NO_TAIL"};
+                                "DTA_LEAN_MASK", "DTA_HALO_TILES", "DTA_NO_WGRAD_NSPLIT", "DTA_NO_WGRAD_STACK", "DTA_NO_WGRAD_D2", "DTA_PIXEL_ORDER", "DTA_NO_STAGGER", "DTA_NO_WGRAD_PAIR", "DTA_FANIN", "DTA_NO_TAIL", "DTA_LEAD"};
   for (const char* n : names)
     if (dev_getenv(n)) fprintf(stderr, "[libdta_hip] developer switch %s is set: kernel plans (and possibly roundings) differ from the default build\n", n);
   return {dev_getenv("DTA_NO_FUSED_INPUT") != nullptr, dev_getenv("DTA_NO_TAIL_MERGE") != nullptr, dev_getenv("DTA_BN_INKERNEL") != nullptr,
@@ -74,7 +75,8 @@ inline Switches read_switches() {
           dev_getenv("DTA_LEAN_MASK") ? atoi(dev_getenv("DTA_LEAN_MASK")) : DTA_LEAN_DEFAULT, dev_getenv("DTA_HALO_TILES") != nullptr,
           dev_getenv("DTA_NO_WGRAD_NSPLIT") == nullptr, (dev_getenv("DTA_PIXEL_ORDER") ? 1 : 0) | (dev_getenv("DTA_NO_STAGGER") ? 2 : 0), dev_getenv("DTA_NO_WGRAD_PAIR") != nullptr,
           dev_getenv("DTA_FANIN") ? atoi(dev_getenv("DTA_FANIN")) : 0,       // bit 0: forward BatchNorm statistics folded in-launch, bit 1: backward batch sums
-          dev_getenv("DTA_NO_TAIL") != nullptr};                             // the fused forward tail (stage.hip: k_tail_fwd) off: stage 3 + head GEMMs + blend / loss launches
+          dev_getenv("DTA_NO_TAIL") != nullptr,                              // the fused forward tail (stage.hip: k_tail_fwd) off: stage 3 + head GEMMs + blend / loss launches
+          dev_getenv("DTA_LEAD") ? atoi(dev_getenv("DTA_LEAD")) : DTA_LEAD_DEFAULT};      // bit 0: forward BatchNorm finalize as lead workgroups of the stage launch, bit 1: backward
 }
 Switches g_switches = read_switches();      // re-read only by dta_dev_reload_switches()
 inline const Switches& switches() { return g_switches; }
@@ -111,6 +113,7 @@ struct Plan {
   size_t scores_all, scores_bytes, dfeat_all, dfeat_bytes;
   // BatchNorm statistics / batch sums folded inside the producing launches (kernels.h, FanIn): arrival counters (zeroed by
   // the forward's prep launch, self re-arming), per layer FAN_R rows of forward sums and of backward sums
+  size_t lead;          // 64 counters of the lead workgroups (stage.hip: bn_lead_block), cleared with the scores by k_forward_prep
   size_t fan_cnt, fan_cnt_bytes, fan_ctr, fan_fwd[3], fan_bwd[3];      // fan_cnt..: the cleared range (rows, then the counters at fan_ctr)
   size_t fct; int fct_ld;              // Hang2020: the two last heads' weights transposed, [128 + 512][classes padded to 4] (fused forward tail)
   size_t total;
@@ -254,8 +257,9 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
   // (rows + counters sit directly in front of the scores: one clearing job for all -- a logical group without
   //  workgroups, e.g. a launch of fewer than FAN_R workgroups, leaves its row untouched, and a zero row adds nothing)
   p->fan_cnt = p->fan_fwd[0];
-  p->fan_cnt_bytes = c.off - p->fan_cnt;
   p->fan_ctr = c.off - (((size_t)2 * 3 * MAXG * FAN_R * 4 + 255) & ~(size_t)255);
+  p->lead = c.take(256);
+  p->fan_cnt_bytes = c.off - p->fan_cnt;
   p->scores_all = c.off;
   for (int g = 0; g < G; ++g)
     for (int L = 0; L < 3; ++L) p->scores[g][L] = c.take((size_t)B * p->classes * 4);
@@ -418,7 +422,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     }
     // the split-K GEMM targets (and, for the DTA_FANIN experiment, the fan-in rows and counters directly in front of them)
     if (switches().fanin) { pa.zero = at<float>(ws, p.fan_cnt); pa.zero_n4 = (p.fan_cnt_bytes + (d->heads_mask ? p.scores_bytes : 0) + 15) / 16; }
-    else if (d->heads_mask) { pa.zero = at<float>(ws, p.scores_all); pa.zero_n4 = (p.scores_bytes + 15) / 16; }
+    else { pa.zero = at<float>(ws, p.lead); pa.zero_n4 = (256 + (d->heads_mask ? p.scores_bytes : 0) + 15) / 16; }      // (lead counters sit directly in front of the scores)
     if (launch_forward_prep<T>(pa, st)) return 1;
   }
   for (int L = 0; L < 3; ++L) {
@@ -477,6 +481,12 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     // launch), so it stays a separate wide-and-shallow launch; DTA_BN_INKERNEL=1 re-enables it for experiments
     if (fan_fwd) { bf.fsum = ca.fan_sums; sa.bn_inkernel = 1; sa.bnfin = bn_finalize_kargs(bf); }
     else if ((!d->training || switches().bn_inkernel) && p.nwg[L] <= BN_INKERNEL_MAX_NWG) { sa.bn_inkernel = 1; sa.bnfin = bn_finalize_kargs(bf); }
+    else if ((switches().lead & 1) && !(L == 2 && tail) && stage_fwd_will_be_lean(sa, G)) {
+      // DTA_LEAD=1 (experiment): no finalize launch -- the first workgroups of the stage launch do its work while the
+      // others' loads are in flight
+      sa.bnfin = bn_finalize_kargs(bf);
+      sa.lead = G * ((sa.bnfin.C + 7) / 8); sa.lead_flag = at<unsigned>(ws, p.lead) + L; sa.lead_need = (unsigned)sa.lead;
+    }
     else if (launch_bn_finalize(bf, G, st)) return 1;
     if (d->heads_mask & DTA_FORWARD_ONLY) sa.attsave = nullptr;   // attention state is kept for the backward only
     if (L == 2 && tail) {

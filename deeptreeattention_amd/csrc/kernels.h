@@ -276,6 +276,9 @@ struct StageArgs {
   // (conv partials in training mode, running statistics otherwise) in its prologue; workgroup 0 of each group also
   // writes them to `coef` for the backward and updates the running statistics
   int bn_inkernel; BnFinK bnfin;
+  // lead > 0 (lean kernels, training): no finalize launch ran -- the first `lead` = G * ceil(C / 8) workgroups of row 0 compute
+  // the coefficients from `bnfin` (bn_lead_block) and the others wait for lead_flag[0] >= lead_need (cleared by k_forward_prep)
+  int lead; unsigned* lead_flag; unsigned lead_need;
   int lean;                            // allow the lean register-resident kernels for the 11x11 network stages
 };
 template <typename T> int launch_stage_fwd(const StageArgs& a, int G, hipStream_t st);
@@ -303,6 +306,7 @@ struct StageBwdArgs {
 int launch_stage_bwd(const StageBwdArgs& a, int G, hipStream_t st);
 bool stage_bwd_is_lean(const StageBwdArgs& a, int G);
 bool stage_fwd_is_lean(const StageArgs& a);
+bool stage_fwd_will_be_lean(const StageArgs& a, int G);      // (after the vslot choice launch_stage_fwd makes)
 
 struct BnBwdFinalizeArgs {
   const float* bnpart; size_t bnpart_gs; int B, C, HW;

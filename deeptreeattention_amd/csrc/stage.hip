@@ -192,6 +192,79 @@ __device__ __forceinline__ void bn_coef_block(const BnFinK& a, int g, float* lc,
   }
 }
 
+// "Lead" workgroups: the BatchNorm statistics WITHOUT a launch of their own.  The first `lead` workgroups of the consuming
+// (stage) launch do k_bn_finalize's work -- workgroup idx = (group, 8-channel tile), NTHR / 8 slices of the conv partials per
+// channel -- publish the coefficients with agent-scope stores and count themselves into `flag`; every other workgroup of the
+// launch has its own loads (conv output, attention weights) in flight meanwhile and reads the coefficients once the count is
+// complete (bn_lead_wait).  Lead workgroups have the lowest block ids, so they are dispatched before any waiter; the counter is
+// cleared by the step's first launch (k_forward_prep).  scratch: NTHR / 64 * 24 doubles of LDS.
+template <int NTHR>
+__device__ __forceinline__ void bn_lead_block(const BnFinK& a, int idx, unsigned* flag, double* red) {
+  constexpr int SL = NTHR / 8, NW = NTHR / 64;
+  const int t = threadIdx.x, C = a.C, nblk = (C + 7) / 8;
+  const int g = idx / nblk, cl = t & 7, sl = t >> 3, lane = t & 63, wave = t >> 6, c = (idx % nblk) * 8 + cl;
+  float* coef = a.coef + (size_t)g * C * 4;
+  const float* st = a.stats + (size_t)g * a.stats_goff;
+  float pgam = 0.f, pbet = 0.f, prm = 0.f, prv = 0.f, pgate = 1.f;
+  if (t < 8 && c < C) {
+    pgam = a.gamma[g][c]; pbet = a.beta[g][c];
+    if (a.rmean[g]) { prm = a.rmean[g][c]; prv = a.rvar[g][c]; }
+    if (a.gate) pgate = a.gate[g];
+  }
+  double s[3] = {0, 0, 0};
+  if (c < C) {
+#pragma unroll 8
+    for (int wg = sl; wg < a.nwg; wg += SL) {
+      const float2 v = *reinterpret_cast<const float2*>(st + ((size_t)wg * a.stats_ld + c) * 2);
+      const double nb = conv_wg_count(wg, a.HW, a.MWG, a.B), m = (double)v.x;
+      s[0] += nb * m; s[1] += nb * m * m; s[2] += (double)v.y;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double v = s[k];
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    if (lane < 8) red[wave * 24 + k * 8 + lane] = v;
+  }
+  __syncthreads();
+  if (t < 8 && c < C) {
+    double tot[3] = {0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { tot[0] += red[w * 24 + t]; tot[1] += red[w * 24 + 8 + t]; tot[2] += red[w * 24 + 16 + t]; }
+    const double n = (double)a.B * a.HW, mean = tot[0] / n;
+    double m2 = tot[2] + tot[1] - n * mean * mean;
+    m2 = m2 > 0 ? m2 : 0;
+    const double var = m2 / n;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps)), sc = pgam * rstd;
+    fan_store2(coef + c * 4, sc, pbet - (float)mean * sc);
+    fan_store2(coef + c * 4 + 2, (float)mean, rstd);
+    if (a.rmean[g] && pgate > 0.f) {      // (a year the step skips keeps its statistics, year.py:27)
+      const double unb = n > 1 ? m2 / (n - 1) : var;
+      a.rmean[g][c] = (1.f - a.momentum) * prm + a.momentum * (float)mean;
+      a.rvar[g][c] = (1.f - a.momentum) * prv + a.momentum * (float)unb;
+      if (c == 0 && a.nbt[g]) a.nbt[g][0] += 1;
+    }
+  }
+  if (wave == 0) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the coefficient stores are performed
+    if (t == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// The waiters' side: thread 0 polls the count (bounded: a lost lead workgroup poisons the step with NaN instead of hanging the
+// device), then every thread may read the coefficients with bn_lead_coef2.
+__device__ __forceinline__ bool bn_lead_wait(const unsigned* flag, unsigned need, int* ok_lds) {
+  if (threadIdx.x == 0) {
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    *ok_lds = ok;
+  }
+  __syncthreads();
+  return *ok_lds != 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-patch stage: LDS plan (floats).  Rows padded to C+1 so per-pixel loops over channels and
 // per-channel loops over pixels are both bank-conflict free.  The spatial branch keeps its single-channel
@@ -640,6 +713,12 @@ bool stage_fwd_is_lean(const StageArgs& a) {
   if (!((a.lean & 1) && a.apply_bn && a.relu && !a.a_nchw)) return false;
   if (stage_net_cfg(a)) return a.y_fmt == FMT_F32 || a.y_fmt == FMT_F16;
   return stage_net24_cfg(a) && a.y_fmt == FMT_F16;      // (bf16 mode only: the configuration BASELINE names)
+}
+
+bool stage_fwd_will_be_lean(const StageArgs& a_in, int G) {
+  StageArgs a = a_in;
+  a.vslot = stage_vslot_for(a, G);
+  return stage_fwd_is_lean(a);
 }
 
 template <typename T>
@@ -1717,8 +1796,13 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
   constexpr int C = CFG::C, NO = CFG::NO, NP = CFG::NP, TPP = CFG::TPP, IPT = CFG::IPT, PPW = CFG::PPW, WZ = CFG::WZ;
   constexpr int K = CFG::K, R = CFG::R, WP = CFG::WP, NPAD = CFG::NPAD;
   // (groups dispatched last-first, as in the backward kernel below: the heavier spatial branch goes first)
+  if (a.lead > 0 && (int)blockIdx.x < a.lead) {        // lead workgroups: the BatchNorm statistics of ALL groups (row 0 only)
+    if (blockIdx.y == 0) bn_lead_block<CFG::NT>(a.bnfin, blockIdx.x, a.lead_flag, reinterpret_cast<double*>(sm));
+    return;
+  }
+  const int bx = (int)blockIdx.x - a.lead;
   const int g = gridDim.y - 1 - blockIdx.y, t = threadIdx.x, slot = t / TPP, lt = t % TPP;
-  const int b = blockIdx.x * PPW + slot;
+  const int b = bx * PPW + slot;
   const bool live = b < a.B;
   const int kind = a.kind[g];
   float* coefL = sm;                                   // [C][2] scale, shift
@@ -1755,8 +1839,16 @@ __global__ __launch_bounds__(CFG::NT) void k_stage_fwd_lean(StageArgs a) {
   // ---- BatchNorm coefficients (from the finalize launch, or derived here in eval mode) ----
   if (a.bn_inkernel) {
     float* lc = red;                                    // [C][4], C <= 128 -> 512 floats, then 514 of scratch
-    bn_coef_block<CFG::NT>(a.bnfin, g, lc, red + 4 * C, blockIdx.x == 0);
+    bn_coef_block<CFG::NT>(a.bnfin, g, lc, red + 4 * C, bx == 0);
     for (int i = t; i < 2 * C; i += CFG::NT) coefL[i] = lc[(i >> 1) * 4 + (i & 1)];
+  } else if (a.lead > 0) {
+    // the coefficients come from THIS launch's lead workgroups (everything above is in flight while they work)
+    const bool ok = bn_lead_wait(a.lead_flag, a.lead_need, reinterpret_cast<int*>(red));
+    const float* coef = a.coef + (size_t)g * a.coef_gs;
+    for (int i = t; i < C; i += CFG::NT) {
+      const float2 q = fan_load2(coef + i * 4);
+      coefL[2 * i] = ok ? q.x : __builtin_nanf(""); coefL[2 * i + 1] = ok ? q.y : __builtin_nanf("");
+    }
   } else {
     const float* coef = a.coef + (size_t)g * a.coef_gs;
     for (int i = t; i < 2 * C; i += CFG::NT) coefL[i] = coef[(i >> 1) * 4 + (i & 1)];
@@ -2435,7 +2527,8 @@ static int launch_stage_fwd_lean_c(const StageArgs& a, int G, hipStream_t st) {
     static DevOnce attr_once;
     if (attr_once.first()) hipFuncSetAttribute((const void*)k_stage_fwd_lean<T, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
-  hipLaunchKernelGGL((k_stage_fwd_lean<T, CFG>), dim3((a.B + CFG::PPW - 1) / CFG::PPW, G), dim3(CFG::NT), lds, st, a);
+  if (a.lead > 0 && lds < (size_t)CFG::NT / 64 * 24 * 8) { dta_set_error("stage_fwd_lean: no room for the lead workgroups' scratch"); return 1; }
+  hipLaunchKernelGGL((k_stage_fwd_lean<T, CFG>), dim3((a.B + CFG::PPW - 1) / CFG::PPW + a.lead, G), dim3(CFG::NT), lds, st, a);
   DTA_CHECK_LAUNCH("k_stage_fwd_lean");
   return 0;
 }

@@ -235,3 +235,101 @@ def test_fused_forward_tail_matches_the_separate_launches(precision, B, monkeypa
         if b[4][k].numel() < 1000 or not b[4][k].dtype.is_floating_point:
             continue
         assert rel_l2(a[4][k].double().cpu().numpy(), b[4][k].double().cpu().numpy()) < (2e-3 if precision == "fp32" else 5e-3), k
+
+
+@pytest.mark.devlib
+@pytest.mark.parametrize("precision,B", [("fp32", 3), ("fp32", 130), ("bf16", 5), ("bf16", 1026)])
+def test_lead_workgroups_match_the_finalize_launches(precision, B, monkeypatch, devlib):
+    """BatchNorm statistics as LEAD workgroups of the consuming launch (stage.hip bn_lead_block / bn_lead_wait: developer
+    switch DTA_LEAD=1, an experiment that removes two launches and measured -1 us per step) against the separate
+    k_bn_finalize launches (the default): the same sums in double, other slice counts -- coefficients, running statistics
+    (Hang2020.py:24-31 BatchNorm2d in train mode), loss, scores and gradients agree to rounding of the last float32 bit of
+    a coefficient."""
+    import copy
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.engine import FusedTrainer
+    torch.manual_seed(B + 1)
+    bands, classes = 24, 11
+    m0 = H.Hang2020(bands, classes, precision=precision).cuda().train()
+    x = torch.rand(B, bands, 11, 11, device="cuda")
+    y = torch.randint(0, classes, (B,), device="cuda")
+    L = devlib
+
+    def run():
+        m = copy.deepcopy(m0)
+        tr = FusedTrainer(m, lr=1e-3, keep_grads=True)
+        l1 = float(tr.train_step(x, y))
+        out = tr.logits.clone()
+        g = {k: tr.grad_of(p).clone() for k, p in m.named_parameters() if p.dtype == torch.float32}
+        st = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+        return l1, out, g, st
+
+    monkeypatch.delenv("DTA_LEAD", raising=False)
+    L.dta_dev_reload_switches()
+    b = run()
+    monkeypatch.setenv("DTA_LEAD", "1")
+    L.dta_dev_reload_switches()
+    try:
+        a = run()
+    finally:
+        monkeypatch.delenv("DTA_LEAD", raising=False)
+        L.dta_dev_reload_switches()
+    tol = 2e-6 if precision == "fp32" else 2e-3
+    assert abs(a[0] - b[0]) < tol * max(1.0, abs(b[0]))
+    assert rel_l2(a[1].cpu().numpy(), b[1].cpu().numpy()) < tol
+    for k in b[3]:
+        if k.endswith("num_batches_tracked"):
+            assert int(a[3][k]) == int(b[3][k]) == 1, k
+        else:
+            assert rel_l2(a[3][k].double().cpu().numpy(), b[3][k].double().cpu().numpy()) < (1e-6 if precision == "fp32" else 2e-3), k
+    num = den = 0.0
+    for k in b[2]:
+        if k.endswith("conv_layer.bias"):
+            continue
+        ga, gb = a[2][k].double().cpu().numpy(), b[2][k].double().cpu().numpy()
+        num += float(((ga - gb) ** 2).sum()); den += float((gb ** 2).sum())
+    assert (num / den) ** 0.5 < (2e-5 if precision == "fp32" else 5e-3)
+
+
+@pytest.mark.devlib
+def test_lead_workgroups_in_a_year_ensemble_keep_a_skipped_years_statistics(monkeypatch, devlib):
+    """Three spectral year models in one grouped launch, the second year's input all zero (year.py:27: skipped): the lead
+    workgroups honour the device-side gate exactly as k_bn_finalize does -- the skipped year's running statistics and
+    num_batches_tracked stay, the others move, and both routes agree."""
+    import copy
+    from deeptreeattention_amd.year import learned_ensemble
+    from deeptreeattention_amd.engine import EnsembleTrainer
+    torch.manual_seed(4)
+    years, bands, classes, B = 3, 12, 5, 10
+    m0 = learned_ensemble(years, classes, {"pretrain_state_dict": None, "bands": bands}).cuda().train()
+    xs = [torch.rand(B, bands, 11, 11, device="cuda") for _ in range(years)]
+    xs[1].zero_()
+    y = torch.randint(0, classes, (B,), device="cuda")
+    L = devlib
+
+    def run():
+        m = copy.deepcopy(m0)
+        tr = EnsembleTrainer(m, lr=1e-3)
+        loss = float(tr.train_step(xs, y))
+        return loss, {k: v.clone() for k, v in m.state_dict().items()}
+
+    monkeypatch.delenv("DTA_LEAD", raising=False)
+    L.dta_dev_reload_switches()
+    b = run()
+    monkeypatch.setenv("DTA_LEAD", "1")
+    L.dta_dev_reload_switches()
+    try:
+        a = run()
+    finally:
+        monkeypatch.delenv("DTA_LEAD", raising=False)
+        L.dta_dev_reload_switches()
+    assert abs(a[0] - b[0]) < 2e-3 * max(1.0, abs(b[0]))
+    before = m0.state_dict()
+    for k in b[1]:
+        if "running_" in k or "num_batches" in k:
+            skipped = k.startswith("year_models.1.")
+            assert torch.equal(a[1][k], before[k]) == skipped, k
+            if k.endswith("num_batches_tracked"):
+                assert int(a[1][k]) == int(b[1][k]), k
+            else:
+                assert rel_l2(a[1][k].double().cpu().numpy(), b[1][k].double().cpu().numpy()) < 2e-3, k
