@@ -26,16 +26,16 @@ def _free_port():
     return port
 
 
-def _batch(rank, B):
+def _batch(rank, B, bands=BANDS, classes=CLASSES):
     from oracle import prng
-    return prng.uniform01(300 + rank, 1, (B, BANDS, 11, 11)), prng.randint(300 + rank, 2, (B,), CLASSES)
+    return prng.uniform01(300 + rank, 1, (B, bands, 11, 11)), prng.randint(300 + rank, 2, (B,), classes)
 
 
-def _weights():
-    return (0.1 + (np.arange(CLASSES) % 7)).astype(np.float32)
+def _weights(classes=CLASSES):
+    return (0.1 + (np.arange(classes) % 7)).astype(np.float32)
 
 
-def _worker(rank, world, port, B, exchange, out):
+def _worker(rank, world, port, B, exchange, out, bands=BANDS, classes=CLASSES):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -46,13 +46,13 @@ def _worker(rank, world, port, B, exchange, out):
     from deeptreeattention_amd.engine import FusedTrainer
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    p = O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=SEED)
-    m = H.Hang2020(BANDS, CLASSES, precision="bf16")
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=SEED)
+    m = H.Hang2020(bands, classes, precision="bf16")
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in p.items()})
     m = m.to(dev).train()
     overlap = exchange != "peer0"          # "peer0": the peer exchange WITHOUT the overlapped head segment (one launch does all)
     exchange = "peer" if exchange == "peer0" else exchange
-    tr = FusedTrainer(m, lr=1e-3, loss_weight=torch.from_numpy(_weights()), keep_grads=True, exchange=exchange,
+    tr = FusedTrainer(m, lr=1e-3, loss_weight=torch.from_numpy(_weights(classes)), keep_grads=True, exchange=exchange,
                       overlap_comm=overlap,
                       exchange_opts={"max_workgroups": 32, "timeout_s": 30.0} if exchange == "peer" else None)
     assert tr.exchange == exchange and tr.world == world
@@ -60,7 +60,7 @@ def _worker(rank, world, port, B, exchange, out):
         assert tr.overlap and tr.ex.split == tr.split and tr.split % 4 == 0
     elif exchange == "peer":
         assert not tr.overlap and tr.ex.split == 0
-    x, y = _batch(rank, B)
+    x, y = _batch(rank, B, bands, classes)
     loss = tr.train_step(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
     torch.cuda.synchronize()
     tr.check_exchange()
@@ -77,21 +77,25 @@ def _worker(rank, world, port, B, exchange, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,world,B", [("peer", 2, 530), ("peer", 4, 530), ("peer", 2, 1024), ("peer0", 2, 530),
-                                              ("torch", 2, 530), ("torch", 2, 1024)])
-def test_dp_step_at_bench_batch_vs_oracle(exchange, world, B):
+@pytest.mark.parametrize("exchange,world,B,bands,classes", [
+    ("peer", 2, 530, BANDS, CLASSES), ("peer", 4, 530, BANDS, CLASSES), ("peer", 2, 1024, BANDS, CLASSES),
+    ("peer0", 2, 530, BANDS, CLASSES), ("torch", 2, 530, BANDS, CLASSES), ("torch", 2, 1024, BANDS, CLASSES),
+    # the geometry BASELINE.json's metric is quoted on (369 bands, 200 classes: the real 900 k-element flat layout, its
+    # head / tail split and alpha slot), values against the oracle -- not only the bench line's schema
+    ("peer", 2, 530, 369, 200), ("torch", 2, 530, 369, 200)])
+def test_dp_step_at_bench_batch_vs_oracle(exchange, world, B, bands, classes, bf16_yardstick):
     from conftest import rel_l2
     from oracle import hang2020_np as O
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), B, exchange, out), nprocs=world, join=True)
-    p = O.init_params(O.hang2020_spec(BANDS, CLASSES), seed=SEED)
-    w = _weights()
+    mp.spawn(_worker, args=(world, _free_port(), B, exchange, out, bands, classes), nprocs=world, join=True)
+    p = O.init_params(O.hang2020_spec(bands, classes), seed=SEED)
+    w = _weights(classes)
     grads, losses, upds = [], [], []
     O.bf16_mode(True)
     try:
         for rank in range(world):
-            x, y = _batch(rank, B)
+            x, y = _batch(rank, B, bands, classes)
             logits, cache, upd = O.hang2020_fwd(p, x, True, np.float64)
             loss, dl = O.weighted_cross_entropy(logits, y, w)
             grads.append(O.hang2020_bwd(p, cache, dl, np.float64))
@@ -111,7 +115,10 @@ def test_dp_step_at_bench_batch_vs_oracle(exchange, world, B):
             assert abs(np.linalg.norm(got) - np.linalg.norm(v)) <= 1e-2 * np.linalg.norm(v), k
     whole = float(np.sqrt(num / den))
     print(f"{exchange} world={world} B={B}: whole-gradient rel-L2 vs bf16-mode oracle mean gradient {whole:.2e}")
-    assert whole < 1e-2
+    # element-wise, 369 bands: two float accumulations of the SAME rounded step are 8e-3 apart (tests/test_hip_benched_path.py);
+    # the bound there, a quarter of the reference's own bf16-autocast deviation on this geometry, applies here as well
+    ref_whole = bf16_yardstick.ref("hang1024/whole_elem_dev")
+    assert whole < (min(1.5e-2, 0.25 * ref_whole) if bands > 100 else 1e-2)
     ga = float(mean_g["alpha"])
     assert abs(out[0]["alpha_g"] / world - ga) <= 1e-2 * abs(ga) + 1e-7
     for rank in range(world):
