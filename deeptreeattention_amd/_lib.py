@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdta_hip_dev.so" if os.environ.get("DTA_DEV_LIB") == "1" else "libdta_hip.so")
 
 DTA_F32, DTA_BF16 = 0, 1
-MAX_YEARS = 4   # DTA_MAX_YEARS
+ABI_VERSION = 2    # DTA_ABI_VERSION
+MAX_YEARS = 16   # DTA_MAX_YEARS
 FORWARD_ONLY = 8   # DTA_FORWARD_ONLY (heads_mask flag)
 XCHG_HANDLE_BYTES = 128   # DTA_XCHG_HANDLE_BYTES
 SKIP_BLEND = 16    # DTA_SKIP_BLEND (heads_mask flag): the blend is left to dta_net_loss
@@ -65,10 +66,20 @@ class AttentionDesc(C.Structure):
 
 class AdamSegment(C.Structure):     # dta_adam_segment
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_size_t),
-                ("active", C.c_void_p), ("dev_step", C.c_void_p), ("dev_step_next", C.c_void_p), ("step", C.c_int)]
+                ("active", C.c_void_p), ("dev_step", C.c_void_p), ("dev_step_next", C.c_void_p), ("step", C.c_int),
+                ("lr", C.c_float)]
 
 
-ADAM_MAX_SEGMENTS = 8   # DTA_ADAM_MAX_SEGMENTS
+class Level(C.Structure):           # dta_level
+    _fields_ = [("classes", C.c_int), ("first", C.c_int), ("count", C.c_int), ("labels", C.c_void_p), ("weight", C.c_void_p),
+                ("mean_scores", C.c_void_p), ("kept", C.c_void_p), ("loss", C.c_void_p), ("dscore", C.c_void_p),
+                ("scratch", C.c_void_p)]
+
+
+MAX_LEVELS = 8   # DTA_MAX_LEVELS
+
+
+ADAM_MAX_SEGMENTS = 16   # DTA_ADAM_MAX_SEGMENTS
 
 
 class MetaParams(C.Structure):      # dta_meta_params
@@ -158,6 +169,14 @@ def lib():
         L.dta_adam_step_multi.restype = C.c_int
         L.dta_adam_step_multi.argtypes = [C.c_int, C.POINTER(AdamSegment), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                           C.c_int, C.c_void_p]
+        L.dta_multistage_workspace_bytes.restype = C.c_size_t
+        L.dta_multistage_workspace_bytes.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(Level)]
+        L.dta_multistage_forward_loss.restype = C.c_int
+        L.dta_multistage_forward_loss.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(Level), C.POINTER(SubnetParams),
+                                                  C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_multistage_backward.restype = C.c_int
+        L.dta_multistage_backward.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(Level), C.POINTER(SubnetParams), C.c_void_p,
+                                              C.POINTER(SubnetGrads), C.c_void_p, C.c_void_p]
         L.dta_net_forward_loss.restype = C.c_int
         L.dta_net_forward_loss.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -262,8 +281,9 @@ def lib():
         L.dta_xchg_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.dta_xchg_destroy.restype = C.c_int
         L.dta_xchg_destroy.argtypes = [C.c_void_p]
-        if L.dta_abi_version() != 1:
-            raise RuntimeError("libdta_hip.so ABI version mismatch")
+        if L.dta_abi_version() != ABI_VERSION:
+            raise RuntimeError("libdta_hip.so ABI version mismatch: the library says {}, this binding is written for {} "
+                               "(rebuild: python -m deeptreeattention_amd.build --force)".format(L.dta_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

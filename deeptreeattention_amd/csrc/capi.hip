@@ -93,6 +93,7 @@ struct Carver {
 // All workspace offsets for one network description (identical in forward and backward).
 struct Plan {
   int G, B, bands, H, W, classes, esz;
+  int cls[MAXG];   // class count of each group's classifier heads (= classes, except for the levels of a multi-stage step)
   int kinds[MAXG];
   int shared_x;   // Hang2020: both branches read the same input, so the first conv is ONE launch over [branch0|branch1] columns
   size_t x_tl_gs;  // bytes between the groups' network-input tiles (0 when shared)
@@ -119,7 +120,7 @@ struct Plan {
   size_t total;
 };
 
-int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
+int build_plan(const dta_net_desc* d, Plan* p, int years = 0, const int* group_classes = nullptr) {
   memset(p, 0, sizeof(*p));
   if (d->batch < 1 || d->bands < 1 || d->height < 4 || d->width < 4 || d->classes < 1) {
     dta_set_error("bad descriptor: batch=%d bands=%d H=%d W=%d classes=%d", d->batch, d->bands, d->height, d->width, d->classes);
@@ -142,6 +143,10 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
     if (d->kind != DTA_NET_SPECTRAL || years > MAXG) { dta_set_error("an ensemble is 1..%d spectral networks", MAXG); return 1; }
     p->G = years;
     for (int g = 0; g < years; ++g) p->kinds[g] = KIND_SPECTRAL;
+  }
+  for (int g = 0; g < MAXG; ++g) {
+    p->cls[g] = (group_classes && g < p->G) ? group_classes[g] : d->classes;
+    if (p->cls[g] < 1) { dta_set_error("bad descriptor: group %d has %d classes", g, p->cls[g]); return 1; }
   }
   const int G = p->G, B = p->B;
   p->NC0 = (d->bands + 15) / 16;
@@ -262,7 +267,7 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0) {
   p->fan_cnt_bytes = c.off - p->fan_cnt;
   p->scores_all = c.off;
   for (int g = 0; g < G; ++g)
-    for (int L = 0; L < 3; ++L) p->scores[g][L] = c.take((size_t)B * p->classes * 4);
+    for (int L = 0; L < 3; ++L) p->scores[g][L] = c.take((size_t)B * p->cls[g] * 4);
   p->scores_bytes = c.off - p->scores_all;
   // backward
   p->dfeat_all = c.off;
@@ -527,14 +532,14 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
         float* out = at<float>(ws, p.scores[g][L]);
         // K slices of ~128 (at most 4): measured best for this launch (23 us vs 30 us with 2 slices of 256; 8 slices
         // lose to the longer same-address atomic chains)
-        ga.M = B; ga.N = p.classes; ga.K = F; ga.ksplit = min(4, max(1, (F + 63) / 64)); ga.accumulate = 0;
+        ga.M = B; ga.N = p.cls[g]; ga.K = F; ga.ksplit = min(4, max(1, (F + 63) / 64)); ga.accumulate = 0;
         float* user = (scores && scores[g][L]) ? scores[g][L] : nullptr;
         if (d->kind == DTA_NET_VANILLA && joint) user = joint;
         if (user) {
           out = user;
-          if (ga.ksplit > 1) hipMemsetAsync(user, 0, (size_t)B * p.classes * 4, st);
+          if (ga.ksplit > 1) hipMemsetAsync(user, 0, (size_t)B * p.cls[g] * 4, st);
         }
-        ga.C = out; ga.sc_m = p.classes; ga.sc_n = 1;
+        ga.C = out; ga.sc_m = p.cls[g]; ga.sc_n = 1;
         ga.bias = nets[g].fc_b[L];
         if (!heads.add(ga)) { dta_set_error("too many head GEMMs"); return 1; }
       }
@@ -698,20 +703,20 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
           hipMemsetAsync(at<float>(ws, p.dfeat[L]) + (size_t)g2 * fgs, 0, (size_t)B * p.F[g2][L] * 4, st);
       GemmArgs ga;
       memset(&ga, 0, sizeof(ga));
-      ga.A = dsc[g][L]; ga.sa_m = p.classes; ga.sa_k = 1;
+      ga.A = dsc[g][L]; ga.sa_m = p.cls[g]; ga.sa_k = 1;
       ga.Bm = nets[g].fc_w[L]; ga.sb_k = F; ga.sb_n = 1;
       ga.C = at<float>(ws, p.dfeat[L]) + (size_t)g * fgs; ga.sc_m = F; ga.sc_n = 1;
-      ga.M = B; ga.N = F; ga.K = p.classes; ga.ksplit = 1;   // plain stores: dfeat needs no clearing
+      ga.M = B; ga.N = F; ga.K = p.cls[g]; ga.ksplit = 1;   // plain stores: dfeat needs no clearing
       ga.gate = gate ? gate + g : nullptr;
       if (L == 2 && dsc_mode[g]) { ga.sig_alpha = alpha; ga.sig_mode = dsc_mode[g]; }
       dfeat_grp.add(ga);
       if (grads[g].fc_w[L]) {
         memset(&ga, 0, sizeof(ga));
-        ga.A = dsc[g][L]; ga.sa_m = 1; ga.sa_k = p.classes;
+        ga.A = dsc[g][L]; ga.sa_m = 1; ga.sa_k = p.cls[g];
         ga.Bm = at<float>(ws, p.feat[L]) + (size_t)g * fgs; ga.sb_k = F; ga.sb_n = 1;
         ga.C = grads[g].fc_w[L]; ga.sc_m = F; ga.sc_n = 1;
-        ga.M = p.classes; ga.N = F; ga.K = B;
-        ga.ksplit = gemm_auto_ksplit(p.classes, F, B);
+        ga.M = p.cls[g]; ga.N = F; ga.K = B;
+        ga.ksplit = gemm_auto_ksplit(p.cls[g], F, B);
         ga.rowsum_out = grads[g].fc_b[L];      // db[n] = sum_b dscore[b][n]
         ga.gate = gate ? gate + g : nullptr;
         if (L == 2 && dsc_mode[g]) { ga.sig_alpha = alpha; ga.sig_mode = dsc_mode[g]; }
@@ -1104,6 +1109,77 @@ int dta_ensemble_backward_xchg(const dta_net_desc* d, int years, const dta_subne
   return 1;
 }
 
+// ---- multi-stage step: the levels x years networks of the reference's hierarchical model as the groups of ONE set of
+//      launches (reference src/models/multi_stage.py:41-66 one learned_ensemble per level, :277-288 one loss per level) ----
+static int multistage_desc(const dta_net_desc* d, int levels, const dta_level* lv, dta_net_desc* out, Plan* p, const char* who) {
+  if (!d || !lv || levels < 1 || levels > DTA_MAX_LEVELS) { dta_set_error("%s: 1..%d levels", who, DTA_MAX_LEVELS); return 1; }
+  static_assert(DTA_MAX_LEVELS == BLEND_CE_MULTI_MAX, "header and kernel disagree");
+  if (d->kind != DTA_NET_SPECTRAL) { dta_set_error("%s: the descriptor's kind must be DTA_NET_SPECTRAL", who); return 1; }
+  int cls[MAXG] = {}, G = 0;
+  for (int l = 0; l < levels; ++l) {
+    if (lv[l].count < 1 || lv[l].first != G) { dta_set_error("%s: level %d: its groups must be [first, first + count) with count >= 1, levels in order and adjacent", who, l); return 1; }
+    if (G + lv[l].count > MAXG) { dta_set_error("%s: at most %d networks (levels x kept years) per step", who, MAXG); return 1; }
+    if (lv[l].classes < 1) { dta_set_error("%s: level %d has %d classes", who, l, lv[l].classes); return 1; }
+    for (int k = 0; k < lv[l].count; ++k) cls[G++] = lv[l].classes;
+  }
+  *out = *d;
+  out->heads_mask = 4 | (d->heads_mask & DTA_FORWARD_ONLY);   // each year's last head only (reference year.py:30)
+  out->classes = cls[0];
+  return build_plan(out, p, G, cls);
+}
+
+size_t dta_multistage_workspace_bytes(const dta_net_desc* d, int levels, const dta_level* lv) {
+  Plan p; dta_net_desc dd;
+  if (multistage_desc(d, levels, lv, &dd, &p, "dta_multistage_workspace_bytes")) return 0;
+  return p.total;
+}
+
+int dta_multistage_forward_loss(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
+                                const float* const* x, const float* gate, void* workspace, void* stream) {
+  Plan p; dta_net_desc dd;
+  if (!nets || !x || !workspace) { dta_set_error("dta_multistage_forward_loss: null argument"); return 1; }
+  if (multistage_desc(d, levels, lv, &dd, &p, "dta_multistage_forward_loss")) return 1;
+  for (int g = 0; g < p.G; ++g)
+    if (!x[g]) { dta_set_error("dta_multistage_forward_loss: null input for network %d", g); return 1; }
+  for (int l = 0; l < levels; ++l)
+    if (!lv[l].labels || !lv[l].loss || !lv[l].scratch) { dta_set_error("dta_multistage_forward_loss: level %d: labels, loss and scratch are required", l); return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (dd.dtype == DTA_BF16) rc = forward_t<bf16_t>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st, nullptr, gate);
+  else if (dd.dtype == DTA_F32) rc = forward_t<float>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st, nullptr, gate);
+  else { dta_set_error("unknown dtype %d", dd.dtype); return 1; }
+  if (rc) return rc;
+  BlendCeMulti m;
+  memset(&m, 0, sizeof(m));
+  m.n = levels;
+  for (int l = 0; l < levels; ++l) {
+    BlendCeArgs& a = m.a[l];
+    a.gscale = 1.f;
+    for (int k = 0; k < lv[l].count; ++k) a.src[k] = at<float>(workspace, p.scores[lv[l].first + k][2]);
+    a.nsrc = lv[l].count; a.src_gate = gate ? gate + lv[l].first : nullptr; a.kept_out = lv[l].kept; a.joint = lv[l].mean_scores;
+    a.labels = lv[l].labels; a.weight = lv[l].weight; a.dlogits = lv[l].dscore; a.loss = lv[l].loss; a.rowtmp = lv[l].scratch;
+    a.B = p.B; a.classes = lv[l].classes;
+  }
+  return launch_blend_ce_multi(m, st);
+}
+
+int dta_multistage_backward(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
+                            void* workspace, const dta_subnet_grads* grads, const float* gate, void* stream) {
+  Plan p; dta_net_desc dd;
+  if (!nets || !workspace || !grads) { dta_set_error("dta_multistage_backward: null argument"); return 1; }
+  if (multistage_desc(d, levels, lv, &dd, &p, "dta_multistage_backward")) return 1;
+  const float* dsc[MAXG][3] = {};
+  for (int l = 0; l < levels; ++l) {
+    if (!lv[l].dscore) { dta_set_error("dta_multistage_backward: level %d has no score gradient", l); return 1; }
+    for (int k = 0; k < lv[l].count; ++k) dsc[lv[l].first + k][2] = lv[l].dscore;   // d(mean)/d(year score) is the same for every kept year
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dd.dtype == DTA_BF16) return backward_t<bf16_t>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, 3, st, nullptr, nullptr, gate);
+  if (dd.dtype == DTA_F32) return backward_t<float>(p, &dd, nets, nullptr, workspace, dsc, nullptr, grads, nullptr, 3, st, nullptr, nullptr, gate);
+  dta_set_error("unknown dtype %d", dd.dtype);
+  return 1;
+}
+
 int dta_net_backward(const dta_net_desc* d, const dta_subnet_params* nets, const double* alpha, void* workspace,
                      const float* const dscores[2][3], const float* djoint, const dta_subnet_grads* grads,
                      double* dalpha, int phases, void* stream) {
@@ -1252,7 +1328,7 @@ int dta_adam_step_multi(int nseg, const dta_adam_segment* segs, float lr, float 
     a.gz = zero_grad ? sgm.g : nullptr;
     a.active = sgm.active; a.dev_step = sgm.dev_step; a.dev_step_out = sgm.dev_step_next;
     a.g_inactive = sgm.active ? sgm.g : nullptr;
-    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
+    a.lr = sgm.lr > 0.f ? sgm.lr : lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
     const int step = sgm.active ? 1 : sgm.step;
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));

@@ -678,6 +678,20 @@ int launch_blend_ce(const BlendCeArgs& a, hipStream_t st) {
   DTA_CHECK_LAUNCH("k_blend_ce");
   return 0;
 }
+__global__ __launch_bounds__(256) void k_blend_ce_multi(BlendCeMulti m) {
+  __shared__ float sc[8];
+  __shared__ double sd[256];
+  __shared__ int is_last;
+  blend_ce_body(m.a[blockIdx.y], sc, sd, &is_last);
+}
+int launch_blend_ce_multi(const BlendCeMulti& m, hipStream_t st) {
+  if (m.n < 1 || m.n > BLEND_CE_MULTI_MAX) { dta_set_error("blend_ce_multi: 1..%d losses", BLEND_CE_MULTI_MAX); return 1; }
+  for (int i = 1; i < m.n; ++i)
+    if (m.a[i].B != m.a[0].B) { dta_set_error("blend_ce_multi: every loss of the launch needs the same batch size"); return 1; }
+  hipLaunchKernelGGL(k_blend_ce_multi, dim3((m.a[0].B + 3) / 4, m.n), dim3(256), 0, st, m);
+  DTA_CHECK_LAUNCH("k_blend_ce_multi");
+  return 0;
+}
 int launch_weighted_ce(const CeArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_ce_rows, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
   DTA_CHECK_LAUNCH("k_ce_rows");

@@ -5,7 +5,9 @@
 namespace dta {
 
 enum { KIND_SPECTRAL = 0, KIND_SPATIAL = 1, KIND_PLAIN = 2 };
-constexpr int MAXG = 4;   // groups per launch: Hang2020's two branches, or up to four years of an ensemble
+constexpr int MAXG = 16;  // groups per launch: Hang2020's two branches, the years of an ensemble, or the levels x years of a
+                          // multi-stage step (reference multi_stage.py:41-66: 5 levels x the data's years); every per-group array of
+                          // a kernel-argument struct is this long, and every such struct stays under the 4 KB kernarg segment
 
 // ---- conv.hip ----------------------------------------------------------------------------------
 struct PackWArgs {
@@ -342,9 +344,9 @@ template <typename T> int launch_bn_bwd_apply(const BnBwdApplyArgs& a, int G, hi
 // ---- heads.hip -----------------------------------------------------------------------------------
 // C[m][n] (+)= sum_k A(m,k) * B(k,n) + bias[n]; arbitrary element strides; fp32 MFMA 32x32x2.
 struct GemmArgs {
-  const float* A; long sa_m, sa_k;
-  const float* Bm; long sb_k, sb_n;
-  float* C; long sc_m, sc_n;
+  const float* A; int sa_m, sa_k;         // (element strides: 32-bit -- 22 descriptors + the slab-reduction jobs share one 4 KB kernarg segment)
+  const float* Bm; int sb_k, sb_n;
+  float* C; int sc_m, sc_n;
   const float* bias;
   float* rowsum_out;                  // optional: rowsum_out[m] += sum_k A(m,k) (atomic; must be pre-zeroed)
   int M, N, K, ksplit, accumulate;    // ksplit > 1: atomic accumulation into a pre-zeroed C
@@ -357,7 +359,7 @@ struct GemmArgs {
   // epilogue options (plain-store GEMMs only: ksplit == 1, no accumulate): relu != 0 -> C = max(C, 0) after the bias;
   // mask != null -> C(m, n) is kept where mask[m * mask_m + n] > 0 and zeroed elsewhere (a ReLU's backward, the mask being
   // the ReLU's output)
-  int relu; const float* mask; long mask_m;
+  int relu; const float* mask; int mask_m;
 };
 // (22: the 21 deferred parameter-gradient GEMMs of a three-year ensemble ride in the step's last launch instead of forcing a
 //  flush in the middle of the backward; 22 x 160 B + the slab-reduction jobs stay inside the 4 KB kernel-argument segment)
@@ -510,9 +512,15 @@ struct BlendCeArgs {
   // k_mean_scores forms it (sum in source order, selected by src_gate > 0 -- NULL = all --, times 1 / kept); `joint` receives
   // the mean, kept_out (may be NULL) {kept, 1 / kept}, and dlogits = d(loss)/d(ONE source's scores) = d(loss)/d(mean) / kept
   // (gscale / gscale_dev are ignored); nothing kept: NaN scores and loss, exact-zero dlogits
-  const float* src[MAXG] = {nullptr, nullptr, nullptr, nullptr}; int nsrc = 0; const float* src_gate = nullptr; float* kept_out = nullptr;
+  const float* src[MAXG] = {}; int nsrc = 0; const float* src_gate = nullptr; float* kept_out = nullptr;
 };
 int launch_blend_ce(const BlendCeArgs& a, hipStream_t st);
+// several independent losses in ONE launch (blockIdx.y = loss): the levels of a multi-stage step, each with its own class
+// count, labels, class weights, sources and outputs (reference multi_stage.py:277-288: one F.cross_entropy per level);
+// every entry has the same batch size (the grid's x extent is the loss kernel's last-arriver count)
+constexpr int BLEND_CE_MULTI_MAX = 8;
+struct BlendCeMulti { BlendCeArgs a[BLEND_CE_MULTI_MAX]; int n = 0; };
+int launch_blend_ce_multi(const BlendCeMulti& m, hipStream_t st);
 // ---- stage.hip: fused forward tail of Hang2020 on 11x11 patches ------------------------------------------------------
 // The third stage of BOTH branches (BatchNorm -> ReLU -> 2x2 pool -> spectral / spatial attention -> features), the two
 // last-head classifiers, the sigmoid(alpha) blend and -- when ce.labels is set -- the class-weighted cross-entropy with
@@ -543,7 +551,7 @@ struct AdamArgs {
   float* g_inactive = nullptr;         // gated: a group that is not stepped has no gradient -- its buffer is cleared whatever gz says
 };
 int launch_adam(const AdamArgs& a, hipStream_t st);
-constexpr int ADAM_MAX_SEG = 8;
+constexpr int ADAM_MAX_SEG = 16;
 struct AdamMulti { AdamArgs seg[ADAM_MAX_SEG]; int n; };
 int launch_adam_multi(const AdamMulti& m, hipStream_t st);      // blockIdx.y = segment
 int launch_softmax_top2(const float* logits, int B, int classes, float* probs, long long* top_idx, float* top_score,

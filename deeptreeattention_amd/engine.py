@@ -1084,6 +1084,141 @@ class MultiStageTrainer:
     def __init__(self, models, lrs, loss_weights=None, **kwargs):
         loss_weights = loss_weights or [None] * len(models)
         self.levels = [EnsembleTrainer(m, lr, w, **kwargs) for m, lr, w in zip(models, lrs, loss_weights)]
+        self._ws = None
+        self._ws_key = None
+        self._gate_banks = None
+        self._gate_bank = 0
+        self.batched_last = False        # did the last training_step_all run as one launch chain?
+
+    # ---- every level of a batch in ONE launch chain (reference train.py:75-100 + multi_stage.py:277-288: Lightning calls
+    #      training_step once per optimizer -- i.e. per level -- on every batch; the levels are independent networks) ----
+    def _batchable(self, xs_levels):
+        """The levels' steps can share one set of launches when nothing is exchanged between ranks, every level brings the
+        same batch size / crop shape / precision / mode, and the networks fit one grouped launch."""
+        if len(self.levels) > _lib.MAX_LEVELS or any(t.comm for t in self.levels):
+            return False
+        shapes = {tuple(x.shape) for xs in xs_levels for x in xs}
+        if len(shapes) != 1:
+            return False
+        m0 = self.levels[0].model.year_models[0]
+        for t in self.levels:
+            for m in t.model.year_models:
+                if m.precision != m0.precision or m.training != m0.training or not m.training:
+                    return False
+        return True
+
+    def training_step_all(self, batch, batch_idx=0, present=None):
+        """One optimisation step of EVERY level on its batch: batch[l] = (individual, {"HSI": [year tensors]}, labels) as
+        Lightning hands them to MultiStage.training_step (multi_stage.py:277-288, once per optimizer_idx).  Returns the
+        list of per-level losses (fresh 0-d device tensors).  The levels x kept-years networks run as the groups of ONE
+        launch chain -- one forward, ONE loss launch over the levels, one backward, one optimizer launch per 16 parameter
+        segments, each level with its own class weights and learning rate (dta_multistage_*); results are those of
+        training_step(batch, ., l) for l = 0, 1, ... in turn.  present: None (missing years decided on the device, no host
+        synchronisation), or one list of booleans per level.  Steps the levels one after the other when they cannot share a
+        launch chain (different batch sizes or shapes, more than 16 kept networks, data-parallel trainers)."""
+        nl = len(self.levels)
+        if len(batch) != nl:
+            raise ValueError("expected one batch per level ({}), got {}".format(nl, len(batch)))
+        if present is not None and len(present) != nl:
+            raise ValueError("present: one list of year flags per level")
+        xs_levels = [[H._check_input(x) for x in b[1]["HSI"]] for b in batch]
+        for t, xs in zip(self.levels, xs_levels):
+            if len(xs) != len(t.years):
+                raise ValueError("expected one image tensor per year ({}), got {}".format(len(t.years), len(xs)))
+        if present is None:
+            kept = [list(range(len(t.years))) for t in self.levels]
+        else:
+            kept = [[i for i, k in enumerate(t._kept(xs, pr)) if k] for t, xs, pr in zip(self.levels, xs_levels, present)]
+        total = sum(len(k) for k in kept)
+        self.batched_last = self._batchable(xs_levels) and total <= _lib.MAX_YEARS and all(kept)
+        if not self.batched_last:
+            return [self.training_step(batch, batch_idx, l, None if present is None else present[l]) for l in range(nl)]
+        L = _lib.lib()
+        st = _lib.current_stream_ptr()
+        dev = self.levels[0].device
+        nets, grads, xptr, live, lv = [], [], [], [], []
+        B = xs_levels[0][0].shape[0]
+        key = None
+        for l, (t, xs, b) in enumerate(zip(self.levels, xs_levels, batch)):
+            t.check_exchange()
+            y = t.years[0]._labels(b[2])
+            classes = t.model.year_models[0]._classes
+            t._buffers(B, classes)
+            t._counters_to("device" if present is None else "host")
+            t.loss = torch.empty((), dtype=torch.float32, device=dev)      # fresh per step (see FusedTrainer._loss)
+            first = len(nets)
+            for i in kept[l]:
+                k = t.years[i]._describe(xs[i])
+                key = key or k
+                nets.append(t.years[i].nets[0]); grads.append(t.years[i].grads[0]); xptr.append(xs[i].data_ptr())
+            live.append((xs, y))
+            lv.append(_lib.Level(classes, first, len(kept[l]), y.data_ptr(), _lib.ptr(t.loss_weight), t.scores.data_ptr(),
+                                 t.kept_dev.data_ptr(), t.loss.data_ptr(), t.dscores.data_ptr(), t.ce_scratch.data_ptr()))
+        n = len(nets)
+        nets_a = (_lib.SubnetParams * n)(*nets)
+        grads_a = (_lib.SubnetGrads * n)(*grads)
+        x_a = (C.c_void_p * n)(*xptr)
+        lv_a = (_lib.Level * nl)(*lv)
+        desc = self.levels[0].years[kept[0][0]].desc
+        ws_key = (tuple((v.classes, v.count) for v in lv),) + key
+        if ws_key != self._ws_key:
+            nbytes = L.dta_multistage_workspace_bytes(C.byref(desc), nl, lv_a)
+            if nbytes == 0:
+                raise RuntimeError("dta_multistage_workspace_bytes: " + L.dta_last_error().decode())
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._ws_key = ws_key
+        gate = None
+        if present is None:
+            # the reference's missing-year test (year.py:27) for every network of the step in one launch, on the device
+            if self._gate_banks is None or self._gate_banks.shape[1] != n:
+                self._gate_banks = torch.zeros(2, n, dtype=torch.float32, device=dev)
+                self._gate_bank = 0
+            self._gate_bank ^= 1
+            gate = self._gate_banks[self._gate_bank]
+            _lib.check(L.dta_year_flags(x_a, n, xs_levels[0][0].numel(), _lib.ptr(gate),
+                                        _lib.ptr(self._gate_banks[self._gate_bank ^ 1]), st), "dta_year_flags")
+        _lib.check(L.dta_multistage_forward_loss(C.byref(desc), nl, lv_a, nets_a, x_a, _lib.ptr(gate), _lib.ptr(self._ws), st),
+                   "dta_multistage_forward_loss")
+        for t, ks in zip(self.levels, kept):
+            for i in ks:
+                t.years[i]._zero_grads()      # C-ABI contract: gradient buffers arrive zero-filled
+        _lib.check(L.dta_multistage_backward(C.byref(desc), nl, lv_a, nets_a, _lib.ptr(self._ws), grads_a, _lib.ptr(gate), st),
+                   "dta_multistage_backward")
+        # ---- one Adam per level (multi_stage.py:258-262: its own learning rate), all of them in launches of 16 segments ----
+        segs, g = [], 0
+        for l, (t, ks) in enumerate(zip(self.levels, kept)):
+            cur, nxt = t._bank, 1 - t._bank
+            Y = len(t.years)
+            for i in ks:
+                yr = t.years[i]
+                yr._grads_clear = False
+                if present is None:
+                    active = gate.data_ptr() + 4 * g
+                    step = t.dev_steps.data_ptr() + 4 * (cur * Y + i)
+                    step_next = t.dev_steps.data_ptr() + 4 * (nxt * Y + i)
+                    for k, (p, gr, m, v, cnt) in enumerate(t._year_segments(yr)):
+                        segs.append(_lib.AdamSegment(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), cnt, active, step,
+                                                     step_next if k == 0 else None, 0, yr.lr))
+                else:
+                    yr.step_count += 1
+                    for p, gr, m, v, cnt in t._year_segments(yr):
+                        segs.append(_lib.AdamSegment(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), cnt, None, None, None,
+                                                     yr.step_count, yr.lr))
+                yr._grads_clear = not t.keep_grads
+                g += 1
+            if present is None:
+                t._bank = nxt
+                t.local_flags = gate[lv[l].first:lv[l].first + lv[l].count]
+        t0 = self.levels[0]
+        if any(t.betas != t0.betas or t.eps != t0.eps or t.keep_grads != t0.keep_grads for t in self.levels):
+            raise RuntimeError("training_step_all: the levels' Adam settings (betas, eps, keep_grads) must agree")
+        for lo in range(0, len(segs), _lib.ADAM_MAX_SEGMENTS):
+            part = segs[lo:lo + _lib.ADAM_MAX_SEGMENTS]
+            arr = (_lib.AdamSegment * len(part))(*part)
+            _lib.check(L.dta_adam_step_multi(len(part), arr, t0.lr, t0.betas[0], t0.betas[1], t0.eps, t0.sync.grad_scale,
+                                             0 if t0.keep_grads else 1, st), "dta_adam_step_multi")
+        self._live = live      # inputs and labels stay referenced until the step's launches are enqueued
+        return [t.loss for t in self.levels]
 
     def training_step(self, batch, batch_idx, optimizer_idx, present=None):
         """multi_stage.py:277-288: the level's batch is batch[optimizer_idx]."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DTA_ABI_VERSION 1
+#define DTA_ABI_VERSION 2   /* 2: DTA_MAX_YEARS 16, dta_adam_segment::lr, dta_multistage_*, 16 Adam segments per launch */
 
 enum { DTA_F32 = 0, DTA_BF16 = 1 };               /* arithmetic type of the conv contractions */
 enum { DTA_NET_HANG2020 = 0, DTA_NET_SPECTRAL = 1, DTA_NET_SPATIAL = 2, DTA_NET_VANILLA = 3 };
@@ -165,7 +165,7 @@ int dta_net_forward_loss(const dta_net_desc* d, const dta_subnet_params* nets, c
  *  d      : kind DTA_NET_SPECTRAL; heads_mask is ignored (only the last head is evaluated)
  *  nets   : `years` entries;  x : `years` device pointers, each float32 NCHW [batch][bands][height][width]
  *  mean_scores : float32 [batch][classes] */
-#define DTA_MAX_YEARS 4
+#define DTA_MAX_YEARS 16
 size_t dta_ensemble_workspace_bytes(const dta_net_desc* d, int years);
 int dta_ensemble_forward(const dta_net_desc* d, int years, const dta_subnet_params* nets, const float* const* x,
                          void* workspace, float* mean_scores, void* stream);
@@ -304,14 +304,42 @@ int dta_adam_step_gated(float* p, float* g, float* m, float* v, size_t n, const 
  * segment.  Each segment is stepped exactly as dta_adam_step (active == NULL: host step count `step` >= 1) or as
  * dta_adam_step_gated (active != NULL: device gate + device step counter; `step` ignored) would step it; zero_grad and the
  * hyper-parameters are common.  1 <= nseg <= DTA_ADAM_MAX_SEGMENTS. */
-#define DTA_ADAM_MAX_SEGMENTS 8
+#define DTA_ADAM_MAX_SEGMENTS 16
 typedef struct dta_adam_segment {
   float* p; float* g; float* m; float* v; size_t n;
   const float* active; const int* dev_step; int* dev_step_next;   /* gated form, or all NULL */
   int step;                                                        /* host step count (ungated form) */
+  float lr;                                                        /* > 0: this segment's learning rate instead of the call's (one Adam per
+                                                                      level, reference multi_stage.py:258-262); 0: the call's */
 } dta_adam_segment;
 int dta_adam_step_multi(int nseg, const dta_adam_segment* segs, float lr, float beta1, float beta2, float eps, float grad_scale,
                         int zero_grad, void* stream);
+
+/* ---- Multi-stage step (reference src/models/multi_stage.py:41-66: one learned_ensemble per level of the hierarchy, each with
+ * its own class count; :277-288: per level weighted cross-entropy of the mean over the years; train.py:75-100 trains all
+ * levels on every batch).  The levels x kept-years spectral networks run as the groups of ONE set of launches -- one forward
+ * chain, ONE loss launch over the levels, one backward chain -- instead of one chain per level.  Every level's batch has
+ * the same size (d->batch) and crop shape; d->classes is ignored (each level carries its own).
+ *  lv[l].first / count : the level's networks are nets[first .. first + count) (likewise x, grads, gate); levels in order,
+ *                        adjacent, the total at most DTA_MAX_YEARS networks
+ *  gate (device, float[total], may be NULL): as for dta_ensemble_forward_gated -- a network whose flag is <= 0 is left out
+ *                        of its level's mean, keeps its BatchNorm statistics and gets exact-zero gradients */
+#define DTA_MAX_LEVELS 8
+typedef struct dta_level {
+  int classes, first, count;
+  const long long* labels;   /* device int64 [batch] */
+  const float* weight;       /* device float32 [classes], NULL = ones (reference multi_stage.py:67-79 loss_weight_{level}) */
+  float* mean_scores;        /* out, device [batch][classes]: mean over the level's kept years (may be NULL) */
+  float* kept;               /* out, device {kept years, 1 / kept years} (may be NULL) */
+  float* loss;               /* out, device scalar */
+  float* dscore;             /* out, device [batch][classes] = d(loss) / d(ONE kept year's scores); NULL: no gradient */
+  float* scratch;            /* device, batch + 2 floats; the last word must be zero on entry and is left zero */
+} dta_level;
+size_t dta_multistage_workspace_bytes(const dta_net_desc* d, int levels, const dta_level* lv);
+int dta_multistage_forward_loss(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
+                                const float* const* x, const float* gate, void* workspace, void* stream);
+int dta_multistage_backward(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
+                            void* workspace, const dta_subnet_grads* grads, const float* gate, void* stream);
 
 /* ---- Peer gradient exchange: data-parallel training with one process per GPU of ONE node (reference train.py:89-98:
  * Lightning DDP all-reduces every parameter's gradient between loss.backward() and optimizer.step()).  Here the sum over

@@ -291,6 +291,50 @@ def case_ensemble_steps():
     print("ensemble_steps.npz", len(out))
 
 
+from oracle.recipes import MULTISTAGE, multistage_inputs, multistage_weight  # noqa: E402
+
+
+def case_multistage_steps():
+    """The reference's MultiStage training loop over TWO levels (src/models/multi_stage.py:41-66: one learned_ensemble per
+    level, each with its own class count; :258-275 one Adam per level with its own learning rate; :277-288 training_step,
+    which Lightning calls once per optimizer_idx on every batch -- train.py:75-100): per level
+    `loss = F.cross_entropy(models[idx](images), y, weight=loss_weight_idx)`, backward, that level's Adam step.  Three
+    steps; on two of them one level has an all-zero year (skipped by year.py:27)."""
+    out = {}
+    c = MULTISTAGE
+    years, bands, B = c["years"], c["bands"], c["B"]
+    models, opts, ws = [], [], []
+    for l, classes in enumerate(c["classes"]):
+        m = RY.learned_ensemble(years=years, classes=classes, config={"pretrain_state_dict": None, "bands": bands})
+        load(m, O.init_params(O.learned_ensemble_spec(years, bands, classes), seed=301 + l))
+        m.train()
+        models.append(m)
+        opts.append(torch.optim.Adam(m.parameters(), lr=c["lrs"][l]))
+        ws.append(torch.from_numpy(multistage_weight(classes)))
+    for step in range(c["steps"]):
+        for l, m in enumerate(models):      # Lightning: training_step(batch, batch_idx, optimizer_idx) for every optimizer
+            imgs, y = multistage_inputs(step, l, years, B, bands, c["classes"][l])
+            opts[l].zero_grad(set_to_none=True)
+            s = m([torch.from_numpy(a) for a in imgs])
+            loss = F.cross_entropy(s, torch.from_numpy(y), weight=ws[l])
+            loss.backward()
+            opts[l].step()
+            tag = f"step{step}/level{l}"
+            out[f"{tag}/score"] = s.detach().numpy()
+            out[f"{tag}/loss"] = np.float64(loss.item())
+            for k, prm in m.named_parameters():
+                a = prm.detach().numpy()
+                out[f"{tag}/pnorm/{k}"] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+                if a.size <= 4096:
+                    out[f"{tag}/pfull/{k}"] = a.copy()
+                else:
+                    out[f"{tag}/psamp/{k}"] = a.reshape(-1)[sample_idx(a.size)].copy()
+            for k, b in m.named_buffers():
+                out[f"{tag}/buf/{k}"] = b.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "multistage_steps.npz"), **out)
+    print("multistage_steps.npz", len(out))
+
+
 def case_three_head():
     """The north-star's "three-head weighted cross-entropy" (the Hang et al. training recipe; the reference's own step
     keeps only the last head): the reference's sub-networks return three heads each
@@ -722,6 +766,7 @@ if __name__ == "__main__":
     case_hang_small()
     case_subnets()
     case_ensemble_steps()
+    case_multistage_steps()
     case_three_head()
     case_preprocess()
     case_hang_full()

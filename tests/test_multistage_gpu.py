@@ -1,0 +1,192 @@
+"""The reference's multi-stage step -- every level of the hierarchy on every batch (train.py:75-100, multi_stage.py:41-66,
+:258-288) -- as ONE launch chain over levels x years (dta_multistage_*), against the reference's own golden steps and against
+the level-by-level trainers; year ensembles of more than four years through the fused trainer."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import hang2020_np as O
+from oracle import prng
+from oracle.recipes import MULTISTAGE, multistage_inputs, multistage_weight
+
+pytestmark = pytest.mark.gpu
+TIGHT = 2e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _load(mod, params):
+    mod.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in params.items()})
+    return mod.to(dev())
+
+
+def _levels(prec="fp32"):
+    from deeptreeattention_amd.year import learned_ensemble
+    c = MULTISTAGE
+    models, ws = [], []
+    for l, classes in enumerate(c["classes"]):
+        m = _load(learned_ensemble(years=c["years"], classes=classes, config={"pretrain_state_dict": None, "bands": c["bands"]}),
+                  O.init_params(O.learned_ensemble_spec(c["years"], c["bands"], classes), seed=301 + l))
+        for net in m.year_models:
+            net.precision = prec
+        m.train()
+        models.append(m)
+        ws.append(torch.from_numpy(multistage_weight(classes)))
+    return models, ws
+
+
+def _batch(step):
+    c = MULTISTAGE
+    batch, present = [], []
+    for l, classes in enumerate(c["classes"]):
+        imgs, y = multistage_inputs(step, l, c["years"], c["B"], c["bands"], classes)
+        present.append([bool(a.any()) for a in imgs])
+        batch.append((["id"] * c["B"], {"HSI": [torch.from_numpy(a).to(dev()) for a in imgs]}, torch.from_numpy(y).to(dev())))
+    return batch, present
+
+
+def _check_level(g, tag, tr, m, loss, lr=1e-3):
+    assert rel_l2(tr.scores.cpu().numpy(), g[f"{tag}/score"]) < TIGHT, tag
+    ref = float(g[f"{tag}/loss"])
+    assert abs(float(loss) - ref) < TIGHT * abs(ref), tag
+    for k, prm in m.named_parameters():
+        if k.endswith("conv_layer.bias"):
+            continue   # conv biases under BN: gradient is rounding noise, Adam turns its sign into +-lr steps
+        a = prm.detach().cpu().numpy()
+        ref = float(g[f"{tag}/pnorm/{k}"])
+        assert abs(np.sqrt((a.astype(np.float64) ** 2).sum()) - ref) <= 1e-3 * ref, (tag, k)
+        if f"{tag}/pfull/{k}" in g:
+            assert rel_l2(a, g[f"{tag}/pfull/{k}"]) < 2e-3, (tag, k)
+        else:
+            idx = (prng.hash_u64(7, 99, 256) % np.uint64(a.size)).astype(np.int64)
+            assert rel_l2(a.reshape(-1)[idx], g[f"{tag}/psamp/{k}"]) < 2e-3, (tag, k)
+    for k, b in m.named_buffers():
+        # running means carry the conv bias, whose gradient under BatchNorm is rounding noise that Adam turns into +-lr steps
+        # (tests/test_hip_modules.py holds 2e-3 at lr 1e-3): the bound scales with the level's learning rate
+        tol = 2e-3 * (lr / 1e-3) if k.endswith("running_mean") else TIGHT
+        assert rel_l2(b.cpu().numpy(), g[f"{tag}/buf/{k}"]) < tol, (tag, k)
+
+
+@pytest.mark.parametrize("use_present", [False, True])
+def test_multistage_batched_steps_vs_reference_golden(golden, use_present):
+    """Two levels (3 and 5 classes, learning rates 1e-3 and 2e-3) x three years, three steps, two of them with an all-zero
+    year in one level: scores, loss, every parameter and every BatchNorm buffer of BOTH levels after each step against the
+    reference's per-level learned_ensemble + F.cross_entropy + torch Adam -- all networks of a step in one launch chain."""
+    from deeptreeattention_amd.engine import MultiStageTrainer
+    g = golden("multistage_steps.npz")
+    models, ws = _levels()
+    driver = MultiStageTrainer(models, list(MULTISTAGE["lrs"]), ws)
+    for step in range(MULTISTAGE["steps"]):
+        batch, present = _batch(step)
+        losses = driver.training_step_all(batch, step, present if use_present else None)
+        assert driver.batched_last
+        for l, (tr, m) in enumerate(zip(driver.levels, models)):
+            _check_level(g, f"step{step}/level{l}", tr, m, losses[l], MULTISTAGE["lrs"][l])
+    # the skipped years' optimizer step counts did not advance (torch's Adam passes over grad-None parameters)
+    assert driver.levels[0].step_counts() == [2, 3, 3]
+    assert driver.levels[1].step_counts() == [3, 3, 2]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_multistage_batched_equals_level_by_level(prec):
+    """The one-chain step against the same levels stepped one after the other (training_step per optimizer_idx, as
+    Lightning does): the same kernels on the same data in another grouping -- parameters after three steps agree to float32
+    rounding of the reductions whose split depends on the group count."""
+    from deeptreeattention_amd.engine import MultiStageTrainer
+    ma, wa = _levels(prec)
+    mb, wb = _levels(prec)
+    a = MultiStageTrainer(ma, list(MULTISTAGE["lrs"]), wa)
+    b = MultiStageTrainer(mb, list(MULTISTAGE["lrs"]), wb)
+    for step in range(MULTISTAGE["steps"]):
+        batch, present = _batch(step)
+        la = a.training_step_all(batch, step, present)
+        lb = [b.training_step(batch, step, l, present[l]) for l in range(len(mb))]
+        assert a.batched_last
+        for x, y in zip(la, lb):
+            assert abs(float(x) - float(y)) <= 1e-5 * abs(float(y))
+    tol = 1e-5 if prec == "fp32" else 2e-3
+    for m1, m2 in zip(ma, mb):
+        for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            if k.endswith("conv_layer.bias"):
+                continue
+            assert rel_l2(p1.detach().cpu().numpy(), p2.detach().cpu().numpy()) < tol, k
+        for (k, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+            assert rel_l2(b1.cpu().numpy(), b2.cpu().numpy()) < max(tol, 1e-5), k
+
+
+def test_multistage_five_levels_full_width():
+    """The reference's shape: 5 levels x 3 years of spectral_network(369, classes_l) on 11x11 crops, batch 128
+    (config.yml:58), bf16: one chain of 15 networks; the losses equal the level-by-level step's."""
+    from deeptreeattention_amd.engine import MultiStageTrainer
+    from deeptreeattention_amd.year import learned_ensemble
+    classes = [2, 2, 12, 7, 5]
+    cfg = {"pretrain_state_dict": None, "bands": 369}
+
+    def build():
+        torch.manual_seed(5)
+        ms = []
+        for c in classes:
+            m = learned_ensemble(3, c, cfg).to(dev()).train()
+            for net in m.year_models:
+                net.precision = "bf16"
+            ms.append(m)
+        return MultiStageTrainer(ms, [1e-4] * 5)
+    a, b = build(), build()
+    torch.manual_seed(6)
+    batch = [(None, {"HSI": [torch.rand(128, 369, 11, 11, device=dev()) for _ in range(3)]}, torch.randint(0, c, (128,), device=dev()))
+             for c in classes]
+    for step in range(2):
+        la = a.training_step_all(batch, step)
+        assert a.batched_last
+        lb = [b.training_step(batch, step, l) for l in range(5)]
+        for x, y in zip(la, lb):
+            assert torch.isfinite(x) and abs(float(x) - float(y)) <= 2e-3 * abs(float(y)), (step, float(x), float(y))
+
+
+def test_multistage_falls_back_when_levels_differ():
+    """Levels whose batches differ in size cannot share a chain: stepped one after the other, same results as ever."""
+    from deeptreeattention_amd.engine import MultiStageTrainer
+    models, ws = _levels()
+    driver = MultiStageTrainer(models, list(MULTISTAGE["lrs"]), ws)
+    batch, present = _batch(0)
+    ind, inp, y = batch[1]
+    batch[1] = (ind[:4], {"HSI": [x[:4].contiguous() for x in inp["HSI"]]}, y[:4])
+    losses = driver.training_step_all(batch, 0, present)
+    assert not driver.batched_last and len(losses) == 2 and all(torch.isfinite(v) for v in losses)
+
+
+@pytest.mark.parametrize("years", [5, 7])
+def test_fused_ensemble_trainer_more_than_four_years(years):
+    """A year ensemble of more than four years through the fused trainer (the reference takes the year count from the data,
+    multi_stage.py:39, :61-66): against the module path (autograd.Function per network + torch Adam), two steps, one year
+    all-zero."""
+    from deeptreeattention_amd.engine import EnsembleTrainer
+    from deeptreeattention_amd.year import learned_ensemble
+    bands, classes, B = 16, 6, 10
+    cfg = {"pretrain_state_dict": None, "bands": bands}
+    torch.manual_seed(11)
+    m1 = learned_ensemble(years, classes, cfg).to(dev()).train()
+    m2 = learned_ensemble(years, classes, cfg).to(dev()).train()
+    m2.load_state_dict(m1.state_dict())
+    for m in (m1, m2):
+        for net in m.year_models:
+            net.precision = "fp32"
+    tr = EnsembleTrainer(m1, lr=1e-3)
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    for step in range(2):
+        imgs = [torch.rand(B, bands, 11, 11, device=dev()) for _ in range(years)]
+        imgs[step + 1].zero_()
+        y = torch.randint(0, classes, (B,), device=dev())
+        loss = tr.train_step(imgs, y, present=None if step == 0 else [bool(x.any()) for x in imgs])
+        opt.zero_grad(set_to_none=True)
+        ref = torch.nn.functional.cross_entropy(m2(imgs), y)
+        ref.backward()
+        opt.step()
+        assert abs(float(loss) - float(ref)) <= 1e-4 * abs(float(ref)), step
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if k.endswith("conv_layer.bias"):
+            continue
+        assert rel_l2(p1.detach().cpu().numpy(), p2.detach().cpu().numpy()) < 2e-3, k

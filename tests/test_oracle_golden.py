@@ -263,6 +263,34 @@ def test_torch_oracle_ensemble_steps_match_reference_golden(golden):
                 <= 1e-5 * float(g[f"step{step}/pnorm/{k}"]), (step, k)
 
 
+def test_torch_oracle_multistage_steps_match_reference_golden(golden):
+    """The reference's MultiStage loop over two levels with different class counts and learning rates (multi_stage.py:41-66,
+    :258-288; three steps, two of them with an all-zero year in one level): the torch restatement, one EnsembleTrainStep
+    per level, against the reference's own learned_ensembles + per-level F.cross_entropy + per-level Adam."""
+    import torch
+    from oracle import hang2020_torch as OT
+    from oracle.recipes import MULTISTAGE as c, multistage_inputs, multistage_weight
+    g = golden("multistage_steps.npz")
+    steps = []
+    for l, classes in enumerate(c["classes"]):
+        p = OT.to_tensors(O.init_params(O.learned_ensemble_spec(c["years"], c["bands"], classes), seed=301 + l))
+        steps.append((p, OT.EnsembleTrainStep(p, c["lrs"][l], torch.from_numpy(multistage_weight(classes)))))
+    for step in range(c["steps"]):
+        for l, (p, fn) in enumerate(steps):
+            imgs, y = multistage_inputs(step, l, c["years"], c["B"], c["bands"], c["classes"][l])
+            s, loss = fn([torch.from_numpy(a) for a in imgs], torch.from_numpy(y))
+            tag = f"step{step}/level{l}"
+            assert rel_l2(s.numpy(), g[f"{tag}/score"]) < 1e-4, tag
+            assert abs(float(loss) - float(g[f"{tag}/loss"])) < 1e-4 * abs(float(g[f"{tag}/loss"])), tag
+            for k, t in p.items():
+                if not t.requires_grad:
+                    assert rel_l2(t.numpy(), g[f"{tag}/buf/{k}"]) < 1e-4, (tag, k)
+                    continue
+                a = t.detach().numpy()
+                ref = float(g[f"{tag}/pnorm/{k}"])
+                assert abs(np.sqrt((a.astype(np.float64) ** 2).sum()) - ref) <= 1e-5 * ref, (tag, k)
+
+
 def _metadata_params(g, bands, classes):
     """Sensor weights from the portable PRNG, the small site branch / fusion layer from the stored torch init."""
     import torch
