@@ -11,8 +11,8 @@ launcher (`python bench.py --gpus N`, no RANK in the environment) it spawns its 
 Synthetic patches (U[0,1), like the reference's min-max-scaled crops) are resident in HBM before the timed region.
 Rank 0 prints ONE JSON line.  `roofline.frac` prices SURVEY.md 8(d)'s COMPULSORY bytes of the conv1 forward (input in +
 output out); the bf16 tile by-product it also writes is in `frac_with_byproduct`.  The one-GPU line also carries, timed
-after the contract's region (20 steps each): `fp32` (the reference's own precision), `ensemble24` (BASELINE configs[4]), `metadata` (BASELINE configs[3])
-and `module_path` (the unchanged reference step on the plugin modules with optim.DtaAdam / optim.cross_entropy).  Inside the timed loop the two first-conv kernels are timed with HIP events recorded on their own
+after the contract's region (20 steps each): `fp32` (the reference's own precision), `ensemble24` (BASELINE configs[4]), `metadata` (BASELINE configs[3]),
+`multistage` (the reference's train.py path: 5 levels x 3 years, one launch chain vs level by level) and `module_path` (the unchanged reference step on the plugin modules with optim.DtaAdam / optim.cross_entropy).  Inside the timed loop the two first-conv kernels are timed with HIP events recorded on their own
 stream: `roofline` = the conv1 forward (the step's longest kernel; HBM-bound since it also converts the fp32 input and
 emits the bf16 tiles), `roofline_mfma` = the conv1 weight gradient (the longest MFMA-bound kernel); `step_roofline`
 prices the whole step's algorithmic FLOPs / bytes against the MI355X peaks.  `value` comes from the
@@ -282,6 +282,50 @@ def side_metadata(a, dev, steps=20, sites=23):
            "note": "MetadataTrainer(metadata_sensor_fusion(369, 23 sites, 200)): HSI branch = the fused Hang2020 step, site MLP + "
                    "fusion layer + loss = torch ops on (B, 200) tensors; wall clock around the steps after 5 warm-up steps"}
     del tr, m, x
+    torch.cuda.empty_cache()
+    return out
+
+
+def side_multistage(a, dev, steps=20, years=3, classes=(2, 2, 12, 7, 5), lrs=(1e-6, 1e-6, 5e-6, 1e-4, 5e-6)):
+    """The path the reference's train.py trains (train.py:75-100, src/models/multi_stage.py:41-66, :258-288): five levels x
+    `years` spectral_network(369, classes_l) year ensembles on 11x11 crops, every level stepped on every batch (Lightning
+    calls training_step once per optimizer), per-level class weights / Adam / learning rate (config.yml:62-66).  Timed at
+    the reference's batch size (config.yml:58: 128) and at 1024: all levels x years networks as ONE launch chain
+    (MultiStageTrainer.training_step_all, dta_multistage_*) against the level-by-level step."""
+    from deeptreeattention_amd.engine import MultiStageTrainer
+    from deeptreeattention_amd.year import learned_ensemble
+    import deeptreeattention_amd
+    deeptreeattention_amd.set_default_precision(a.precision)
+    cfg = {"pretrain_state_dict": None, "bands": BANDS}
+    torch.manual_seed(4321)
+    tr = MultiStageTrainer([learned_ensemble(years, c, cfg).to(dev).train() for c in classes], list(lrs))
+    out = {"dtype": a.precision, "steps": steps, "levels": len(classes), "years": years, "classes": list(classes),
+           "note": "wall clock around the steps after 5 warm-up steps; present= flags (no year missing); batched = one launch chain "
+                   "over the 15 networks, serial = one chain per level (what Lightning's per-optimizer loop does)"}
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    for B in (128, 1024):
+        batch = [(None, {"HSI": [torch.rand(B, BANDS, HW, HW, device=dev, generator=g) for _ in range(years)]},
+                  torch.randint(0, c, (B,), device=dev, generator=g)) for c in classes]
+        present = [[True] * years] * len(classes)
+
+        def timed(fn):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                losses = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3, losses
+        ms_serial, _ = timed(lambda: [tr.training_step(batch, 0, l, present[l]) for l in range(len(classes))])
+        ms_batched, losses = timed(lambda: tr.training_step_all(batch, 0, present))
+        out["B%d" % B] = {"per_level_batch": B, "batched_ms_per_step": round(ms_batched, 4), "serial_ms_per_step": round(ms_serial, 4),
+                          "speedup": round(ms_serial / ms_batched, 2), "one_chain": bool(tr.batched_last),
+                          "crops_per_s": round(len(classes) * B / ms_batched * 1e3, 1),
+                          "final_losses": [round(float(v), 5) for v in losses]}
+        del batch
+    del tr
     torch.cuda.empty_cache()
     return out
 
@@ -711,6 +755,7 @@ def main():
             for name, fn in (("fp32", lambda: side_fp32(a, dev)),
                              ("ensemble24", lambda: main_ensemble24(argparse.Namespace(**dict(vars(a), steps=20, warmup=5, prime_seconds=0.0, batch=1024, site="fwd0")), emit=False)),
                              ("metadata", lambda: side_metadata(a, dev)),
+                             ("multistage", lambda: side_multistage(a, dev)),
                              ("module_path", lambda: side_module_path(a, dev, fused_ms))):
                 try:
                     out[name] = fn()

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void k_forward_prep(PrepArgs a) {
   int y = blockIdx.y;
   if (y < a.ncg * a.nx) {
     const int gi = y / a.ncg;
+    if ((int)blockIdx.x >= a.B) return;      // (the grid's x extent is at least PREP_MIN_BLOCKS: see launch_forward_prep)
     pack_input_block<T>(a.x[gi], (T*)((char*)a.x_tl + (size_t)gi * a.x_tl_gs), a.B, a.C, a.H, a.W, a.NC, a.CG, blockIdx.x,
                         y - gi * a.ncg, smem, a.x_compact != 0);
     return;
@@ -198,7 +199,10 @@ int launch_forward_prep(PrepArgs a, hipStream_t st) {
   size_t lds;
   if (pack_input_plan(a.C, a.H, a.W, &a.NC, &a.CG, &lds)) return 1;
   a.ncg = (a.NC + a.CG - 1) / a.CG;
-  dim3 grid(a.B, a.ncg * a.nx + a.packs.n + a.spacks.n + a.trans.n + (a.zero ? 1 : 0));
+  // one block per patch for the input-pack jobs; the weight re-layout jobs are grid-stride loops over up to 16 networks'
+  // weights (a multi-stage step at batch 128: 1.7 M elements per job), so small batches still get a full-width grid
+  constexpr int PREP_MIN_BLOCKS = 1024;
+  dim3 grid(a.B > PREP_MIN_BLOCKS ? a.B : PREP_MIN_BLOCKS, a.ncg * a.nx + a.packs.n + a.spacks.n + a.trans.n + (a.zero ? 1 : 0));
   hipLaunchKernelGGL(k_forward_prep<T>, grid, dim3(256), lds, st, a);
   DTA_CHECK_LAUNCH("k_forward_prep");
   return 0;

@@ -38,14 +38,15 @@ def _batch(years, B=4, bands=12, classes=5, seed=0, zero=()):
     return xs, torch.randint(0, classes, (B,), device=dev(), generator=g)
 
 
-def test_dta_adam_steps_a_five_year_ensemble_like_torch_adam():
-    """Five years > DTA_MAX_YEARS = 4: learned_ensemble.forward takes its host-decided path (year.py:27 on the host, the
-    kept years in chunks of four).  DtaAdam must step the kept years and pass over the skipped ones -- torch.optim.Adam on a
-    copy of the model is the yardstick (a skipped year has grad None there)."""
+@pytest.mark.parametrize("beyond", [False, True])
+def test_dta_adam_steps_a_many_year_ensemble_like_torch_adam(beyond):
+    """More years than one grouped launch takes (DTA_MAX_YEARS = 16 since round 6; 4 before): learned_ensemble.forward takes
+    its host-decided path (year.py:27 on the host, the kept years in chunks of DTA_MAX_YEARS).  DtaAdam must step the kept
+    years and pass over the skipped ones -- torch.optim.Adam on a copy of the model is the yardstick (a skipped year has grad
+    None there).  beyond=False: five years, which one device-gated launch chain now takes."""
     from deeptreeattention_amd.optim import DtaAdam
     from deeptreeattention_amd import _lib
-    years = 5
-    assert years > _lib.MAX_YEARS
+    years = _lib.MAX_YEARS + 1 if beyond else 5
     a = _ensemble(years)
     b = copy.deepcopy(a)
     opt_a = DtaAdam(a.parameters(), lr=1e-3)
@@ -69,7 +70,7 @@ def test_dta_adam_steps_a_five_year_ensemble_like_torch_adam():
         if k in before and "classifier1" not in k and "classifier2" not in k:
             moved += int(not torch.equal(sa[k], before[k]))
     assert moved > 100                                     # the ensemble WAS stepped (the bug left every parameter where it was)
-    assert opt_a.step_counts() == [2, 2, 3, 3, 2]
+    assert opt_a.step_counts() == [2, 2, 3, 3, 2] + [3] * (years - 5)
 
 
 def test_no_grad_forward_between_training_forward_and_backward_keeps_the_flags():
