@@ -306,6 +306,8 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0, const int* group_c
 inline bool fused_input(const Plan& p) {
   const int launchG = p.shared_x ? 1 : p.G;
   // (tiles that keep their halo -- 24x24-class crops -- take the same route as long as a workgroup owns whole patches)
+  // (no fused-input kernel exists for 576-row x 64-column workgroups -- two branches on 24x24-class crops: it would spill)
+  if (p.shared_x && p.MWG[0] == 576) return false;
   return p.esz == 2 && p.HWc[0] <= p.MWG[0] && p.nwg[0] * launchG >= 100 && !switches().no_fused_input;
 }
 

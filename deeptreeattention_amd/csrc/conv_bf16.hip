@@ -58,6 +58,24 @@ struct WgStamp {
 #define WGSTAMP(id)
 #endif
 #ifdef DTA_TICKS
+// fused-input first conv (XN): per chunk half-interval, waves 0 (stages first) and NW/2 (multiplies first) of workgroup 100:
+// [0] tile-out, [1] multiply phase when first, [2] staging (wait for the input loads, convert, LDS writes, next fetches),
+// [3] multiply phase when second, [4] barrier wait; summed over the chunks -> g_xticks[wave class][5], + [5] whole loop
+__device__ long long g_xticks[2][8];
+__device__ long long g_xticks2[2][4];      // staging split: [0] input wait + convert + LDS writes, [1] weight LDS writes, [2] fetch issue
+extern "C" int dta_debug_xticks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xticks), sizeof(long long) * 16); }
+extern "C" int dta_debug_xticks2(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xticks2), sizeof(long long) * 8); }
+#define XS(i) xs_[i] = clock64();
+#define XS_ACC { xsacc_[0] += xs_[1] - xs_[0]; xsacc_[1] += xs_[2] - xs_[1]; xsacc_[2] += xs_[3] - xs_[2]; }
+#define XT(i) xt_[i] = clock64();
+#define XT_ACC { _Pragma("unroll") for (int k_ = 0; k_ < 5; ++k_) xacc_[k_] += xt_[k_ + 1] - xt_[k_]; }
+#else
+#define XT(i)
+#define XT_ACC
+#define XS(i)
+#define XS_ACC
+#endif
+#ifdef DTA_TICKS
 __device__ long long g_cticks[16];
 extern "C" int dta_debug_cticks(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cticks), sizeof(long long) * 16); }
 #define CTICK(i) do { if (!XN && a.N == 64 && a.NC == 2 && a.stats && blockIdx.x == 100 && blockIdx.y == 0 && threadIdx.x == 0) g_cticks[i] = clock64(); } while (0)
@@ -141,10 +159,15 @@ template <int MT, int NT, bool XN, int NWV = 8, int MINW = 1>
 __global__ __launch_bounds__(NWV * 64, MINW) void k_conv3x3_bf16(ConvArgs a) {
   WGSTAMP(XN ? 0 : (a.stats ? (a.N == 64 ? 1 : 2) : -1));      // first conv, second conv, third conv (forward launches)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef DTA_TICKS
+  const long long xentry_ = clock64();
+#endif
   CTICK(0);
   constexpr int NW = NWV, NTHR = NW * 64;       // eight waves, or four for maps so small that 256-row tiles leave CUs idle
   constexpr int MWG = NW * MT * 32;
   constexpr int N = NT * 32;
+  constexpr bool TAP_PIPE = true;
+  static_assert(!(XN && MT * NT >= 6), "six accumulator tiles + the fp32 staging sets spill (see launch_conv_bf16_t)");
   int* rowtab = (int*)smem;                 // [MWG] global output row or -1
   int* plq = rowtab + MWG;                  // [MWG] (pl << 16) | q_topleft
   float* red = (float*)(plq + MWG);         // [NW][N]
@@ -181,7 +204,9 @@ _Pragma("unroll") \
       abase[mt] = ((v >> 16) * Q + (v & 0xFFFF)) * RB + khalf16; \
     } \
   }
-  if (XN) DTA_TABLES    // (the fused-input kernel is at its register limit: tables first, nothing else live)
+  // (measured, round 6: building the tables UNDER the first chunk's loads instead -- issued first, 4 k of the 19 k cycles in
+  //  front of the loop -- leaves this kernel at 79.9 us and makes the STEP 4-5 us slower in 4 of 4 same-box alternations)
+  if (XN) DTA_TABLES
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -297,16 +322,42 @@ _Pragma("unroll") \
     _Pragma("unroll") for (int u = 0; u < WV; ++u)                                                    \
         if (tid + u * NTHR < wvec) *reinterpret_cast<u32x4*>((sw_) + wdst[u]) = rw[u];                \
   }
-#define DTA_COMPUTE(sx_, sw_)                                                                         \
-  _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                               \
-    const int toffB = ((tap / 3) * W2 + (tap % 3)) * RB;                                              \
-    bf16x8 af[MT], bf[NT];                                                                            \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[mt] = lds_b128((sx_), abase[mt] + toffB);    \
+// The nine taps of a chunk, software-pipelined two taps deep: the fragment reads of tap t + 2 are issued right behind the
+// MFMAs of tap t (two fragment sets, alternating), so a read has two tap times (~256 matrix-pipe cycles) to land instead of
+// being requested when its MFMAs are next in line -- at any moment only ONE of a SIMD's two waves multiplies (the other
+// stages), so nothing else covers the LDS latency.  The order is pinned with sched_group_barrier (DS reads 0x100, MFMA
+// 0x008); the wait counts stay the compiler's.
+#define DTA_TAP_LOAD(set_, tap_, sx_, sw_)                                                            \
+  {                                                                                                   \
+    const int toffB_ = (((tap_) / 3) * W2 + ((tap_) % 3)) * RB;                                       \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[set_][mt] = lds_b128((sx_), abase[mt] + toffB_); \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                 \
-        bf[nt] = lds_b128((sw_), bbase + (tap * N + nt * 32) * RB);                                   \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                               \
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0); \
+        bf[set_][nt] = lds_b128((sw_), bbase + ((tap_) * N + nt * 32) * RB);                          \
+  }
+#define DTA_COMPUTE(sx_, sw_)                                                                         \
+  if constexpr (TAP_PIPE) {                                                                           \
+    bf16x8 af[2][MT], bf[2][NT];                                                                      \
+    DTA_TAP_LOAD(0, 0, sx_, sw_)                                                                      \
+    DTA_TAP_LOAD(1, 1, sx_, sw_)                                                                      \
+    _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                             \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                             \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][mt], bf[tap & 1][nt], acc[mt][nt], 0, 0, 0); \
+      if (tap + 2 < 9) DTA_TAP_LOAD(tap & 1, tap + 2, sx_, sw_)                                       \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MT + NT), 0);                                    \
+    _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                             \
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                                        \
+      if (tap + 2 < 9) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);                       \
+    }                                                                                                 \
+  } else {                                                                                            \
+    _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                             \
+      bf16x8 af[1][MT], bf[1][NT];                                                                    \
+      DTA_TAP_LOAD(0, tap, sx_, sw_)                                                                  \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                               \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                             \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mt], bf[0][nt], acc[mt][nt], 0, 0, 0); \
+    }                                                                                                 \
   }
 
   if (XN && dbuf) {
@@ -358,31 +409,68 @@ _Pragma("unroll") \
     // stages afterwards -- nobody reads the stage being written before the barrier, so the order inside the interval is
     // free, and the matrix pipe has one wave's MFMAs to run while the other wave's staging waits on memory.
     const bool late = !(a.pixel_order & 2) && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+#ifdef DTA_TICKS
+    long long xt_[6] = {0, 0, 0, 0, 0, 0}, xacc_[5] = {0, 0, 0, 0, 0}, xs_[4] = {0, 0, 0, 0}, xsacc_[3] = {0, 0, 0};
+    const long long xt0_ = clock64();
+    if (blockIdx.x == 100 && blockIdx.y == 0 && tid == 0) g_xticks[0][6] = xt0_ - xentry_;
+#endif
     for (int chunk = 0; chunk < a.NC; chunk += 2) {
       // even chunk in stage 0; chunk+1 (set rf) goes to stage 1, then rf refills with chunk+3
+      XT(0)
       DTA_TILE_OUT(s0, chunk)
+      XT(1)
       if (late) { DTA_COMPUTE(s0, s0 + xbytes) }
+      XT(2)
       if (chunk + 1 < a.NC) {
+        XS(0)
         DTA_STORE_XF(rf, s1)
+        XS(1)
         DTA_STORE_W(s1 + xbytes)
+        XS(2)
         if (chunk + 2 < a.NC) DTA_FETCH_W(chunk + 2)
         if (chunk + 3 < a.NC) DTA_FETCH_XF(rf, chunk + 3)
+        XS(3)
+        XS_ACC
       }
+      XT(3)
       if (!late) { DTA_COMPUTE(s0, s0 + xbytes) }
+      XT(4)
       __syncthreads();
+      XT(5)
+      XT_ACC
       if (chunk + 1 >= a.NC) break;
       // odd chunk in stage 1; chunk+2 (set rg) goes to stage 0, then rg refills with chunk+4
+      XT(0)
       DTA_TILE_OUT(s1, chunk + 1)
+      XT(1)
       if (late) { DTA_COMPUTE(s1, s1 + xbytes) }
+      XT(2)
       if (chunk + 2 < a.NC) {
+        XS(0)
         DTA_STORE_XF(rg, s0)
+        XS(1)
         DTA_STORE_W(s0 + xbytes)
+        XS(2)
         if (chunk + 3 < a.NC) DTA_FETCH_W(chunk + 3)
         if (chunk + 4 < a.NC) DTA_FETCH_XF(rg, chunk + 4)
+        XS(3)
+        XS_ACC
       }
+      XT(3)
       if (!late) { DTA_COMPUTE(s1, s1 + xbytes) }
+      XT(4)
       __syncthreads();
+      XT(5)
+      XT_ACC
     }
+#ifdef DTA_TICKS
+    if (blockIdx.x == 100 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == NW / 2)) {
+      long long* o_ = g_xticks[wave ? 1 : 0];
+      for (int k_ = 0; k_ < 5; ++k_) o_[k_] = xacc_[k_];
+      o_[5] = clock64() - xt0_;
+      for (int k_ = 0; k_ < 3; ++k_) g_xticks2[wave ? 1 : 0][k_] = xsacc_[k_];
+    }
+#endif
 #undef DTA_TILE_OUT
 #undef DTA_STORE_W
 #undef DTA_FETCH_W
@@ -423,11 +511,15 @@ _Pragma("unroll") \
   }
   }
 #undef DTA_COMPUTE
+#undef DTA_TAP_LOAD
 #undef DTA_TABLES
 #undef DTA_STORE
 #undef DTA_FETCH
 
   CTICK(3);
+#ifdef DTA_TICKS
+  const long long xloopend_ = clock64();
+#endif
   // ---- epilogue: bias, store, per-workgroup (mean, M2) per column ----
   if (XN) {      // (the fused-input kernel had no register to spare for the bias during its loop)
 #pragma unroll
@@ -527,6 +619,9 @@ _Pragma("unroll") \
     }
   }
   CTICK(4);
+#ifdef DTA_TICKS
+  if (XN && blockIdx.x == 100 && blockIdx.y == 0 && tid == 0) g_xticks[0][7] = clock64() - xloopend_;
+#endif
   if (a.stats == nullptr) return;
   const int cnt = (a.spp == 1) ? npatch * HW : min(MWG, HW - split * MWG);
 #pragma unroll
@@ -549,6 +644,9 @@ _Pragma("unroll") \
     else { o[0] = cmean[tid]; o[1] = m2; }
   }
   CTICK(5);
+#ifdef DTA_TICKS
+  if (XN && blockIdx.x == 100 && blockIdx.y == 0 && tid == 0) g_xticks[1][7] = clock64() - xloopend_;
+#endif
   // no finalize launch: the last workgroup of each logical group folds the group's rows (kernels.h); the staging area is free
   if (a.fan_count) conv_stats_fanin<NTHR>(a, g, N, HW, MWG, reinterpret_cast<double*>(sbuf), reinterpret_cast<int*>(cmean));
 }
@@ -572,11 +670,14 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   static DevOnce attr_once;      // (function attributes are per device)
   if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, false, NW, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (MT * NT < 6) hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, NT, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   if (a.x_nchw[0]) {
     if (a.spp != 1) { dta_set_error("conv3x3(bf16): the fused-input first conv needs whole patches per workgroup"); return 1; }
-    hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, true, NW>), dim3(nwg, G), dim3(NW * 64), lds, st, a);
+    // (six accumulator tiles + two fp32 staging sets do not fit 256 registers -- the instantiation spilled 26..71 of them --
+    //  so a 576-row x 64-column first conv is not offered with the fused input: capi.hip's fused_input() plans the pack job)
+    if constexpr (MT * NT < 6) hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, true, NW>), dim3(nwg, G), dim3(NW * 64), lds, st, a);
+    else { dta_set_error("conv3x3(bf16): no fused-input kernel for %d-row x %d-column workgroups", MWG, N); return 1; }
   } else {
     hipLaunchKernelGGL((k_conv3x3_bf16<MT, NT, false, NW, MINW>), dim3(nwg, G, a.ncg > 1 ? a.ncg : 1), dim3(NW * 64), lds, st, a);
   }
