@@ -90,6 +90,10 @@ struct Carver {
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
 };
 
+// row tables of a conv launch's full workgroups (kernels.h: ConvArgs::tabs): slots 0-2 = the forward convs, 3-4 = the
+// input-gradient convs of layers 2 and 3
+constexpr size_t CONV_TAB_BYTES = (size_t)2 * 576 * 4;
+
 // All workspace offsets for one network description (identical in forward and backward).
 struct Plan {
   int G, B, bands, H, W, classes, esz;
@@ -116,6 +120,7 @@ struct Plan {
   // the forward's prep launch, self re-arming), per layer FAN_R rows of forward sums and of backward sums
   size_t lead;          // 64 counters of the lead workgroups (stage.hip: bn_lead_block), cleared with the scores by k_forward_prep
   size_t fan_cnt, fan_cnt_bytes, fan_ctr, fan_fwd[3], fan_bwd[3];      // fan_cnt..: the cleared range (rows, then the counters at fan_ctr)
+  size_t rowtabs;      // bf16: row tables of the step's five conv launches (conv_tab_slot), built by the forward's prep launch
   size_t fct; int fct_ld;              // Hang2020: the two last heads' weights transposed, [128 + 512][classes padded to 4] (fused forward tail)
   size_t total;
 };
@@ -294,6 +299,7 @@ int build_plan(const dta_net_desc* d, Plan* p, int years = 0, const int* group_c
     int launchG = (L == 0 && p->shared_x) ? 1 : G;
     p->wpart[L] = c.take((size_t)launchG * p->S[L] * 9 * p->CpadW[L] * Nconv * 4);
   }
+  p->rowtabs = c.take((size_t)5 * CONV_TAB_BYTES);
   p->fct_ld = (p->classes + 3) / 4 * 4;
   p->fct = d->kind == DTA_NET_HANG2020 ? c.take((size_t)(p->F[0][2] + p->F[1][2]) * p->fct_ld * 4) : 0;
   p->total = c.off;
@@ -349,6 +355,49 @@ StageArgs stage_args(const Plan& p, const dta_net_desc* d, const dta_subnet_para
   s.feat_gs = (size_t)B * (p.Fmax[L] > 0 ? p.Fmax[L] : 1);
   // per-group row length of feat is F[g] (rows packed per group)
   return s;
+}
+
+// Geometry (the fields the bf16 launcher's tile choice reads: conv_bf16_rows) of the forward conv of layer L and of the
+// input-gradient conv of layer L -- shared by the launches and by the prep launch's row-table jobs, so they cannot disagree.
+ConvArgs fwd_conv_geom(const Plan& p, const dta_net_desc* d, int L, bool fan_fwd) {
+  ConvArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  const bool cat = L == 0 && p.shared_x;
+  const int Nconv = cat ? 32 * p.G : CH[L];
+  ca.mwg = p.MWG[L];
+  ca.stats = d->training ? reinterpret_cast<float*>(1) : nullptr;      // (only its null-ness matters here; the launch sets the pointer)
+  static const bool no_nsplit = dev_getenv("DTA_NO_NSPLIT") != nullptr;
+  // bf16, 128 output channels (third conv) on maps of 12x12 and up: two 64-column groups per row tile -- half-width
+  // workgroups stage half the weight slab each, twice as many of them (same-box alternation, 3 x 369 x 24x24: 1.0215 ->
+  // 1.0148 ms; the 5x5 maps of the 11x11 networks measured 0.5248 -> 0.5260 ms with it and keep the full-width tile)
+  if (p.esz == 2 && Nconv == 128 && p.HWc[L] >= 64 && !fan_fwd && !no_nsplit) ca.ncg = 2;
+  ca.B = p.B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
+  return ca;
+}
+ConvArgs dgrad_conv_geom(const Plan& p, int L) {
+  ConvArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.B = p.B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = CH[L] / 16; ca.N = CH[L - 1]; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
+  return ca;
+}
+inline int conv_tab_slot_fwd(int L) { return L; }
+inline int conv_tab_slot_dgrad(int L) { return 2 + L; }
+// points ca.tabs at its slot when the launcher's tile is one the prep launch tabulated (whole patches per workgroup)
+void use_conv_tabs(const Plan& p, void* ws, ConvArgs& ca, int G, int slot) {
+  if (p.esz != 2) return;
+  const int rows = conv_bf16_rows(ca, G);
+  if (rows <= 0 || ca.HW > rows) return;
+  ca.tabs = reinterpret_cast<const int*>(reinterpret_cast<char*>(ws) + p.rowtabs + (size_t)slot * CONV_TAB_BYTES);
+  ca.tabs_rows = rows;
+}
+bool add_conv_tab_job(const Plan& p, void* ws, const ConvArgs& geom, int G, int slot, ConvTabGroup& tg) {
+  ConvArgs ca = geom;
+  use_conv_tabs(p, ws, ca, G, slot);
+  if (!ca.tabs) return false;
+  ConvTabJob& j = tg.job[tg.n++];
+  j.HW = ca.HW; j.W = ca.W; j.Q = ca.Q; j.rows = ca.tabs_rows; j.ppw = ca.tabs_rows / ca.HW; j.order = switches().conv_order;
+  j.dst = const_cast<int*>(ca.tabs);
+  return true;
 }
 
 // the loss of a single-score network, taken in the same call as its forward (dta_net_forward_loss)
@@ -418,6 +467,12 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
     pa.x_compact = p.x_compact;
     pa.packs = packs; pa.spacks = spacks;
+    if (sizeof(T) == 2) {      // row tables of the step's conv launches (full workgroups read them instead of building their own)
+      const bool fan_fwd0 = d->training && (switches().fanin & 1);
+      for (int L = 0; L < 3; ++L) add_conv_tab_job(p, ws, fwd_conv_geom(p, d, L, fan_fwd0), (L == 0 && p.shared_x) ? 1 : G, conv_tab_slot_fwd(L), pa.tabs);
+      if (d->training && !(d->heads_mask & DTA_FORWARD_ONLY))
+        for (int L = 1; L < 3; ++L) add_conv_tab_job(p, ws, dgrad_conv_geom(p, L), G, conv_tab_slot_dgrad(L), pa.tabs);
+    }
     if (tail) {      // the last heads' weights [classes][F] -> [F][classes padded to 4], spectral rows first
       for (int g = 0; g < 2; ++g) {
         if (!nets[g].fc_w[2] || !nets[g].fc_b[2]) { dta_set_error("Hang2020 forward: the last heads' parameters are missing"); return 1; }
@@ -438,8 +493,9 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     const int Nconv = cat ? 32 * G : C;
     const int launchG = cat ? 1 : G;
     // conv
-    ConvArgs ca;
-    memset(&ca, 0, sizeof(ca));
+    const bool fan_fwd = d->training && (switches().fanin & 1);
+    ConvArgs ca = fwd_conv_geom(p, d, L, fan_fwd);
+    use_conv_tabs(p, ws, ca, launchG, conv_tab_slot_fwd(L));
     ca.pixel_order = switches().conv_order;
     if (L == 0) {
       ca.x_tl = x_tiles ? x_tiles : at<char>(ws, p.x_tl); ca.x_gs = p.x_tl_gs / p.esz; ca.x_compact = p.x_compact;
@@ -452,19 +508,12 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     ca.wp = at<char>(ws, p.wp[L]);
     for (int g = 0; g < G; ++g) ca.bias[g] = nets[g].conv_b[L];
     ca.bias_mode = pack_mode[L]; ca.bias_split = 32;
-    ca.y = at<float>(ws, p.y[L]); ca.y_fmt = p.y_fmt; ca.mwg = p.MWG[L];
+    ca.y = at<float>(ws, p.y[L]); ca.y_fmt = p.y_fmt;
     if (cat) { ca.y_gs = 0; ca.y_rs = Nconv; } else { ca.y_gs = (size_t)B * p.HWc[L] * C; ca.y_rs = C; }
     ca.stats = d->training ? at<float>(ws, p.stats[L]) : nullptr;
     // DTA_FANIN=1 (experiment, measured SLOWER than the finalize launch it removes: profiles/README.md, round 4): the conv
     // launch folds its BatchNorm partials itself (FAN_R rows of raw sums), the stage workgroups add those up in their prologue
-    const bool fan_fwd = d->training && (switches().fanin & 1);
     if (fan_fwd) { ca.fan_count = at<unsigned>(ws, p.fan_ctr) + (size_t)L * MAXG * FAN_R; ca.fan_sums = at<double>(ws, p.fan_fwd[L]); }
-    // bf16, 128 output channels (third conv) on maps of 12x12 and up: two 64-column groups per row tile -- half-width
-    // workgroups stage half the weight slab each, twice as many of them (same-box alternation, 3 x 369 x 24x24: 1.0215 ->
-    // 1.0148 ms; the 5x5 maps of the 11x11 networks measured 0.5248 -> 0.5260 ms with it and keep the full-width tile)
-    static const bool no_nsplit = dev_getenv("DTA_NO_NSPLIT") != nullptr;
-    if (sizeof(T) == 2 && Nconv == 128 && p.HWc[L] >= 64 && !fan_fwd && !no_nsplit) ca.ncg = 2;
-    ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = p.NCin[L]; ca.N = Nconv; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
     prof_begin(DTA_SITE_CONV_FWD + L, st);
     if (launch_conv3x3<T>(ca, launchG, st)) return 1;
     prof_end(DTA_SITE_CONV_FWD + L, st);
@@ -853,13 +902,12 @@ int backward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* ne
       for (int g = 0; g < G; ++g) pw.src[g] = nets[g].conv_w[L];
       if (!d->training)   // a training forward already packed the transposed weights into the workspace
         if (launch_pack_conv_w<T>(pw, at<char>(ws, p.wd[L]), st)) return 1;
-      ConvArgs ca;
-      memset(&ca, 0, sizeof(ca));
+      ConvArgs ca = dgrad_conv_geom(p, L);
+      if (d->training) use_conv_tabs(p, ws, ca, G, conv_tab_slot_dgrad(L));      // (built by the training forward's prep launch)
       ca.pixel_order = switches().conv_order;
       ca.x_tl = ap.dy_tl; ca.x_gs = ap.dy_gs; ca.wp = at<char>(ws, p.wd[L]); ca.x_compact = p.tl_compact;
       ca.y = at<float>(ws, p.da[L]); ca.y_gs = (size_t)B * p.HWc[L] * CH[L - 1]; ca.y_rs = CH[L - 1];
       ca.y_fmt = (lean_lvl[L - 1] && g16) ? FMT_BF16 : FMT_F32;      // read by stage L-1's backward
-      ca.B = B; ca.H = p.Hc[L]; ca.W = p.Wc[L]; ca.NC = C / 16; ca.N = CH[L - 1]; ca.Q = p.Qin[L]; ca.HW = p.HWc[L];
       prof_begin(DTA_SITE_CONV_DGRAD + L, st);
       if (launch_conv3x3<T>(ca, G, st)) return 1;
       prof_end(DTA_SITE_CONV_DGRAD + L, st);

@@ -170,10 +170,35 @@ template int launch_pack_conv_w<bf16_t>(const PackWArgs&, void*, hipStream_t);
 // and none depends on another): input patches -> tiles, conv weights -> MFMA operand images, spectral-attention
 // centre taps -> dense matrices, and the clearing of the split-K targets.  blockIdx.y selects the job.
 // ------------------------------------------------------------------------------------------------
+// The row tables every FULL workgroup of a bf16 conv launch shares (kernels.h: conv_row_tables; rows relative to the
+// workgroup's first patch), built once per forward instead of by each of the launch's 200-1000 workgroups.
+template <int ROWS>
+__device__ __forceinline__ void conv_tab_rows(const ConvTabJob& j, int* tab_s) {
+  ConvArgs c;      // (geometry fields only)
+  c.HW = j.HW; c.W = j.W; c.Q = j.Q; c.spp = 1; c.ppw = j.ppw; c.pixel_order = j.order;
+  int* rowtab = tab_s; int* plq = tab_s + ROWS; int* hist = plq + ROWS; int* flag = hist + 256;
+  conv_row_tables<ROWS, 256>(c, rowtab, plq, hist, flag, 0, j.ppw, 0);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * ROWS; i += 256) j.dst[i] = tab_s[i];
+}
+__device__ __forceinline__ void conv_tab_job(const ConvTabJob& j) {
+  __shared__ int tab_s[2 * 576 + 256 + 4];
+  if (j.rows == 256) conv_tab_rows<256>(j, tab_s);
+  else if (j.rows == 512) conv_tab_rows<512>(j, tab_s);
+  else if (j.rows == 576) conv_tab_rows<576>(j, tab_s);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_forward_prep(PrepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int y = blockIdx.y;
+  if (a.tabs.n > 0) {      // row tables of the step's conv launches: ONE grid row, block x = job (a row per job would add a
+    if (y == 0) {          // thousand empty workgroups per job: +3.5 us measured), and the FIRST row: a one-block job is a
+      if ((int)blockIdx.x < a.tabs.n) conv_tab_job(a.tabs.job[blockIdx.x]);   // ~3 us chain that must start when the launch starts,
+      return;              // not behind the dispatch of 13 k other workgroups (last row: the launch ran 11 us instead of 8)
+    }
+    y -= 1;
+  }
   if (y < a.ncg * a.nx) {
     const int gi = y / a.ncg;
     if ((int)blockIdx.x >= a.B) return;      // (the grid's x extent is at least PREP_MIN_BLOCKS: see launch_forward_prep)
@@ -188,6 +213,7 @@ __global__ __launch_bounds__(256) void k_forward_prep(PrepArgs a) {
   if (y < a.spacks.n) { pack_spectral_att_job(a.spacks, y, tid, nthreads); return; }
   y -= a.spacks.n;
   if (y < a.trans.n) { transpose_job(a.trans, y, tid, nthreads); return; }
+  y -= a.trans.n;
   if (a.zero) {
     float4* z = (float4*)a.zero;   // workspace regions are 256-byte aligned and padded
     for (size_t i = tid; i < a.zero_n4; i += nthreads) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -202,7 +228,7 @@ int launch_forward_prep(PrepArgs a, hipStream_t st) {
   // one block per patch for the input-pack jobs; the weight re-layout jobs are grid-stride loops over up to 16 networks'
   // weights (a multi-stage step at batch 128: 1.7 M elements per job), so small batches still get a full-width grid
   constexpr int PREP_MIN_BLOCKS = 1024;
-  dim3 grid(a.B > PREP_MIN_BLOCKS ? a.B : PREP_MIN_BLOCKS, a.ncg * a.nx + a.packs.n + a.spacks.n + a.trans.n + (a.zero ? 1 : 0));
+  dim3 grid(a.B > PREP_MIN_BLOCKS ? a.B : PREP_MIN_BLOCKS, a.ncg * a.nx + a.packs.n + a.spacks.n + a.trans.n + (a.tabs.n > 0 ? 1 : 0) + (a.zero ? 1 : 0));
   hipLaunchKernelGGL(k_forward_prep<T>, grid, dim3(256), lds, st, a);
   DTA_CHECK_LAUNCH("k_forward_prep");
   return 0;

@@ -82,79 +82,6 @@ extern "C" int dta_debug_cticks(long long* out) { return (int)hipMemcpyFromSymbo
 #else
 #define CTICK(i)
 #endif
-// Row tables of a conv workgroup: which pixel each of its MWG tile rows computes (rowtab: global output row or -1;
-// plq: (patch << 16) | haloed-grid row of the window's top-left tap).
-//
-// The A fragments are ds_read_b128 reads of 16 haloed-grid rows per lane group, RB = 48 bytes apart: a lane group is
-// conflict-free exactly when its 16 rows differ mod 16 (48 B = 12 banks, 12 i mod 64 is a bijection of i mod 16 onto the
-// sixteen 16-byte slots of the bank row).  Consecutive pixels do NOT have that property -- every image-row end skips two
-// halo rows -- and the hardware's lane groups are not contiguous ({0-3,12-15,20-27}, {4-11,16-19,28-31}, same +32): in pixel
-// order the A reads cost 2.25 LDS cycles per group instead of 1 (SQ_LDS_BANK_CONFLICT was 43 % of SQ_LDS_IDX_ACTIVE in
-// the first conv).  So pixels are dealt to lane groups by residue: the k-th pixel (in pixel order) whose row is = c mod 16
-// goes to lane group k, slot c.  Any assignment of pixels to tile rows is valid -- outputs and statistics go through
-// rowtab -- and unused slots point at row `slot` (same residue class), so every group reads 16 distinct slots.
-// If some residue class has more pixels than there are groups (possible for split maps), pixel order is kept.
-template <int MWG, int NTHR>
-__device__ __forceinline__ void conv_row_tables(const ConvArgs& a, int* rowtab, int* plq, int* hist, int* flag, int b0, int npatch, int split) {
-  constexpr int PASSES = (MWG + NTHR - 1) / NTHR, NWAVE = NTHR / 64, NGROUP = MWG / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int HW = a.HW, W2 = a.W + 2, Q = a.Q;
-  int orow[PASSES], pq[PASSES], res[PASSES], rank[PASSES];
-  const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
-    const int lr = tid + p * NTHR;
-    int pl, pix;
-    bool valid;
-    if (a.spp == 1) { pl = lr / HW; pix = lr - pl * HW; valid = lr < MWG && pl < npatch; }
-    else { pl = 0; pix = split * MWG + lr; valid = lr < MWG && pix < HW; }
-    const int h = valid ? pix / a.W : 0, w = valid ? pix - h * a.W : 0;
-    orow[p] = valid ? (b0 + pl) * HW + pix : -1;
-    pq[p] = valid ? ((pl << 16) | (h * W2 + w)) : 0;
-    res[p] = valid ? (pl * Q + h * W2 + w) & 15 : -1;
-    int mine = 0, cnt = 0;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const unsigned long long m = __ballot(res[p] == c);
-      if (res[p] == c) mine = __popcll(m & lt);
-      if (lane == c) cnt = __popcll(m);
-    }
-    rank[p] = mine;
-    if (lane < 16) hist[(p * NWAVE + wave) * 16 + lane] = cnt;
-    // unused slots: no output row, and a window row of the slot's own residue class
-    if (lr < MWG) {
-      const int li = lr & 31;
-      const int slot = li < 4 ? li : li < 12 ? li - 4 : li < 16 ? li - 8 : li < 20 ? li - 8 : li < 28 ? li - 12 : li - 16;
-      rowtab[lr] = -1;
-      plq[lr] = (Q * a.ppw > 17 + 2 * W2) ? slot : 0;
-    }
-  }
-  if (tid == 0) *flag = a.pixel_order & 1;
-  __syncthreads();
-#pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
-    if (res[p] >= 0) {
-      for (int j = 0; j < p * NWAVE + wave; ++j) rank[p] += hist[j * 16 + res[p]];
-      if (rank[p] >= NGROUP) *flag = 1;
-    }
-  }
-  __syncthreads();
-  const int over = *flag;
-#pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
-    const int lr = tid + p * NTHR;
-    if (over) {
-      if (lr < MWG) { rowtab[lr] = orow[p]; plq[lr] = pq[p]; }
-    } else if (res[p] >= 0) {
-      const int k = rank[p], c = res[p];
-      const int li = (k & 1) ? (c < 8 ? c + 4 : c < 12 ? c + 8 : c + 16) : (c < 4 ? c : c < 8 ? c + 8 : c + 12);
-      const int dst = (k >> 1) * 32 + li;
-      rowtab[dst] = orow[p];
-      plq[dst] = pq[p];
-    }
-  }
-}
-
 template <int MT, int NT, bool XN, int NWV = 8, int MINW = 1>
 __global__ __launch_bounds__(NWV * 64, MINW) void k_conv3x3_bf16(ConvArgs a) {
   WGSTAMP(XN ? 0 : (a.stats ? (a.N == 64 ? 1 : 2) : -1));      // first conv, second conv, third conv (forward launches)
@@ -183,6 +110,15 @@ __global__ __launch_bounds__(NWV * 64, MINW) void k_conv3x3_bf16(ConvArgs a) {
   const int b0 = pg * a.ppw;
   const int npatch = min(a.ppw, a.B - b0);
 
+  // the launch's row tables (ConvArgs::tabs: [MWG] row relative to the workgroup's first patch or -1, then [MWG] plq), requested
+  // at kernel entry so that the round trip runs under the first chunk's loads; partial workgroups build their own
+  int tab0_[2] = {-1, -1}, tab1_[2] = {0, 0};
+  static_assert(MWG <= 2 * NTHR, "two table entries per thread at most");
+  if (a.tabs && a.spp == 1 && npatch == a.ppw) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + k * NTHR < MWG) { tab0_[k] = a.tabs[tid + k * NTHR]; tab1_[k] = a.tabs[MWG + tid + k * NTHR]; }
+  }
   const int khalf16 = (lane >> 5) * 16;
   int abase[MT];
   const int bbase = (lane & 31) * RB + khalf16;
@@ -191,7 +127,12 @@ __global__ __launch_bounds__(NWV * 64, MINW) void k_conv3x3_bf16(ConvArgs a) {
   // (cycle stamps of a two-chunk workgroup: tables 4.0 k cycles, then 2.3 k waiting for the first chunk)
 #define DTA_TABLES \
   { \
-    conv_row_tables<MWG, NTHR>(a, rowtab, plq, reinterpret_cast<int*>(red), reinterpret_cast<int*>(cmean), b0, npatch, split); \
+    if (a.tabs && a.spp == 1 && npatch == a.ppw) {   /* a full workgroup: the launch's common tables, built once by the prep launch */ \
+      _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) {                                              \
+        const int lr_ = tid + k_ * NTHR;                                                              \
+        if (lr_ < MWG) { rowtab[lr_] = tab0_[k_] < 0 ? -1 : b0 * HW + tab0_[k_]; plq[lr_] = tab1_[k_]; } \
+      }                                                                                               \
+    } else conv_row_tables<MWG, NTHR>(a, rowtab, plq, reinterpret_cast<int*>(red), reinterpret_cast<int*>(cmean), b0, npatch, split); \
     if (xc || XN) {   /* (the fused-input kernel writes interior pixels only, whatever the HBM tile format) */ \
       u32x4* z = reinterpret_cast<u32x4*>(sbuf); \
       const u32x4 zero = {0u, 0u, 0u, 0u}; \
@@ -656,6 +597,7 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   constexpr int MWG = NW * MT * 32, N = NT * 32;
   int nwg;
   conv_geometry(a.HW, MWG, a.B, &a.ppw, &a.spp, &nwg);
+  if (a.tabs_rows != MWG) a.tabs = nullptr;      // (tables of another tile: every workgroup builds its own)
   size_t tab = (size_t)MWG * 8 + (size_t)17 * N * 4, stage = ((size_t)a.ppw * a.Q + (size_t)9 * N) * RB;
   // few chunks (the 32- and 64-channel layers): one LDS stage, so that two or three workgroups share a CU and overlap
   // each other's prologue / epilogue instead of double-buffering a two-iteration loop
@@ -691,6 +633,22 @@ int conv_mwg_bf16(int N, int HW) {
     if (r576 < r512) return 576;
   }
   return conv_mwg(N);
+}
+
+// Output rows per workgroup the launcher below will use for `a` (geometry fields only: N, HW, B, mwg, stats, ncg): the
+// prep launch builds the row tables of exactly that tile (capi.hip).  Keep in step with the switch below.
+int conv_bf16_rows(const ConvArgs& a, int G) {
+  switch (a.N) {
+    case 32: return (a.mwg == 576 || (a.stats == nullptr && conv_mwg_bf16(32, a.HW) == 576)) ? 576 : 512;
+    case 64: {
+      int ppw, spp, nwg;
+      conv_geometry(a.HW, 512, a.B, &ppw, &spp, &nwg);
+      if (a.stats == nullptr && nwg * G <= 128) return 256;
+      return a.mwg == 256 ? 256 : a.mwg == 576 ? 576 : 512;
+    }
+    case 128: return (a.ncg == 2 && a.mwg == 576) ? 576 : 256;
+  }
+  return 0;
 }
 
 template <>

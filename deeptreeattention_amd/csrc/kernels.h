@@ -33,6 +33,10 @@ struct ConvArgs {
   // logical groups folds that group's (mean, M2) rows into one row of raw sums; the stage kernels add the FAN_R rows up
   int ncg;                            // bf16 kernels: column groups (blockIdx.z) of N / ncg columns each (0 / 1 = one); the
                                       // weight slab, bias, outputs and statistics rows keep their full-width layouts
+  // bf16 kernels: row tables of a FULL workgroup of this launch (conv_row_tables below), built once per forward by the prep
+  // launch: [tabs_rows] output row relative to the workgroup's first patch (or -1), then [tabs_rows] plq; null = every workgroup
+  // builds its own (a few-chunk workgroup spent 4 k of its 21 k cycles there)
+  const int* tabs; int tabs_rows;
   unsigned* fan_count;                // [gridDim.y][FAN_R] arrival counters (zero on entry, left zero) or null
   double* fan_sums;                   // [gridDim.y][FAN_R][N][3] = sum n m, sum n m^2, sum M2 per column
 };
@@ -212,7 +216,85 @@ __device__ __forceinline__ void conv_stats_fanin(const ConvArgs& a, int g, int N
   }
 }
 #endif
+#if defined(__HIPCC__)
+// Row tables of a conv workgroup: which pixel each of its MWG tile rows computes (rowtab: global output row or -1;
+// plq: (patch << 16) | haloed-grid row of the window's top-left tap).
+//
+// The A fragments are ds_read_b128 reads of 16 haloed-grid rows per lane group, RB = 48 bytes apart: a lane group is
+// conflict-free exactly when its 16 rows differ mod 16 (48 B = 12 banks, 12 i mod 64 is a bijection of i mod 16 onto the
+// sixteen 16-byte slots of the bank row).  Consecutive pixels do NOT have that property -- every image-row end skips two
+// halo rows -- and the hardware's lane groups are not contiguous ({0-3,12-15,20-27}, {4-11,16-19,28-31}, same +32): in pixel
+// order the A reads cost 2.25 LDS cycles per group instead of 1 (SQ_LDS_BANK_CONFLICT was 43 % of SQ_LDS_IDX_ACTIVE in
+// the first conv).  So pixels are dealt to lane groups by residue: the k-th pixel (in pixel order) whose row is = c mod 16
+// goes to lane group k, slot c.  Any assignment of pixels to tile rows is valid -- outputs and statistics go through
+// rowtab -- and unused slots point at row `slot` (same residue class), so every group reads 16 distinct slots.
+// If some residue class has more pixels than there are groups (possible for split maps), pixel order is kept.
+template <int MWG, int NTHR>
+__device__ __forceinline__ void conv_row_tables(const ConvArgs& a, int* rowtab, int* plq, int* hist, int* flag, int b0, int npatch, int split) {
+  constexpr int PASSES = (MWG + NTHR - 1) / NTHR, NWAVE = NTHR / 64, NGROUP = MWG / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HW = a.HW, W2 = a.W + 2, Q = a.Q;
+  int orow[PASSES], pq[PASSES], res[PASSES], rank[PASSES];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int lr = tid + p * NTHR;
+    int pl, pix;
+    bool valid;
+    if (a.spp == 1) { pl = lr / HW; pix = lr - pl * HW; valid = lr < MWG && pl < npatch; }
+    else { pl = 0; pix = split * MWG + lr; valid = lr < MWG && pix < HW; }
+    const int h = valid ? pix / a.W : 0, w = valid ? pix - h * a.W : 0;
+    orow[p] = valid ? (b0 + pl) * HW + pix : -1;
+    pq[p] = valid ? ((pl << 16) | (h * W2 + w)) : 0;
+    res[p] = valid ? (pl * Q + h * W2 + w) & 15 : -1;
+    int mine = 0, cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const unsigned long long m = __ballot(res[p] == c);
+      if (res[p] == c) mine = __popcll(m & lt);
+      if (lane == c) cnt = __popcll(m);
+    }
+    rank[p] = mine;
+    if (lane < 16) hist[(p * NWAVE + wave) * 16 + lane] = cnt;
+    // unused slots: no output row, and a window row of the slot's own residue class
+    if (lr < MWG) {
+      const int li = lr & 31;
+      const int slot = li < 4 ? li : li < 12 ? li - 4 : li < 16 ? li - 8 : li < 20 ? li - 8 : li < 28 ? li - 12 : li - 16;
+      rowtab[lr] = -1;
+      plq[lr] = (Q * a.ppw > 17 + 2 * W2) ? slot : 0;
+    }
+  }
+  if (tid == 0) *flag = a.pixel_order & 1;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    if (res[p] >= 0) {
+      for (int j = 0; j < p * NWAVE + wave; ++j) rank[p] += hist[j * 16 + res[p]];
+      if (rank[p] >= NGROUP) *flag = 1;
+    }
+  }
+  __syncthreads();
+  const int over = *flag;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int lr = tid + p * NTHR;
+    if (over) {
+      if (lr < MWG) { rowtab[lr] = orow[p]; plq[lr] = pq[p]; }
+    } else if (res[p] >= 0) {
+      const int k = rank[p], c = res[p];
+      const int li = (k & 1) ? (c < 8 ? c + 4 : c < 12 ? c + 8 : c + 16) : (c < 4 ? c : c < 8 ? c + 8 : c + 12);
+      const int dst = (k >> 1) * 32 + li;
+      rowtab[dst] = orow[p];
+      plq[dst] = pq[p];
+    }
+  }
+}
+#endif
 void conv_geometry(int HW, int MWG, int B, int* ppw, int* spp, int* nwg);
+int conv_bf16_rows(const ConvArgs& a, int G);      // conv_bf16.hip: rows per workgroup its launcher will choose
+// row tables of up to six conv launches of a step, built by extra blocks of the prep launch (one block per job)
+struct ConvTabJob { int HW, W, Q, rows, ppw, order; int* dst; };
+struct ConvTabGroup { ConvTabJob job[6]; int n = 0; };
 int conv_mwg(int N);
 // bf16 kernels: output rows per workgroup for an HW-pixel map -- 576 (six waves x three 32-row tiles) when that wastes
 // fewer rows than 512 (a 24x24 map is exactly one 576-row workgroup instead of 512 + 64 rows of two)
@@ -474,7 +556,7 @@ __device__ __forceinline__ void transpose_job(const TransposeGroup& tg, int j, s
 struct PrepArgs {
   const float* x[MAXG]; int nx; size_t x_tl_gs;   // nx inputs (one per group with its own input), tile group stride in bytes
   void* x_tl; int B, C, H, W, NC, CG, ncg, x_compact;
-  PackWGroup packs; SpecPackGroup spacks; TransposeGroup trans;
+  PackWGroup packs; SpecPackGroup spacks; TransposeGroup trans; ConvTabGroup tabs;
   float* zero; size_t zero_n4;         // float4 count to clear, or zero == null
 };
 template <typename T> int launch_forward_prep(PrepArgs a, hipStream_t st);
