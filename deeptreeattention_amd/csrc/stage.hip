@@ -1536,7 +1536,8 @@ struct LeanCfg {
   static constexpr int NPART = NT / C;                    // matvec: input slices per output
   // waves per SIMD the backward is compiled for (register budget 512 / MINW): two 512-thread or three 256-thread
   // workgroups per CU; the 128-wide stage needs its 256 registers
-  static constexpr int MINW = HC > 11 ? 2 : (C == 32 ? 4 : (C == 64 ? 3 : 2));      // (24x24 crops: 3-5 items per thread)
+  // (the fp32 step's 64-wide stage holds twice the raw bytes per item: compiled for three waves it spilled 15 registers)
+  static constexpr int MINW = HC > 11 ? 2 : (C == 32 ? 4 : (C == 64 ? (YF == FMT_F32 ? 2 : 3) : 2));      // (24x24 crops: 3-5 items per thread)
   static constexpr bool PERSIST = C < 128 && HC <= 11;    // backward: persistent workgroups with next-batch prefetch
   // LDS floats per patch slot: the patch [NP][C], then vectors: spectral pooled|h|gate, spatial m|t1 (padded) | s
   static constexpr int VEC = 3 * C > 2 * NPAD + NP ? 3 * C : 2 * NPAD + NP;
@@ -2536,9 +2537,16 @@ template <typename T>
 int launch_stage_fwd_lean(const StageArgs& a, int G, hipStream_t st) {
   const bool h = a.y_fmt == FMT_F16;
   if (a.Hc != 11 && a.Hc != 5) {      // 24x24 crops (spectral networks, bf16 mode): several items per thread
-    if (a.C == 32) return launch_stage_fwd_lean_c<T, LeanCfg<32, 24, 24, 0, FMT_F16>>(a, G, st);
-    if (a.C == 64) return launch_stage_fwd_lean_c<T, LeanCfg<64, 24, 24, 1, FMT_F16>>(a, G, st);
-    return launch_stage_fwd_lean_c<T, LeanCfg<128, 12, 12, 1, FMT_F16>>(a, G, st);
+    // (bf16 mode only: half conv outputs exist with 16-bit tiles alone, so the float-tile instantiations are never
+    //  launched -- and one of them carried 176 B of scratch; stage_fwd_is_lean() admits these shapes for y_fmt F16 only)
+    if constexpr (sizeof(T) == 2) {
+      if (a.C == 32) return launch_stage_fwd_lean_c<T, LeanCfg<32, 24, 24, 0, FMT_F16>>(a, G, st);
+      if (a.C == 64) return launch_stage_fwd_lean_c<T, LeanCfg<64, 24, 24, 1, FMT_F16>>(a, G, st);
+      return launch_stage_fwd_lean_c<T, LeanCfg<128, 12, 12, 1, FMT_F16>>(a, G, st);
+    } else {
+      dta_set_error("lean stage forward: 24x24-class maps are a bf16-mode plan");
+      return 1;
+    }
   }
   if (a.C == 32) return h ? launch_stage_fwd_lean_c<T, LeanCfg<32, 11, 11, 0, FMT_F16>>(a, G, st) : launch_stage_fwd_lean_c<T, LeanCfg<32, 11, 11, 0, FMT_F32>>(a, G, st);
   if (a.C == 64) return h ? launch_stage_fwd_lean_c<T, LeanCfg<64, 11, 11, 1, FMT_F16>>(a, G, st) : launch_stage_fwd_lean_c<T, LeanCfg<64, 11, 11, 1, FMT_F32>>(a, G, st);

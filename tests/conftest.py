@@ -55,13 +55,14 @@ class Bf16Yardstick:
     def check_gradients(self, tag, got, exact, prefix="", min_size=1000, verbose=True, norms=True):
         """got / exact: {name: ndarray} (exact = the fp64 oracle, pinned to the reference's fp32 golden).  Asserts, against
         the reference-autocast yardstick of case `tag`: every tensor of >= min_size elements keeps its norm and its
-        element-wise distance within bound(); so do the whole gradient vector and the total norm (all tensors).
+        element-wise distance within bound(); every SMALLER tensor its norm within bound() or an absolute deviation of
+        at most 1e-3 of the total gradient norm; so do the whole gradient vector and the total norm (all tensors).
         norms=False (batches of <= 16 patches): a tensor's norm deviation is the projection of its rounding noise on the
         gradient itself -- one draw of a random sign and size, anywhere between 0 and the element-wise distance -- and with a
         handful of patches the reference's single draw is no yardstick for another implementation's; there only the
         element-wise distance is held per tensor (the norms still through the total)."""
         num = den = t_got = t_ex = 0.0
-        fails = []
+        fails, small = [], []
         for k, v in exact.items():
             key = prefix + k
             if f"{tag}gnorm_dev/{key}" not in self.table:
@@ -70,6 +71,7 @@ class Bf16Yardstick:
             na, nb = np.linalg.norm(a), np.linalg.norm(b)
             num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum()); t_got += na ** 2; t_ex += nb ** 2
             if b.size < min_size:
+                small.append((key, a, b, na, nb))      # judged below, once the total gradient norm is known
                 continue
             dn, de = abs(na - nb) / nb, np.linalg.norm(a - b) / nb
             bn, be = self.bound(f"{tag}gnorm_dev/{key}"), self.bound(f"{tag}gelem_dev/{key}")
@@ -78,6 +80,26 @@ class Bf16Yardstick:
                       f"elem {de:.2e} (reference bf16 {self.ref(tag + 'gelem_dev/' + key):.2e})")
             if (norms and dn > bn) or de > be:
                 fails.append((key, dn, bn, de, be))
+        # Tensors under min_size elements (BatchNorm gamma / beta, biases, the spatial-attention stencils and channel pools:
+        # two thirds of the gradient tensors): each keeps its norm within bound() -- the reference's own bf16 figure x 1.5 --
+        # OR moves by no more than 1e-3 of the TOTAL gradient norm in absolute terms (cancellation-dominated scalars whose own
+        # norm is rounding-sized: a relative figure on them measures noise against noise).  Which branch held is printed.
+        gtot = np.sqrt(t_ex)
+        held = {"norm": 0, "absolute": 0}
+        for key, a, b, na, nb in small:
+            dn = abs(na - nb) / nb if nb > 0 else (0.0 if na == 0 else np.inf)
+            bn = self.bound(f"{tag}gnorm_dev/{key}")
+            dabs = np.linalg.norm(a - b) / gtot
+            branch = "norm" if dn <= bn else ("absolute" if dabs <= 1e-3 else None)
+            if verbose:
+                print(f"  {tag}{key:62s} {b.size:7d} norm dev {dn:.2e} (bound {bn:.2e}, reference bf16 {self.ref(tag + 'gnorm_dev/' + key):.2e}) "
+                      f"|diff| / |total gradient| {dabs:.2e} -> {branch or 'FAIL'}")
+            if branch is None:
+                fails.append((key, dn, bn, dabs, 1e-3))
+            else:
+                held[branch] += 1
+        if small:
+            print(f"  {tag} {len(small)} tensors under {min_size} elements: {held['norm']} held by their norm bound, {held['absolute']} by the absolute one")
         whole = np.sqrt(num / den)
         tot = abs(np.sqrt(t_got) - np.sqrt(t_ex)) / np.sqrt(t_ex)
         print(f"  {tag} whole gradient vector: elem {whole:.2e} (reference bf16 {self.ref(tag + 'whole_elem_dev'):.2e}), "

@@ -121,3 +121,35 @@ def test_multistage_and_treemodel_checkpoint_key_mapping(tmp_path, golden):
     assert [k[len("model."):] for k in tm] == list(golden("hang2020_3_10.npz")["keys"])
     CK.load_treemodel({"state_dict": tm}, m)
     assert torch.equal(m.state_dict()["spectral_network.conv1.conv_layer.weight"], tm["model.spectral_network.conv1.conv_layer.weight"])
+
+
+def test_no_kernel_of_the_product_library_has_a_private_segment(tmp_path):
+    """Every kernel of libdta_hip.so runs out of registers and LDS alone: .private_segment_fixed_size == 0 in the code
+    objects' metadata notes (a spilling instantiation hides behind a template argument nobody benchmarks; rounds 4-5 each
+    shipped some).  Needs the ROCm LLVM tools (llvm-objdump --offloading, llvm-readelf); skipped where they are absent."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objdump, readelf = os.path.join(llvm, "llvm-objdump"), os.path.join(llvm, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("ROCm LLVM tools not installed")
+    from deeptreeattention_amd import _lib
+    lib = os.path.join(str(tmp_path), "libdta_hip.so")
+    shutil.copy(os.path.join(os.path.dirname(_lib.LIB_PATH), "libdta_hip.so"), lib)
+    subprocess.run([objdump, "--offloading", lib], cwd=str(tmp_path), capture_output=True, check=True)
+    objs = sorted(glob.glob(lib + ".*gfx950*"))
+    assert objs, "no gfx950 code object found in the library"
+    seen, bad = 0, []
+    for f in objs:
+        notes = subprocess.run([readelf, "--notes", f], capture_output=True, text=True, check=True).stdout
+        for blk in re.split(r"\n\s+- \.", notes):
+            name = re.search(r"\.?name:\s+(\S+)", blk)
+            seg = re.search(r"private_segment_fixed_size:\s+(\d+)", blk)
+            if name and seg:
+                seen += 1
+                if int(seg.group(1)) > 0:
+                    bad.append((name.group(1), int(seg.group(1))))
+    assert seen > 100, seen          # (166 kernels at the time of writing)
+    assert not bad, bad

@@ -82,7 +82,8 @@ def _worker(rank, world, port, B, exchange, out, bands=BANDS, classes=CLASSES):
     ("peer0", 2, 530, BANDS, CLASSES), ("torch", 2, 530, BANDS, CLASSES), ("torch", 2, 1024, BANDS, CLASSES),
     # the geometry BASELINE.json's metric is quoted on (369 bands, 200 classes: the real 900 k-element flat layout, its
     # head / tail split and alpha slot), values against the oracle -- not only the bench line's schema
-    ("peer", 2, 530, 369, 200), ("torch", 2, 530, 369, 200)])
+    ("peer", 2, 530, 369, 200), ("torch", 2, 530, 369, 200),
+    ("peer", 4, 530, 369, 200)])      # four ranks on the real layout: four shards, four reduce-scatter owners
 def test_dp_step_at_bench_batch_vs_oracle(exchange, world, B, bands, classes, bf16_yardstick):
     from conftest import rel_l2
     from oracle import hang2020_np as O
