@@ -575,13 +575,16 @@ def main():
     for i in range(a.steps):
         loss = trainer.train_step(xs[i % nb], ys[i % nb])
     torch.cuda.synchronize()
+    el_own = time.perf_counter() - t0        # this rank's own steps, before it waits for the others: rank skew shows here
     barrier()
     el = time.perf_counter() - t0
     trainer.check_exchange()                 # a peer-exchange step that timed out waiting for a rank raises here
+    rank_ms = {"min": round(el_own / a.steps * 1e3, 4), "max": round(el_own / a.steps * 1e3, 4)}
     if dist_on:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el, el_own, -el_own], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        el = float(t.item())
+        el = float(t[0].item())
+        rank_ms = {"min": round(-float(t[2].item()) / a.steps * 1e3, 4), "max": round(float(t[1].item()) / a.steps * 1e3, 4)}
     final_loss = float(loss.item())
 
     def collect(site):
@@ -724,6 +727,7 @@ def main():
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "exchange": trainer.exchange, "exchange_fallbacks": fallbacks,
                        "overlap_comm": bool(trainer.overlap), "ranks_seen": ranks_seen,
+                       "rank_ms_per_step": rank_ms,      # each rank's own K steps before the closing barrier: min / max over ranks
                        "collectives_per_step": (0 if trainer.exchange in (None, "peer") else (2 if trainer.overlap else 1)),
                        "exchange_launches_per_step": (1 if trainer.exchange == "peer" else 0)},
             "library_build_id": build_id, "priming_steps_before_warmup": primed,

@@ -275,6 +275,10 @@ def lib():
                                             C.c_longlong, C.c_void_p]
         L.dta_xchg_selftest_fill.restype = C.c_int
         L.dta_xchg_selftest_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.dta_xchg_selftest_verify.restype = C.c_int
+        L.dta_xchg_selftest_verify.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.dta_xchg_selftest_mismatches.restype = C.c_int
+        L.dta_xchg_selftest_mismatches.argtypes = [C.c_void_p]
         L.dta_xchg_status.restype = C.c_int
         L.dta_xchg_status.argtypes = [C.c_void_p]
         L.dta_xchg_last_timing.restype = C.c_int

@@ -8,6 +8,7 @@
 // n_s = #samples of site s the batch statistics are mean_f = sum_s n_s E[s][f] / B, var_f = sum_s n_s (E[s][f] - mean_f)^2 / B,
 // and the backward's batch sums are sums over sites of per-site gradient sums.  Everything is evaluated in a fixed order
 // (no float atomics): reruns give the same bits.
+#include <atomic>
 #include <string.h>
 
 #include "../../include/dta_hip.h"
@@ -264,17 +265,25 @@ __global__ __launch_bounds__(1024) void k_meta_back(BackArgs a) {
   }
 }
 
-// Dynamic LDS a workgroup of the head's two one-workgroup kernels may use on this device (queried once per process): the
-// device's per-workgroup limit (160 KB on gfx950) minus 4 KB for their static part.  0 = the query failed (no device): every shape is then refused, and the Python side falls back.
+// Dynamic LDS a workgroup of the head's two one-workgroup kernels may use on the CURRENT device (cached per device ordinal,
+// as DevOnce does): the larger of the device's reported per-workgroup limit and the 160 KB every gfx950 CU has (some ROCm
+// stacks report 64 KB for hipDeviceAttributeMaxSharedMemoryPerBlock; hipFuncSetAttribute is what really decides, and the
+// callers check its status), minus 4 KB for the kernels' static part.  0 = no device: every shape is then refused, and the
+// Python side falls back.
 size_t lds_budget() {
-  static const size_t cap = []() -> size_t {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) return 0;
-    // (the two kernels also hold a few hundred bytes of static LDS: the dynamic part gets the device's limit minus 4 KB)
-    return (size_t)v > 8192 ? (size_t)v - 4096 : 0;
-  }();
-  return cap;
+  static std::atomic<size_t> cap[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::atomic<size_t>& c = cap[dev & 63];
+  size_t v = c.load(std::memory_order_relaxed);
+  if (v == 0) {
+    int q = 0;
+    if (hipDeviceGetAttribute(&q, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || q <= 0) q = 0;
+    const size_t lim = (size_t)q > (size_t)160 * 1024 ? (size_t)q : (size_t)160 * 1024;
+    v = lim - 4096;
+    c.store(v, std::memory_order_relaxed);
+  }
+  return v;
 }
 size_t meta_back_lds(int B, int S) { return ((size_t)S * MW + (S + 1) + (size_t)S * MW + B + B + (size_t)B * MW + (size_t)S * MW) * 4; }
 

@@ -188,6 +188,22 @@ __global__ void k_xchg_selftest_fill(float* g, size_t n, int rank, int step) {
   }
 }
 
+// the sum over ranks (in rank order, as the exchange sums) of the pattern above vs the buffer: mismatches are COUNTED on the
+// device (status word 4, pinned host memory), so a burst of fill -> exchange -> verify triples needs no host synchronisation
+// between its steps -- back-to-back launches are what a training loop issues
+__global__ void k_xchg_selftest_verify(const float* g, size_t n, int world, int step, int* mismatches) {
+  int bad = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float want = 0.f;
+    for (int r = 0; r < world; ++r) {
+      const long long v = ((long long)i * 2654435761ll + (long long)r * 40503ll + (long long)step * 9973ll) % 2001ll - 1000ll;
+      want += (float)v / 1024.0f;
+    }
+    bad += g[i] != want;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace dta
 
 using namespace dta;
@@ -235,7 +251,7 @@ int dta_xchg_create(int rank, int world, size_t n_floats, dta_xchg** out) {
   }
   if (e == hipSuccess) { e = hipHostMalloc((void**)&x->status_host, 64, hipHostMallocMapped); why = "hipHostMalloc(status)"; }
   if (e == hipSuccess) { e = hipHostGetDevicePointer((void**)&x->status_dev, x->status_host, 0); why = "hipHostGetDevicePointer"; }
-  if (e == hipSuccess) { x->status_host[0] = 0; e = hipMemset(x->grads, 0, x->n_pad * sizeof(float)); why = "hipMemset"; }
+  if (e == hipSuccess) { x->status_host[0] = 0; x->status_host[4] = 0; e = hipMemset(x->grads, 0, x->n_pad * sizeof(float)); why = "hipMemset"; }
   if (e == hipSuccess) e = hipMemset(x->sig, 0, x->sig_bytes);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
@@ -356,6 +372,14 @@ int dta_xchg_selftest_fill(dta_xchg* x, int step, void* stream) {
   DTA_CHECK_LAUNCH("k_xchg_selftest_fill");
   return 0;
 }
+
+int dta_xchg_selftest_verify(dta_xchg* x, int step, void* stream) {
+  if (!x) { dta_set_error("dta_xchg_selftest_verify: null exchange"); return 1; }
+  hipLaunchKernelGGL(k_xchg_selftest_verify, dim3(64), dim3(256), 0, (hipStream_t)stream, x->grads, x->n, x->world, step, x->status_dev + 4);
+  DTA_CHECK_LAUNCH("k_xchg_selftest_verify");
+  return 0;
+}
+int dta_xchg_selftest_mismatches(dta_xchg* x) { return x ? ((volatile int*)x->status_host)[4] : -1; }
 
 int dta_xchg_allreduce(dta_xchg* x, const double* alpha_g, long long alpha_slot, void* stream) {
   if (!x) { dta_set_error("dta_xchg_allreduce: null exchange"); return 1; }

@@ -1008,6 +1008,13 @@ class EnsembleTrainer:
         self.check_exchange()
         y = self.years[0]._labels(y)
         gate = None
+        if present is not None and self.ex is not None and self.ex.split:
+            # overlapped peer exchange: the head's sum rides in the years' first-conv weight-gradient launch, and whether that
+            # combined kernel exists depends on how many years a rank launches.  Host flags differ from rank to rank (and a
+            # rank may call with present=None while another passes flags), so the launch plan would too, one rank waiting for
+            # head flags another never posts.  Every rank therefore takes the device-decided form -- all Y years
+            # launched, the missing ones gated by dta_year_flags, which computes exactly what truthful host flags say.
+            present = None
         if present is None:
             self._counters_to("device")
             kept = self._forward_gated(images, y, True)
@@ -1028,6 +1035,11 @@ class EnsembleTrainer:
         # data-parallel: every rank issues the same collectives whatever it kept; skipped years send their zeros
         if self.ex is not None:
             self.flags.copy_(local_flags)       # (before the backward: the flags ride in the head segment)
+            # The head's sum rides in the years' first-conv weight-gradient launch only when EVERY rank launches the same
+            # plan: with host-side present= flags each rank launches its own kept years, and whether the combined kernel
+            # exists for a plan depends on the group count (capi.hip: launch_conv_wgrad_bf16_xchg) -- ranks that kept
+            # different year counts could disagree, one waiting for head flags another never posts.  The
+            # device-decided step launches all Y years on every rank (train_step turns present= calls into it when ex.split).
             if self.ex.split:
                 self._backward_xchg(kept, gate) # head summed beside the first convs' weight gradients
             else:

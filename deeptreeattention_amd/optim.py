@@ -371,10 +371,17 @@ class DtaAdam(torch.optim.Optimizer):
             gr = p.grad
             if self.world > 1:
                 # every rank joins the collective whatever its own gradient is (a rank without one sends zeros): ranks that
-                # disagreed about `grad is None` would otherwise wait for each other forever
-                gr = torch.zeros_like(p) if gr is None else gr.clone()
-                torch.distributed.all_reduce(gr, group=self.pg)
-                gr /= self.world
+                # disagreed about `grad is None` would otherwise wait for each other forever.  One extra element carries
+                # "this rank produced a gradient": when NO rank did, the parameter is passed over exactly as torch.optim.Adam
+                # -- and the reference under DDP -- pass over a grad-None parameter (no state, no moment decay, no move)
+                buf = torch.zeros(p.numel() + 1, dtype=p.dtype, device=p.device)
+                if gr is not None:
+                    buf[:-1].copy_(gr.reshape(-1))
+                    buf[-1] = 1
+                torch.distributed.all_reduce(buf, group=self.pg)
+                if float(buf[-1]) == 0.0:      # (these are the few small parameters outside the flat buffers: one scalar read each)
+                    continue
+                gr = (buf[:-1] / self.world).view_as(p)
             s = self.state.setdefault(p, {})
             if not s:
                 s["step"], s["exp_avg"], s["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)

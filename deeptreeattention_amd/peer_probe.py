@@ -18,6 +18,8 @@ import time
 import numpy as np
 
 N = 1 << 18
+N_REAL = 900788      # the flat gradient buffer of Hang2020(369, 200): 900,736 parameters + slots, the size a train step exchanges
+BURST = 12
 
 
 def _pattern(rank, step, n):
@@ -88,6 +90,46 @@ def _phase(L, hip, d, rank, world, deadline, tag, split):
     return ok
 
 
+def _burst(L, hip, d, rank, world, deadline, tag):
+    """The train loop's situation at the train step's size: BURST fill -> all-reduce -> verify triples on the real
+    900,788-float layout (head / tail split as the overlapped trainers use it), enqueued BACK TO BACK with no host
+    synchronisation between steps -- every step's gradients are written by a kernel immediately before the exchange that
+    peers read them in, every step's sums are checked on the device (dta_xchg_selftest_verify) before the next fill
+    overwrites them.  A node whose kernel-boundary write-back towards PEER devices is lazier than towards the same device
+    (the one assumption of csrc/xchg.hip that a one-GPU box cannot exercise) fails here, and the trainers fall back to RCCL."""
+    import _lib
+    h = C.c_void_p()
+    _lib.check(L.dta_xchg_create(rank, world, N_REAL, C.byref(h)), "dta_xchg_create")
+    L.dta_xchg_set_timeout(h, 10.0)
+    L.dta_xchg_set_max_workgroups(h, 32)
+    _lib.check(L.dta_xchg_set_split(h, (3 * N_REAL // 4) & ~3), "dta_xchg_set_split")
+    mine = C.create_string_buffer(_lib.XCHG_HANDLE_BYTES)
+    _lib.check(L.dta_xchg_export(h, mine), "dta_xchg_export")
+    _put(d, f"{tag}h{rank}", mine.raw)
+    _wait_files(d, f"{tag}h", world, deadline)
+    blob = b"".join(open(os.path.join(d, f"{tag}h{r}"), "rb").read() for r in range(world))
+    _lib.check(L.dta_xchg_connect(h, C.create_string_buffer(blob, len(blob))), "dta_xchg_connect")
+    _put(d, f"{tag}c{rank}")
+    _wait_files(d, f"{tag}c", world, deadline)
+    for step in range(BURST):
+        _lib.check(L.dta_xchg_selftest_fill(h, 100 + step, None), "dta_xchg_selftest_fill")
+        if step & 1:
+            _lib.check(L.dta_xchg_reduce_head(h, None, -1, None), "dta_xchg_reduce_head")
+        _lib.check(L.dta_xchg_allreduce(h, None, -1, None), "dta_xchg_allreduce")
+        _lib.check(L.dta_xchg_selftest_verify(h, 100 + step, None), "dta_xchg_selftest_verify")
+    if hip.hipDeviceSynchronize() != 0:
+        raise RuntimeError("exchange kernel failed")
+    if L.dta_xchg_status(h) != 0:
+        raise RuntimeError(L.dta_last_error().decode())
+    bad = L.dta_xchg_selftest_mismatches(h)
+    _put(d, f"{tag}d{rank}")
+    _wait_files(d, f"{tag}d", world, deadline)
+    L.dta_xchg_destroy(h)
+    if bad:
+        sys.stderr.write(f"peer probe: {bad} wrong elements in {BURST} back-to-back exchanges of {N_REAL} floats\n")
+    return bad == 0
+
+
 def main(d, rank, world, device, budget_s=60.0):
     import _lib          # the package's ctypes binding, imported by path: the package itself would pull in torch
     deadline = time.time() + budget_s
@@ -99,6 +141,8 @@ def main(d, rank, world, device, budget_s=60.0):
     ok = _phase(L, hip, d, rank, world, deadline, "a", 0)
     # the two-segment buffer of the overlapped trainers: head = 3/4 of the buffer (a multiple of 4 floats), plain and overlapped
     ok = _phase(L, hip, d, rank, world, deadline, "b", (3 * N // 4) & ~3) and ok
+    # the train loop's situation: back-to-back steps at the train step's size, sums checked on the device
+    ok = _burst(L, hip, d, rank, world, deadline, "c") and ok
     return 0 if ok else 3
 
 

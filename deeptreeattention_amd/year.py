@@ -251,14 +251,15 @@ class learned_ensemble(nn.Module):
             self._register_gates()
         return hit[1]
 
-    def _next_flags(self, dev, publish):
+    def _next_flags(self, dev, publish, own=None):
         """(flags, clear_next) for one dta_year_flags call.  A training forward (publish) gets a fresh tensor of its own
         (clear_next None: the library zero-fills it in the same call) and queues it for the optimizer; a forward without a
         graph alternates two private banks (each call clears the other one: no clearing launch)."""
         Y = len(self.year_models)
-        if publish:
+        if publish or own:      # own: a graph-building forward keeps a tensor of its own for its backward, published or not
             flags = torch.empty(Y, dtype=torch.float32, device=dev)
-            self._publish_flags(flags)
+            if publish:
+                self._publish_flags(flags)
             return flags, None
         fs = self.__dict__["_scratch_flags"]
         if fs is None or fs[0].device != dev:
@@ -300,7 +301,11 @@ class learned_ensemble(nn.Module):
             xs = [Hang2020._check_input(x) for x in images]
             if any(x.shape != xs[0].shape for x in xs):
                 raise ValueError("all years of a batch must have the same shape")
-            flags, other = self._next_flags(xs[0].device, publish=train_graph)
+            # flags are published for the optimizer only by TRAINING-mode forwards that build a graph: an eval-mode forward
+            # with grad enabled (a saliency map, a validation loop that forgot no_grad) must not mark its years as kept for
+            # the next DtaAdam.step() -- that year would be stepped on zero gradients (moment decay + a momentum move),
+            # where the reference passes over it
+            flags, other = self._next_flags(xs[0].device, publish=train_graph and self.training, own=train_graph)
             if train_graph:      # (the parameters belong to a DtaAdam: one anchor input instead of 123 parameter inputs)
                 anchor = next(p for p in params if p.requires_grad)
                 return _EnsembleGatedFn.apply(self, flags, other, *xs, anchor)

@@ -395,6 +395,12 @@ int dta_xchg_adam_step(dta_xchg* x, float* p, float* m, float* v, size_t n, doub
  * that an exchange enqueued right behind it tests exactly what a train step relies on -- gradients written by the kernel
  * before the exchange on the same stream are visible to the peers' system-scope loads (kernel-boundary write-back). */
 int dta_xchg_selftest_fill(dta_xchg* x, int step, void* stream);
+/* ... and its counterpart behind the exchange: compares the buffer with the sum over ranks of step `step`'s patterns ON THE
+ * DEVICE and adds the number of differing elements to a counter (dta_xchg_selftest_mismatches reads it after a
+ * synchronisation).  fill -> all-reduce -> verify triples can so be enqueued back to back, with no host synchronisation
+ * between steps -- what a training loop does, and what a lazily written-back buffer would not survive. */
+int dta_xchg_selftest_verify(dta_xchg* x, int step, void* stream);
+int dta_xchg_selftest_mismatches(dta_xchg* x);
 /* 0 = every step so far completed; otherwise (phase << 8 | rank waited for) of the first timed-out wait (host-side read of
  * a pinned word, no synchronisation: a launch that timed out has written it by the time it ends; trainers poll it at the
  * start of every step). */

@@ -204,3 +204,27 @@ def test_ensemble_forward_loss_in_one_call_equals_forward_then_loss():
         ref_loss = cross_entropy(ref_scores, y, weight=w)
         assert torch.equal(scores, ref_scores), zero
         assert torch.equal(loss, ref_loss), (zero, float(loss), float(ref_loss))
+
+
+def test_eval_mode_forward_with_grad_does_not_mark_years_for_the_next_step():
+    """model.eval() forward with grad enabled (a saliency map; a validation loop without no_grad) that keeps a
+    year must NOT make DtaAdam step that year when the TRAINING batch lacks it: the reference passes over a skipped year
+    (grad None), a step on zero gradients would still decay its moments and move it by its momentum."""
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    years = 3
+    a = _ensemble(years)
+    opt = DtaAdam(a.parameters(), lr=1e-3)
+    xs, y = _batch(years, seed=1)
+    opt.zero_grad(); cross_entropy(a(xs), y).backward(); opt.step()          # every year has momentum now
+    before = {k: v.detach().clone() for k, v in a.named_parameters()}
+    xv, _ = _batch(years, seed=2)                     # validation batch: all years present
+    a.eval()
+    s = a(xv)                                         # grad enabled, eval mode
+    s.sum().backward()                                # (its own backward still sees its own flags)
+    a.train()
+    xs, y = _batch(years, seed=3, zero=(2,))          # the training batch lacks year 2
+    opt.zero_grad(); cross_entropy(a(xs), y).backward(); opt.step()
+    assert opt.step_counts() == [2, 2, 1]
+    for k, p in a.named_parameters():
+        if k.startswith("year_models.2."):
+            assert torch.equal(p, before[k]), k
