@@ -9,8 +9,8 @@ all-reduce when >1 GPU) at bands=369, 11x11, 200 classes (BASELINE.json metric /
 One process per GPU; per-GPU batch is fixed (weak scaling; 1024 per GPU = 8192 global on 8 GPUs).  Started WITHOUT a
 launcher (`python bench.py --gpus N`, no RANK in the environment) it spawns its own N ranks under torch.distributed.run.
 Synthetic patches (U[0,1), like the reference's min-max-scaled crops) are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line.  `roofline.frac` prices SURVEY.md 8(d)'s COMPULSORY bytes of the conv1 forward (input in +
-output out); the bf16 tile by-product it also writes is in `frac_with_byproduct`.  The one-GPU line also carries, timed
+Rank 0 prints ONE JSON line.  `roofline.frac` prices SURVEY.md 8(d)'s per-patch bytes of the conv1 forward (the fp32 input:
+182.9 MB per launch at B = 1024); with the half output: `frac_with_output`; with the bf16 tile by-product too: `frac_with_byproduct`.  The one-GPU line also carries, timed
 after the contract's region (20 steps each): `fp32` (the reference's own precision), `ensemble24` (BASELINE configs[4]), `metadata` (BASELINE configs[3]),
 `multistage` (the reference's train.py path: 5 levels x 3 years, one launch chain vs level by level) and `module_path` (the unchanged reference step on the plugin modules with optim.DtaAdam / optim.cross_entropy).  Inside the timed loop the two first-conv kernels are timed with HIP events recorded on their own
 stream: `roofline` = the conv1 forward (the step's longest kernel; HBM-bound since it also converts the fp32 input and
@@ -192,16 +192,37 @@ def main_ensemble24(a, emit=True):
                 "frac": round(ach / PEAK_TFLOPS[a.precision], 4), "traffic": None, "avg_launch_ms": round(avg, 4),
                 "launches": len(ms), "algorithmic_flop_per_launch": flops,
                 "measured_in": f"HIP events around every {max(1, a.site_stride)}th launch inside the timed steps"}
+        # HBM bytes per launch from committed PMC passes of THIS build (tools/run_profiles.sh: separate FETCH_SIZE / WRITE_SIZE
+        # runs of this command; tools/step_traffic.py): null when the newest file was taken on another build of the kernels
+        import glob
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic_ensemble24.json")))
+        roof["traffic_source"] = "none: no profiles/r*_traffic_ensemble24.json"
+        if cands and B == 256 and a.precision == "bf16":
+            tj = json.load(open(cands[-1]))
+            build_id = L.dta_build_id().decode()
+            if tj.get("library_build_id") == build_id:
+                want = "k_conv3x3_bf16<3, 1, true" if a.site == "fwd0" else "k_conv_wgrad_bf16<4, 1"
+                for row in tj.get("kernels", []):
+                    if row["kernel"].startswith(want):
+                        roof["traffic"] = row["hbm_bytes_per_launch"]
+                roof["step_traffic"] = int(tj.get("hbm_mb_per_step", 0) * 1e6) or None
+                roof["traffic_source"] = (f"PMC passes of this very build ({os.path.relpath(cands[-1], REPO)}, library_build_id {build_id}): "
+                                          "2 x FETCH_SIZE + WRITE_SIZE in separate rocprofv3 runs")
+            else:
+                roof["traffic_source"] = (f"none: {os.path.relpath(cands[-1], REPO)} was measured on library build "
+                                          f"{tj.get('library_build_id')}, this run is build {build_id}")
         if a.site == "fwd0" and a.precision == "bf16":
             # the bf16 first conv reads the fp32 crops itself and leaves the (haloed) bf16 tiles behind for the weight
             # gradient: per crop-year 369*576*4 B in, 384*676*2 B of tiles + 32*576*2 B of half output out -> HBM-bound
             # `frac` prices the COMPULSORY bytes only (the fp32 crop in, the half conv output out); the
             # bf16 tile by-product the kernel also writes (for its own weight gradient) is reported beside it
             withby = B * YEARS * (BANDS * px * 4 + 384 * (CROP + 2) * (CROP + 2) * 2 + 32 * px * 2)
-            nbytes = B * YEARS * (BANDS * px * 4 + 32 * px * 2)
+            without = B * YEARS * (BANDS * px * 4 + 32 * px * 2)
+            nbytes = B * YEARS * (BANDS * px * 4)          # the fp32 crops alone (as for the headline workload)
             gbs = nbytes / (avg * 1e-3) / 1e9
             roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
+                         "frac_with_output": round(without / (avg * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "frac_with_byproduct": round(withby / (avg * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "bytes_per_launch_with_byproduct": withby, "mfma_tflops": round(ach, 2),
                          "kernel": "k_conv3x3_bf16<3,1,XN,6> (conv1 forward of the three years, one grouped launch; converts "
@@ -704,10 +725,15 @@ def main():
                 # `achieved` / `frac` price SURVEY.md 8(d)'s COMPULSORY bytes only (input in + conv output out); the
                 # bf16 tiles are a by-product for the kernel's own weight gradient and are reported beside it
                 withby = a.batch * (BANDS * HW * HW * 4 + 384 * HW * HW * 2 + 64 * HW * HW * 2)
-                nbytes = a.batch * (BANDS * HW * HW * 4 + 64 * HW * HW * 2)
+                without = a.batch * (BANDS * HW * HW * 4 + 64 * HW * HW * 2)
+                # SURVEY.md 8(d)'s per-patch figure for this kernel is the fp32 input alone (369 * 121 * 4 B = 178,596 B ->
+                # 182.9 MB per launch at B = 1024): that is what `achieved` / `frac` price since round 6 (rounds 4-5 counted
+                # the 15.9 MB half output in as well: `frac_with_output`)
+                nbytes = a.batch * (BANDS * HW * HW * 4)
                 gbs = nbytes / (avg_ms * 1e-3) / 1e9
                 r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
+                          "frac_with_output": round(without / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                           "frac_with_byproduct": round(withby / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                           "bytes_per_launch_with_byproduct": withby,
                           "mfma_tflops": round(ach, 2), "mfma_frac": round(ach / PEAK_TFLOPS[a.precision], 4),

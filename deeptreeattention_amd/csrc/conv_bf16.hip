@@ -739,6 +739,9 @@ extern "C" int dta_debug_wticks(long long* out) { return (int)hipMemcpyFromSymbo
 template <int CT, int NTT, bool BIGW, bool STACK = false, bool D2 = false>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx, unsigned char* smem) {
   WGSTAMP(CT == 2 ? 3 : -1);      // first conv's weight gradient
+#ifdef DTA_TICKS
+  const long long wentry_ = clock64();
+#endif
   constexpr int NTHR = 512;
   // CT 32-channel input tiles x NTT 32-column tiles per workgroup = PAIRS wave tiles; the 8 waves are PAIRS tiles x
   // KS k-slices (KS = 2 for the usual 4 tiles; 4 when the layer has only 32 input channels: CT = 1, NTT = 2)
@@ -896,6 +899,9 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
   }
   __syncthreads();
   WTICK_DECL
+#ifdef DTA_TICKS
+  if (blockIdx.x == 17 && threadIdx.x == 0 && a.N == 64 && a.NCx > 8) g_wticks[6] = wt0_ - wentry_;      // entry -> loop
+#endif
   // one iteration; RX_/RY_ = the register set that holds window it + 1 (and then receives window it + AHEAD)
 #define DTA_WGRAD_ITER(RX_, RY_, it)                                                                              \
   {                                                                                                               \
@@ -950,6 +956,9 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
 #undef DTA_STORE
 #undef DTA_FETCH
   WTICK_DUMP
+#ifdef DTA_TICKS
+  const long long wloopend_ = clock64();
+#endif
   // the odd-k waves hand their partial sums to their even-k partners through LDS (the staging buffers are free now:
   // the loop ended on a barrier), two tap tiles per pass
   float* red = reinterpret_cast<float*>(smem);
@@ -976,6 +985,9 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
     }
     __syncthreads();
   }
+#ifdef DTA_TICKS
+  if (blockIdx.x == 17 && threadIdx.x == 0 && a.N == 64 && a.NCx > 8) g_wticks[7] = clock64() - wloopend_;      // k-slice hand-over
+#endif
   if (khalf != 0) return;
   // partial[g][tap][c][s][n]: the S partial sums of one output row are contiguous for the reduction
   float* out = a.partial + (size_t)g * 9 * a.Cpad * a.S * a.N + (size_t)s * a.N + ng * N;     // (a.N = ngr * N columns per row)
@@ -987,6 +999,13 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& a, const int bx
       if (c < a.Cpad) __builtin_nontemporal_store(acc[j][r], &out[((size_t)j * a.Cpad + c) * a.S * a.N + nt * 32 + (lane & 31)]);
     }
   }
+#ifdef DTA_TICKS
+  if (blockIdx.x == 17 && threadIdx.x == 0 && a.N == 64 && a.NCx > 8) {
+    g_wticks[14] = clock64() - wloopend_;      // ... + slab stores issued
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+    g_wticks[15] = clock64() - wloopend_;      // ... + slab stores performed
+  }
+#endif
 }
 
 template <int CT, int NTT, bool BIGW, bool STACK = false, bool D2 = false>

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--trace-steps", type=int, required=True, help="train steps in the --kernel-trace run (warmup + timed)")
     ap.add_argument("--pmc-steps", type=int, required=True, help="train steps in each PMC run (warmup + timed)")
     ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--algo-bytes", type=float, default=None, help="algorithmic bytes per step of another workload (default: SURVEY 8(d) x batch + parameter state)")
+    ap.add_argument("--workload", default="hang2020")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
@@ -81,12 +83,12 @@ def main():
         tot_bytes += nbytes * per_step
         tot_us += avg_us * per_step
     rows.sort(key=lambda r: -r["us_per_step"])
-    algo = ALGO_BYTES_PER_PATCH * a.batch + PARAM_STATE_BYTES
+    algo = a.algo_bytes if a.algo_bytes else ALGO_BYTES_PER_PATCH * a.batch + PARAM_STATE_BYTES
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from deeptreeattention_amd import _lib
     out = {"note": __doc__.split("\n\n")[2].replace("\n", " ").strip(),
            "library_build_id": _lib.lib().dta_build_id().decode(),      # bench.py quotes these counters only on this build
-           "batch": a.batch, "launches_per_step": round(sum(r["launches_per_step"] for r in rows), 1),
+           "workload": a.workload, "batch": a.batch, "launches_per_step": round(sum(r["launches_per_step"] for r in rows), 1),
            "kernel_us_per_step": round(tot_us, 1), "hbm_mb_per_step": round(tot_bytes / 1e6, 1),
            "algorithmic_mb_per_step": round(algo / 1e6, 1), "traffic_over_algorithmic": round(tot_bytes / algo, 2),
            "kernels": rows}

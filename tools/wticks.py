@@ -13,3 +13,4 @@ L.dta_debug_wticks(buf)
 for w in range(8):
     t = [buf[w * 8 + i] for i in range(6)]
     print("wave", w, "stageA", t[0], "ksteps", t[1], "stageB", t[2], "barrier", t[5], "loop total", t[3], "niter", t[4])
+print("wave 0: entry -> loop", buf[6], "cycles; loop end -> k-slice hand-over done", buf[7], "; -> slab stores issued", buf[14], "; -> performed", buf[15])
