@@ -12,6 +12,6 @@ L = _lib.lib()
 buf = (C.c_longlong * 16)()
 L.dta_debug_cticks(buf)
 t = [buf[i] for i in range(6)]
-names = ["tables + LDS zero", "first chunk fetched, stored, barrier", "chunk loop", "output store", "statistics"]
-for i, n in enumerate(names): print(f"{n:<40} {t[i + 1] - t[i]:>8} cycles")
+names = ["entry -> staging plan ready (kernel arguments, divisions, bias request)", "first chunk fetched + row tables + stored, barrier", "chunk loop", "output store", "statistics"]
+for i, n in enumerate(names): print(f"{n:<76} {t[i + 1] - t[i]:>8} cycles")
 print("total", t[5] - t[0])
