@@ -547,9 +547,12 @@ _Pragma("unroll") \
       }
     }
     };
+    CTICK(6);
     if (a.y_fmt == FMT_F16) pack_tile(std::integral_constant<int, FMT_F16>{});
     else pack_tile(std::integral_constant<int, FMT_BF16>{});
+    CTICK(7);
     __syncthreads();
+    CTICK(8);
     constexpr int VPR = N / 8;                      // 16-byte vectors per output row
 #pragma unroll
     for (int u = 0; u < MWG * VPR / NTHR; ++u) {

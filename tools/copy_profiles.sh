@@ -13,6 +13,7 @@ cp $S/private_segment.txt profiles/${R}_private_segment.txt
 cp $S/infer.txt profiles/${R}_inference.txt
 cp $S/kernel_trace.txt profiles/${R}_kernel_trace_bf16_B1024.txt
 cp $S/kernel_trace_ensemble24.txt profiles/${R}_kernel_trace_ensemble24.txt
+[ -f $S/kernel_trace_multistage_B128.txt ] && cp $S/kernel_trace_multistage_B128.txt profiles/${R}_kernel_trace_multistage_B128.txt
 cp $S/kernel_trace_dispatches.csv profiles/${R}_kernel_trace_bf16_B1024_dispatches.csv
 cp $S/kernel_trace_ensemble24_dispatches.csv profiles/${R}_kernel_trace_ensemble24_dispatches.csv
 cp $S/pmc_fetch.csv profiles/${R}_pmc_fetch.csv

@@ -15,3 +15,4 @@ t = [buf[i] for i in range(6)]
 names = ["entry -> staging plan ready (kernel arguments, divisions, bias request)", "first chunk fetched + row tables + stored, barrier", "chunk loop", "output store", "statistics"]
 for i, n in enumerate(names): print(f"{n:<76} {t[i + 1] - t[i]:>8} cycles")
 print("total", t[5] - t[0])
+print("epilogue split: loop end -> shift/bias ready", buf[6] - t[3], "| pack + statistics sums + LDS writes", buf[7] - buf[6], "| barrier", buf[8] - buf[7], "| LDS -> global stores issued", t[4] - buf[8])

@@ -28,6 +28,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch_e24 -o f -- $E24 --steps 3
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write_e24 -o w -- $E24 --steps 3 --warmup 2 > $O/write_e24.log 2>&1
 cd $R
 python tools/prof_summary.py $O/kt_e24/kt_results.db 35 > $O/kernel_trace_ensemble24.txt
+cd /tmp; rocprofv3 --kernel-trace --stats -d $O/kt_ms -o kt -- python $R/tools/ms_trace.py 128 20 > $O/kt_ms.log 2>&1; cd $R
+python tools/prof_summary.py $O/kt_ms/kt_results.db 20 > $O/kernel_trace_multistage_B128.txt; rm -rf $O/kt_ms
 # ensemble24: 3 years x 256 crops x 2 reads of the fp32 crop (forward + conv1 weight gradient) + parameter state of 3 networks
 python tools/step_traffic.py --workload ensemble24 --batch 256 --algo-bytes $((3*256*2*369*576*4 + 3*4*4*521432)) --trace $O/kt_e24/kt_results.db --fetch $O/fetch_e24/f_results.db --write $O/write_e24/w_results.db --trace-steps 35 --pmc-steps 5 --out $O/traffic_ensemble24.json > $O/traffic_ensemble24.txt
 python tools/prof_summary.py $O/kt/kt_results.db 60 > $O/kernel_trace.txt
