@@ -273,6 +273,8 @@ def lib():
         L.dta_net_backward_xchg.argtypes = [C.POINTER(NetDesc), C.POINTER(SubnetParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.POINTER(ScoreTable), C.c_void_p, C.POINTER(SubnetGrads), C.c_void_p, C.c_void_p,
                                             C.c_longlong, C.c_void_p]
+        L.dta_xchg_disconnect.restype = C.c_int
+        L.dta_xchg_disconnect.argtypes = [C.c_void_p]
         L.dta_xchg_selftest_fill.restype = C.c_int
         L.dta_xchg_selftest_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.dta_xchg_selftest_verify.restype = C.c_int

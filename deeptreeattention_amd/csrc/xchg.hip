@@ -430,13 +430,20 @@ int dta_xchg_last_timing(dta_xchg* x, float* wait_us, float* exchange_us) {
   return 0;
 }
 
-int dta_xchg_destroy(dta_xchg* x) {
+int dta_xchg_disconnect(dta_xchg* x) {
   if (!x) return 0;
   for (int s = 0; s < x->world; ++s) {
     if (s == x->rank || !x->connected) continue;
-    if (x->peer_grads[s]) hipIpcCloseMemHandle(x->peer_grads[s]);
-    if (x->peer_sig[s]) hipIpcCloseMemHandle(x->peer_sig[s]);
+    if (x->peer_grads[s]) { hipIpcCloseMemHandle(x->peer_grads[s]); x->peer_grads[s] = nullptr; }
+    if (x->peer_sig[s]) { hipIpcCloseMemHandle(x->peer_sig[s]); x->peer_sig[s] = nullptr; }
   }
+  x->connected = false;
+  return 0;
+}
+
+int dta_xchg_destroy(dta_xchg* x) {
+  if (!x) return 0;
+  dta_xchg_disconnect(x);
   hipFree(x->grads);
   hipFree(x->sig);
   hipHostFree(x->status_host);

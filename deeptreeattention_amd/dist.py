@@ -225,6 +225,8 @@ class PeerExchange:
             torch.cuda.synchronize()
             if self.world > 1 and dist.is_initialized():
                 dist.barrier(group=self.group)
+                self._L.dta_xchg_disconnect(self._h)      # unmap the peers' buffers ...
+                dist.barrier(group=self.group)             # ... and free only what nobody has mapped any more
             self.grad = None
             self._owner.destroy()
             self._h = None

@@ -408,6 +408,12 @@ int dta_xchg_status(dta_xchg* x);
 /* Development aid: how long workgroup 0 of the LAST exchange launch waited for the ranks to arrive and how long the
  * exchange proper took afterwards, in microseconds (pinned host words: synchronise the stream first). */
 int dta_xchg_last_timing(dta_xchg* x, float* wait_us, float* exchange_us);
+/* Orderly teardown in two collective steps: every rank UNMAPS its peers' buffers (dta_xchg_disconnect), the ranks meet at a
+ * barrier, and only then does anybody free what the others had mapped (dta_xchg_destroy, which also disconnects when that
+ * was not done).  Freeing while a peer still holds a mapping is safe for the peer, but a buffer re-created at the same address
+ * right away (probe -> trainer, one trainer after another) then races with the peer's close of the old mapping: seen as
+ * hipIpcGetMemHandle / stale-mapping failures with eight processes on one test GPU. */
+int dta_xchg_disconnect(dta_xchg* x);
 int dta_xchg_destroy(dta_xchg* x);
 
 /* ---- stand-alone building blocks (same kernels as the network-level path) ------------------------------------ */
