@@ -19,6 +19,11 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hw_bf16x2));
 }
 
+// n / d for the small non-negative operands of the staging plans: magic = ceil(2^32 / d), exact for n * d < 2^32
+__device__ __forceinline__ int fastdiv(int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); }
+static inline unsigned fastdiv_magic(int d) { return d > 1 ? (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d) : 0u; }
+__device__ __forceinline__ int fastdiv1(int n, int d, unsigned magic) { return d > 1 ? fastdiv(n, magic) : n; }
+
 __device__ __forceinline__ bf16x8 lds_b128(const unsigned char* base, int off) {
   return *reinterpret_cast<const bf16x8*>(base + off);
 }
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void k_conv3x3_bf16(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.y;
-  const int pg = blockIdx.x / a.spp, split = blockIdx.x - pg * a.spp;
+  const int pg = a.spp == 1 ? (int)blockIdx.x : (int)blockIdx.x / a.spp, split = blockIdx.x - pg * a.spp;      // (whole patches per workgroup: no division)
   const int b0 = pg * a.ppw;
   const int npatch = min(a.ppw, a.B - b0);
 
@@ -190,9 +195,9 @@ _Pragma("unroll") \
 #pragma unroll
   for (int u = 0; u < XV; ++u) {
     int v = min(tid + u * NTHR, max(nxv, 1) - 1);
-    int pl = v / vpp, o = v - pl * vpp;
+    int pl = fastdiv(v, a.m_vpp), o = v - pl * vpp;
     int row = o >> 1;
-    if (xc) { const int hh = row / a.W; row = (hh + 1) * W2 + (row - hh * a.W) + 1; }   // pixel -> haloed-grid row
+    if (xc) { const int hh = fastdiv(row, a.m_W); row = (hh + 1) * W2 + (row - hh * a.W) + 1; }   // pixel -> haloed-grid row
     xsrc[u] = (unsigned)(((size_t)pl * a.NC) * xchunk + (size_t)o * 8);
     xdst[u] = (pl * Q + row) * RB + (o & 1) * 16;
   }
@@ -208,9 +213,9 @@ _Pragma("unroll") \
 #pragma unroll
   for (int u = 0; u < QV; ++u) {
     int q = min(tid + u * NTHR, max(nquad, 1) - 1);
-    int pl = q / (4 * HW), rem = q - pl * 4 * HW;
-    int cq = rem / HW, px = rem - cq * HW;
-    const int hh = px / a.W;
+    int pl = fastdiv(q, a.m_4HW), rem = q - pl * 4 * HW;
+    int cq = fastdiv(rem, a.m_HW), px = rem - cq * HW;
+    const int hh = fastdiv(px, a.m_W);
     const int row = (hh + 1) * W2 + (px - hh * a.W) + 1;
     qsrc[u] = (unsigned)((size_t)pl * a.Cx * HW + px);    // channel 0 of the patch, relative to the workgroup's first
     qdst[u] = (pl * Q + row) * RB + cq * 8;
@@ -601,6 +606,7 @@ static int launch_conv_bf16_t(ConvArgs a, int G, hipStream_t st) {
   int nwg;
   conv_geometry(a.HW, MWG, a.B, &a.ppw, &a.spp, &nwg);
   if (a.tabs_rows != MWG) a.tabs = nullptr;      // (tables of another tile: every workgroup builds its own)
+  a.m_vpp = fastdiv_magic((a.x_compact ? a.HW : a.Q) * 2); a.m_W = fastdiv_magic(a.W); a.m_HW = fastdiv_magic(a.HW); a.m_4HW = fastdiv_magic(4 * a.HW);
   size_t tab = (size_t)MWG * 8 + (size_t)17 * N * 4, stage = ((size_t)a.ppw * a.Q + (size_t)9 * N) * RB;
   // few chunks (the 32- and 64-channel layers): one LDS stage, so that two or three workgroups share a CU and overlap
   // each other's prologue / epilogue instead of double-buffering a two-iteration loop

@@ -37,6 +37,10 @@ struct ConvArgs {
   // launch: [tabs_rows] output row relative to the workgroup's first patch (or -1), then [tabs_rows] plq; null = every workgroup
   // builds its own (a few-chunk workgroup spent 4 k of its 21 k cycles there)
   const int* tabs; int tabs_rows;
+  // bf16 kernels: reciprocals of the per-thread staging plan's divisors (magic = ceil(2^32 / d); n / d = umulhi(n, magic) for
+  // n * d < 2^32), filled by the launcher: the plan's eight to twenty runtime integer divisions were ~1.5 k of a few-chunk
+  // workgroup's 19 k cycles
+  unsigned m_vpp, m_W, m_HW, m_4HW;
   unsigned* fan_count;                // [gridDim.y][FAN_R] arrival counters (zero on entry, left zero) or null
   double* fan_sums;                   // [gridDim.y][FAN_R][N][3] = sum n m, sum n m^2, sum M2 per column
 };
