@@ -841,7 +841,7 @@ class EnsembleTrainer:
         if not kept:
             raise RuntimeError("every year of this rank's batch is all-zero: nothing to average (reference year.py:33)")
         if len(kept) > _lib.MAX_YEARS:
-            raise RuntimeError("at most {} years per grouped launch".format(_lib.MAX_YEARS))
+            raise RuntimeError("at most {} years per grouped launch (train_step / forward_loss chunk beyond that)".format(_lib.MAX_YEARS))
         xs = [H._check_input(images[i]) for i in kept]
         if any(x.shape != xs[0].shape for x in xs):
             raise ValueError("all years of a batch must have the same shape")
@@ -919,6 +919,68 @@ class EnsembleTrainer:
                        "dta_ensemble_forward_gated")
         self._live = xs
         return list(range(Y))
+
+    # ---- more kept years than one grouped launch takes (DTA_MAX_YEARS = 16): chunks of 16, single process ----
+    def _chunked_forward(self, images, local, y, want_grad):
+        """The kept years in chunks of DTA_MAX_YEARS networks: one grouped forward per chunk (its mean over ITS years,
+        dta_ensemble_forward, own workspace), the ensemble's scores = the chunk means weighted by their year counts
+        (reference year.py:33: the mean over all kept years), then the level's weighted CE with d(mean)/d(year score) =
+        1 / kept folded into the gradient (dta_weighted_ce_scaled).  Leaves what _chunked_backward needs in self._chunks."""
+        L = _lib.lib()
+        kept = [i for i, k in enumerate(local) if k]
+        st = _lib.current_stream_ptr()
+        xs_all = {i: H._check_input(images[i]) for i in kept}
+        shape = xs_all[kept[0]].shape
+        if any(x.shape != shape for x in xs_all.values()):
+            raise ValueError("all years of a batch must have the same shape")
+        B, classes = shape[0], self.model.year_models[0]._classes
+        self._buffers(B, classes)
+        cache = self.__dict__.setdefault("_chunk_ws", {})
+        chunks = []
+        self.scores.zero_()
+        for ci, lo in enumerate(range(0, len(kept), _lib.MAX_YEARS)):
+            part = kept[lo:lo + _lib.MAX_YEARS]
+            xs = [xs_all[i] for i in part]
+            keys = [self.years[i]._describe(x) for i, x in zip(part, xs)]
+            n = len(part)
+            nets = (_lib.SubnetParams * n)(*[self.years[i].nets[0] for i in part])
+            grads = (_lib.SubnetGrads * n)(*[self.years[i].grads[0] for i in part])
+            xptr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+            desc = self.years[part[0]].desc
+            wkey = (ci, n) + keys[0]
+            hit = cache.get(ci)
+            if hit is None or hit[0] != wkey:
+                nbytes = L.dta_ensemble_workspace_bytes(C.byref(desc), n)
+                if nbytes == 0:
+                    raise RuntimeError("dta_ensemble_workspace_bytes: " + L.dta_last_error().decode())
+                hit = cache[ci] = (wkey, torch.empty(nbytes, dtype=torch.uint8, device=self.device),
+                                   torch.empty(B, classes, dtype=torch.float32, device=self.device))
+            ws, mean_c = hit[1], hit[2]
+            _lib.check(L.dta_ensemble_forward(C.byref(desc), n, nets, xptr, _lib.ptr(ws), _lib.ptr(mean_c), st), "dta_ensemble_forward")
+            self.scores.add_(mean_c, alpha=n / len(kept))
+            chunks.append((part, desc, nets, grads, ws, xs))
+        self.loss = torch.empty((), dtype=torch.float32, device=self.device)
+        _lib.check(L.dta_weighted_ce_scaled(_lib.ptr(self.scores), _lib.ptr(y), _lib.ptr(self.loss_weight), B, classes,
+                                            1.0 / len(kept), _lib.ptr(self.loss), _lib.ptr(self.dscores) if want_grad else None,
+                                            _lib.ptr(self.ce_scratch), st), "dta_weighted_ce_scaled")
+        self._chunks = chunks
+        return kept
+
+    def _chunked_backward(self):
+        L = _lib.lib()
+        st = _lib.current_stream_ptr()
+        for part, desc, nets, grads, ws, xs in self._chunks:
+            for i in part:
+                self.years[i]._zero_grads()
+            _lib.check(L.dta_ensemble_backward_gated(C.byref(desc), len(part), nets, _lib.ptr(ws), _lib.ptr(self.dscores), grads,
+                                                     None, 3, st), "dta_ensemble_backward")
+            for i in part:
+                self.years[i]._grads_clear = False
+
+    def _host_flags(self, images):
+        """year.py:27 for every year in ONE transfer (the chunked path only: beyond DTA_MAX_YEARS networks the missing-year
+        decision is the host's, as on the module path)."""
+        return [bool(v) for v in torch.stack([x.ne(0).any() for x in images]).tolist()]
 
     def _backward_xchg(self, kept, gate=None):
         """The whole backward with the exchange's head segment (every gradient but the years' first-conv weights, and the
@@ -1008,6 +1070,19 @@ class EnsembleTrainer:
         self.check_exchange()
         y = self.years[0]._labels(y)
         gate = None
+        if len(self.years) > _lib.MAX_YEARS:
+            # more years than one grouped launch takes: chunks of DTA_MAX_YEARS (the reference takes the year count from the
+            # data, multi_stage.py:39, :61-66); missing years decided on the host there (one transfer), single process only
+            if self.comm:
+                raise RuntimeError("a data-parallel year ensemble takes at most {} years".format(_lib.MAX_YEARS))
+            local = self._kept(images, present if present is not None else self._host_flags(images))
+            if sum(local) > _lib.MAX_YEARS:
+                self._counters_to("host")
+                self._chunked_forward(images, local, y, True)
+                self._chunked_backward()
+                self._adam_present(local)
+                return self.loss
+            present = local
         if present is not None and self.ex is not None and self.ex.split:
             # overlapped peer exchange: the head's sum rides in the years' first-conv weight-gradient launch, and whether that
             # combined kernel exists depends on how many years a rank launches.  Host flags differ from rank to rank (and a
@@ -1081,7 +1156,13 @@ class EnsembleTrainer:
     def forward_loss(self, images, y, present=None):
         """validation_step of the level (multi_stage.py:290-304): ensemble scores + weighted CE, no update."""
         y = self.years[0]._labels(y)
-        if present is None:
+        if len(self.years) > _lib.MAX_YEARS:
+            local = self._kept(images, present if present is not None else self._host_flags(images))
+            if sum(local) > _lib.MAX_YEARS:
+                self._chunked_forward(images, local, y, False)
+            else:
+                self._forward(images, local, y, False)
+        elif present is None:
             self._forward_gated(images, y, False)
         else:
             self._forward(images, self._kept(images, present), y, False)
