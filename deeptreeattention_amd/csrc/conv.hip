@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_forward_prep(PrepArgs a) {
   }
   if (y < a.ncg * a.nx) {
     const int gi = y / a.ncg;
-    if ((int)blockIdx.x >= a.B) return;      // (the grid's x extent is at least PREP_MIN_BLOCKS: see launch_forward_prep)
+    if ((int)blockIdx.x >= a.B) return;      // (the grid may be wider than the batch: see launch_forward_prep)
     pack_input_block<T>(a.x[gi], (T*)((char*)a.x_tl + (size_t)gi * a.x_tl_gs), a.B, a.C, a.H, a.W, a.NC, a.CG, blockIdx.x,
                         y - gi * a.ncg, smem, a.x_compact != 0);
     return;
@@ -225,10 +225,18 @@ int launch_forward_prep(PrepArgs a, hipStream_t st) {
   size_t lds;
   if (pack_input_plan(a.C, a.H, a.W, &a.NC, &a.CG, &lds)) return 1;
   a.ncg = (a.NC + a.CG - 1) / a.CG;
-  // one block per patch for the input-pack jobs; the weight re-layout jobs are grid-stride loops over up to 16 networks'
-  // weights (a multi-stage step at batch 128: 1.7 M elements per job), so small batches still get a full-width grid
   constexpr int PREP_MIN_BLOCKS = 1024;
-  dim3 grid(a.B > PREP_MIN_BLOCKS ? a.B : PREP_MIN_BLOCKS, a.ncg * a.nx + a.packs.n + a.spacks.n + a.trans.n + (a.tabs.n > 0 ? 1 : 0) + (a.zero ? 1 : 0));
+  // grid x extent: every job is a grid-stride loop, and what the launch costs is mostly the DISPATCH of its workgroups (13 rows x
+  // 1024 blocks for a Hang2020 step whose largest job is 0.3 M elements: 9.4 us; x 256: 7.3; x 128: 8.7; x 64: 12.8) -- so
+  // about four elements per thread of the largest job, between 256 and 1024 blocks; the input-pack rows need one block per patch
+  size_t most = a.zero ? a.zero_n4 : 0;
+  for (int j = 0; j < a.packs.n; ++j) { const PackWArgs& w = a.packs.job[j]; const size_t e = (size_t)w.G * w.NC * 9 * w.N * 16; if (e > most) most = e; }
+  for (int j = 0; j < a.spacks.n; ++j) { const size_t e = (size_t)a.spacks.C[j] * a.spacks.C[j]; if (e > most) most = e; }
+  for (int j = 0; j < a.trans.n; ++j) { const size_t e = (size_t)a.trans.cols[j] * a.trans.ld[j]; if (e > most) most = e; }
+  int gx = (int)((most + 1023) / 1024);
+  gx = gx < 256 ? 256 : (gx > PREP_MIN_BLOCKS ? PREP_MIN_BLOCKS : gx);
+  if (a.nx > 0 && gx < a.B) gx = a.B;
+  dim3 grid(gx, a.ncg * a.nx + a.packs.n + a.spacks.n + a.trans.n + (a.tabs.n > 0 ? 1 : 0) + (a.zero ? 1 : 0));
   hipLaunchKernelGGL(k_forward_prep<T>, grid, dim3(256), lds, st, a);
   DTA_CHECK_LAUNCH("k_forward_prep");
   return 0;
