@@ -153,3 +153,10 @@ def test_no_kernel_of_the_product_library_has_a_private_segment(tmp_path):
                     bad.append((name.group(1), int(seg.group(1))))
     assert seen > 100, seen          # (166 kernels at the time of writing)
     assert not bad, bad
+
+
+def test_graft_entry_build_runs_on_cpu():
+    """__graft_entry__.build() is the driver's "does it build" check: compile (a no-op when the objects are current), load,
+    ABI version and exported symbols.  (Round 6 bumped DTA_ABI_VERSION and the entry still asserted the old one.)"""
+    import __graft_entry__ as entry
+    entry.build()
