@@ -109,32 +109,44 @@ template int launch_pack_input<bf16_t>(const float*, void*, int, int, int, int, 
 //   mode 1: forward, G==1, output columns concatenated     val = (n<nsplit ? W_0[n] : W_1[n-nsplit])[kc][tap]
 //   mode 2: input-gradient form (transposed + flipped)     val = W_g[kc][n][8-tap]   (W_g is [Kdim][N][9])
 // ------------------------------------------------------------------------------------------------
+// (an item is one 16-wide row of the image -- (group, chunk, tap, n) decoded ONCE with 32-bit arithmetic, its sixteen values
+//  gathered with all loads in flight and written as one contiguous 32- / 64-byte run; the element-per-thread form decoded every
+//  element with four 64-bit divisions: 33 us of a 15-network multi-stage step's prep launch)
 template <typename T>
 __device__ __forceinline__ void pack_conv_w_job(const PackWArgs& a, T* __restrict__ dst, size_t i0, size_t stride) {
   const int N = a.N, NC = a.NC;
-  size_t total = (size_t)a.G * NC * 9 * N * 16;
-  for (size_t i = i0; i < total; i += stride) {
-    int pos = i & 15;
-    size_t r = i >> 4;
-    int n = r % N; r /= N;
-    int tap = r % 9; r /= 9;
-    int chunk = r % NC;
-    int g = r / NC;
-    int row = tap * N + n;
-    int kc = chunk * 16 + tl_pos<T>(row, pos);
-    float v = 0.f;
-    if (kc < a.K) {
-      if (a.mode == 0) {
-        v = a.src[g][((size_t)n * a.K + kc) * 9 + tap];
-      } else if (a.mode == 1) {
-        const float* w = n < a.nsplit ? a.src[0] : a.src[1];
-        int nn = n < a.nsplit ? n : n - a.nsplit;
-        v = w[((size_t)nn * a.K + kc) * 9 + tap];
-      } else {
-        v = a.src[g][((size_t)kc * N + n) * 9 + (8 - tap)];
-      }
+  const unsigned rows = (unsigned)a.G * NC * 9 * N;
+  for (unsigned r0 = (unsigned)i0; r0 < rows; r0 += (unsigned)stride) {
+    unsigned r = r0;
+    const int n = r % (unsigned)N; r /= (unsigned)N;
+    const int tap = r % 9u; r /= 9u;
+    const int chunk = r % (unsigned)NC;
+    const int g = r / (unsigned)NC;
+    const int row = tap * N + n;
+    const float* w;
+    size_t base, kstride;      // value of contraction channel kc: w[base + kc * kstride]
+    if (a.mode == 0) { w = a.src[g]; base = (size_t)n * a.K * 9 + tap; kstride = 9; }
+    else if (a.mode == 1) { w = n < a.nsplit ? a.src[0] : a.src[1]; base = (size_t)(n < a.nsplit ? n : n - a.nsplit) * a.K * 9 + tap; kstride = 9; }
+    else { w = a.src[g]; base = (size_t)n * 9 + (8 - tap); kstride = (size_t)N * 9; }
+    float v[16];
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) {
+      const int kc = chunk * 16 + tl_pos<T>(row, pos);
+      v[pos] = kc < a.K ? w[base + (size_t)kc * kstride] : 0.f;
     }
-    dst[i] = Cvt<T>::to(v);
+    T* o = dst + (size_t)r0 * 16;
+    if constexpr (sizeof(T) == 2) {
+      u32x4 lo, hi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lo[j] = (unsigned)Cvt<T>::to(v[2 * j]) | ((unsigned)Cvt<T>::to(v[2 * j + 1]) << 16);
+        hi[j] = (unsigned)Cvt<T>::to(v[8 + 2 * j]) | ((unsigned)Cvt<T>::to(v[8 + 2 * j + 1]) << 16);
+      }
+      reinterpret_cast<u32x4*>(o)[0] = lo; reinterpret_cast<u32x4*>(o)[1] = hi;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const f32x4 q = {v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]}; reinterpret_cast<f32x4*>(o)[j] = q; }
+    }
   }
 }
 
@@ -230,7 +242,7 @@ int launch_forward_prep(PrepArgs a, hipStream_t st) {
   // 1024 blocks for a Hang2020 step whose largest job is 0.3 M elements: 9.4 us; x 256: 7.3; x 128: 8.7; x 64: 12.8) -- so
   // about four elements per thread of the largest job, between 256 and 1024 blocks; the input-pack rows need one block per patch
   size_t most = a.zero ? a.zero_n4 : 0;
-  for (int j = 0; j < a.packs.n; ++j) { const PackWArgs& w = a.packs.job[j]; const size_t e = (size_t)w.G * w.NC * 9 * w.N * 16; if (e > most) most = e; }
+  for (int j = 0; j < a.packs.n; ++j) { const PackWArgs& w = a.packs.job[j]; const size_t e = (size_t)w.G * w.NC * 9 * w.N * 4; if (e > most) most = e; }      // (row items: 16 elements each, weighed as 4)
   for (int j = 0; j < a.spacks.n; ++j) { const size_t e = (size_t)a.spacks.C[j] * a.spacks.C[j]; if (e > most) most = e; }
   for (int j = 0; j < a.trans.n; ++j) { const size_t e = (size_t)a.trans.cols[j] * a.trans.ld[j]; if (e > most) most = e; }
   int gx = (int)((most + 1023) / 1024);
