@@ -9,7 +9,9 @@ Lightning itself is out of scope; what a user of the hot path need
                               torch.optim.Optimizer, so torch's scheduler cannot attach to it);
   * `SyntheticTreeDataset`  - the batch structure of the reference's TreeDataset (src/data.py:284-310:
                               `(individual, {"HSI": ...}, label)`), synthetic, resident on the device;
-  * `fit`                   - epochs of `training_step` / `validation_step` + the scheduler, as Trainer.fit runs them.
+  * `fit`                   - epochs of `training_step` / `validation_step` + the scheduler, as Trainer.fit runs them;
+  * `fit_multistage`        - the same for the reference's MultiStage module (train.py:75-100): every level of a batch in one
+                              launch chain, per-level validation loaders and plateau schedulers.
 No arithmetic happens here; every step is the HIP path behind `engine.FusedTrainer` and friends.
 """
 import torch
@@ -139,6 +141,56 @@ def fit(trainer, train_data, val_data=None, epochs=1, batch_size=64, scheduler=N
             if scheduler is not None:
                 scheduler.step(rec["val_loss"])
         rec["lr"] = float(trainer.lr)
+        history.append(rec)
+        if log:
+            log(rec)
+    return history
+
+
+def fit_multistage(trainer, train_data, val_data=None, epochs=1, batch_size=128, schedulers=None, shuffle=True, log=None):
+    """The epoch loop `train.py:75-100` runs for the reference's MultiStage module: `train_dataloader()` returns one loader
+    per level (multi_stage.py:212-229), Lightning zips them into a list-of-batches and calls `training_step` once per
+    optimizer -- here ALL levels of a batch are one launch chain (`MultiStageTrainer.training_step_all`; a level whose
+    loader ran out is cycled, as Lightning's "max_size_cycle" mode does) --, then `validation_step(batch, i, level)` over every
+    level's own validation loader (multi_stage.py:231-246, :290-304), `val_loss/dataloader_idx_{level}` = mean of its batch
+    losses, and one plateau scheduler per level monitoring it (multi_stage.py:258-275).
+    trainer: engine.MultiStageTrainer; train_data / val_data: one SyntheticTreeDataset(years=...) (or anything with
+    `.loader(batch_size, shuffle, seed)`) per level; schedulers: one PlateauScheduler per level (on `trainer.levels[l]`) or
+    None.  Returns a list of {"epoch", "train_loss": [...], "val_loss": [...], "lr": [...]} records."""
+    import itertools
+    nl = len(trainer.levels)
+    if len(train_data) != nl or (val_data is not None and len(val_data) != nl):
+        raise ValueError("one dataset per level ({})".format(nl))
+    history = []
+    for epoch in range(int(epochs)):
+        loaders = [list(d.loader(batch_size, shuffle, seed=epoch)) for d in train_data]
+        steps = max(len(b) for b in loaders)
+        sums = [[] for _ in range(nl)]
+        for i in range(steps):
+            batch = [b[i % len(b)] for b in loaders]               # shorter loaders cycle ("max_size_cycle")
+            for l, loss in enumerate(trainer.training_step_all(batch, i)):
+                sums[l].append(loss.reshape(()))
+        rec = {"epoch": epoch, "train_loss": [float(torch.stack(s).mean()) for s in sums], "val_loss": None}
+        if val_data is not None:
+            models = [t.model for t in trainer.levels]
+            was = [bool(m.training) for m in models]
+            for m in models:
+                m.eval()                     # Lightning's validation loop: running BatchNorm statistics, no updates
+            try:
+                vl = []
+                for l, d in enumerate(val_data):
+                    out = [trainer.validation_step(b, i, l)["val_loss"].reshape(()).float() for i, b in enumerate(d.loader(batch_size))]
+                    vl.append(float(torch.stack(out).mean()))
+            finally:
+                for m, w in zip(models, was):
+                    if w:
+                        m.train()
+            rec["val_loss"] = vl
+            if schedulers is not None:
+                for l, sch in enumerate(schedulers):
+                    if sch is not None:
+                        sch.step(vl[l])
+        rec["lr"] = [float(t.lr) for t in trainer.levels]
         history.append(rec)
         if log:
             log(rec)

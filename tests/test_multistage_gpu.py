@@ -190,3 +190,31 @@ def test_fused_ensemble_trainer_more_than_four_years(years):
         if k.endswith("conv_layer.bias"):
             continue
         assert rel_l2(p1.detach().cpu().numpy(), p2.detach().cpu().numpy()) < 2e-3, k
+
+
+def test_fit_multistage_epochs_reduce_every_levels_loss():
+    """loop.fit_multistage: the reference's train.py loop over a MultiStage module (train.py:75-100) -- per-level loaders of
+    different lengths zipped per batch (the shorter one cycles), every level of a batch in one launch chain, per-level
+    validation and plateau schedulers.  On a small separable problem every level's training loss falls."""
+    from deeptreeattention_amd.engine import MultiStageTrainer
+    from deeptreeattention_amd.loop import PlateauScheduler, SyntheticTreeDataset, fit_multistage
+    from deeptreeattention_amd.year import learned_ensemble
+    classes, bands, years = [2, 3], 12, 3
+    torch.manual_seed(7)
+    models = [learned_ensemble(years, c, {"pretrain_state_dict": None, "bands": bands}).to(dev()).train() for c in classes]
+    for m in models:
+        for net in m.year_models:
+            net.precision = "fp32"
+    tr = MultiStageTrainer(models, [2e-3, 2e-3])
+    train = [SyntheticTreeDataset(64, bands, classes[0], years=years, missing=0.2, seed=1, device=dev()),
+             SyntheticTreeDataset(48, bands, classes[1], years=years, seed=2, device=dev())]      # 4 and 3 batches of 16
+    val = [SyntheticTreeDataset(16, bands, c, years=years, seed=3 + i, device=dev()) for i, c in enumerate(classes)]
+    sch = [PlateauScheduler(t, patience=0) for t in tr.levels]
+    hist = fit_multistage(tr, train, val, epochs=6, batch_size=16, schedulers=sch, shuffle=False)
+    assert tr.batched_last and len(hist) == 6
+    for l in range(2):
+        assert hist[-1]["train_loss"][l] < hist[0]["train_loss"][l], (l, hist[0], hist[-1])
+        assert np.isfinite(hist[-1]["val_loss"][l])
+    assert all(h["lr"][0] <= 2e-3 for h in hist)
+    for m in models:
+        assert m.training
