@@ -346,7 +346,29 @@ def side_multistage(a, dev, steps=20, years=3, classes=(2, 2, 12, 7, 5), lrs=(1e
                           "crops_per_s": round(len(classes) * B / ms_batched * 1e3, 1),
                           "final_losses": [round(float(v), 5) for v in losses]}
         del batch
-    del tr
+    # MultiStage.predict_step (multi_stage.py:306-318; config.yml:80 predict_batch_size 64): every level's ensemble on the SAME crops
+    from deeptreeattention_amd.engine import MultiStagePredictor, Predictor
+    for t in tr.levels:
+        t.model.eval()
+    per = [Predictor(t.model) for t in tr.levels]
+    one = MultiStagePredictor([t.model for t in tr.levels])
+    x = [torch.rand(64, BANDS, HW, HW, device=dev, generator=g) for _ in range(years)]
+
+    def timed_p(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5 * steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (5 * steps) * 1e3
+    ms_per, ms_one = timed_p(lambda: [p(x) for p in per]), timed_p(lambda: one(x))
+    out["predict_B64"] = {"batch": 64, "one_chain_ms": round(ms_one, 4), "per_level_ms": round(ms_per, 4), "speedup": round(ms_per / ms_one, 2),
+                          "crops_per_s": round(64 / ms_one * 1e3, 1),
+                          "note": "eval forward of all levels x years networks on the same crops + per-level softmax / top-2: one launch chain "
+                                  "(MultiStagePredictor) vs a Predictor per level"}
+    del tr, per, one
     torch.cuda.empty_cache()
     return out
 

@@ -1213,6 +1213,31 @@ int dta_multistage_forward_loss(const dta_net_desc* d, int levels, const dta_lev
   return launch_blend_ce_multi(m, st);
 }
 
+int dta_multistage_forward(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
+                           const float* const* x, const float* gate, void* workspace, void* stream) {
+  Plan p; dta_net_desc dd;
+  if (!nets || !x || !workspace) { dta_set_error("dta_multistage_forward: null argument"); return 1; }
+  if (multistage_desc(d, levels, lv, &dd, &p, "dta_multistage_forward")) return 1;
+  for (int g = 0; g < p.G; ++g)
+    if (!x[g]) { dta_set_error("dta_multistage_forward: null input for network %d", g); return 1; }
+  for (int l = 0; l < levels; ++l)
+    if (!lv[l].mean_scores) { dta_set_error("dta_multistage_forward: level %d has no score output", l); return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (dd.dtype == DTA_BF16) rc = forward_t<bf16_t>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st, nullptr, gate);
+  else if (dd.dtype == DTA_F32) rc = forward_t<float>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st, nullptr, gate);
+  else { dta_set_error("unknown dtype %d", dd.dtype); return 1; }
+  if (rc) return rc;
+  for (int l = 0; l < levels; ++l) {      // each level's mean over its kept years (reference year.py:33)
+    MeanArgs ma = {};
+    for (int k = 0; k < lv[l].count; ++k) ma.src[k] = at<float>(workspace, p.scores[lv[l].first + k][2]);
+    ma.n = lv[l].count; ma.dst = lv[l].mean_scores; ma.count = (size_t)p.B * lv[l].classes;
+    ma.gate = gate ? gate + lv[l].first : nullptr; ma.kept = lv[l].kept;
+    if (launch_mean_scores(ma, st)) return 1;
+  }
+  return 0;
+}
+
 int dta_multistage_backward(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
                             void* workspace, const dta_subnet_grads* grads, const float* gate, void* stream) {
   Plan p; dta_net_desc dd;

@@ -1325,12 +1325,18 @@ class MultiStageTrainer:
         return {"individual": individual, "yhat": torch.softmax(scores, dim=1), "label": y, "val_loss": loss}
 
     def predict_step(self, batch, batch_idx=0, present=None):
-        """multi_stage.py:306-318: every level's softmax scores for the same crops (eval-mode forward through a cached
-        Predictor per level; the year ensembles' zero years are skipped as in training)."""
+        """multi_stage.py:306-318: every level's softmax scores for the same crops: ONE eval-mode launch chain over the
+        levels x years networks (MultiStagePredictor; a cached Predictor per level when they cannot share a chain); the year
+        ensembles' zero years are skipped as in training."""
         individual, inputs = batch
         if not hasattr(self, "_predictors"):
             self._predictors = [Predictor(t.model) for t in self.levels]
-        return individual, [pr(inputs["HSI"], True, present)[0].clone() for pr in self._predictors]
+            self._ms_predictor = MultiStagePredictor([t.model for t in self.levels])
+        images = inputs["HSI"]
+        if self._ms_predictor.supported(len(images)):
+            # every level sees the same crops: all levels x years networks in ONE eval-mode launch chain
+            return individual, [o[0].clone() for o in self._ms_predictor(images, True, present)]
+        return individual, [pr(images, True, present)[0].clone() for pr in self._predictors]
 
 
 class MetadataTrainer:
@@ -1763,6 +1769,93 @@ class Predictor:
                                       _lib.ptr(self.top_idx), _lib.ptr(self.top_score), _lib.current_stream_ptr()),
                    "dta_softmax_top2")
         return (self.probs if return_probs else None), self.top_idx, self.top_score
+
+
+class MultiStagePredictor:
+    """`MultiStage.predict_step` (reference src/models/multi_stage.py:306-318: `for model in self.models: softmax(model(images))`
+    on the SAME crops) as ONE launch chain: the levels x years networks are the groups of one eval-mode forward
+    (dta_multistage_forward; every level's year-y network reads the same input tensor), each level's mean over its kept years,
+    then softmax + top-2 per level (dta_softmax_top2).  Tile prediction is the reference's largest wall-clock consumer
+    (SLURM/predict.sh), at `predict_batch_size: 64` -- where one chain per level is pure launch-latency floor.
+    models: the levels' learned_ensembles (same year count, bands and precision).  Missing years are decided on the device
+    unless `present` (one list of booleans, shared by the levels: they see the same crops) is passed."""
+
+    def __init__(self, models):
+        self.preds = [Predictor(m) for m in models]
+        if not all(p.ensemble for p in self.preds):
+            raise TypeError("MultiStagePredictor needs year.learned_ensemble levels")
+        self.device = self.preds[0].device
+        self._key = None
+
+    def supported(self, n_years):
+        return (len(self.preds) <= _lib.MAX_LEVELS and len(self.preds) * n_years <= _lib.MAX_YEARS
+                and all(len(p.nets_mod) == n_years for p in self.preds))
+
+    def _prepare(self, shape, kept):
+        L = _lib.lib()
+        mods = [p.nets_mod for p in self.preds]
+        m0 = mods[0][0]
+        key = (tuple(shape), m0.precision, tuple(kept)) + tuple(p._fingerprint() for p in self.preds)
+        if key == self._key:
+            return
+        if any(m.precision != m0.precision for ms in mods for m in ms):
+            raise ValueError("all levels must run in the same precision")
+        B, bands, Hh, Ww = shape
+        self.desc = _lib.NetDesc(B, bands, Hh, Ww, m0._classes, _lib.NET_SPECTRAL, _lib.dtype_code(m0.precision), 0,
+                                 4 | _lib.FORWARD_ONLY, H.BN_MOMENTUM, H.BN_EPS)
+        nets, lv = [], []
+        self.logits, self.probs, self.top_idx, self.top_score = [], [], [], []
+        for p, ms in zip(self.preds, mods):
+            classes = ms[0]._classes
+            tables = p._tables([ms[i] for i in kept])
+            first = len(nets)
+            nets += [t[0] for t in tables]
+            self.logits.append(torch.empty(B, classes, dtype=torch.float32, device=self.device))
+            self.probs.append(torch.empty(B, classes, dtype=torch.float32, device=self.device))
+            self.top_idx.append(torch.empty(B, 2, dtype=torch.int64, device=self.device))
+            self.top_score.append(torch.empty(B, 2, dtype=torch.float32, device=self.device))
+            lv.append(_lib.Level(classes, first, len(kept), None, None, self.logits[-1].data_ptr(), None, None, None, None))
+        self.nets = (_lib.SubnetParams * len(nets))(*nets)
+        self.lv = (_lib.Level * len(lv))(*lv)
+        nbytes = L.dta_multistage_workspace_bytes(C.byref(self.desc), len(lv), self.lv)
+        if nbytes == 0:
+            raise RuntimeError("dta_multistage_workspace_bytes: " + L.dta_last_error().decode())
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._flags = torch.zeros(len(self.preds[0].nets_mod), dtype=torch.float32, device=self.device)
+        self._key = key
+
+    def __call__(self, images, return_probs=True, present=None):
+        """Returns one (probs or None, top_idx [B,2], top_score [B,2]) triple per level; buffers are reused across calls."""
+        L = _lib.lib()
+        st = _lib.current_stream_ptr()
+        nl = len(self.preds)
+        Y = len(images)
+        if present is None:
+            kept = list(range(Y))
+        else:
+            kept = [i for i, k in enumerate(present) if k]
+            if not kept:
+                raise RuntimeError("every year of the batch is all-zero: nothing to average (reference year.py:33)")
+        xs = [H._check_input(images[i]) for i in kept]
+        if any(x.shape != xs[0].shape for x in xs):
+            raise ValueError("all years of a batch must have the same shape")
+        self._prepare(xs[0].shape, kept)
+        xptr = (C.c_void_p * (nl * len(kept)))(*([x.data_ptr() for x in xs] * nl))      # every level reads the same crops
+        gate = None
+        if present is None:
+            yptr = (C.c_void_p * Y)(*[x.data_ptr() for x in xs])
+            _lib.check(L.dta_year_flags(yptr, Y, xs[0].numel(), _lib.ptr(self._flags), None, st), "dta_year_flags")
+            gate = self._flags.repeat(nl)           # the (level, year) groups' flags: the years' flags once per level
+        _lib.check(L.dta_multistage_forward(C.byref(self.desc), nl, self.lv, self.nets, xptr, _lib.ptr(gate), _lib.ptr(self.ws), st),
+                   "dta_multistage_forward")
+        out = []
+        for l in range(nl):
+            Bn, classes = self.logits[l].shape
+            _lib.check(L.dta_softmax_top2(_lib.ptr(self.logits[l]), Bn, classes, _lib.ptr(self.probs[l]) if return_probs else None,
+                                          _lib.ptr(self.top_idx[l]), _lib.ptr(self.top_score[l]), st), "dta_softmax_top2")
+            out.append((self.probs[l] if return_probs else None, self.top_idx[l], self.top_score[l]))
+        self._live = (xs, gate)
+        return out
 
 
 _PREDICTORS = None      # model -> Predictor, weakly keyed: nothing is stored on the module (deepcopy / torch.save stay clean)

@@ -338,6 +338,11 @@ typedef struct dta_level {
 size_t dta_multistage_workspace_bytes(const dta_net_desc* d, int levels, const dta_level* lv);
 int dta_multistage_forward_loss(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
                                 const float* const* x, const float* gate, void* workspace, void* stream);
+/* The forward alone (reference MultiStage.predict_step, multi_stage.py:306-318: every level's model on the SAME crops -- the
+ * x entries of the levels may point at the same tensors; and validation): lv[l].mean_scores receives each level's mean over its
+ * kept years, lv[l].kept (may be NULL) {kept, 1 / kept}; labels / loss / dscore / scratch are not read. */
+int dta_multistage_forward(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
+                           const float* const* x, const float* gate, void* workspace, void* stream);
 int dta_multistage_backward(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
                             void* workspace, const dta_subnet_grads* grads, const float* gate, void* stream);
 

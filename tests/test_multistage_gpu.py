@@ -218,3 +218,34 @@ def test_fit_multistage_epochs_reduce_every_levels_loss():
     assert all(h["lr"][0] <= 2e-3 for h in hist)
     for m in models:
         assert m.training
+
+
+@pytest.mark.parametrize("use_present", [False, True])
+def test_multistage_predict_step_one_chain_equals_per_level_predictors(use_present):
+    """MultiStage.predict_step (multi_stage.py:306-318: every level's model on the SAME crops): the one-chain eval forward
+    over levels x years (MultiStagePredictor) against a Predictor per level and against the modules' own eval forward; one
+    year of the batch is all-zero."""
+    from deeptreeattention_amd.engine import MultiStagePredictor, MultiStageTrainer, Predictor
+    models, ws = _levels()
+    driver = MultiStageTrainer(models, list(MULTISTAGE["lrs"]), ws)
+    batch, present = _batch(1)                      # step 1: level 1's inputs have year 2 zeroed
+    for step in range(2):                           # move the BatchNorm running statistics off their initial values
+        b, pr = _batch(step)
+        driver.training_step_all(b, step, pr)
+    individual, inputs, _ = batch[1]
+    pres = present[1] if use_present else None
+    ids, yhats = driver.predict_step((individual, inputs), 0, pres)
+    assert ids == individual and len(yhats) == 2 and driver._ms_predictor._key is not None
+    for l, m in enumerate(models):
+        want = Predictor(m)(inputs["HSI"], True, pres)[0]
+        assert torch.equal(yhats[l], want), l       # same kernels, same order of the mean: identical bits
+        m.eval()
+        with torch.no_grad():
+            ref = torch.softmax(m(inputs["HSI"]), dim=1)
+        m.train()
+        assert rel_l2(yhats[l].cpu().numpy(), ref.cpu().numpy()) < 1e-5, l
+        assert abs(float(yhats[l].sum()) - MULTISTAGE["B"]) < 1e-4
+    top = MultiStagePredictor(models)(inputs["HSI"], True, pres)
+    for l in range(2):
+        tv, ti = torch.topk(yhats[l], 2, dim=1)
+        assert torch.equal(top[l][1].cpu(), ti.cpu())
