@@ -160,3 +160,31 @@ def test_graft_entry_build_runs_on_cpu():
     ABI version and exported symbols.  (Round 6 bumped DTA_ABI_VERSION and the entry still asserted the old one.)"""
     import __graft_entry__ as entry
     entry.build()
+
+
+def test_multistage_plan_and_argument_checks_on_cpu():
+    """dta_multistage_workspace_bytes needs no GPU (host-side plan): a valid 5-level x 3-year description gets a workspace,
+    and the argument errors a binding can make are reported through dta_last_error -- levels not adjacent, more networks
+    than one launch takes, a level without classes, too many levels."""
+    from deeptreeattention_amd import _lib
+    L = _lib.lib()
+    desc = _lib.NetDesc(128, 369, 11, 11, 2, _lib.NET_SPECTRAL, _lib.DTA_BF16, 1, 4, 0.1, 1e-5)
+
+    def levels(spec):
+        return (_lib.Level * len(spec))(*[_lib.Level(c, f, n, None, None, None, None, None, None, None) for c, f, n in spec])
+    ok = levels([(2, 0, 3), (2, 3, 3), (12, 6, 3), (7, 9, 3), (5, 12, 3)])
+    n5 = L.dta_multistage_workspace_bytes(C.byref(desc), 5, ok)
+    assert n5 > 0
+    one = L.dta_multistage_workspace_bytes(C.byref(desc), 1, levels([(2, 0, 3)]))
+    assert 0 < one < n5
+    # the same networks as ONE 15-year ensemble of the widest class count need at least as much (score buffers per group)
+    desc12 = _lib.NetDesc(128, 369, 11, 11, 12, _lib.NET_SPECTRAL, _lib.DTA_BF16, 1, 4, 0.1, 1e-5)
+    assert L.dta_ensemble_workspace_bytes(C.byref(desc12), 15) >= n5
+    for bad, what in (([(2, 0, 3), (2, 4, 3)], "adjacent"), ([(2, 0, 9), (2, 9, 9)], "at most"), ([(0, 0, 3)], "classes"),
+                      ([(2, 3 * i, 3) for i in range(9)], "levels")):
+        arr = levels(bad)
+        assert L.dta_multistage_workspace_bytes(C.byref(desc), len(bad), arr) == 0
+        assert what in L.dta_last_error().decode(), (what, L.dta_last_error().decode())
+    hang = _lib.NetDesc(128, 369, 11, 11, 2, _lib.NET_HANG2020, _lib.DTA_BF16, 1, 4, 0.1, 1e-5)
+    assert L.dta_multistage_workspace_bytes(C.byref(hang), 1, levels([(2, 0, 3)])) == 0
+    assert "DTA_NET_SPECTRAL" in L.dta_last_error().decode()
