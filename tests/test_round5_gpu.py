@@ -228,3 +228,56 @@ def test_eval_mode_forward_with_grad_does_not_mark_years_for_the_next_step():
     for k, p in a.named_parameters():
         if k.startswith("year_models.2."):
             assert torch.equal(p, before[k]), k
+
+
+# ---- DtaAdam under data parallelism passes over an 'other' parameter NO rank produced a gradient for --------
+def _others_worker(rank, world, port, out):
+    import datetime
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from deeptreeattention_amd import Hang2020 as H
+    from deeptreeattention_amd.optim import DtaAdam, cross_entropy
+    d = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    torch.manual_seed(5)
+    m = H.spectral_network(12, 5).to(d).train()
+    # a parameter DtaAdam cannot keep in its float32 flat buffers (float64, more than one element): stepped by `_step_others`
+    extra = torch.nn.Parameter(torch.full((7,), 0.5, device=d, dtype=torch.float64))
+    opt = DtaAdam(list(m.parameters()) + [extra], lr=1e-2, exchange="torch")
+    g = torch.Generator(device=d); g.manual_seed(40 + rank)
+    hist = []
+    # step 0: every rank uses `extra`; step 1: nobody does (grad None everywhere -> passed over, as torch.optim.Adam / DDP do);
+    # step 2: only rank 1 does (rank 0 sends zeros: the mean gradient is half of rank 1's)
+    for step, use in enumerate([True, False, rank == 1]):
+        x = torch.rand(4, 12, 11, 11, device=d, generator=g)
+        y = torch.randint(0, 5, (4,), device=d, generator=g)
+        opt.zero_grad(set_to_none=True)
+        loss = cross_entropy(m(x)[-1], y)
+        if use:
+            loss = loss + (extra * extra).sum().float()
+        loss.backward()
+        opt.step()
+        hist.append(extra.detach().cpu().numpy().copy())
+    out[rank] = (hist, int(opt.state[extra]["step"]) if extra in opt.state else 0)
+    opt.close()
+    dist.destroy_process_group()
+
+
+def test_dta_adam_dp_passes_over_an_other_parameter_without_any_gradient():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_others_worker, args=(2, port, out), nprocs=2, join=True)
+    (h0, n0), (h1, n1) = out[0], out[1]
+    for a, b in zip(h0, h1):
+        assert np.array_equal(a, b)                 # replicas stay identical
+    assert np.all(h0[0] < 0.5)                      # step 0: stepped
+    assert np.array_equal(h0[1], h0[0])             # step 1: NO rank had a gradient -> untouched (no momentum move, no decay)
+    assert np.all(h0[2] < h0[1])                    # step 2: one rank's gradient is enough
+    assert n0 == n1 == 2                            # two steps counted, not three
