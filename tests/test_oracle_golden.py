@@ -447,3 +447,16 @@ def test_oracle_bf16_mode_against_the_references_own_bf16_run(bf16_yardstick, ta
     assert rel_l2(q_logits, e_logits) <= bf16_yardstick.bound(tag + "scores_dev")
     assert abs(q_loss - e_loss) / e_loss <= bf16_yardstick.bound(tag + "loss_dev")
     bf16_yardstick.check_gradients(tag, q_g, e_g, verbose=False, norms=B >= 64)
+
+
+def test_golden_fixtures_are_the_committed_ones():
+    """tests/golden/SHA256SUMS pins every fixture file (written when make_golden.py produced them from /root/reference in the
+    build container): a fixture edited by hand, or regenerated by a script other than the committed one, fails here."""
+    import hashlib
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    want = dict(line.split()[::-1] for line in open(os.path.join(here, "SHA256SUMS")).read().splitlines() if line.strip())
+    have = sorted(f for f in os.listdir(here) if f.endswith(".npz"))
+    assert have == sorted(want), (have, sorted(want))
+    for f in have:
+        assert hashlib.sha256(open(os.path.join(here, f), "rb").read()).hexdigest() == want[f], f
