@@ -177,6 +177,10 @@ def lib():
         L.dta_multistage_forward.restype = C.c_int
         L.dta_multistage_forward.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(Level), C.POINTER(SubnetParams),
                                              C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dta_multistage_predict.restype = C.c_int
+        L.dta_multistage_predict.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(Level), C.POINTER(SubnetParams),
+                                             C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]
         L.dta_multistage_backward.restype = C.c_int
         L.dta_multistage_backward.argtypes = [C.POINTER(NetDesc), C.c_int, C.POINTER(Level), C.POINTER(SubnetParams), C.c_void_p,
                                               C.POINTER(SubnetGrads), C.c_void_p, C.c_void_p]

@@ -1238,6 +1238,32 @@ int dta_multistage_forward(const dta_net_desc* d, int levels, const dta_level* l
   return 0;
 }
 
+int dta_multistage_predict(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
+                           const float* const* x, const float* gate, void* workspace, float* const* probs,
+                           long long* const* top_idx, float* const* top_score, void* stream) {
+  Plan p; dta_net_desc dd;
+  if (!nets || !x || !workspace || !top_idx || !top_score) { dta_set_error("dta_multistage_predict: null argument"); return 1; }
+  if (multistage_desc(d, levels, lv, &dd, &p, "dta_multistage_predict")) return 1;
+  for (int g = 0; g < p.G; ++g)
+    if (!x[g]) { dta_set_error("dta_multistage_predict: null input for network %d", g); return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (dd.dtype == DTA_BF16) rc = forward_t<bf16_t>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st, nullptr, gate);
+  else if (dd.dtype == DTA_F32) rc = forward_t<float>(p, &dd, nets, nullptr, x, workspace, nullptr, nullptr, st, nullptr, gate);
+  else { dta_set_error("unknown dtype %d", dd.dtype); return 1; }
+  if (rc) return rc;
+  SoftmaxMulti m;
+  memset(&m, 0, sizeof(m));
+  m.n = levels; m.B = p.B;
+  for (int l = 0; l < levels; ++l) {
+    SoftmaxLevel& a = m.lv[l];
+    for (int k = 0; k < lv[l].count; ++k) a.src[k] = at<float>(workspace, p.scores[lv[l].first + k][2]);
+    a.nsrc = lv[l].count; a.gate = gate ? gate + lv[l].first : nullptr; a.mean_out = lv[l].mean_scores; a.classes = lv[l].classes;
+    a.probs = probs ? probs[l] : nullptr; a.top_idx = top_idx[l]; a.top_score = top_score[l];
+  }
+  return launch_softmax_top2_multi(m, st);
+}
+
 int dta_multistage_backward(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
                             void* workspace, const dta_subnet_grads* grads, const float* gate, void* stream) {
   Plan p; dta_net_desc dd;

@@ -745,6 +745,83 @@ __global__ __launch_bounds__(256) void k_softmax_top2(const float* logits, int B
     top_score[row * 2] = b1; top_score[row * 2 + 1] = b2;
   }
 }
+__global__ __launch_bounds__(256) void k_softmax_top2_multi(SoftmaxMulti m) {
+  const SoftmaxLevel& a = m.lv[blockIdx.y];
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m.B) return;
+  const int classes = a.classes;
+  float kept = 0.f;
+  unsigned use = 0u;
+#pragma unroll
+  for (int k = 0; k < MAXG; ++k)
+    if (k < a.nsrc && (!a.gate || a.gate[k] > 0.f)) { use |= 1u << k; kept += 1.f; }
+  const float kinv = 1.f / kept;                      // nothing kept: inf, 0 * inf = NaN -- an empty mean, as k_mean_scores
+  auto zat = [&](int n) __attribute__((always_inline)) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXG; ++k)
+      if ((use >> k) & 1u) acc += a.src[k][(size_t)row * classes + n];
+    return acc * kinv;
+  };
+  // the first 256 classes of the row live in registers (four per lane); wider rows re-form the rest
+  float zc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int n = lane + 64 * k; zc[k] = n < classes ? zat(n) : -3.4e38f; }
+  // visit this lane's classes in ascending order: the register-held ones statically indexed, then the re-formed tail
+  auto each = [&](auto&& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int n = lane + 64 * k; if (n < classes) f(n, zc[k]); }
+    for (int n = lane + 256; n < classes; n += 64) f(n, zat(n));
+  };
+  float mx = -3.4e38f;
+  each([&](int, float z) __attribute__((always_inline)) { mx = fmaxf(mx, z); });
+  mx = wave_max(mx);
+  float se = 0.f;
+  each([&](int, float z) __attribute__((always_inline)) { se += __expf(z - mx); });
+  se = wave_sum(se);
+  const float inv = 1.f / se;
+  float b1 = -1.f, b2 = -1.f;
+  int i1 = -1, i2 = -1;
+#define DTA_ROW_OUT(n_, z_)                                                                      \
+  {                                                                                              \
+    const int nn = (n_);                                                                         \
+    const float zz = (z_);                                                                       \
+    if (a.mean_out) a.mean_out[(size_t)row * classes + nn] = zz;                                 \
+    const float pr = __expf(zz - mx) * inv;                                                      \
+    if (a.probs) a.probs[(size_t)row * classes + nn] = pr;                                       \
+    if (pr > b1) { b2 = b1; i2 = i1; b1 = pr; i1 = nn; }                                         \
+    else if (pr > b2) { b2 = pr; i2 = nn; }                                                      \
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int n = lane + 64 * k; if (n < classes) DTA_ROW_OUT(n, zc[k]) }
+  for (int n = lane + 256; n < classes; n += 64) DTA_ROW_OUT(n, zat(n))
+#undef DTA_ROW_OUT
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob1 = __shfl_xor(b1, o), ob2 = __shfl_xor(b2, o);
+    int oi1 = __shfl_xor(i1, o), oi2 = __shfl_xor(i2, o);
+    auto better = [](float a_, int ia, float b_, int ib) { return a_ > b_ || (a_ == b_ && ia >= 0 && (ib < 0 || ia < ib)); };
+    float n1, n2; int j1, j2;
+    if (better(b1, i1, ob1, oi1)) {
+      n1 = b1; j1 = i1;
+      if (better(b2, i2, ob1, oi1)) { n2 = b2; j2 = i2; } else { n2 = ob1; j2 = oi1; }
+    } else {
+      n1 = ob1; j1 = oi1;
+      if (better(b1, i1, ob2, oi2)) { n2 = b1; j2 = i1; } else { n2 = ob2; j2 = oi2; }
+    }
+    b1 = n1; i1 = j1; b2 = n2; i2 = j2;
+  }
+  if (lane == 0) {
+    if (a.top_idx) { a.top_idx[row * 2] = i1; a.top_idx[row * 2 + 1] = i2; }
+    if (a.top_score) { a.top_score[row * 2] = b1; a.top_score[row * 2 + 1] = b2; }
+  }
+}
+int launch_softmax_top2_multi(const SoftmaxMulti& m, hipStream_t st) {
+  if (m.n < 1 || m.n > BLEND_CE_MULTI_MAX) { dta_set_error("softmax_top2_multi: 1..%d levels", BLEND_CE_MULTI_MAX); return 1; }
+  hipLaunchKernelGGL(k_softmax_top2_multi, dim3((m.B + 3) / 4, m.n), dim3(256), 0, st, m);
+  DTA_CHECK_LAUNCH("k_softmax_top2_multi");
+  return 0;
+}
 int launch_softmax_top2(const float* logits, int B, int classes, float* probs, long long* top_idx, float* top_score,
                         hipStream_t st) {
   hipLaunchKernelGGL(k_softmax_top2, dim3((B + 3) / 4), dim3(256), 0, st, logits, B, classes, probs, top_idx, top_score);

@@ -642,5 +642,12 @@ struct AdamMulti { AdamArgs seg[ADAM_MAX_SEG]; int n; };
 int launch_adam_multi(const AdamMulti& m, hipStream_t st);      // blockIdx.y = segment
 int launch_softmax_top2(const float* logits, int B, int classes, float* probs, long long* top_idx, float* top_score,
                         hipStream_t st);
+// the same for up to 8 levels in ONE launch (blockIdx.y = level), each row's scores formed on the fly as the mean over the
+// level's kept sources exactly as k_mean_scores forms it (sum in source order, selected by gate > 0, times 1 / kept):
+// MultiStage.predict_step's per-level `softmax(mean over years)` (reference multi_stage.py:306-318, year.py:33)
+struct SoftmaxLevel { const float* src[MAXG]; int nsrc; const float* gate; float* mean_out; int classes;
+                      float* probs; long long* top_idx; float* top_score; };
+struct SoftmaxMulti { SoftmaxLevel lv[BLEND_CE_MULTI_MAX]; int n, B; };
+int launch_softmax_top2_multi(const SoftmaxMulti& m, hipStream_t st);
 
 }  // namespace dta

@@ -1817,6 +1817,9 @@ class MultiStagePredictor:
             lv.append(_lib.Level(classes, first, len(kept), None, None, self.logits[-1].data_ptr(), None, None, None, None))
         self.nets = (_lib.SubnetParams * len(nets))(*nets)
         self.lv = (_lib.Level * len(lv))(*lv)
+        self._pp = (C.c_void_p * len(lv))(*[t.data_ptr() for t in self.probs])
+        self._pi = (C.c_void_p * len(lv))(*[t.data_ptr() for t in self.top_idx])
+        self._ps = (C.c_void_p * len(lv))(*[t.data_ptr() for t in self.top_score])
         nbytes = L.dta_multistage_workspace_bytes(C.byref(self.desc), len(lv), self.lv)
         if nbytes == 0:
             raise RuntimeError("dta_multistage_workspace_bytes: " + L.dta_last_error().decode())
@@ -1846,16 +1849,11 @@ class MultiStagePredictor:
             yptr = (C.c_void_p * Y)(*[x.data_ptr() for x in xs])
             _lib.check(L.dta_year_flags(yptr, Y, xs[0].numel(), _lib.ptr(self._flags), None, st), "dta_year_flags")
             gate = self._flags.repeat(nl)           # the (level, year) groups' flags: the years' flags once per level
-        _lib.check(L.dta_multistage_forward(C.byref(self.desc), nl, self.lv, self.nets, xptr, _lib.ptr(gate), _lib.ptr(self.ws), st),
-                   "dta_multistage_forward")
-        out = []
-        for l in range(nl):
-            Bn, classes = self.logits[l].shape
-            _lib.check(L.dta_softmax_top2(_lib.ptr(self.logits[l]), Bn, classes, _lib.ptr(self.probs[l]) if return_probs else None,
-                                          _lib.ptr(self.top_idx[l]), _lib.ptr(self.top_score[l]), st), "dta_softmax_top2")
-            out.append((self.probs[l] if return_probs else None, self.top_idx[l], self.top_score[l]))
+        # forward of all levels x years + ONE launch for every level's mean over its years, softmax and top-2
+        _lib.check(L.dta_multistage_predict(C.byref(self.desc), nl, self.lv, self.nets, xptr, _lib.ptr(gate), _lib.ptr(self.ws),
+                                            self._pp if return_probs else None, self._pi, self._ps, st), "dta_multistage_predict")
         self._live = (xs, gate)
-        return out
+        return [(self.probs[l] if return_probs else None, self.top_idx[l], self.top_score[l]) for l in range(nl)]
 
 
 _PREDICTORS = None      # model -> Predictor, weakly keyed: nothing is stored on the module (deepcopy / torch.save stay clean)

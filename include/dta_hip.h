@@ -343,6 +343,13 @@ int dta_multistage_forward_loss(const dta_net_desc* d, int levels, const dta_lev
  * kept years, lv[l].kept (may be NULL) {kept, 1 / kept}; labels / loss / dscore / scratch are not read. */
 int dta_multistage_forward(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
                            const float* const* x, const float* gate, void* workspace, void* stream);
+/* ... and with the inference epilogue of every level in the SAME call: each level's mean over its kept years, softmax over
+ * its classes and the top-2 labels / scores (reference multi_stage.py:306-318 + main.py:190-205) in ONE launch behind the
+ * forward.  probs (may be NULL, entries may be NULL) / top_idx / top_score: HOST arrays of `levels` device pointers
+ * ([batch][classes] float32, [batch][2] int64, [batch][2] float32); lv[l].mean_scores (may be NULL) receives the scores. */
+int dta_multistage_predict(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
+                           const float* const* x, const float* gate, void* workspace, float* const* probs,
+                           long long* const* top_idx, float* const* top_score, void* stream);
 int dta_multistage_backward(const dta_net_desc* d, int levels, const dta_level* lv, const dta_subnet_params* nets,
                             void* workspace, const dta_subnet_grads* grads, const float* gate, void* stream);
 

@@ -249,3 +249,22 @@ def test_multistage_predict_step_one_chain_equals_per_level_predictors(use_prese
     for l in range(2):
         tv, ti = torch.topk(yhats[l], 2, dim=1)
         assert torch.equal(top[l][1].cpu(), ti.cpu())
+
+
+def test_multistage_predict_wide_levels_take_the_re_formed_tail():
+    """dta_multistage_predict's one-launch epilogue keeps 256 classes of a row in registers and re-forms the rest: a level
+    wider than that (300 classes) beside a 2-class level, scores/top-2 identical to the per-level Predictor."""
+    from deeptreeattention_amd.engine import MultiStagePredictor, Predictor
+    from deeptreeattention_amd.year import learned_ensemble
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    cfg = {"pretrain_state_dict": None, "bands": 12}
+    models = [learned_ensemble(2, c, cfg).to(dev).eval() for c in (300, 2)]
+    xs = [torch.rand(9, 12, 11, 11, device=dev) for _ in range(2)]
+    xs[1][:] = 0                                     # one empty year: the gate drops it from every level's mean
+    got = MultiStagePredictor(models)(xs, True, None)
+    for l, m in enumerate(models):
+        probs, ti, ts = Predictor(m)(xs, True, None)
+        assert torch.equal(got[l][0], probs), l
+        assert torch.equal(got[l][1], ti) and torch.equal(got[l][2], ts), l
+        assert int(got[l][1].max()) < (300, 2)[l]
