@@ -188,3 +188,6 @@ def test_multistage_plan_and_argument_checks_on_cpu():
     hang = _lib.NetDesc(128, 369, 11, 11, 2, _lib.NET_HANG2020, _lib.DTA_BF16, 1, 4, 0.1, 1e-5)
     assert L.dta_multistage_workspace_bytes(C.byref(hang), 1, levels([(2, 0, 3)])) == 0
     assert "DTA_NET_SPECTRAL" in L.dta_last_error().decode()
+    # dta_multistage_predict: null pointers and a bad level table are refused before anything is launched
+    assert L.dta_multistage_predict(C.byref(desc), 5, ok, None, None, None, None, None, None, None, None) == 1
+    assert "null argument" in L.dta_last_error().decode()
