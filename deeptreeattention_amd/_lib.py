@@ -16,6 +16,7 @@ DTA_F32, DTA_BF16 = 0, 1
 ABI_VERSION = 2    # DTA_ABI_VERSION
 MAX_YEARS = 16   # DTA_MAX_YEARS
 FORWARD_ONLY = 8   # DTA_FORWARD_ONLY (heads_mask flag)
+REUSE_PACKED = 32  # DTA_REUSE_PACKED (heads_mask flag: frozen-weight inference keeps the re-laid-out weights in the workspace)
 XCHG_HANDLE_BYTES = 128   # DTA_XCHG_HANDLE_BYTES
 SKIP_BLEND = 16    # DTA_SKIP_BLEND (heads_mask flag): the blend is left to dta_net_loss
 NET_HANG2020, NET_SPECTRAL, NET_SPATIAL, NET_VANILLA = 0, 1, 2, 3

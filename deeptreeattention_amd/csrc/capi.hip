@@ -458,6 +458,9 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
         spacks.packed[j] = at<float>(ws, p.attpk[g][L]); spacks.C[j] = C; spacks.K[j] = SPEC_K[L];
       }
   }
+  // frozen-weight inference (DTA_REUSE_PACKED): the re-layouts and row tables of an earlier call are still in the workspace
+  const bool reuse = !d->training && (d->heads_mask & DTA_FORWARD_ONLY) && (d->heads_mask & DTA_REUSE_PACKED);
+  if (reuse) { packs.n = 0; spacks.n = 0; }
   {
     PrepArgs pa = {};
     // bf16, halo-free input tiles: the first conv reads the caller's fp32 tensor itself (and leaves the bf16 tiles
@@ -467,7 +470,7 @@ int forward_t(const Plan& p, const dta_net_desc* d, const dta_subnet_params* net
     pa.x_tl = at<char>(ws, p.x_tl); pa.B = B; pa.C = p.bands; pa.H = p.H; pa.W = p.W;
     pa.x_compact = p.x_compact;
     pa.packs = packs; pa.spacks = spacks;
-    if (sizeof(T) == 2) {      // row tables of the step's conv launches (full workgroups read them instead of building their own)
+    if (sizeof(T) == 2 && !reuse) {      // row tables of the step's conv launches (full workgroups read them instead of building their own)
       const bool fan_fwd0 = d->training && (switches().fanin & 1);
       for (int L = 0; L < 3; ++L) add_conv_tab_job(p, ws, fwd_conv_geom(p, d, L, fan_fwd0), (L == 0 && p.shared_x) ? 1 : G, conv_tab_slot_fwd(L), pa.tabs);
       if (d->training && !(d->heads_mask & DTA_FORWARD_ONLY))
@@ -1049,7 +1052,7 @@ static int ensemble_desc(const dta_net_desc* d, int years, dta_net_desc* out, Pl
   if (!d || years < 1 || years > MAXG) { dta_set_error("%s: 1..%d years", who, MAXG); return 1; }
   if (d->kind != DTA_NET_SPECTRAL) { dta_set_error("%s: the descriptor's kind must be DTA_NET_SPECTRAL", who); return 1; }
   *out = *d;
-  out->heads_mask = 4 | (d->heads_mask & DTA_FORWARD_ONLY);   // the ensemble keeps each year's last head only (reference year.py:30)
+  out->heads_mask = 4 | (d->heads_mask & (DTA_FORWARD_ONLY | DTA_REUSE_PACKED));   // the ensemble keeps each year's last head only (reference year.py:30)
   return build_plan(out, p, years);
 }
 
@@ -1173,7 +1176,7 @@ static int multistage_desc(const dta_net_desc* d, int levels, const dta_level* l
     for (int k = 0; k < lv[l].count; ++k) cls[G++] = lv[l].classes;
   }
   *out = *d;
-  out->heads_mask = 4 | (d->heads_mask & DTA_FORWARD_ONLY);   // each year's last head only (reference year.py:30)
+  out->heads_mask = 4 | (d->heads_mask & (DTA_FORWARD_ONLY | DTA_REUSE_PACKED));   // each year's last head only (reference year.py:30)
   out->classes = cls[0];
   return build_plan(out, p, G, cls);
 }

@@ -1632,10 +1632,15 @@ class Predictor:
     model: a network of this package (Hang2020, vanilla_CNN; spectral/spatial_network -> last head) or a
     year.learned_ensemble (zero years are skipped as in training: one host transfer per call, or pass `present`).
     The pointer tables are rebuilt when the batch shape changes; call refresh() after replacing parameter tensors
-    (in-place updates, e.g. by FusedTrainer or load_state_dict, need nothing)."""
+    (in-place updates, e.g. by FusedTrainer or load_state_dict, need nothing).
+    frozen=True (tile prediction with a trained model, reference predict.py:140-151): the conv / attention weight
+    re-layouts of the first call stay in the workspace and later calls skip them (DTA_REUSE_PACKED) -- then in-place weight
+    updates need refresh() too."""
 
-    def __init__(self, model):
+    def __init__(self, model, frozen=False):
         import weakref
+        self.frozen = bool(frozen)
+        self._packed = False
         from .year import learned_ensemble
         self._model_ref = weakref.ref(model)        # no strong reference: the cache must not keep the model alive
         self.ensemble = isinstance(model, learned_ensemble)
@@ -1660,6 +1665,10 @@ class Predictor:
     def refresh(self):
         self._key = None
         self._tensors = None
+
+    def _desc(self):
+        """The descriptor of this call: with frozen weights every call after the first on a workspace reuses its re-layouts."""
+        return self.desc_reuse if (self.frozen and self._packed) else self.desc
 
     def _fingerprint(self):
         """Storage addresses of every parameter and BatchNorm buffer the pointer tables were built from.  The tables
@@ -1703,6 +1712,9 @@ class Predictor:
         single = m0._net_code in (_lib.NET_HANG2020, _lib.NET_VANILLA)
         self.desc = _lib.NetDesc(B, bands, Hh, Ww, m0._classes, m0._net_code, _lib.dtype_code(m0.precision), 0,
                                  4 | _lib.FORWARD_ONLY, H.BN_MOMENTUM, H.BN_EPS)
+        self.desc_reuse = _lib.NetDesc(B, bands, Hh, Ww, m0._classes, m0._net_code, _lib.dtype_code(m0.precision), 0,
+                                       4 | _lib.FORWARD_ONLY | _lib.REUSE_PACKED, H.BN_MOMENTUM, H.BN_EPS)
+        self._packed = False
         tables = self._tables([nets_mod[i] for i in kept])
         if self.ensemble:
             self.nets = (_lib.SubnetParams * len(kept))(*[t[0] for t in tables])
@@ -1729,13 +1741,19 @@ class Predictor:
             xs = [H._check_input(x) for x in images]
             kept = list(range(len(xs)))
             self._prepare(xs[0].shape, kept)
-            if getattr(self, "_flags", None) is None or self._flags.numel() != len(xs):
-                self._flags = torch.zeros(len(xs), dtype=torch.float32, device=self.device)
+            if getattr(self, "_banks", None) is None or self._banks[0].numel() != len(xs):
+                # two flag banks: a call writes one and zeroes the other for the next call (no clearing launch)
+                self._banks = [torch.zeros(len(xs), dtype=torch.float32, device=self.device) for _ in range(2)]
+                self._bank = 0
+            flags, nxt = self._banks[self._bank], self._banks[self._bank ^ 1]
+            self._bank ^= 1
+            self._flags = flags
             xptr = (C.c_void_p * len(kept))(*[x.data_ptr() for x in xs])
-            _lib.check(L.dta_year_flags(xptr, len(xs), xs[0].numel(), _lib.ptr(self._flags), None, st), "dta_year_flags")
-            _lib.check(L.dta_ensemble_forward_gated(C.byref(self.desc), len(kept), self.nets, xptr, _lib.ptr(self._flags),
+            _lib.check(L.dta_year_flags(xptr, len(xs), xs[0].numel(), _lib.ptr(flags), _lib.ptr(nxt), st), "dta_year_flags")
+            _lib.check(L.dta_ensemble_forward_gated(C.byref(self._desc()), len(kept), self.nets, xptr, _lib.ptr(flags),
                                                     _lib.ptr(self.ws), _lib.ptr(self.logits), None, st),
                        "dta_ensemble_forward_gated")
+            self._packed = True
             return self.logits
         if self.ensemble:
             kept = [i for i, k in enumerate(present) if k]
@@ -1744,8 +1762,9 @@ class Predictor:
             xs = [H._check_input(images[i]) for i in kept]
             self._prepare(xs[0].shape, kept)
             xptr = (C.c_void_p * len(kept))(*[x.data_ptr() for x in xs])
-            _lib.check(L.dta_ensemble_forward(C.byref(self.desc), len(kept), self.nets, xptr, _lib.ptr(self.ws),
+            _lib.check(L.dta_ensemble_forward(C.byref(self._desc()), len(kept), self.nets, xptr, _lib.ptr(self.ws),
                                               _lib.ptr(self.logits), st), "dta_ensemble_forward")
+            self._packed = True
             return self.logits
         x = H._check_input(images)
         self._prepare(x.shape, [0])
@@ -1756,8 +1775,9 @@ class Predictor:
             table[0][2] = self.logits.data_ptr()
             joint = None
         alpha = _lib.ptr(m.alpha) if m._net_code == _lib.NET_HANG2020 else None
-        _lib.check(L.dta_net_forward(C.byref(self.desc), self.nets, alpha, _lib.ptr(x), _lib.ptr(self.ws),
+        _lib.check(L.dta_net_forward(C.byref(self._desc()), self.nets, alpha, _lib.ptr(x), _lib.ptr(self.ws),
                                      C.byref(table), joint, st), "dta_net_forward")
+        self._packed = True
         return self.logits
 
     def __call__(self, images, return_probs=True, present=None):
@@ -1780,12 +1800,20 @@ class MultiStagePredictor:
     models: the levels' learned_ensembles (same year count, bands and precision).  Missing years are decided on the device
     unless `present` (one list of booleans, shared by the levels: they see the same crops) is passed."""
 
-    def __init__(self, models):
+    def __init__(self, models, frozen=False):
+        self.frozen = bool(frozen)      # as Predictor: keep the weight re-layouts of the first call (refresh() after updates)
+        self._packed = False
         self.preds = [Predictor(m) for m in models]
         if not all(p.ensemble for p in self.preds):
             raise TypeError("MultiStagePredictor needs year.learned_ensemble levels")
         self.device = self.preds[0].device
         self._key = None
+
+    def refresh(self):
+        """After in-place weight updates of a frozen predictor (or replaced parameter tensors): rebuild everything."""
+        self._key = None
+        for p in self.preds:
+            p.refresh()
 
     def supported(self, n_years):
         return (len(self.preds) <= _lib.MAX_LEVELS and len(self.preds) * n_years <= _lib.MAX_YEARS
@@ -1803,6 +1831,9 @@ class MultiStagePredictor:
         B, bands, Hh, Ww = shape
         self.desc = _lib.NetDesc(B, bands, Hh, Ww, m0._classes, _lib.NET_SPECTRAL, _lib.dtype_code(m0.precision), 0,
                                  4 | _lib.FORWARD_ONLY, H.BN_MOMENTUM, H.BN_EPS)
+        self.desc_reuse = _lib.NetDesc(B, bands, Hh, Ww, m0._classes, _lib.NET_SPECTRAL, _lib.dtype_code(m0.precision), 0,
+                                       4 | _lib.FORWARD_ONLY | _lib.REUSE_PACKED, H.BN_MOMENTUM, H.BN_EPS)
+        self._packed = False
         nets, lv = [], []
         self.logits, self.probs, self.top_idx, self.top_score = [], [], [], []
         for p, ms in zip(self.preds, mods):
@@ -1824,7 +1855,9 @@ class MultiStagePredictor:
         if nbytes == 0:
             raise RuntimeError("dta_multistage_workspace_bytes: " + L.dta_last_error().decode())
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        self._flags = torch.zeros(len(self.preds[0].nets_mod), dtype=torch.float32, device=self.device)
+        # two flag banks: a call writes one and zeroes the other for the next call (no clearing launch)
+        self._banks = [torch.zeros(len(self.preds[0].nets_mod), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._bank = 0
         self._key = key
 
     def __call__(self, images, return_probs=True, present=None):
@@ -1847,11 +1880,15 @@ class MultiStagePredictor:
         gate = None
         if present is None:
             yptr = (C.c_void_p * Y)(*[x.data_ptr() for x in xs])
-            _lib.check(L.dta_year_flags(yptr, Y, xs[0].numel(), _lib.ptr(self._flags), None, st), "dta_year_flags")
-            gate = self._flags.repeat(nl)           # the (level, year) groups' flags: the years' flags once per level
+            flags, nxt = self._banks[self._bank], self._banks[self._bank ^ 1]
+            self._bank ^= 1
+            _lib.check(L.dta_year_flags(yptr, Y, xs[0].numel(), _lib.ptr(flags), _lib.ptr(nxt), st), "dta_year_flags")
+            gate = flags.repeat(nl)                 # the (level, year) groups' flags: the years' flags once per level
         # forward of all levels x years + ONE launch for every level's mean over its years, softmax and top-2
-        _lib.check(L.dta_multistage_predict(C.byref(self.desc), nl, self.lv, self.nets, xptr, _lib.ptr(gate), _lib.ptr(self.ws),
+        desc = self.desc_reuse if (self.frozen and self._packed) else self.desc
+        _lib.check(L.dta_multistage_predict(C.byref(desc), nl, self.lv, self.nets, xptr, _lib.ptr(gate), _lib.ptr(self.ws),
                                             self._pp if return_probs else None, self._pi, self._ps, st), "dta_multistage_predict")
+        self._packed = True
         self._live = (xs, gate)
         return [(self.probs[l] if return_probs else None, self.top_idx[l], self.top_score[l]) for l in range(nl)]
 

@@ -38,7 +38,8 @@ typedef struct dta_net_desc {
   int training;      /* 1: BatchNorm batch statistics + running-stat update; 0: running statistics */
   int heads_mask;    /* bit L-1 set: compute classifier head L (Hang2020.forward only needs head 3 = 4);
                         | DTA_FORWARD_ONLY: no dta_net_backward will follow on this workspace (inference)
-                        | DTA_SKIP_BLEND: Hang2020 forward leaves the sigmoid(alpha) blend to dta_net_loss (joint unused) */
+                        | DTA_SKIP_BLEND: Hang2020 forward leaves the sigmoid(alpha) blend to dta_net_loss (joint unused)
+                        | DTA_REUSE_PACKED: inference with frozen weights (below) */
   float bn_momentum, bn_eps;
 } dta_net_desc;
 
@@ -66,6 +67,14 @@ typedef struct dta_subnet_grads {
 /* heads_mask flag: the forward skips what only a backward would read (saved attention state, the bf16 input tiles) */
 #define DTA_FORWARD_ONLY 8
 #define DTA_SKIP_BLEND 16
+/* heads_mask flag, inference only (training == 0 and DTA_FORWARD_ONLY; ignored otherwise): the conv / spectral-attention
+ * weight re-layouts and the conv row tables that an earlier forward with the SAME descriptor, parameter table and workspace
+ * left in the workspace are used as they are -- the caller guarantees that those weights have not changed since that
+ * call and that nothing else wrote to the workspace.  The first forward on a workspace must not carry the flag.
+ * (Tile prediction, reference predict.py:140-151 / main.py:165-205: one trained model, thousands of 64-crop batches --
+ * the re-layout of 15 networks' weights is 19 us of a 145 us MultiStage.predict_step.)  BatchNorm running statistics,
+ * biases and the classifier heads are read from the parameter table in every call either way. */
+#define DTA_REUSE_PACKED 32
 
 int dta_abi_version(void);
 /* Hash of the sources this library was built from (python -m deeptreeattention_amd.build): measurement artifacts record

@@ -268,3 +268,59 @@ def test_multistage_predict_wide_levels_take_the_re_formed_tail():
         assert torch.equal(got[l][0], probs), l
         assert torch.equal(got[l][1], ti) and torch.equal(got[l][2], ts), l
         assert int(got[l][1].max()) < (300, 2)[l]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_frozen_predictors_reuse_the_weight_re_layouts(prec):
+    """DTA_REUSE_PACKED (tile prediction with a trained model, reference predict.py:140-151): a frozen predictor packs the
+    conv / attention weights once per workspace; every later batch must give the bits of a predictor that re-packs each call.
+    BatchNorm statistics stay live; an in-place WEIGHT update needs refresh()."""
+    import deeptreeattention_amd
+    from deeptreeattention_amd.engine import MultiStagePredictor, Predictor
+    from deeptreeattention_amd.Hang2020 import Hang2020, get_default_precision
+    from deeptreeattention_amd.year import learned_ensemble
+    default = get_default_precision()
+    deeptreeattention_amd.set_default_precision(prec)
+    try:
+        torch.manual_seed(11)
+        dev = torch.device("cuda:0")
+        cfg = {"pretrain_state_dict": None, "bands": 20}
+        levels = [learned_ensemble(2, c, cfg).to(dev).eval() for c in (3, 6)]
+        hang = Hang2020(20, 7).to(dev).eval()
+        live, frozen = MultiStagePredictor(levels), MultiStagePredictor(levels, frozen=True)
+        live1, frozen1 = Predictor(hang), Predictor(hang, frozen=True)
+        for step in range(3):
+            xs = [torch.rand(10, 20, 11, 11, device=dev) for _ in range(2)]
+            if step == 2:
+                xs[0][:] = 0
+            a, b = live(xs), frozen(xs)
+            for l in range(2):
+                for u, v in zip(a[l], b[l]):
+                    assert torch.equal(u, v), (step, l)
+            for u, v in zip(live1(xs[1]), frozen1(xs[1])):
+                assert torch.equal(u, v), step
+        assert frozen._packed and frozen1._packed
+        xs = [torch.rand(10, 20, 11, 11, device=dev) for _ in range(2)]
+        # running statistics are read in every call: an in-place change is seen by the frozen predictors too
+        with torch.no_grad():
+            levels[0].year_models[0].conv1.bn1.running_mean.add_(0.05)
+            hang.spectral_network.conv2.bn1.running_var.mul_(1.5)
+        for u, v in zip(live(xs)[0], frozen(xs)[0]):
+            assert torch.equal(u, v)
+        for u, v in zip(live1(xs[0]), frozen1(xs[0])):
+            assert torch.equal(u, v)
+        # a weight update is NOT seen until refresh()
+        before = [t.clone() for t in frozen(xs)[1]]
+        before1 = frozen1(xs[0])[0].clone()
+        with torch.no_grad():
+            levels[1].year_models[1].conv1.conv_layer.weight.mul_(1.5)
+            hang.spatial_network.conv1.conv_layer.weight.mul_(0.5)
+        assert torch.equal(frozen(xs)[1][0], before[0]) and torch.equal(frozen1(xs[0])[0], before1)
+        assert not torch.equal(live(xs)[1][0], before[0])
+        frozen.refresh(); frozen1.refresh()
+        for u, v in zip(live(xs)[1], frozen(xs)[1]):
+            assert torch.equal(u, v)
+        for u, v in zip(live1(xs[0]), frozen1(xs[0])):
+            assert torch.equal(u, v)
+    finally:
+        deeptreeattention_amd.set_default_precision(default)

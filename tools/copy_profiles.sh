@@ -7,7 +7,7 @@ cp $S/bench_ensemble24.json profiles/${R}_bench_ensemble24.json
 cp $S/bench_ensemble24_wgrad0.json profiles/${R}_bench_ensemble24_site_wgrad0.json
 cp $S/dp_one_rank.txt profiles/${R}_dp_one_rank.txt
 cp $S/batch_sweep.txt profiles/${R}_batch_sweep.txt
-for f in multistage probe_stream probe_events traffic_ensemble24; do [ -f $S/$f.txt ] && cp $S/$f.txt profiles/${R}_$f.txt; done
+for f in multistage multistage_predict probe_stream probe_events traffic_ensemble24; do [ -f $S/$f.txt ] && cp $S/$f.txt profiles/${R}_$f.txt; done
 [ -f $S/traffic_ensemble24.json ] && cp $S/traffic_ensemble24.json profiles/${R}_traffic_ensemble24.json
 cp $S/private_segment.txt profiles/${R}_private_segment.txt
 cp $S/infer.txt profiles/${R}_inference.txt

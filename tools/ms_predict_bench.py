@@ -15,6 +15,7 @@ models = [learned_ensemble(3, c, cfg).to(dev).eval() for c in [2, 2, 12, 7, 5]]
 x = [torch.rand(B, 369, 11, 11, device=dev) for _ in range(3)]
 per = [Predictor(m) for m in models]
 one = MultiStagePredictor(models)
+frz = MultiStagePredictor(models, frozen=True)
 
 
 def timed(fn):
@@ -27,6 +28,7 @@ def timed(fn):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-a = timed(lambda: [p(x) for p in per]); b = timed(lambda: one(x))
+a = timed(lambda: [p(x) for p in per]); b = timed(lambda: one(x)); c = timed(lambda: frz(x))
 print(json.dumps({"workload": "MultiStage.predict_step: 5 levels x 3 years, 369 bands, 11x11, bf16", "batch": B, "per_level_ms": round(a, 4),
-                  "one_chain_ms": round(b, 4), "speedup": round(a / b, 2), "crops_per_s_one_chain": round(B / b * 1e3, 1)}))
+                  "one_chain_ms": round(b, 4), "speedup": round(a / b, 2), "crops_per_s_one_chain": round(B / b * 1e3, 1),
+                  "one_chain_frozen_weights_ms": round(c, 4), "crops_per_s_frozen": round(B / c * 1e3, 1)}))

@@ -16,6 +16,7 @@ python tools/multistagebench.py 1024 40 >> $O/multistage.txt 2>> $O/bench_defaul
 ./tools/bin/probe_stream > $O/probe_stream.txt 2>&1
 ./tools/bin/probe_events > $O/probe_events.txt 2>&1
 python tools/inferbench.py > $O/infer.txt 2>> $O/bench_default.err
+python tools/ms_predict_bench.py > $O/multistage_predict.txt 2>> $O/bench_default.err
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-side --steady-steps 0 --tile-steps 0 --other-steps 0 --prime-seconds 0"
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B --steps 50 --warmup 10 > $O/kt.log 2>&1
