@@ -1634,8 +1634,10 @@ class Predictor:
     The pointer tables are rebuilt when the batch shape changes; call refresh() after replacing parameter tensors
     (in-place updates, e.g. by FusedTrainer or load_state_dict, need nothing).
     frozen=True (tile prediction with a trained model, reference predict.py:140-151): the conv / attention weight
-    re-layouts of the first call stay in the workspace and later calls skip them (DTA_REUSE_PACKED) -- then in-place weight
-    updates need refresh() too."""
+    re-layouts of the first call stay in the workspace and later calls skip them (DTA_REUSE_PACKED), and the per-call walk over
+    the model's tensors shrinks to one sentinel per network (_fingerprint): whole-model changes made through torch (.to(),
+    load_state_dict, an optimizer step) are still noticed; single edited tensors and this package's fused trainers need
+    refresh()."""
 
     def __init__(self, model, frozen=False):
         import weakref
@@ -1670,7 +1672,7 @@ class Predictor:
         """The descriptor of this call: with frozen weights every call after the first on a workspace reuses its re-layouts."""
         return self.desc_reuse if (self.frozen and self._packed) else self.desc
 
-    def _fingerprint(self):
+    def _fingerprint(self, versions=False):
         """Storage addresses of every parameter and BatchNorm buffer the pointer tables were built from.  The tables
         hold raw device pointers, so anything that re-homes a tensor (FusedTrainer moving the parameters into its flat
         buffer, model.to(), load_state_dict(assign=True)) must rebuild them: ~8 us of data_ptr() calls per batch buy
@@ -1683,7 +1685,15 @@ class Predictor:
             for n in nets:
                 ts += list(n.parameters()) + list(n.buffers())
             self._tensors = (epoch, ts)
-        return (epoch,) + tuple(t.data_ptr() for t in self._tensors[1])
+            self._sentinels = [next(t for t in n.parameters() if t.dim() == 4) for n in nets]
+        if versions or self.frozen:
+            # frozen weights: nothing but one sentinel per network -- its first conv weight's address and torch version
+            # counter -- is looked at per call (the full walk is 65 us of host time for a 15-network MultiStage, more than
+            # the re-layouts it guards cost on the device).  That catches what touches a whole model at once: .to(),
+            # load_state_dict, a torch optimizer step, a trainer moving the parameters into its flat buffer.  A single edited
+            # tensor, or updates by this package's fused trainers (raw pointers: no version counter moves), need refresh().
+            return (epoch,) + tuple(v for t in self._sentinels for v in (t.data_ptr(), t._version))
+        return (epoch,) + tuple(map(torch.Tensor.data_ptr, self._tensors[1]))
 
     def _tables(self, mods):
         out = []
@@ -1823,7 +1833,7 @@ class MultiStagePredictor:
         L = _lib.lib()
         mods = [p.nets_mod for p in self.preds]
         m0 = mods[0][0]
-        key = (tuple(shape), m0.precision, tuple(kept)) + tuple(p._fingerprint() for p in self.preds)
+        key = (tuple(shape), m0.precision, tuple(kept)) + tuple(p._fingerprint(self.frozen) for p in self.preds)
         if key == self._key:
             return
         if any(m.precision != m0.precision for ms in mods for m in ms):
