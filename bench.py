@@ -364,11 +364,14 @@ def side_multistage(a, dev, steps=20, years=3, classes=(2, 2, 12, 7, 5), lrs=(1e
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / (5 * steps) * 1e3
     ms_per, ms_one = timed_p(lambda: [p(x) for p in per]), timed_p(lambda: one(x))
+    frz = MultiStagePredictor([t.model for t in tr.levels], frozen=True)      # trained weights: re-layouts kept in the workspace (DTA_REUSE_PACKED)
+    ms_frz = timed_p(lambda: frz(x))
     out["predict_B64"] = {"batch": 64, "one_chain_ms": round(ms_one, 4), "per_level_ms": round(ms_per, 4), "speedup": round(ms_per / ms_one, 2),
                           "crops_per_s": round(64 / ms_one * 1e3, 1),
+                          "one_chain_frozen_weights_ms": round(ms_frz, 4), "crops_per_s_frozen_weights": round(64 / ms_frz * 1e3, 1),
                           "note": "eval forward of all levels x years networks on the same crops + per-level softmax / top-2: one launch chain "
                                   "(MultiStagePredictor) vs a Predictor per level"}
-    del tr, per, one
+    del tr, per, one, frz
     torch.cuda.empty_cache()
     return out
 
